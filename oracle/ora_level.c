@@ -1,0 +1,218 @@
+/*
+ * ora_level.c -- CPU oracle (TEST INFRASTRUCTURE ONLY, see castro_oracle.h).
+ * Single-box, single-level mirror of the reference's time-step driver around
+ * the hot path:
+ *   Castro::advance / initialize_advance    Source/driver/Castro_advance.cpp:19-121,232-410
+ *   Castro::do_advance_ctu                  Source/driver/Castro_advance_ctu.cpp:15-397
+ *   initialize_do_advance (FillPatch+clean) Source/driver/Castro_advance.cpp:124-209
+ *   estTimeStep / computeNewDt / computeInitialDt / initialTimeStep
+ *                                           Source/driver/Castro.cpp:1490-1866
+ * plus the Sod initial data (Exec/hydro_tests/Sod/problem_initialize*.H).
+ */
+#include <stdio.h>
+#include <time.h>
+#include "ora_internal.h"
+
+struct ora_level {
+    int n[3];
+    int lo[3], hi[3];       /* valid box = domain */
+    int glo[3], ghi[3];     /* grown by NUM_GROW */
+    ora_geom G;
+    ora_params P;
+    int nthreads;
+    int tile[3];
+    double *S_new, *S_old, *Sborder;
+    double *fluxes[3], *mass_fluxes[3];
+    double hydro_seconds;
+};
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+ora_level *ora_level_create(const int n[3], const ora_geom *G, const ora_params *P, int nthreads)
+{
+    ora_level *L = (ora_level *)calloc(1, sizeof(ora_level));
+    L->G = *G;
+    L->P = *P;
+    L->nthreads = nthreads;
+    /* hydro_tile_size default on CPU, Source/driver/Castro.cpp:133 */
+    L->tile[0] = 1024; L->tile[1] = 16; L->tile[2] = 16;
+    size_t nv = 1, ng = 1;
+    for (int d = 0; d < 3; ++d) {
+        L->n[d] = n[d];
+        L->lo[d] = G->domlo[d];
+        L->hi[d] = G->domlo[d] + n[d] - 1;
+        L->glo[d] = L->lo[d] - NUM_GROW;
+        L->ghi[d] = L->hi[d] + NUM_GROW;
+        nv *= (size_t)n[d];
+        ng *= (size_t)(n[d] + 2 * NUM_GROW);
+    }
+    L->S_new = (double *)calloc(nv * NUM_STATE, sizeof(double));
+    L->S_old = (double *)calloc(nv * NUM_STATE, sizeof(double));
+    L->Sborder = (double *)calloc(ng * NUM_STATE, sizeof(double));
+    for (int d = 0; d < 3; ++d) {
+        size_t nf = nv / n[d] * (n[d] + 1);
+        L->fluxes[d] = (double *)calloc(nf * NUM_STATE, sizeof(double));
+        L->mass_fluxes[d] = (double *)calloc(nf, sizeof(double));
+    }
+    return L;
+}
+
+void ora_level_destroy(ora_level *L)
+{
+    if (!L) return;
+    free(L->S_new); free(L->S_old); free(L->Sborder);
+    for (int d = 0; d < 3; ++d) { free(L->fluxes[d]); free(L->mass_fluxes[d]); }
+    free(L);
+}
+
+double *ora_level_state(ora_level *L) { return L->S_new; }
+double *ora_level_flux(ora_level *L, int dir) { return L->fluxes[dir]; }
+double *ora_level_mass_flux(ora_level *L, int dir) { return L->mass_fluxes[dir]; }
+void ora_level_set_tile(ora_level *L, const int tile[3]) { for (int d = 0; d < 3; ++d) L->tile[d] = tile[d]; }
+double ora_level_last_hydro_seconds(ora_level *L) { return L->hydro_seconds; }
+
+/* Castro::initData tail: clean_state on the fresh data (Castro.cpp:1100-1160) */
+void ora_level_post_init(ora_level *L)
+{
+    ora_a4 S = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
+    ora_clean_state(L->lo, L->hi, S, &L->P);
+}
+
+/* Castro::estTimeStep, Castro.cpp:1507-1626 (hydro limiter only; max_dt = 1e200) */
+double ora_level_est_time_step(ora_level *L)
+{
+    ora_a4 S = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
+    double estdt = 1.e200;
+    double estdt_hydro = ora_estdt_cfl(L->lo, L->hi, S, &L->G, &L->P);
+    estdt_hydro *= L->P.cfl;
+    if (estdt_hydro < estdt) estdt = estdt_hydro;
+    return estdt;
+}
+
+/* computeInitialDt (Castro.cpp:1822-1866) with initialTimeStep (:1490-1504) */
+double ora_level_initial_dt(ora_level *L, double stop_time)
+{
+    double dt_0 = L->P.init_shrink * ora_level_est_time_step(L);
+    const double eps = 0.001 * dt_0;
+    double cur_time = 0.0;
+    if (stop_time >= 0.0) {
+        if ((cur_time + dt_0) > (stop_time - eps)) dt_0 = stop_time - cur_time;
+    }
+    return dt_0;
+}
+
+/* computeNewDt (Castro.cpp:1629-1819), single level, no plot_per limiting */
+double ora_level_new_dt(ora_level *L, double dt_old, double cur_time, double stop_time)
+{
+    double dt_0 = ora_level_est_time_step(L);
+    dt_0 = (dt_0 < L->P.change_max * dt_old) ? dt_0 : L->P.change_max * dt_old;   /* std::min */
+    const double eps = 2.220446049250313e-16;
+    if (stop_time >= 0.0) {
+        if ((cur_time + dt_0) >= (stop_time - eps)) dt_0 = stop_time - cur_time;
+    }
+    return dt_0;
+}
+
+/* One level advance.  0 ok; 1 = density failure; 2 = dt validity check failed */
+int ora_level_advance(ora_level *L, double time, double dt)
+{
+    const ora_params *P = &L->P;
+    size_t nv = (size_t)L->n[0] * L->n[1] * L->n[2];
+
+    /* initialize_advance: swap_state_time_levels; clean_state(S_old) */
+    { double *t = L->S_old; L->S_old = L->S_new; L->S_new = t; }
+    ora_a4 S_old = ora_make_a4(L->S_old, L->lo, L->hi, NUM_STATE);
+    ora_a4 S_new = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
+    ora_clean_state(L->lo, L->hi, S_old, P);
+
+    /* zero the flux registers (Castro_advance.cpp:391-394) */
+    ora_a4 fl[3], mf[3], qe[3];
+    for (int d = 0; d < 3; ++d) {
+        int fhi[3] = { L->hi[0], L->hi[1], L->hi[2] };
+        fhi[d] += 1;
+        fl[d] = ora_make_a4(L->fluxes[d], L->lo, fhi, NUM_STATE);
+        mf[d] = ora_make_a4(L->mass_fluxes[d], L->lo, fhi, 1);
+        memset(L->fluxes[d], 0, sizeof(double) * (size_t)fl[d].sn * NUM_STATE);
+        memset(L->mass_fluxes[d], 0, sizeof(double) * (size_t)mf[d].sn);
+        qe[d].p = NULL;
+    }
+
+    /* initialize_do_advance: Sborder = FillPatch(S_old, 4 ghosts); clean_state(Sborder, 4) */
+    ora_a4 Sb = ora_make_a4(L->Sborder, L->glo, L->ghi, NUM_STATE);
+    ora_fill_interior_copy(Sb, S_old, L->lo, L->hi);
+    ora_bc_fill(Sb, &L->G);
+    ora_clean_state(L->glo, L->ghi, Sb, P);
+
+    /* MultiFab::Copy(S_new, Sborder) (Castro_advance_ctu.cpp:94) */
+    ora_fill_interior_copy(S_new, Sb, L->lo, L->hi);
+
+    /* construct_ctu_hydro_source (:156) */
+    ora_a4 nosrc; memset(&nosrc, 0, sizeof(nosrc));
+    double t0 = now_s();
+    int bad = ora_construct_ctu_hydro_source(L->lo, L->hi, Sb, nosrc, S_new, fl, mf, qe, &L->G, P,
+                                             time, dt, L->tile, L->nthreads);
+    L->hydro_seconds = now_s() - t0;
+    (void)bad;
+
+    /* small/negative density check (:168-216) */
+    if (ora_min_density(L->lo, L->hi, S_new) < P->small_dens) return 1;
+
+    /* clean_state(S_new) (:221-225) */
+    ora_clean_state(L->lo, L->hi, S_new, P);
+
+    /* timestep validity check (:386-392) */
+    double new_dt = ora_level_est_time_step(L);
+    if (P->change_max * new_dt < dt) return 2;
+
+    (void)nv;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Exec/hydro_tests/Sod/problem_initialize.H + problem_initialize_state_data.H
+ * (use_Tinit = 0).  idir is 1-based as in the reference's probin. */
+void ora_sod_init(const int lo[3], const int hi[3], ora_a4 state, const ora_geom *G, const ora_params *P,
+                  double rho_l, double u_l, double p_l, double rho_r, double u_r, double p_r,
+                  int idir, double frac)
+{
+    double split[3];
+    for (int d = 0; d < 3; ++d) split[d] = frac * (G->problo[d] + G->probhi[d]);
+
+    ora_eos_t es;
+    es.rho = rho_l; es.p = p_l; es.T = 100000.0;
+    ora_eos_rp(P, &es);
+    const double rhoe_l = rho_l * es.e;
+    const double T_l = es.T;
+
+    es.rho = rho_r; es.p = p_r; es.T = 100000.0;
+    ora_eos_rp(P, &es);
+    const double rhoe_r = rho_r * es.e;
+    const double T_r = es.T;
+
+    const double *dx = G->dx;
+    for (int k = lo[2]; k <= hi[2]; ++k)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+    for (int i = lo[0]; i <= hi[0]; ++i) {
+        double xyz[3] = { G->problo[0] + dx[0] * ((double)i + 0.5),
+                          G->problo[1] + dx[1] * ((double)j + 0.5),
+                          G->problo[2] + dx[2] * ((double)k + 0.5) };
+        int left = xyz[idir - 1] <= split[idir - 1];
+        double rho = left ? rho_l : rho_r;
+        double u = left ? u_l : u_r;
+        double rhoe = left ? rhoe_l : rhoe_r;
+        A4(state,i,j,k,URHO) = rho;
+        A4(state,i,j,k,UMX) = 0.0;
+        A4(state,i,j,k,UMY) = 0.0;
+        A4(state,i,j,k,UMZ) = 0.0;
+        A4(state,i,j,k,UMX + idir - 1) = rho * u;
+        A4(state,i,j,k,UEDEN) = rhoe + 0.5 * rho * u * u;
+        A4(state,i,j,k,UEINT) = rhoe;
+        A4(state,i,j,k,UTEMP) = left ? T_l : T_r;
+        A4(state,i,j,k,UFS) = A4(state,i,j,k,URHO);
+    }
+}

@@ -1,0 +1,278 @@
+"""ctypes binding of the CPU oracle (oracle/libcastro_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() -- never by the castro_amd package (see castro_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcastro_oracle.so")
+
+URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
+QRHO, QU, QV, QW, QPRES, QREINT, QTEMP, QFS = range(8)
+NUM_STATE, NQ, NQAUX, NGDNV, NUM_GROW = 8, 8, 2, 4, 4
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "ppm_type", "riemann_solver", "use_flattening", "hybrid_riemann", "first_order_hydro",
+        "cg_maxiter", "cg_blend", "transverse_use_eos", "transverse_reset_density",
+        "transverse_reset_rhoe", "ppm_temp_fix", "plm_iorder", "plm_limiter", "plm_well_balanced")] + \
+        [(n, C.c_double) for n in (
+            "difmag", "small_dens", "small_temp", "small_pres", "small_ener", "cg_tol",
+            "dual_energy_eta1", "dual_energy_eta2", "cfl", "init_shrink", "change_max",
+            "eos_gamma", "small_x", "T_guess", "abar")]
+
+
+class Geom(C.Structure):
+    _fields_ = [("dx", C.c_double * 3), ("problo", C.c_double * 3), ("probhi", C.c_double * 3),
+                ("domlo", C.c_int * 3), ("domhi", C.c_int * 3),
+                ("lo_bc", C.c_int * 3), ("hi_bc", C.c_int * 3), ("coord", C.c_int)]
+
+
+class A4(C.Structure):
+    _fields_ = [("p", C.POINTER(C.c_double)), ("lo", C.c_int * 3), ("hi", C.c_int * 3),
+                ("nc", C.c_int), ("sy", C.c_long), ("sz", C.c_long), ("sn", C.c_long)]
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (gcc)."""
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        I3 = C.POINTER(C.c_int)
+        L.ora_default_params.argtypes = [C.POINTER(Params)]
+        L.ora_finalize_params.argtypes = [C.POINTER(Params)]
+        L.ora_construct_ctu_hydro_source.restype = C.c_int
+        L.ora_construct_ctu_hydro_source.argtypes = [
+            I3, I3, A4, A4, A4, C.POINTER(A4), C.POINTER(A4), C.POINTER(A4),
+            C.POINTER(Geom), C.POINTER(Params), C.c_double, C.c_double, I3, C.c_int]
+        L.ora_clean_state.argtypes = [I3, I3, A4, C.POINTER(Params)]
+        L.ora_estdt_cfl.restype = C.c_double
+        L.ora_estdt_cfl.argtypes = [I3, I3, A4, C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_min_density.restype = C.c_double
+        L.ora_min_density.argtypes = [I3, I3, A4]
+        L.ora_bc_fill.argtypes = [A4, C.POINTER(Geom)]
+        L.ora_sedov_init.argtypes = [I3, I3, A4, C.POINTER(Geom), C.POINTER(Params),
+                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.ora_sod_init.argtypes = [I3, I3, A4, C.POINTER(Geom), C.POINTER(Params)] + [C.c_double] * 6 + \
+            [C.c_int, C.c_double]
+        L.ora_riemann_single.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.c_double, C.c_double, C.c_double, C.POINTER(Params),
+                                         C.POINTER(C.c_double)]
+        L.ora_ppm_reconstruct.argtypes = [C.POINTER(C.c_double), C.c_double,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ora_ppm_int_profile.argtypes = [C.c_double] * 6 + [C.POINTER(C.c_double)] * 2
+        L.ora_ctoprim.restype = C.c_int
+        L.ora_ctoprim.argtypes = [I3, I3, A4, A4, A4, C.POINTER(Params)]
+        L.ora_uflatten.argtypes = [I3, I3, A4, A4, C.c_int]
+        L.ora_divu.argtypes = [I3, I3, A4, A4, C.POINTER(Geom)]
+        L.ora_trace_ppm.argtypes = [I3, I3, C.c_int, A4, A4, A4, A4, A4, A4, I3, I3, C.c_double,
+                                    C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_cmpflx_plus_godunov.argtypes = [I3, I3, A4, A4, A4, A4, A4, A4, C.c_int,
+                                              C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_level_create.restype = C.c_void_p
+        L.ora_level_create.argtypes = [I3, C.POINTER(Geom), C.POINTER(Params), C.c_int]
+        L.ora_level_destroy.argtypes = [C.c_void_p]
+        L.ora_level_state.restype = C.POINTER(C.c_double)
+        L.ora_level_state.argtypes = [C.c_void_p]
+        L.ora_level_flux.restype = C.POINTER(C.c_double)
+        L.ora_level_flux.argtypes = [C.c_void_p, C.c_int]
+        L.ora_level_mass_flux.restype = C.POINTER(C.c_double)
+        L.ora_level_mass_flux.argtypes = [C.c_void_p, C.c_int]
+        L.ora_level_set_tile.argtypes = [C.c_void_p, I3]
+        L.ora_level_post_init.argtypes = [C.c_void_p]
+        L.ora_level_est_time_step.restype = C.c_double
+        L.ora_level_est_time_step.argtypes = [C.c_void_p]
+        L.ora_level_initial_dt.restype = C.c_double
+        L.ora_level_initial_dt.argtypes = [C.c_void_p, C.c_double]
+        L.ora_level_new_dt.restype = C.c_double
+        L.ora_level_new_dt.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.ora_level_advance.restype = C.c_int
+        L.ora_level_advance.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ora_level_last_hydro_seconds.restype = C.c_double
+        L.ora_level_last_hydro_seconds.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def default_params(**kw):
+    p = Params()
+    lib().ora_default_params(C.byref(p))
+    if kw:
+        for k, v in kw.items():
+            setattr(p, k, v)
+        # floors are derived from eos_gamma etc.: recompute like Castro_setup.cpp:259-288
+        if any(k in kw for k in ("eos_gamma", "small_dens", "small_temp", "abar")):
+            if "small_pres" not in kw:
+                p.small_pres = 1.e-100
+            if "small_ener" not in kw:
+                p.small_ener = 1.e-100
+            lib().ora_finalize_params(C.byref(p))
+    return p
+
+
+def make_geom(n, problo=(0., 0., 0.), probhi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
+              domlo=(0, 0, 0)):
+    g = Geom()
+    for d in range(3):
+        g.problo[d] = problo[d]
+        g.probhi[d] = probhi[d]
+        g.dx[d] = (probhi[d] - problo[d]) / n[d]
+        g.domlo[d] = domlo[d]
+        g.domhi[d] = domlo[d] + n[d] - 1
+        g.lo_bc[d] = lo_bc[d]
+        g.hi_bc[d] = hi_bc[d]
+    g.coord = 0
+    return g
+
+
+def a4(arr, lo, hi, nc=None):
+    """Wrap a numpy array laid out (nc, nz, ny, nx) [C order == FAB layout] as an Array4."""
+    a = A4()
+    if arr is None:
+        a.p = None
+        return a
+    assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
+    nx, ny, nz = hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1
+    if nc is None:
+        nc = arr.size // (nx * ny * nz)
+    assert arr.size == nc * nx * ny * nz, (arr.shape, nc, nx, ny, nz)
+    a.p = arr.ctypes.data_as(C.POINTER(C.c_double))
+    for d in range(3):
+        a.lo[d] = lo[d]
+        a.hi[d] = hi[d]
+    a.nc = nc
+    a.sy = nx
+    a.sz = nx * ny
+    a.sn = nx * ny * nz
+    return a
+
+
+def fab(lo, hi, nc, fill=0.0):
+    """numpy array (nc, nz, ny, nx) for the box [lo, hi]."""
+    shape = (nc, hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
+    return np.full(shape, fill, dtype=np.float64)
+
+
+def ctu_hydro(bxlo, bxhi, Sborder, sb_lo, sb_hi, S_new, geom, params, dt, time=0.0,
+              src=None, src_lo=None, src_hi=None, tile=(0, 0, 0), nthreads=0, want_qe=False):
+    """Run the oracle's construct_ctu_hydro_source on one box.  Returns
+    (status, fluxes[3], mass_fluxes[3], qe[3] or None); S_new is updated in place."""
+    L = lib()
+    fl, mf, qe = [], [], []
+    fa, ma, qa = (A4 * 3)(), (A4 * 3)(), (A4 * 3)()
+    for d in range(3):
+        fhi = list(bxhi)
+        fhi[d] += 1
+        fl.append(fab(bxlo, fhi, NUM_STATE))
+        mf.append(fab(bxlo, fhi, 1))
+        fa[d] = a4(fl[d], bxlo, fhi)
+        ma[d] = a4(mf[d], bxlo, fhi)
+        if want_qe:
+            qe.append(fab(bxlo, fhi, NGDNV))
+            qa[d] = a4(qe[d], bxlo, fhi)
+        else:
+            qa[d] = a4(None, bxlo, fhi)
+    st = L.ora_construct_ctu_hydro_source(
+        i3(bxlo), i3(bxhi), a4(Sborder, sb_lo, sb_hi), a4(src, src_lo, src_hi) if src is not None else a4(None, bxlo, bxhi),
+        a4(S_new, bxlo, bxhi), fa, ma, qa, C.byref(geom), C.byref(params),
+        float(time), float(dt), i3(tile), int(nthreads))
+    return st, fl, mf, (qe if want_qe else None)
+
+
+class Level:
+    """Single-box level driver (oracle mirror of Castro::advance for max_level=0)."""
+
+    def __init__(self, n, geom, params, nthreads=0):
+        self.n = tuple(int(x) for x in n)
+        self.geom = geom
+        self.params = params
+        self.h = lib().ora_level_create(i3(n), C.byref(geom), C.byref(params), int(nthreads))
+        self.lo = tuple(geom.domlo[d] for d in range(3))
+        self.hi = tuple(geom.domhi[d] for d in range(3))
+        self.time = 0.0
+        self.dt = 0.0
+        self.nstep = 0
+
+    def close(self):
+        if self.h:
+            lib().ora_level_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def state(self):
+        """View of S_new as (NUM_STATE, nz, ny, nx). Re-fetch after every advance (buffers swap)."""
+        p = lib().ora_level_state(self.h)
+        nx, ny, nz = self.n
+        return np.ctypeslib.as_array(p, shape=(NUM_STATE, nz, ny, nx))
+
+    def flux(self, d):
+        p = lib().ora_level_flux(self.h, d)
+        shp = [self.n[2], self.n[1], self.n[0]]
+        shp[2 - d] += 1
+        return np.ctypeslib.as_array(p, shape=(NUM_STATE, *shp))
+
+    def set_tile(self, tile):
+        lib().ora_level_set_tile(self.h, i3(tile))
+
+    def init_sedov(self, r_init=0.01, p_ambient=1.e-5, exp_energy=1.0, dens_ambient=1.0, nsub=10):
+        S = self.state()
+        lib().ora_sedov_init(i3(self.lo), i3(self.hi), a4(S, self.lo, self.hi), C.byref(self.geom),
+                             C.byref(self.params), r_init, p_ambient, exp_energy, dens_ambient, nsub)
+        lib().ora_level_post_init(self.h)
+
+    def init_sod(self, rho_l, u_l, p_l, rho_r, u_r, p_r, idir=1, frac=0.5):
+        S = self.state()
+        lib().ora_sod_init(i3(self.lo), i3(self.hi), a4(S, self.lo, self.hi), C.byref(self.geom),
+                           C.byref(self.params), rho_l, u_l, p_l, rho_r, u_r, p_r, idir, frac)
+        lib().ora_level_post_init(self.h)
+
+    def est_time_step(self):
+        return lib().ora_level_est_time_step(self.h)
+
+    def step(self, stop_time=-1.0):
+        """One coarse time step with the reference's dt control. Returns dt used."""
+        L = lib()
+        if self.nstep == 0:
+            self.dt = L.ora_level_initial_dt(self.h, stop_time)
+        else:
+            self.dt = L.ora_level_new_dt(self.h, self.dt, self.time, stop_time)
+        st = L.ora_level_advance(self.h, self.time, self.dt)
+        if st != 0:
+            raise RuntimeError("oracle advance failed with status %d (retry logic not restated)" % st)
+        self.time += self.dt
+        self.nstep += 1
+        return self.dt
+
+    def run(self, stop_time, max_step=100000):
+        eps = 2.220446049250313e-16
+        while self.nstep < max_step and self.time < stop_time - eps:
+            self.step(stop_time)
+        return self.nstep
+
+    def last_hydro_seconds(self):
+        return lib().ora_level_last_hydro_seconds(self.h)
