@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of the CTU hydro advance on the Sedov 3-D 256^3 single-level problem.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL halo exchange)
+
+A "step" is one coarse time step of the level (Castro::advance: clean_state, FillPatch,
+construct_ctu_hydro_source, clean_state, dt estimate), i.e. the reference's own FOM
+("zones advanced per microsecond", Source/driver/Castro_advance.cpp:461-471).  Inputs are
+synthetic (the Sedov initial data generated on the device) and resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PATH_BYTES_PER_CELL = 600.0    # contract traffic of construct_ctu_hydro_source
+
+# algorithmic (compulsory) bytes per processed unit of each hot-path kernel: every input and
+# output array element exactly once (DESIGN.md "Kernels").  Unit = one zone/face of the kernel's box.
+KERNEL_BYTES_PER_UNIT = {
+    "k_ctoprim": 8 * (8 + 8),
+    "k_divu": 8 * (3 + 1),
+    "k_trace": 8 * (8 + 42),
+    "k_riemann1": 8 * (14 + 1 + 8),
+    "k_trans1": 8 * (14 + 16 + 1 + 16),
+    "k_final": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),
+    "k_consup": 8 * (27 + 8 + 8),
+    "k_clean_state": 8 * (8 + 8),
+    "k_estdt": 8 * 5,
+}
+
+
+def kernel_units(name, n):
+    nx, ny, nz = n
+    return {
+        "k_ctoprim": (nx + 8) * (ny + 8) * (nz + 8),
+        "k_divu": (nx + 2) * (ny + 2) * (nz + 2),
+        "k_trace": (nx + 2) * (ny + 2) * (nz + 2),
+        "k_riemann1": ((nx + 1) * (ny + 2) * (nz + 2) + (nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 3.0,
+        "k_trans1": ((nx + 1) * (ny + 2) * (nz + 2) + (nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 3.0,
+        "k_final": ((nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + 1)) / 3.0,
+        "k_consup": nx * ny * nz,
+        "k_clean_state": nx * ny * nz,
+        "k_estdt": nx * ny * nz,
+    }.get(name, nx * ny * nz)
+
+
+def cpu_baseline(ncell, steps):
+    """The CPU oracle (a port organised like the reference's CPU path: ~75 sweeps per tile,
+    tiles 1024x16x16, OpenMP over tiles) timed on this host on a bounded Sedov sample."""
+    from oracle import oracle_lib as O
+    n = (ncell, ncell, ncell)
+    ntiles = max(1, (ncell // 16)) ** 2
+    threads = max(1, min(os.cpu_count() or 1, ntiles))
+    lev = O.Level(n, O.make_geom(n), O.default_params(), nthreads=threads)
+    lev.init_sedov()
+    lev.step(0.01)                    # untimed first step (page faults, scratch allocation)
+    t0 = time.time()
+    for _ in range(steps):
+        lev.step(0.01)
+    wall = time.time() - t0
+    lev.close()
+    return {"value": ncell ** 3 * steps / wall, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+            "sample": "Sedov 3D %d^3 single level, %d coarse steps (whole advance), oracle/libcastro_oracle.so, "
+                      "OpenMP over 1024x16x16 tiles" % (ncell, steps),
+            "seconds": wall}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ncell", type=int, default=256, help="global zones per side (strong scaling: fixed as N grows)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: ncell^3 zones PER GPU (config 3: 512^3 on 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ncell", type=int, default=96)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import castro_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        comm = castro_amd.DistComm()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    grid = castro_amd.default_grid(world)
+    if args.weak:
+        n_cell = tuple(args.ncell * grid[d] for d in range(3))
+    else:
+        n_cell = (args.ncell,) * 3
+
+    c = castro_amd.Castro(n_cell, comm=comm, grid=grid, overlap=(False if args.no_overlap else None))
+    c.initData("sedov")                      # synthetic input, generated on the device
+    for _ in range(args.warmup):
+        c.step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
+            torch.cuda.synchronize()
+
+    c.hydro.profile(True)
+    c.hydro.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c.step()
+    sync()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    if comm is not None:
+        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        comm.dist.all_reduce(w, op=comm.dist.ReduceOp.MAX)
+        wall = w.item()
+    prof = c.hydro.profile_report()
+    c.hydro.profile(False)
+
+    total_cells = n_cell[0] * n_cell[1] * n_cell[2]
+    value = total_cells * args.steps / wall
+
+    # dominant kernel (largest total device time over the timed region), hipEvent-timed on its stream
+    roof = None
+    if prof:
+        name, (tot_ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+        avg_s = tot_ms / launches / 1e3
+        units = kernel_units(name, c.n)
+        alg_bytes = KERNEL_BYTES_PER_UNIT.get(name, 0) * units
+        achieved = alg_bytes / avg_s / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": name, "avg_launch_ms": avg_s * 1e3, "launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes}
+    hydro_ms = sum(v[0] for k, v in prof.items() if k in ("k_ctoprim", "k_divu", "k_trace", "k_riemann1", "k_trans1",
+                                                          "k_final", "k_consup")) / max(args.steps, 1)
+    path = {"bytes_per_cell_update": PATH_BYTES_PER_CELL,
+            "achieved_GBs_per_gpu": value / world * PATH_BYTES_PER_CELL / 1e9,
+            "frac_of_hbm_peak": value / world * PATH_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS,
+            "hydro_kernels_ms_per_step": hydro_ms,
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())}}
+
+    out = {
+        "metric": "cell-updates/sec, Sedov 3D 256^3 single-level; % HBM roofline",
+        "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if args.weak else "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Sedov 3D %dx%dx%d single level, gamma-law EOS, PPM + CGF Riemann, CTU" % n_cell,
+                   "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": c.n[0] * c.n[1] * c.n[2],
+                   "overlap_halo": bool(c.overlap), "sim_time": c.time, "nstep": c.nstep},
+        "roofline": roof,
+        "path_roofline": path,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_ncell, args.cpu_steps)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if comm is not None:
+        comm.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

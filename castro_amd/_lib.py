@@ -1,0 +1,165 @@
+"""ctypes binding of castro_amd/libcastro_hydro_amd.so (the C ABI in include/castro_hydro_amd.h).
+
+This module only loads the shared library and declares signatures.  There is NO
+CPU fallback: if the library is missing, or no HIP device is present when a
+context is created, it raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcastro_hydro_amd.so")
+
+NUM_STATE, NGDNV, NUM_GROW = 8, 4, 4
+URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
+UPDATE_ADD, UPDATE_FROM_SBORDER = 0, 1
+
+# every symbol include/castro_hydro_amd.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = (
+    "castro_amd_default_params", "castro_amd_finalize_params",
+    "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
+    "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status",
+    "castro_amd_ctu_hydro_fab", "castro_amd_clean_state_fab", "castro_amd_estdt_fab",
+    "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
+    "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
+    "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
+    "castro_amd_ctx_profile_reset",
+)
+
+
+class Fab(C.Structure):
+    """castro_amd_fab: FArrayBox descriptor (pointer, lo, hi, ncomp)."""
+    _fields_ = [("p", C.c_void_p), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("ncomp", C.c_int)]
+
+
+class Geom(C.Structure):
+    _fields_ = [("dx", C.c_double * 3), ("problo", C.c_double * 3), ("probhi", C.c_double * 3),
+                ("domlo", C.c_int * 3), ("domhi", C.c_int * 3),
+                ("lo_bc", C.c_int * 3), ("hi_bc", C.c_int * 3), ("coord", C.c_int)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "ppm_type", "riemann_solver", "use_flattening", "hybrid_riemann", "first_order_hydro",
+        "cg_maxiter", "cg_blend", "transverse_use_eos", "transverse_reset_density",
+        "transverse_reset_rhoe", "ppm_temp_fix")] + [("reserved_i", C.c_int * 3)] + \
+        [(n, C.c_double) for n in (
+            "difmag", "small_dens", "small_temp", "small_pres", "small_ener", "cg_tol",
+            "dual_energy_eta1", "dual_energy_eta2", "cfl", "init_shrink", "change_max",
+            "eos_gamma", "small_x", "T_guess", "abar")]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "castro_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C castro_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    I3 = C.POINTER(C.c_int)
+    PF = C.POINTER(Fab)
+    L.castro_amd_version.restype = C.c_char_p
+    L.castro_amd_default_params.argtypes = [C.POINTER(Params)]
+    L.castro_amd_finalize_params.argtypes = [C.POINTER(Params)]
+    L.castro_amd_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.castro_amd_ctx_destroy.argtypes = [C.c_void_p]
+    L.castro_amd_ctx_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.castro_amd_ctx_scratch_bytes.restype = C.c_longlong
+    L.castro_amd_ctx_scratch_bytes.argtypes = [C.c_void_p]
+    L.castro_amd_ctx_status.argtypes = [C.c_void_p, C.c_void_p]
+    L.castro_amd_ctu_hydro_fab.argtypes = [
+        C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
+        C.c_double, C.c_double, C.c_int, C.c_void_p]
+    L.castro_amd_clean_state_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]
+    L.castro_amd_estdt_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params),
+                                       C.c_void_p, C.c_void_p]
+    L.castro_amd_bc_fill_fab.argtypes = [C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
+    L.castro_amd_copy_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_void_p]
+    L.castro_amd_pack_fab.argtypes = [C.c_void_p, PF, I3, I3, C.c_void_p, C.c_void_p]
+    L.castro_amd_unpack_fab.argtypes = [C.c_void_p, PF, I3, I3, C.c_void_p, C.c_void_p]
+    L.castro_amd_sedov_init_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params),
+                                            C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    L.castro_amd_sod_init_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params)] + \
+        [C.c_double] * 6 + [C.c_int, C.c_double, C.c_void_p]
+    L.castro_amd_ctx_profile.argtypes = [C.c_void_p, C.c_int]
+    L.castro_amd_ctx_profile_count.argtypes = [C.c_void_p]
+    L.castro_amd_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int,
+                                             C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.castro_amd_ctx_profile_reset.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def default_params(**overrides):
+    """castro_amd_params with the reference defaults for the Sedov setup; keyword overrides are applied
+    and the derived floors recomputed (Castro_setup.cpp:222-288)."""
+    p = Params()
+    load().castro_amd_default_params(C.byref(p))
+    if overrides:
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise AttributeError("castro_amd_params has no field %r" % k)
+            setattr(p, k, v)
+        if any(k in overrides for k in ("eos_gamma", "small_dens", "small_temp", "abar")):
+            if "small_pres" not in overrides:
+                p.small_pres = 1.e-100
+            if "small_ener" not in overrides:
+                p.small_ener = 1.e-100
+            load().castro_amd_finalize_params(C.byref(p))
+    return p
+
+
+def make_geom(n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
+              domlo=(0, 0, 0)):
+    g = Geom()
+    for d in range(3):
+        g.problo[d] = prob_lo[d]
+        g.probhi[d] = prob_hi[d]
+        g.dx[d] = (prob_hi[d] - prob_lo[d]) / n_cell[d]
+        g.domlo[d] = domlo[d]
+        g.domhi[d] = domlo[d] + n_cell[d] - 1
+        g.lo_bc[d] = lo_bc[d]
+        g.hi_bc[d] = hi_bc[d]
+    g.coord = 0
+    return g
+
+
+def fab_desc(ptr, lo, hi, ncomp):
+    f = Fab()
+    f.p = ptr
+    for d in range(3):
+        f.lo[d] = int(lo[d])
+        f.hi[d] = int(hi[d])
+    f.ncomp = int(ncomp)
+    return f
+
+
+def fab_of(tensor, lo, hi):
+    """Descriptor for a contiguous torch tensor shaped (ncomp, nz, ny, nx) covering box [lo, hi]
+    (C order of that shape == AMReX FAB layout: i fastest, component slowest)."""
+    if tensor is None:
+        return fab_desc(None, lo, hi, 0)
+    nx, ny, nz = hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1
+    assert tensor.is_contiguous(), "FAB tensors must be contiguous"
+    assert tuple(tensor.shape[-3:]) == (nz, ny, nx), (tuple(tensor.shape), (nz, ny, nx))
+    ncomp = tensor.numel() // (nx * ny * nz)
+    return fab_desc(tensor.data_ptr(), lo, hi, ncomp)
+
+
+def check(rc, what):
+    if rc != OK:
+        names = {ERR_ARG: "bad argument", ERR_UNSUPPORTED: "unsupported option", ERR_NOMEM: "out of device memory",
+                 ERR_HIP: "HIP runtime error / no device"}
+        raise RuntimeError("castro_amd: %s failed: %s (%d)" % (what, names.get(rc, "error"), rc))

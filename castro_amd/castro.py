@@ -1,0 +1,354 @@
+"""Single-level driver around the hot path, mirroring the reference's `Castro` class.
+
+Method names follow the reference so a reader of Source/driver can map one to the other:
+
+  Castro.initData                 Source/driver/Castro.cpp:934   (+ Exec/<problem>/problem_initialize*.H)
+  Castro.advance / do_advance_ctu Source/driver/Castro_advance.cpp:19, Castro_advance_ctu.cpp:15-397
+  Castro.expand_state (FillPatch) Source/driver/Castro.cpp:4201-4209
+  Castro.clean_state              Source/driver/Castro.cpp:4238-4278
+  Castro.construct_ctu_hydro_source  Source/hydro/Castro_ctu_hydro.cpp:16
+  Castro.estTimeStep / computeInitialDt / computeNewDt   Source/driver/Castro.cpp:1490-1866
+
+Decomposition: one box per rank (one rank per GPU); the level-0 domain is cut into a
+px x py x pz grid of equal boxes.  The FillPatch ghost exchange is point-to-point
+(torch.distributed batch_isend_irecv == grouped ncclSend/ncclRecv on RCCL, one peer per
+xGMI link) on a communication stream, overlapped with the hydro update of the interior
+sub-box, which needs no remote data, on the compute stream.
+"""
+import itertools
+import time as _time
+
+import torch
+
+from . import _lib as L
+
+NUM_STATE, NUM_GROW = L.NUM_STATE, L.NUM_GROW
+
+
+# --------------------------------------------------------------------------------------------
+# communicators
+# --------------------------------------------------------------------------------------------
+class SingleComm:
+    rank, size = 0, 1
+
+    def exchange(self, sends, recvs):
+        assert not sends and not recvs
+
+    def allreduce_min(self, t):
+        return t
+
+    def barrier(self):
+        pass
+
+
+class DistComm:
+    """torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" on CPU for tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def exchange(self, sends, recvs):
+        """sends/recvs: lists of (peer_rank, tag, tensor).  Grouped point-to-point."""
+        dist = self.dist
+        ops = []
+        # post receives first, ordered by (peer, tag) on both sides so the grouped call matches up
+        for peer, tag, buf in sorted(recvs, key=lambda x: (x[0], x[1])):
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group=self.group, tag=tag))
+        for peer, tag, buf in sorted(sends, key=lambda x: (x[0], x[1])):
+            ops.append(dist.P2POp(dist.isend, buf, peer, group=self.group, tag=tag))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def allreduce_min(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+def default_grid(size):
+    """Split z first, then y, then x."""
+    g = [1, 1, 1]
+    d = 2
+    while size > 1:
+        assert size % 2 == 0, "rank count must be a power of two"
+        g[d] *= 2
+        size //= 2
+        d = (d - 1) % 3
+    return tuple(g)
+
+
+class AdvanceFailure(RuntimeError):
+    pass
+
+
+# --------------------------------------------------------------------------------------------
+class Castro:
+    def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
+                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None):
+        self.n_cell = tuple(int(x) for x in n_cell)
+        self.comm = comm if comm is not None else SingleComm()
+        if hydro is None:
+            from .hydro import HipHydro
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            hydro = HipHydro(dev)          # raises without a GPU: no CPU fallback
+        self.hydro = hydro
+        self.params = params if params is not None else (make_params() if make_params else L.default_params())
+        self.geom = (hydro.make_geom if hasattr(hydro, "make_geom") else L.make_geom)(
+            self.n_cell, prob_lo, prob_hi, lo_bc, hi_bc)
+        self.lo_bc, self.hi_bc = tuple(lo_bc), tuple(hi_bc)
+        self.periodic = tuple(lo_bc[d] == 0 and hi_bc[d] == 0 for d in range(3))
+
+        # --- decomposition: one box per rank ---
+        self.grid = tuple(grid) if grid is not None else default_grid(self.comm.size)
+        assert self.grid[0] * self.grid[1] * self.grid[2] == self.comm.size
+        r = self.comm.rank
+        self.coords = (r % self.grid[0], (r // self.grid[0]) % self.grid[1], r // (self.grid[0] * self.grid[1]))
+        self.lo, self.hi = [], []
+        for d in range(3):
+            assert self.n_cell[d] % self.grid[d] == 0, "domain must divide evenly over the rank grid"
+            nloc = self.n_cell[d] // self.grid[d]
+            assert nloc >= 2 * NUM_GROW or self.grid[d] == 1, "boxes must be at least 8 zones wide when decomposed"
+            self.lo.append(self.coords[d] * nloc)
+            self.hi.append(self.lo[d] + nloc - 1)
+        self.lo, self.hi = tuple(self.lo), tuple(self.hi)
+        self.n = tuple(self.hi[d] - self.lo[d] + 1 for d in range(3))
+        self.glo = tuple(x - NUM_GROW for x in self.lo)
+        self.ghi = tuple(x + NUM_GROW for x in self.hi)
+        self.gbox = (self.glo, self.ghi)
+        self.bx = (self.lo, self.hi)
+
+        # --- state: two bordered buffers (Sborder / S_new share storage layout; swap per step) ---
+        self.S_old_b = hydro.alloc(NUM_STATE, self.glo, self.ghi)
+        self.S_new_b = hydro.alloc(NUM_STATE, self.glo, self.ghi)
+        self.flux_boxes, self.fluxes, self.mass_fluxes = [], [], []
+        for d in range(3):
+            fhi = list(self.hi)
+            fhi[d] += 1
+            self.flux_boxes.append((self.lo, tuple(fhi)))
+            self.fluxes.append(hydro.alloc(NUM_STATE, self.lo, fhi))
+            self.mass_fluxes.append(hydro.alloc(1, self.lo, fhi))
+        self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)   # [min dt, min rho]
+
+        self.neighbors = self._build_neighbors()
+        self.overlap = (self.comm.size > 1) if overlap is None else bool(overlap)
+        self._comm_stream = None
+        if self.overlap and self.S_new_b.is_cuda:
+            self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
+
+        self.time = 0.0
+        self.dt = 0.0
+        self.nstep = 0
+        self.hydro_seconds = 0.0
+        if hasattr(hydro, "reserve"):
+            hydro.reserve(*self.n)
+
+    # ----------------------------------------------------------------------------------------
+    def S_new(self):
+        """Valid-region view of the new-time state, shape (NUM_STATE, nz, ny, nx)."""
+        g = NUM_GROW
+        return self.S_new_b[:, g:-g, g:-g, g:-g]
+
+    # ----------------------------------------------------------------------------------------
+    def _build_neighbors(self):
+        """[(peer_rank, send_tag, recv_tag, send_box, recv_box)] for the up-to-26 neighbours."""
+        out = []
+        for off in itertools.product((-1, 0, 1), repeat=3):      # (ox, oy, oz)
+            if off == (0, 0, 0):
+                continue
+            nb = []
+            ok = True
+            for d in range(3):
+                c = self.coords[d] + off[d]
+                if c < 0 or c >= self.grid[d]:
+                    if self.periodic[d]:
+                        c %= self.grid[d]
+                    else:
+                        ok = False
+                        break
+                nb.append(c)
+            if not ok:
+                continue
+            peer = nb[0] + self.grid[0] * (nb[1] + self.grid[1] * nb[2])
+            slo, shi, rlo, rhi = [], [], [], []
+            for d in range(3):
+                if off[d] == -1:
+                    slo.append(self.lo[d]); shi.append(self.lo[d] + NUM_GROW - 1)
+                    rlo.append(self.lo[d] - NUM_GROW); rhi.append(self.lo[d] - 1)
+                elif off[d] == 1:
+                    slo.append(self.hi[d] - NUM_GROW + 1); shi.append(self.hi[d])
+                    rlo.append(self.hi[d] + 1); rhi.append(self.hi[d] + NUM_GROW)
+                else:
+                    slo.append(self.lo[d]); shi.append(self.hi[d])
+                    rlo.append(self.lo[d]); rhi.append(self.hi[d])
+            code = (off[0] + 1) + 3 * (off[1] + 1) + 9 * (off[2] + 1)
+            rcode = (-off[0] + 1) + 3 * (-off[1] + 1) + 9 * (-off[2] + 1)
+            # what I send towards `off` is what the peer receives from direction -off
+            out.append(dict(peer=peer, send_tag=code, recv_tag=rcode, sbox=(tuple(slo), tuple(shi)),
+                            rbox=(tuple(rlo), tuple(rhi)), off=off))
+        for nbr in out:
+            n = 1
+            for d in range(3):
+                n *= nbr["sbox"][1][d] - nbr["sbox"][0][d] + 1
+            nbr["sbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * NUM_STATE - 1, 0, 0)).reshape(-1)
+            nbr["rbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * NUM_STATE - 1, 0, 0)).reshape(-1)
+        return out
+
+    # ---- AmrLevel::FillPatch at a single level: same-level copy + physical BCs ----
+    def expand_state(self, S):
+        h = self.hydro
+        sends, recvs, local = [], [], []
+        for nb in self.neighbors:
+            h.pack(S, self.gbox, nb["sbox"][0], nb["sbox"][1], nb["sbuf"])
+        for nb in self.neighbors:
+            if nb["peer"] == self.comm.rank:
+                local.append(nb)
+            else:
+                sends.append((nb["peer"], nb["send_tag"], nb["sbuf"]))
+                recvs.append((nb["peer"], nb["recv_tag"], nb["rbuf"]))
+        # periodic wrap onto myself: the buffer I send towards `off` is the one I receive from `-off`
+        for nb in local:
+            src = next(x for x in local if x["send_tag"] == nb["recv_tag"])
+            nb["rbuf"].copy_(src["sbuf"])
+        self.comm.exchange(sends, recvs)
+        for nb in self.neighbors:
+            h.unpack(S, self.gbox, nb["rbox"][0], nb["rbox"][1], nb["rbuf"])
+        h.bc_fill(S, self.gbox, self.geom)
+
+    # ---- Castro::clean_state ---------------------------------------------------------------
+    def clean_state(self, S, ntimes=1):
+        self.hydro.clean_state(S, self.gbox, self.lo, self.hi, self.params, ntimes=ntimes)
+
+    # ---- Castro::initData ------------------------------------------------------------------
+    def initData(self, problem="sedov", **kw):
+        h = self.hydro
+        if problem == "sedov":
+            h.sedov_init(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, **kw)
+        elif problem == "sod":
+            h.sod_init(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, **kw)
+        else:
+            raise ValueError(problem)
+        self.clean_state(self.S_new_b, 1)      # Castro.cpp:1100-1160
+        self.time, self.nstep, self.dt = 0.0, 0, 0.0
+
+    # ---- Castro::estTimeStep (hydro limiter) -------------------------------------------------
+    def _reduce(self):
+        """[min dx/(c+|u|), min rho] over the whole level (device reduction + allreduce MIN)."""
+        self.red.fill_(1.e200)
+        self.hydro.estdt_cfl(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, self.red)
+        self.comm.allreduce_min(self.red)
+        v = self.red.tolist()
+        return v[0], v[1]
+
+    def estTimeStep(self):
+        est, _ = self._reduce()
+        return min(1.e200, est * self.params.cfl)
+
+    def computeInitialDt(self, stop_time=-1.0):
+        dt_0 = self.params.init_shrink * self.estTimeStep()
+        eps = 0.001 * dt_0
+        if stop_time >= 0.0 and (self.time + dt_0) > (stop_time - eps):
+            dt_0 = stop_time - self.time
+        return dt_0
+
+    def computeNewDt(self, dt_old, stop_time=-1.0, est=None):
+        dt_0 = self.estTimeStep() if est is None else est
+        dt_0 = min(dt_0, self.params.change_max * dt_old)
+        eps = 2.220446049250313e-16
+        if stop_time >= 0.0 and (self.time + dt_0) >= (stop_time - eps):
+            dt_0 = stop_time - self.time
+        return dt_0
+
+    # ---- Castro::construct_ctu_hydro_source over this rank's box ------------------------------
+    def construct_ctu_hydro_source(self, time, dt, tiles=None):
+        h = self.hydro
+        for bx in (tiles or [self.bx]):
+            h.construct_ctu_hydro_source(bx, self.S_old_b, self.gbox, self.S_new_b, self.gbox, self.geom,
+                                         self.params, time, dt, fluxes=self.fluxes, flux_boxes=self.flux_boxes,
+                                         mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=True)
+
+    def _shell_tiles(self):
+        """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
+        g = NUM_GROW
+        ilo = tuple(self.lo[d] + g for d in range(3))
+        ihi = tuple(self.hi[d] - g for d in range(3))
+        if any(ihi[d] < ilo[d] for d in range(3)):
+            return None, [self.bx]
+        shells = []
+        lo, hi = list(self.lo), list(self.hi)
+        # z slabs take the full x,y extent; y slabs the remaining z; x slabs the remaining y,z
+        shells.append(((lo[0], lo[1], lo[2]), (hi[0], hi[1], ilo[2] - 1)))
+        shells.append(((lo[0], lo[1], ihi[2] + 1), (hi[0], hi[1], hi[2])))
+        shells.append(((lo[0], lo[1], ilo[2]), (hi[0], ilo[1] - 1, ihi[2])))
+        shells.append(((lo[0], ihi[1] + 1, ilo[2]), (hi[0], hi[1], ihi[2])))
+        shells.append(((lo[0], ilo[1], ilo[2]), (ilo[0] - 1, ihi[1], ihi[2])))
+        shells.append(((ihi[0] + 1, ilo[1], ilo[2]), (hi[0], ihi[1], ihi[2])))
+        return (ilo, ihi), shells
+
+    # ---- Castro::do_advance_ctu -------------------------------------------------------------
+    def do_advance_ctu(self, time, dt):
+        h = self.hydro
+        # initialize_advance: swap_state_time_levels
+        self.S_old_b, self.S_new_b = self.S_new_b, self.S_old_b
+        S = self.S_old_b
+        # clean_state(S_old) [Castro_advance.cpp:311] and clean_state(Sborder, 4 ghosts)
+        # [Castro_advance.cpp:186] are both zone-local: on the valid zones they compose to
+        # "clean twice"; ghost zones are copies (or sign-reflected copies) of twice-cleaned
+        # valid zones, so they are filled AFTER the cleaning.  See DESIGN.md "clean_state order".
+        self.clean_state(S, 2)
+        for d in range(3):
+            self.fluxes[d].zero_()          # Castro_advance.cpp:391-394
+            self.mass_fluxes[d].zero_()
+
+        use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
+        t0 = None
+        if use_overlap:
+            interior, shells = self._shell_tiles()
+            cur = torch.cuda.current_stream()
+            self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                self.expand_state(S)                                   # halo exchange + BC fill
+            if interior is not None:
+                self.construct_ctu_hydro_source(time, dt, tiles=[interior])   # overlapped: needs no ghost data
+            cur.wait_stream(self._comm_stream)
+            self.construct_ctu_hydro_source(time, dt, tiles=shells)
+        else:
+            self.expand_state(S)
+            self.construct_ctu_hydro_source(time, dt)
+
+        # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216), on the un-cleaned update
+        _, rho_min = self._reduce()
+        if rho_min < self.params.small_dens:
+            raise AdvanceFailure("negative/small density after the hydro update: %g (retry not implemented)" % rho_min)
+        self.clean_state(self.S_new_b, 1)                              # :221-225
+        est, _ = self._reduce()
+        new_dt = min(1.e200, est * self.params.cfl)
+        if self.params.change_max * new_dt < dt:                       # :386-392
+            raise AdvanceFailure("timestep validity check failed (retry not implemented)")
+        return new_dt
+
+    def advance(self, time, dt):
+        return self.do_advance_ctu(time, dt)
+
+    # ---- Amr::coarseTimeStep loop -----------------------------------------------------------
+    def step(self, stop_time=-1.0):
+        if self.nstep == 0:
+            self.dt = self.computeInitialDt(stop_time)
+        else:
+            self.dt = self.computeNewDt(self.dt, stop_time, est=self._next_est)
+        self._next_est = self.advance(self.time, self.dt)
+        self.time += self.dt
+        self.nstep += 1
+        return self.dt
+
+    def evolve(self, stop_time, max_step=10 ** 9):
+        eps = 2.220446049250313e-16
+        while self.nstep < max_step and self.time < stop_time - eps:
+            self.step(stop_time)
+        return self.nstep

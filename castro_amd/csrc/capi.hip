@@ -1,0 +1,416 @@
+// capi.hip -- the C ABI (include/castro_hydro_amd.h) over the HIP kernels.
+// Plain pointers and sizes only; no torch, no AMReX.  One context per (device, stream).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "../../include/castro_hydro_amd.h"
+#include "ctu_kernels.h"
+
+using namespace cad;
+
+struct castro_amd_ctx {
+    int device = 0;
+    double* arena = nullptr;
+    size_t arena_doubles = 0;
+    int* d_status = nullptr;
+    int* h_status = nullptr;   // pinned
+    Profiler prof;
+};
+
+namespace cad {
+
+// ---- profiler -------------------------------------------------------------------------
+static hipEvent_t prof_event(Profiler* p)
+{
+    if (!p->pool.empty()) { hipEvent_t e = p->pool.back(); p->pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(Profiler* p, const char* name, hipStream_t s)
+{
+    if (!p || !p->enabled) return;
+    int idx = -1;
+    for (size_t n = 0; n < p->recs.size(); ++n) if (p->recs[n].name == name) { idx = (int)n; break; }
+    if (idx < 0) { p->recs.push_back(Profiler::Rec()); p->recs.back().name = name; idx = (int)p->recs.size() - 1; }
+    p->cur = idx;
+    p->cur_e0 = prof_event(p);
+    p->cur_e1 = prof_event(p);
+    hipEventRecord(p->cur_e0, s);
+}
+
+void prof_end(Profiler* p, hipStream_t s)
+{
+    if (!p || !p->enabled || p->cur < 0) return;
+    hipEventRecord(p->cur_e1, s);
+    p->pending.push_back({ p->cur, p->cur_e0, p->cur_e1 });
+    p->cur = -1;
+}
+
+void prof_collect(Profiler* p)
+{
+    for (auto& pe : p->pending) {
+        hipEventSynchronize(pe.e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pe.e0, pe.e1);
+        p->recs[pe.rec].total_ms += ms;
+        p->recs[pe.rec].launches += 1;
+        p->pool.push_back(pe.e0);
+        p->pool.push_back(pe.e1);
+    }
+    p->pending.clear();
+}
+
+} // namespace cad
+
+// ---- helpers ------------------------------------------------------------------------------
+static DFab to_dfab(const castro_amd_fab* f)
+{
+    DFab d;
+    if (!f || !f->p) { d.p = nullptr; d.lo[0] = d.lo[1] = d.lo[2] = 0; d.sy = d.sz = d.sn = 0; return d; }
+    d.p = f->p;
+    long nx = f->hi[0] - f->lo[0] + 1, ny = f->hi[1] - f->lo[1] + 1, nz = f->hi[2] - f->lo[2] + 1;
+    for (int n = 0; n < 3; ++n) d.lo[n] = f->lo[n];
+    d.sy = nx; d.sz = nx * ny; d.sn = nx * ny * nz;
+    return d;
+}
+
+static bool fab_contains(const castro_amd_fab* f, const int lo[3], const int hi[3])
+{
+    for (int d = 0; d < 3; ++d) if (f->lo[d] > lo[d] || f->hi[d] < hi[d]) return false;
+    return true;
+}
+
+static DevParams to_devparams(const castro_amd_params* p)
+{
+    DevParams P;
+    P.gamma = p->eos_gamma;
+    P.small_dens = p->small_dens; P.small_pres = p->small_pres;
+    P.small_temp = p->small_temp; P.small_ener = p->small_ener;
+    P.small_dens_ener = p->small_dens * p->small_ener;
+    P.difmag = p->difmag;
+    P.cg_tol = p->cg_tol;
+    P.eta1 = p->dual_energy_eta1; P.eta2 = p->dual_energy_eta2;
+    P.small_x = p->small_x;
+    P.abar = p->abar;
+    P.riemann_solver = p->riemann_solver; P.use_flattening = p->use_flattening;
+    P.first_order_hydro = p->first_order_hydro; P.hybrid_riemann = p->hybrid_riemann;
+    P.cg_maxiter = p->cg_maxiter; P.cg_blend = p->cg_blend;
+    P.reset_density = p->transverse_reset_density; P.reset_rhoe = p->transverse_reset_rhoe;
+    P.use_eos = p->transverse_use_eos;
+    P.ppm_temp_fix = p->ppm_temp_fix;
+    return P;
+}
+
+static DevGeom to_devgeom(const castro_amd_geom* g)
+{
+    DevGeom G;
+    for (int d = 0; d < 3; ++d) {
+        G.dx[d] = g->dx[d];
+        G.domlo[d] = g->domlo[d]; G.domhi[d] = g->domhi[d];
+        G.wall_lo[d] = (g->lo_bc[d] >= 3) ? 1 : 0;
+        G.wall_hi[d] = (g->hi_bc[d] >= 3) ? 1 : 0;
+    }
+    return G;
+}
+
+static size_t plane_doubles(int nx, int ny, int nz)
+{
+    size_t n = (size_t)(nx + 8) * (ny + 8) * (nz + 8);
+    return (n + 31) & ~(size_t)31;     // keep every component plane 256-byte aligned
+}
+
+// number of component planes in the scratch arena
+static constexpr int kPlanes = NPRIM + 1 + 6 * NEDGE + 3 * NF1 + 6 * NF1 + 3 * NFIN;
+
+extern "C" {
+
+const char* castro_amd_version(void) { return "castro_hydro_amd 0.1 (gfx950, round 1)"; }
+
+// Source/driver/_cpp_parameters defaults + Exec/hydro_tests/Sedov/inputs.3d.sph(.testsuite)
+void castro_amd_default_params(castro_amd_params* p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->ppm_type = 1; p->riemann_solver = 0; p->use_flattening = 1; p->hybrid_riemann = 0;
+    p->first_order_hydro = 0; p->cg_maxiter = 12; p->cg_blend = 2;
+    p->transverse_use_eos = 0; p->transverse_reset_density = 1; p->transverse_reset_rhoe = 0;
+    p->ppm_temp_fix = 0;
+    p->difmag = 0.1;
+    p->small_dens = -1.e200; p->small_temp = -1.e200; p->small_pres = -1.e200; p->small_ener = -1.e200;
+    p->cg_tol = 1.0e-5;
+    p->dual_energy_eta1 = 1.0; p->dual_energy_eta2 = 1.0e-4;
+    p->cfl = 0.5; p->init_shrink = 0.01; p->change_max = 1.1;
+    p->eos_gamma = 1.4; p->small_x = 1.e-30; p->T_guess = 1.e8; p->abar = 1.0;
+    castro_amd_finalize_params(p);
+}
+
+// Castro_setup.cpp:222-236 and :259-288
+void castro_amd_finalize_params(castro_amd_params* p)
+{
+    if (p->small_dens < 0.0) p->small_dens = 1.e-100;
+    if (p->small_temp < 0.0) p->small_temp = 1.e-100;
+    if (p->small_pres < 0.0) p->small_pres = 1.e-100;
+    if (p->small_ener < 0.0) p->small_ener = 1.e-100;
+    // eos(eos_input_rt) at (small_dens, small_temp)
+    double e = K_B * p->small_temp / ((p->eos_gamma - 1.0) * (p->abar * M_U));
+    double pr = (p->eos_gamma - 1.0) * p->small_dens * e;
+    if (p->small_pres < pr) p->small_pres = pr;
+    if (p->small_ener < e) p->small_ener = e;
+}
+
+int castro_amd_ctx_create(castro_amd_ctx** out, int device)
+{
+    if (!out) return CASTRO_AMD_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "castro_hydro_amd: no HIP device available -- this library has no CPU fallback\n");
+        return CASTRO_AMD_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) return CASTRO_AMD_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+    castro_amd_ctx* c = new (std::nothrow) castro_amd_ctx();
+    if (!c) return CASTRO_AMD_ERR_NOMEM;
+    c->device = device;
+    if (hipMalloc(&c->d_status, sizeof(int)) != hipSuccess) { delete c; return CASTRO_AMD_ERR_NOMEM; }
+    hipMemset(c->d_status, 0, sizeof(int));
+    if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
+    *out = c;
+    return CASTRO_AMD_OK;
+}
+
+void castro_amd_ctx_destroy(castro_amd_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    prof_collect(&c->prof);
+    for (auto e : c->prof.pool) hipEventDestroy(e);
+    if (c->arena) hipFree(c->arena);
+    if (c->d_status) hipFree(c->d_status);
+    if (c->h_status) hipHostFree(c->h_status);
+    delete c;
+}
+
+int castro_amd_ctx_reserve(castro_amd_ctx* c, int nx, int ny, int nz)
+{
+    if (!c || nx <= 0 || ny <= 0 || nz <= 0) return CASTRO_AMD_ERR_ARG;
+    size_t need = plane_doubles(nx, ny, nz) * (size_t)kPlanes;
+    if (need <= c->arena_doubles) return CASTRO_AMD_OK;
+    hipSetDevice(c->device);
+    if (c->arena) { hipDeviceSynchronize(); hipFree(c->arena); c->arena = nullptr; c->arena_doubles = 0; }
+    if (hipMalloc(&c->arena, need * sizeof(double)) != hipSuccess) return CASTRO_AMD_ERR_NOMEM;
+    c->arena_doubles = need;
+    return CASTRO_AMD_OK;
+}
+
+long long castro_amd_ctx_scratch_bytes(const castro_amd_ctx* c)
+{
+    return c ? (long long)(c->arena_doubles * sizeof(double)) : 0;
+}
+
+int castro_amd_ctx_status(castro_amd_ctx* c, void* stream)
+{
+    if (!c) return CASTRO_AMD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipMemcpyAsync(c->h_status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, s);
+    hipMemsetAsync(c->d_status, 0, sizeof(int), s);
+    if (hipStreamSynchronize(s) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+    return *c->h_status;
+}
+
+int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3],
+                             const int vbxlo[3], const int vbxhi[3],
+                             const castro_amd_fab* Sborder, const castro_amd_fab* src,
+                             const castro_amd_fab* S_new, const castro_amd_fab flux_out[3],
+                             const castro_amd_fab mass_flux_out[3], const castro_amd_fab qe_out[3],
+                             const castro_amd_geom* geom, const castro_amd_params* params,
+                             double time, double dt, int flags, void* stream)
+{
+    (void)time;
+    if (!c || !bxlo || !bxhi || !Sborder || !Sborder->p || !S_new || !S_new->p || !geom || !params)
+        return CASTRO_AMD_ERR_ARG;
+    if (Sborder->ncomp != NUM_STATE || S_new->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
+    if (geom->coord != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (params->ppm_type != 1) return CASTRO_AMD_ERR_UNSUPPORTED;                 // PLM: SURVEY 8(f-1)
+    if (params->riemann_solver < 0 || params->riemann_solver > 1) return CASTRO_AMD_ERR_UNSUPPORTED; // HLLC: next
+    if (params->hybrid_riemann != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (params->transverse_reset_rhoe != 0 || params->transverse_use_eos != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (src && src->p) return CASTRO_AMD_ERR_UNSUPPORTED;                         // source tracing: SURVEY 8(f-4)
+
+    Tile t;
+    int glo[3], ghi[3];
+    for (int d = 0; d < 3; ++d) {
+        if (bxhi[d] < bxlo[d]) return CASTRO_AMD_ERR_ARG;
+        t.lo[d] = bxlo[d]; t.hi[d] = bxhi[d];
+        t.glo[d] = glo[d] = bxlo[d] - CASTRO_AMD_NUM_GROW;
+        ghi[d] = bxhi[d] + CASTRO_AMD_NUM_GROW;
+    }
+    const int nx = bxhi[0] - bxlo[0] + 1, ny = bxhi[1] - bxlo[1] + 1, nz = bxhi[2] - bxlo[2] + 1;
+    t.NX = nx + 8; t.NY = ny + 8; t.NZ = nz + 8;
+    t.NC = (long)plane_doubles(nx, ny, nz);
+
+    if (!fab_contains(Sborder, glo, ghi)) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(S_new, bxlo, bxhi)) return CASTRO_AMD_ERR_ARG;
+
+    hipSetDevice(c->device);
+    int rc = castro_amd_ctx_reserve(c, nx, ny, nz);
+    if (rc != CASTRO_AMD_OK) return rc;
+
+    DevScratch S;
+    double* p = c->arena;
+    const size_t NC = (size_t)t.NC;
+    S.Q = p; p += NC * NPRIM;
+    S.DIV = p; p += NC;
+    for (int d = 0; d < 3; ++d) { S.QM[d] = p; p += NC * NEDGE; S.QP[d] = p; p += NC * NEDGE; }
+    for (int d = 0; d < 3; ++d) { S.F1[d] = p; p += NC * NF1; }
+    for (int d = 0; d < 6; ++d) { S.F2[d] = p; p += NC * NF1; }
+    for (int d = 0; d < 3; ++d) { S.FL[d] = p; p += NC * NFIN; }
+
+    DFab dS = to_dfab(Sborder), dN = to_dfab(S_new);
+    DFab dF[3], dM[3], dQ[3];
+    int acc_hi[3];
+    for (int d = 0; d < 3; ++d) {
+        int flo[3] = { bxlo[0], bxlo[1], bxlo[2] }, fhi[3] = { bxhi[0], bxhi[1], bxhi[2] };
+        fhi[d] += 1;
+        // mfi.nodaltilebox(d): the high face belongs to this tile only at the valid box's high end
+        acc_hi[d] = bxhi[d] + 1;
+        if (vbxhi && acc_hi[d] <= vbxhi[d]) acc_hi[d] -= 1;
+        (void)vbxlo;
+        fhi[d] = acc_hi[d];
+        const castro_amd_fab* f = flux_out ? &flux_out[d] : nullptr;
+        const castro_amd_fab* m = mass_flux_out ? &mass_flux_out[d] : nullptr;
+        const castro_amd_fab* q = qe_out ? &qe_out[d] : nullptr;
+        if (f && f->p && (f->ncomp != NUM_STATE || !fab_contains(f, flo, fhi))) return CASTRO_AMD_ERR_ARG;
+        if (m && m->p && (m->ncomp != 1 || !fab_contains(m, flo, fhi))) return CASTRO_AMD_ERR_ARG;
+        if (q && q->p && (q->ncomp != NGDNV || !fab_contains(q, flo, fhi))) return CASTRO_AMD_ERR_ARG;
+        dF[d] = to_dfab(f); dM[d] = to_dfab(m); dQ[d] = to_dfab(q);
+    }
+
+    return launch_ctu_hydro(t, S, dS, dN, dF, dM, dQ, to_devgeom(geom), to_devparams(params), dt, flags,
+                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
+                               const castro_amd_params* params, int ntimes, void* stream)
+{
+    if (!c || !state || !state->p || !params || state->ncomp != NUM_STATE || ntimes < 1) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_clean_state(to_dfab(state), lo, hi, to_devparams(params), ntimes, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_estdt_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
+                         const castro_amd_geom* geom, const castro_amd_params* params, double* d_out, void* stream)
+{
+    if (!c || !state || !state->p || !geom || !params || !d_out || state->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_estdt(to_dfab(state), lo, hi, to_devgeom(geom), to_devparams(params), d_out, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_bc_fill_fab(castro_amd_ctx* c, const castro_amd_fab* state, const castro_amd_geom* geom, void* stream)
+{
+    if (!c || !state || !state->p || !geom) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_bc_fill(to_dfab(state), state->lo, state->hi, state->ncomp, to_devgeom(geom),
+                          geom->lo_bc, geom->hi_bc, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_copy_fab(castro_amd_ctx* c, const castro_amd_fab* dst, const castro_amd_fab* src,
+                        const int lo[3], const int hi[3], void* stream)
+{
+    if (!c || !dst || !src || !dst->p || !src->p || dst->ncomp != src->ncomp) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(dst, lo, hi) || !fab_contains(src, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_copy(to_dfab(dst), to_dfab(src), lo, hi, src->ncomp, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_pack_fab(castro_amd_ctx* c, const castro_amd_fab* fab, const int lo[3], const int hi[3],
+                        double* buf, void* stream)
+{
+    if (!c || !fab || !fab->p || !buf || !fab_contains(fab, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_pack(to_dfab(fab), lo, hi, fab->ncomp, buf, 0, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_unpack_fab(castro_amd_ctx* c, const castro_amd_fab* fab, const int lo[3], const int hi[3],
+                          const double* buf, void* stream)
+{
+    if (!c || !fab || !fab->p || !buf || !fab_contains(fab, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_pack(to_dfab(fab), lo, hi, fab->ncomp, const_cast<double*>(buf), 1, (hipStream_t)stream, &c->prof);
+}
+
+// Exec/hydro_tests/Sedov/problem_initialize.H:8-113 (host part) + the per-zone kernel
+int castro_amd_sedov_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
+                              const castro_amd_geom* geom, const castro_amd_params* params,
+                              double r_init, double p_ambient, double exp_energy, double dens_ambient,
+                              int nsub, void* stream)
+{
+    if (!c || !state || !state->p || !geom || !params || state->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    double center[3];
+    for (int n = 0; n < 3; ++n) center[n] = 0.5 * (geom->problo[n] + geom->probhi[n]);
+    // eos(eos_input_rp)
+    const double g = params->eos_gamma;
+    const double e_ambient = p_ambient / ((g - 1.0) * dens_ambient);
+    const double temp_ambient = (g - 1.0) * e_ambient * (params->abar * M_U) / K_B;
+    const double vctr = (4.0 / 3.0) * M_PI * r_init * r_init * r_init;
+    const double e_exp = exp_energy / vctr / dens_ambient;
+    hipSetDevice(c->device);
+    return launch_sedov_init(to_dfab(state), lo, hi, to_devparams(params), geom->dx, geom->problo, center,
+                             r_init, e_exp, e_ambient, temp_ambient, dens_ambient, nsub, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_sod_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
+                            const castro_amd_geom* geom, const castro_amd_params* params,
+                            double rho_l, double u_l, double p_l, double rho_r, double u_r, double p_r,
+                            int idir, double frac, void* stream)
+{
+    if (!c || !state || !state->p || !geom || !params || state->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
+    if (idir < 1 || idir > 3 || !fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    const double g = params->eos_gamma;
+    const double split = frac * (geom->problo[idir - 1] + geom->probhi[idir - 1]);
+    const double e_l = p_l / ((g - 1.0) * rho_l), e_r = p_r / ((g - 1.0) * rho_r);
+    const double T_l = (g - 1.0) * e_l * (params->abar * M_U) / K_B;
+    const double T_r = (g - 1.0) * e_r * (params->abar * M_U) / K_B;
+    hipSetDevice(c->device);
+    return launch_sod_init(to_dfab(state), lo, hi, geom->dx, geom->problo, split, idir - 1,
+                           rho_l, u_l, rho_l * e_l, T_l, rho_r, u_r, rho_r * e_r, T_r, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_ctx_profile(castro_amd_ctx* c, int enable)
+{
+    if (!c) return CASTRO_AMD_ERR_ARG;
+    c->prof.enabled = enable != 0;
+    return CASTRO_AMD_OK;
+}
+
+int castro_amd_ctx_profile_count(castro_amd_ctx* c)
+{
+    if (!c) return 0;
+    prof_collect(&c->prof);
+    return (int)c->prof.recs.size();
+}
+
+int castro_amd_ctx_profile_get(castro_amd_ctx* c, int idx, char* name, int name_len, double* total_ms, long long* launches)
+{
+    if (!c || idx < 0 || idx >= (int)c->prof.recs.size()) return CASTRO_AMD_ERR_ARG;
+    const auto& r = c->prof.recs[idx];
+    if (name && name_len > 0) { std::strncpy(name, r.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (total_ms) *total_ms = r.total_ms;
+    if (launches) *launches = r.launches;
+    return CASTRO_AMD_OK;
+}
+
+void castro_amd_ctx_profile_reset(castro_amd_ctx* c)
+{
+    if (!c) return;
+    prof_collect(&c->prof);
+    for (auto& r : c->prof.recs) { r.total_ms = 0.0; r.launches = 0; }
+}
+
+} // extern "C"

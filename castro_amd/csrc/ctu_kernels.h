@@ -1,0 +1,83 @@
+// ctu_kernels.h -- host/device shared descriptors of the HIP CTU hydro path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "hydro_device.h"
+
+namespace cad {
+
+// one tile of work: bx = [lo,hi]; every scratch array is indexed on grow(bx,4)
+struct Tile {
+    int lo[3], hi[3];
+    int glo[3];
+    int NX, NY, NZ;
+    long NC;       // doubles per component plane (>= NX*NY*NZ, padded for alignment)
+};
+
+// caller-owned FArrayBox on the device
+struct DFab {
+    double* p;
+    int lo[3];
+    long sy, sz, sn;
+};
+
+struct DevGeom {
+    double dx[3];
+    int domlo[3], domhi[3];
+    int wall_lo[3], wall_hi[3];   // Symmetry / SlipWall / NoSlipWall: zero normal flux (riemann.cpp:53-59)
+};
+
+struct DevScratch {
+    double* Q;        // NPRIM planes
+    double* DIV;      // 1 plane
+    double* QM[3];    // NEDGE planes each
+    double* QP[3];
+    double* F1[3];    // NF1 planes each
+    double* F2[6];    // NF1 planes each, slot f2_slot(N,T)
+    double* FL[3];    // NFIN planes each
+};
+
+// hipEvent-based per-kernel timing (enabled on request only: it serialises nothing, the
+// events are recorded on the same stream as the kernels)
+struct Profiler {
+    struct Rec { std::string name; double total_ms = 0.0; long long launches = 0; };
+    bool enabled = false;
+    std::vector<Rec> recs;
+    struct Pending { int rec; hipEvent_t e0, e1; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    int cur = -1;
+    hipEvent_t cur_e0{}, cur_e1{};
+};
+void prof_begin(Profiler* p, const char* name, hipStream_t s);
+void prof_end(Profiler* p, hipStream_t s);
+void prof_collect(Profiler* p);
+
+int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Snew,
+                     const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
+                     const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
+                     int* d_status, hipStream_t stream, Profiler* prof);
+
+// auxiliary per-FAB kernels (aux_kernels.hip)
+int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,
+                       hipStream_t stream, Profiler* prof);
+int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
+                 double* d_out, hipStream_t stream, Profiler* prof);
+int launch_bc_fill(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const DevGeom& g,
+                   const int lo_bc[3], const int hi_bc[3], hipStream_t stream, Profiler* prof);
+int launch_copy(const DFab& dst, const DFab& src, const int lo[3], const int hi[3], int ncomp,
+                hipStream_t stream, Profiler* prof);
+int launch_pack(const DFab& f, const int lo[3], const int hi[3], int ncomp, double* buf, int unpack,
+                hipStream_t stream, Profiler* prof);
+int launch_sedov_init(const DFab& U, const int lo[3], const int hi[3], const DevParams& P,
+                      const double dx[3], const double problo[3], const double center[3],
+                      double r_init, double e_exp, double e_ambient, double temp_ambient,
+                      double dens_ambient, int nsub, hipStream_t stream, Profiler* prof);
+int launch_sod_init(const DFab& U, const int lo[3], const int hi[3], const double dx[3],
+                    const double problo[3], double split, int idir0,
+                    double rho_l, double u_l, double rhoe_l, double T_l,
+                    double rho_r, double u_r, double rhoe_r, double T_r,
+                    hipStream_t stream, Profiler* prof);
+
+} // namespace cad

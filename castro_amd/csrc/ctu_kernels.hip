@@ -1,0 +1,750 @@
+// ctu_kernels.hip -- the CTU hydro advance as HIP kernels for gfx950 (MI355X).
+//
+// Pipeline for one tile bx (replaces the 75 ParallelFor launches of
+// Source/hydro/Castro_ctu_hydro.cpp:130-1480):
+//
+//   k_ctoprim      U(Sborder) -> compact primitives Q = (rho,u,v,w,p,rhoe,X,c)     [ctoprim + EOS]
+//   k_divu         Q -> node-centred div(u)                                        [divu]
+//   k_trace        Q -> flattening coefficient (registers only) -> PPM parabolas ->
+//                  characteristic tracing in x,y,z -> edge states QM/QP            [uflatten + 3x trace_ppm]
+//   k_riemann1<D>  QM/QP[D] -> first transverse fluxes F1[D] (+ Godunov un, p)     [cmpflx_plus_godunov x3]
+//   k_trans1<N>    QM/QP[N] + F1[T1], F1[T2] -> corrected states (registers only)
+//                  -> Riemann -> F2[N|T1], F2[N|T2]                                [6x trans_single (x2) + 6x cmpflx]
+//   k_final<N>     QM/QP[N] + F2[T1|T2], F2[T2|T1] -> ql,qr (registers) -> Riemann ->
+//                  artificial viscosity, species normalisation, scaling,
+//                  fluxes += , mass_fluxes = , qe                                  [trans_final, cmpflx, apply_av,
+//                                                                                   normalize_species_fluxes, scale_flux]
+//   k_consup       S_new (+)= dt*div(F) - dt*p*div(u) term                         [consup_hydro]
+//
+// All scratch arrays share ONE index space: the tile grown by 4 (same as Sborder), unit
+// stride along x, one plane of NC doubles per component (SoA) so every load/store of a
+// wavefront is a contiguous 512-byte run along the x pencil.
+#include <hip/hip_runtime.h>
+#include "hydro_device.h"
+#include "ctu_kernels.h"
+
+namespace cad {
+
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ long gidx(const Tile& t, int i, int j, int k)
+{
+    return (long)(i - t.glo[0]) + (long)t.NX * ((long)(j - t.glo[1]) + (long)t.NY * (long)(k - t.glo[2]));
+}
+
+__device__ __forceinline__ double fab_get(const DFab& f, int i, int j, int k, int n)
+{
+    return f.p[(long)(i - f.lo[0]) + f.sy * (long)(j - f.lo[1]) + f.sz * (long)(k - f.lo[2]) + f.sn * (long)n];
+}
+__device__ __forceinline__ double* fab_ptr(const DFab& f, int i, int j, int k, int n)
+{
+    return f.p + ((long)(i - f.lo[0]) + f.sy * (long)(j - f.lo[1]) + f.sz * (long)(k - f.lo[2]) + f.sn * (long)n);
+}
+
+// decompose a linear thread id into a box position (x fastest)
+__device__ __forceinline__ bool box_thread(const int lo[3], const int n[3], int& i, int& j, int& k)
+{
+    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)n[0] * n[1] * n[2];
+    if (tid >= total) return false;
+    int ii = (int)(tid % n[0]);
+    long r = tid / n[0];
+    int jj = (int)(r % n[1]);
+    int kk = (int)(r / n[1]);
+    i = lo[0] + ii; j = lo[1] + jj; k = lo[2] + kk;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Castro::ctoprim (Source/hydro/advection_util.cpp:26-200) with the gamma-law EOS inlined
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ctoprim(Tile t, DFab U, double* __restrict__ Q, DevParams P, int* status)
+{
+    int lo[3] = { t.glo[0], t.glo[1], t.glo[2] };
+    int n[3] = { t.NX, t.NY, t.NZ };
+    int i, j, k;
+    if (!box_thread(lo, n, i, j, k)) return;
+    const long c = gidx(t, i, j, k);
+
+    const double rho = fab_get(U, i, j, k, URHO);
+    if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
+
+    const double rhoinv = 1.0 / rho;
+    const double u = fab_get(U, i, j, k, UMX) * rhoinv;
+    const double v = fab_get(U, i, j, k, UMY) * rhoinv;
+    const double w = fab_get(U, i, j, k, UMZ) * rhoinv;
+
+    const double kineng = 0.5 * rho * (u * u + v * v + w * w);
+    const double eden = fab_get(U, i, j, k, UEDEN);
+
+    double e;
+    if ((eden - kineng) > P.eta1 * eden) {
+        e = (eden - kineng) * rhoinv;
+    } else {
+        e = fab_get(U, i, j, k, UEINT) * rhoinv;
+    }
+
+    const double X = fab_get(U, i, j, k, UFS) * rhoinv;
+
+    // eos(eos_input_re): p = (gamma-1) rho e ; cs = sqrt(gamma p / rho)
+    const double p = (P.gamma - 1.0) * rho * e;
+    const double cs = sqrt(P.gamma * p / rho);
+
+    Q[PRHO * t.NC + c] = rho;
+    Q[PU * t.NC + c] = u;
+    Q[PV * t.NC + c] = v;
+    Q[PW * t.NC + c] = w;
+    Q[PP * t.NC + c] = p;
+    Q[PRE * t.NC + c] = e * rho;
+    Q[PX * t.NC + c] = X;
+    Q[PC * t.NC + c] = cs;
+}
+
+// ---------------------------------------------------------------------------------------
+// Castro::divu, 3-D branch (Source/hydro/advection_util.cpp:458-475), nodes of grow(bx,1)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_divu(Tile t, const double* __restrict__ Q, double* __restrict__ DIV,
+                                              double dxinv, double dyinv, double dzinv)
+{
+    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
+    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
+    int i, j, k;
+    if (!box_thread(lo, n, i, j, k)) return;
+    const long c = gidx(t, i, j, k);
+    const long sx = 1, sy = t.NX, sz = (long)t.NX * t.NY;
+    const double* QU_ = Q + PU * t.NC;
+    const double* QV_ = Q + PV * t.NC;
+    const double* QW_ = Q + PW * t.NC;
+
+    double ux = 0.25 * (QU_[c] - QU_[c - sx] +
+                        QU_[c - sz] - QU_[c - sx - sz] +
+                        QU_[c - sy] - QU_[c - sx - sy] +
+                        QU_[c - sy - sz] - QU_[c - sx - sy - sz]) * dxinv;
+
+    double vy = 0.25 * (QV_[c] - QV_[c - sy] +
+                        QV_[c - sz] - QV_[c - sy - sz] +
+                        QV_[c - sx] - QV_[c - sx - sy] +
+                        QV_[c - sx - sz] - QV_[c - sx - sy - sz]) * dyinv;
+
+    double wz = 0.25 * (QW_[c] - QW_[c - sz] +
+                        QW_[c - sy] - QW_[c - sy - sz] +
+                        QW_[c - sx] - QW_[c - sx - sz] +
+                        QW_[c - sx - sy] - QW_[c - sx - sy - sz]) * dzinv;
+
+    DIV[c] = ux + vy + wz;
+}
+
+// ---------------------------------------------------------------------------------------
+// flattening + PPM + tracing.  Castro::uflatten (flatten.cpp:12-166) and Castro::trace_ppm
+// (trace_ppm.cpp:15-594, no sources) for the three directions of one zone of grow(bx,1).
+// ---------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void trace_dir(const Tile& t, const double* __restrict__ Q, long c, long sd,
+                                          double flat, double dtdx, const DevParams& P,
+                                          bool do_plus, bool do_minus,
+                                          double* __restrict__ QMd, double* __restrict__ QPd)
+{
+    // trace_ppm.cpp:114-128
+    constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
+    constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
+    constexpr int QUTT = (D == 0) ? PW : (D == 1) ? PU : PV;
+
+    const long NC = t.NC;
+    const double cc = Q[PC * NC + c];
+    const double un = Q[QUN * NC + c];
+
+    double s[5], sm, sp, s6;
+
+#define LOAD5(comp) { const double* a = Q + (long)(comp) * NC + c; \
+        s[0] = a[-2 * sd]; s[1] = a[-sd]; s[2] = a[0]; s[3] = a[sd]; s[4] = a[2 * sd]; }
+
+    // density: three waves
+    double Ip_rho0, Im_rho0, Ip_rho1, Im_rho1, Ip_rho2, Im_rho2;
+    LOAD5(PRHO);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip_rho0, Im_rho0);
+    ppm_int_wave(sm, sp, s6, un, dtdx, Ip_rho1, Im_rho1);
+    ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip_rho2, Im_rho2);
+
+    // normal velocity: u-c and u+c
+    double Ip_un_0, Im_un_0, Ip_un_2, Im_un_2;
+    LOAD5(QUN);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip_un_0, Im_un_0);
+    ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip_un_2, Im_un_2);
+
+    // pressure: three waves
+    double Ip_p0, Im_p0, Ip_p1, Im_p1, Ip_p2, Im_p2;
+    LOAD5(PP);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip_p0, Im_p0);
+    ppm_int_wave(sm, sp, s6, un, dtdx, Ip_p1, Im_p1);
+    ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip_p2, Im_p2);
+
+    // rho e: three waves
+    double Ip_re0, Im_re0, Ip_re1, Im_re1, Ip_re2, Im_re2;
+    LOAD5(PRE);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip_re0, Im_re0);
+    ppm_int_wave(sm, sp, s6, un, dtdx, Ip_re1, Im_re1);
+    ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip_re2, Im_re2);
+
+    // transverse velocities and the passive: contact wave only
+    double Ip_ut, Im_ut, Ip_utt, Im_utt, Ip_X, Im_X;
+    LOAD5(QUT);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un, dtdx, Ip_ut, Im_ut);
+
+    LOAD5(QUTT);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un, dtdx, Ip_utt, Im_utt);
+
+    LOAD5(PX);
+    ppm_reconstruct(s, flat, sm, sp);
+    s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    ppm_int_wave(sm, sp, s6, un, dtdx, Ip_X, Im_X);
+#undef LOAD5
+
+    // gamma_c is the constant eos_gamma for a gamma-law gas: its parabola is flat and
+    // Ip = Im = gamma exactly (sm == sp == s0 => quadratic limiter resets, s6 == 0), so the
+    // reference's QGAMC reconstruction (trace_ppm.cpp:212-223) is elided bit-for-bit.
+    const double gam = P.gamma;
+
+    if (do_plus) {
+        // plus state on face i, trace_ppm.cpp:382-466 (source integrals are zero)
+        double rho_ref = Im_rho0;
+        double un_ref = Im_un_0;
+        double p_ref = Im_p0;
+        double rhoe_g_ref = Im_re0;
+
+        rho_ref = amax(rho_ref, P.small_dens);
+        double rho_ref_inv = 1.0 / rho_ref;
+        p_ref = amax(p_ref, P.small_pres);
+
+        double csq_ref = gam * p_ref * rho_ref_inv;
+        double cc_ref = sqrt(csq_ref);
+        double cc_ref_inv = 1.0 / cc_ref;
+        double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
+
+        double dum = un_ref - Im_un_0;
+        double dptotm = p_ref - Im_p0;
+
+        double drho = rho_ref - Im_rho1;
+        double dptot = p_ref - Im_p1;
+        double drhoe_g = rhoe_g_ref - Im_re1;
+
+        double dup = un_ref - Im_un_2;
+        double dptotp = p_ref - Im_p2;
+
+        double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
+        double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
+        double alpha0r = drho - dptot / csq_ref;
+        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+
+        alpham = un - cc > 0.0 ? 0.0 : -alpham;
+        alphap = un + cc > 0.0 ? 0.0 : -alphap;
+        alpha0r = un > 0.0 ? 0.0 : -alpha0r;
+        alpha0e_g = un > 0.0 ? 0.0 : -alpha0e_g;
+
+        QPd[PRHO * NC + c] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
+        QPd[QUN * NC + c] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
+        QPd[PRE * NC + c] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
+        QPd[PP * NC + c] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        QPd[QUT * NC + c] = Im_ut;
+        QPd[QUTT * NC + c] = Im_utt;
+        QPd[PX * NC + c] = Im_X;
+    }
+
+    if (do_minus) {
+        // minus state on face i+1, trace_ppm.cpp:470-561
+        double rho_ref = Ip_rho2;
+        double un_ref = Ip_un_2;
+        double p_ref = Ip_p2;
+        double rhoe_g_ref = Ip_re2;
+
+        rho_ref = amax(rho_ref, P.small_dens);
+        double rho_ref_inv = 1.0 / rho_ref;
+        p_ref = amax(p_ref, P.small_pres);
+
+        double csq_ref = gam * p_ref * rho_ref_inv;
+        double cc_ref = sqrt(csq_ref);
+        double cc_ref_inv = 1.0 / cc_ref;
+        double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
+
+        double dum = un_ref - Ip_un_0;
+        double dptotm = p_ref - Ip_p0;
+
+        double drho = rho_ref - Ip_rho1;
+        double dptot = p_ref - Ip_p1;
+        double drhoe_g = rhoe_g_ref - Ip_re1;
+
+        double dup = un_ref - Ip_un_2;
+        double dptotp = p_ref - Ip_p2;
+
+        double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
+        double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
+        double alpha0r = drho - dptot / csq_ref;
+        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+
+        alpham = un - cc > 0.0 ? -alpham : 0.0;
+        alphap = un + cc > 0.0 ? -alphap : 0.0;
+        alpha0r = un > 0.0 ? -alpha0r : 0.0;
+        alpha0e_g = un > 0.0 ? -alpha0e_g : 0.0;
+
+        const long cp = c + sd;
+        QMd[PRHO * NC + cp] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
+        QMd[QUN * NC + cp] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
+        QMd[PRE * NC + cp] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
+        QMd[PP * NC + cp] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        QMd[QUT * NC + cp] = Ip_ut;
+        QMd[QUTT * NC + cp] = Ip_utt;
+        QMd[PX * NC + cp] = Ip_X;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_trace(Tile t, const double* __restrict__ Q, DevScratch S,
+                                               double dtdx0, double dtdx1, double dtdx2, DevParams P)
+{
+    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
+    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
+    int i, j, k;
+    if (!box_thread(lo, n, i, j, k)) return;
+    const long c = gidx(t, i, j, k);
+    const long sx = 1, sy = t.NX, sz = (long)t.NX * t.NY;
+
+    // flattening coefficient of this zone (Castro_ctu_hydro.cpp:228-266)
+    double flat;
+    if (P.first_order_hydro == 1) {
+        flat = 0.0;
+    } else if (P.use_flattening == 1) {
+        const double* Pp = Q + PP * t.NC + c;
+        double pv[7], uv[5];
+        {
+            const double* Uu = Q + PU * t.NC + c;
+            for (int m = -3; m <= 3; ++m) pv[m + 3] = Pp[m * sx];
+            for (int m = -2; m <= 2; ++m) uv[m + 2] = Uu[m * sx];
+            flat = flatten_1d(pv, uv);
+        }
+        {
+            const double* Uu = Q + PV * t.NC + c;
+            for (int m = -3; m <= 3; ++m) pv[m + 3] = Pp[m * sy];
+            for (int m = -2; m <= 2; ++m) uv[m + 2] = Uu[m * sy];
+            flat = amin(flat, flatten_1d(pv, uv));
+        }
+        {
+            const double* Uu = Q + PW * t.NC + c;
+            for (int m = -3; m <= 3; ++m) pv[m + 3] = Pp[m * sz];
+            for (int m = -2; m <= 2; ++m) uv[m + 2] = Uu[m * sz];
+            flat = amin(flat, flatten_1d(pv, uv));
+        }
+    } else {
+        flat = 1.0;
+    }
+
+    trace_dir<0>(t, Q, c, sx, flat, dtdx0, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+    trace_dir<1>(t, Q, c, sy, flat, dtdx1, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+    trace_dir<2>(t, Q, c, sz, flat, dtdx2, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+}
+
+// ---------------------------------------------------------------------------------------
+// helpers shared by the Riemann stages
+// ---------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void load_rstate(const double* __restrict__ E, long NC, long c, double gamc,
+                                            RState& q, double& X)
+{
+    q.rho = E[PRHO * NC + c];
+    q.un = E[(PU + RDir<D>::n) * NC + c];
+    q.ut = E[(PU + RDir<D>::t) * NC + c];
+    q.utt = E[(PU + RDir<D>::tt) * NC + c];
+    q.p = E[PP * NC + c];
+    q.rhoe = E[PRE * NC + c];
+    q.gamc = gamc;
+    X = E[PX * NC + c];
+}
+
+template <int D>
+__device__ __forceinline__ void rstate_from_edge(const double q[NEDGE], double gamc, RState& r, double& X)
+{
+    r.rho = q[PRHO];
+    r.un = q[PU + RDir<D>::n];
+    r.ut = q[PU + RDir<D>::t];
+    r.utt = q[PU + RDir<D>::tt];
+    r.p = q[PP];
+    r.rhoe = q[PRE];
+    r.gamc = gamc;
+    X = q[PX];
+}
+
+// wall factor of riemann_state (riemann_solvers.H:1341-1361)
+template <int D>
+__device__ __forceinline__ double wall_fac(const DevGeom& g, int idx)
+{
+    return ((idx == g.domlo[D] && g.wall_lo[D]) || (idx == g.domhi[D] + 1 && g.wall_hi[D])) ? 0.0 : 1.0;
+}
+
+// write a transverse-stage flux record at face index c (global component order)
+template <int D>
+__device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, long c, const IFlux& f)
+{
+    F[FRHO * NC + c] = f.rho;
+    F[(FMX + RDir<D>::n) * NC + c] = f.mn;
+    F[(FMX + RDir<D>::t) * NC + c] = f.mt;
+    F[(FMX + RDir<D>::tt) * NC + c] = f.mtt;
+    F[FE * NC + c] = f.E;
+    F[FX * NC + c] = f.X;
+    F[FUG * NC + c] = f.ugd;
+    F[FPG * NC + c] = f.pgd;
+}
+
+__device__ __forceinline__ void load_f1(const double* __restrict__ F, long NC, long c, double r[NF1])
+{
+#pragma unroll
+    for (int n = 0; n < NF1; ++n) r[n] = F[(long)n * NC + c];
+}
+
+// ---------------------------------------------------------------------------------------
+// first Riemann solves: F^x, F^y, F^z on grow(nodal(bx,D), 1 in both transverse directions)
+// (Castro_ctu_hydro.cpp:719, :796, :875)
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256) k_riemann1(Tile t, const double* __restrict__ Q, DevScratch S,
+                                                  DevGeom g, DevParams P)
+{
+    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
+    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
+    lo[D] = t.lo[D];
+    n[D] = t.hi[D] - t.lo[D] + 2;
+    int i, j, k;
+    if (!box_thread(lo, n, i, j, k)) return;
+    const long c = gidx(t, i, j, k);
+    const long sd = (D == 0) ? 1 : (D == 1) ? (long)t.NX : (long)t.NX * t.NY;
+    const int idx = (D == 0) ? i : (D == 1) ? j : k;
+
+    RState ql, qr;
+    double Xl, Xr;
+    load_rstate<D>(S.QM[D], t.NC, c, P.gamma, ql, Xl);
+    load_rstate<D>(S.QP[D], t.NC, c, P.gamma, qr, Xr);
+    const double cl = Q[PC * t.NC + c - sd];
+    const double cr = Q[PC * t.NC + c];
+
+    IFlux f;
+    interface_flux(ql, qr, Xl, Xr, cl, cr, wall_fac<D>(g, idx), P, f);
+    store_f1<D>(S.F1[D], t.NC, c, f);
+}
+
+// ---------------------------------------------------------------------------------------
+// transverse stage 1 for normal direction N: both trans_single corrections of the N edge
+// states and the Riemann solves on the corrected states.
+//   F2 slot (N|T): flux in direction N from states corrected with the T-direction flux.
+// (Castro_ctu_hydro.cpp:724-945 for the corrections, :949-1135 for the six solves)
+// ---------------------------------------------------------------------------------------
+__host__ __device__ constexpr int f2_slot(int N, int T) { return N * 2 + ((T > N) ? T - 1 : T); }
+
+template <int N, int T>
+__device__ __forceinline__ void trans1_pair(const Tile& t, const double* __restrict__ Q, const DevScratch& S,
+                                            long c, long sn, long st, const double qm[NEDGE], const double qp[NEDGE],
+                                            double cl, double cr, double bnd_fac, double cdtdx, const DevParams& P)
+{
+    double fr[NF1], fl[NF1], qmo[NEDGE], qpo[NEDGE];
+
+    // minus state lives in cell c - sn; its T-faces are (c - sn) and (c - sn + st)
+    load_f1(S.F1[T], t.NC, c - sn + st, fr);
+    load_f1(S.F1[T], t.NC, c - sn, fl);
+    trans_single<T>(qm, fr, fl, P.gamma, cdtdx, P, qmo);
+
+    // plus state lives in cell c
+    load_f1(S.F1[T], t.NC, c + st, fr);
+    load_f1(S.F1[T], t.NC, c, fl);
+    trans_single<T>(qp, fr, fl, P.gamma, cdtdx, P, qpo);
+
+    RState ql, qr;
+    double Xl, Xr;
+    rstate_from_edge<N>(qmo, P.gamma, ql, Xl);
+    rstate_from_edge<N>(qpo, P.gamma, qr, Xr);
+
+    IFlux f;
+    interface_flux(ql, qr, Xl, Xr, cl, cr, bnd_fac, P, f);
+    store_f1<N>(S.F2[f2_slot(N, T)], t.NC, c, f);
+}
+
+template <int N>
+__global__ void __launch_bounds__(256) k_trans1(Tile t, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                double cdtdx_t1, double cdtdx_t2, DevParams P)
+{
+    constexpr int T1 = (N == 0) ? 1 : 0;
+    constexpr int T2 = (N == 2) ? 1 : 2;
+    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
+    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
+    lo[N] = t.lo[N];
+    n[N] = t.hi[N] - t.lo[N] + 2;
+    int ijk[3];
+    if (!box_thread(lo, n, ijk[0], ijk[1], ijk[2])) return;
+    const long c = gidx(t, ijk[0], ijk[1], ijk[2]);
+    const long str[3] = { 1, (long)t.NX, (long)t.NX * t.NY };
+    const long sn = str[N];
+
+    // the (N|T1) states exist where the T1 index is inside bx (T2 index may be in the 1-ring)
+    const bool in_t1 = ijk[T1] >= t.lo[T1] && ijk[T1] <= t.hi[T1];
+    const bool in_t2 = ijk[T2] >= t.lo[T2] && ijk[T2] <= t.hi[T2];
+    if (!in_t1 && !in_t2) return;
+
+    double qm[NEDGE], qp[NEDGE];
+#pragma unroll
+    for (int m = 0; m < NEDGE; ++m) {
+        qm[m] = S.QM[N][(long)m * t.NC + c];
+        qp[m] = S.QP[N][(long)m * t.NC + c];
+    }
+    const double cl = Q[PC * t.NC + c - sn];
+    const double cr = Q[PC * t.NC + c];
+    const double bnd_fac = wall_fac<N>(g, ijk[N]);
+
+    if (in_t1) trans1_pair<N, T1>(t, Q, S, c, sn, str[T1], qm, qp, cl, cr, bnd_fac, cdtdx_t1, P);
+    if (in_t2) trans1_pair<N, T2>(t, Q, S, c, sn, str[T2], qm, qp, cl, cr, bnd_fac, cdtdx_t2, P);
+}
+
+// ---------------------------------------------------------------------------------------
+// final stage for normal direction N: trans_final on both edge states, final Riemann
+// solve, artificial viscosity, species-flux normalisation, flux scaling and accumulation.
+// (Castro_ctu_hydro.cpp:990-1026 / 1068-1106 / 1148-1186, 1192-1243, 1322-1433)
+// ---------------------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(256) k_final(Tile t, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                               DFab U, DFab fluxes, DFab mass, DFab qe,
+                                               double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
+                                               int acc_hi, DevParams P)
+{
+    constexpr int T1 = (N == 0) ? 1 : 0;
+    constexpr int T2 = (N == 2) ? 1 : 2;
+    int lo[3] = { t.lo[0], t.lo[1], t.lo[2] };
+    int n[3] = { t.hi[0] - t.lo[0] + 1, t.hi[1] - t.lo[1] + 1, t.hi[2] - t.lo[2] + 1 };
+    n[N] += 1;
+    int ijk[3];
+    if (!box_thread(lo, n, ijk[0], ijk[1], ijk[2])) return;
+    const int i = ijk[0], j = ijk[1], k = ijk[2];
+    const long c = gidx(t, i, j, k);
+    const long str[3] = { 1, (long)t.NX, (long)t.NX * t.NY };
+    const long sn = str[N], s1 = str[T1], s2 = str[T2];
+    const long NC = t.NC;
+
+    double q[NEDGE], ql[NEDGE], qr[NEDGE];
+    double f1r[NF1], f1l[NF1], f2r[NF1], f2l[NF1];
+    const double* F12 = S.F2[f2_slot(T1, T2)];   // F^{T1|T2}: flux_t1
+    const double* F21 = S.F2[f2_slot(T2, T1)];   // F^{T2|T1}: flux_t2
+
+    // minus state (cell c - sn)
+#pragma unroll
+    for (int m = 0; m < NEDGE; ++m) q[m] = S.QM[N][(long)m * NC + c];
+    load_f1(F12, NC, c - sn + s1, f1r);
+    load_f1(F12, NC, c - sn, f1l);
+    load_f1(F21, NC, c - sn + s2, f2r);
+    load_f1(F21, NC, c - sn, f2l);
+    trans_final(q, f1r, f1l, f2r, f2l, P.gamma, hdtdx_t1, hdtdx_t2, P, ql);
+
+    // plus state (cell c)
+#pragma unroll
+    for (int m = 0; m < NEDGE; ++m) q[m] = S.QP[N][(long)m * NC + c];
+    load_f1(F12, NC, c + s1, f1r);
+    load_f1(F12, NC, c, f1l);
+    load_f1(F21, NC, c + s2, f2r);
+    load_f1(F21, NC, c, f2l);
+    trans_final(q, f1r, f1l, f2r, f2l, P.gamma, hdtdx_t1, hdtdx_t2, P, qr);
+
+    RState rl, rr;
+    double Xl, Xr;
+    rstate_from_edge<N>(ql, P.gamma, rl, Xl);
+    rstate_from_edge<N>(qr, P.gamma, rr, Xr);
+    const double cl = Q[PC * NC + c - sn];
+    const double cr = Q[PC * NC + c];
+
+    IFlux f;
+    interface_flux(rl, rr, Xl, Xr, cl, cr, wall_fac<N>(g, ijk[N]), P, f);
+
+    // flux in conserved-component order
+    double F[NUM_STATE];
+    F[URHO] = f.rho;
+    F[UMX + RDir<N>::n] = f.mn;
+    F[UMX + RDir<N>::t] = f.mt;
+    F[UMX + RDir<N>::tt] = f.mtt;
+    F[UEDEN] = f.E;
+    F[UEINT] = f.eint;
+    F[UTEMP] = 0.0;                       // Castro_ctu_hydro.cpp:1201
+    F[UFS] = f.X;
+
+    // apply_av (advection_util.cpp:482-528)
+    {
+        const double* DIV = S.DIV;
+        double div1 = 0.25 * (DIV[c] + DIV[c + s1] + DIV[c + s2] + DIV[c + s1 + s2]);
+        div1 = P.difmag * amin(0.0, div1);
+        const int im = i - (N == 0), jm = j - (N == 1), km = k - (N == 2);
+#pragma unroll
+        for (int m = 0; m < NUM_STATE; ++m) {
+            if (m == UTEMP) continue;
+            double d1 = div1 * (fab_get(U, i, j, k, m) - fab_get(U, im, jm, km, m));
+            F[m] += dxn * d1;
+        }
+    }
+
+    // normalize_species_fluxes (advection_util.cpp:577-613), NumSpec = 1
+    {
+        double sum = 0.0;
+        sum += F[UFS];
+        double fac = 1.0;
+        if (fabs(sum) > 2.220446049250313e-16 * fabs(F[URHO])) {
+            fac = F[URHO] / sum;
+        }
+        F[UFS] = F[UFS] * fac;
+    }
+
+    // keep the unscaled flux + Godunov (un, p) for consup_hydro
+    double* FL = S.FL[N];
+    FL[GRHO * NC + c] = F[URHO];
+    FL[GMX * NC + c] = F[UMX];
+    FL[GMY * NC + c] = F[UMY];
+    FL[GMZ * NC + c] = F[UMZ];
+    FL[GE * NC + c] = F[UEDEN];
+    FL[GEI * NC + c] = F[UEINT];
+    FL[GX * NC + c] = F[UFS];
+    FL[GUG * NC + c] = f.ugd;
+    FL[GPG * NC + c] = f.pgd;
+
+    // scale_flux (advection_util.cpp:616-641) and accumulation on mfi.nodaltilebox(N)
+    // (Castro_ctu_hydro.cpp:1379-1433)
+    if (ijk[N] <= acc_hi) {
+        if (fluxes.p) {
+#pragma unroll
+            for (int m = 0; m < NUM_STATE; ++m) {
+                if (m == UTEMP) continue;       // += dt*0*area leaves the register unchanged
+                double* dst = fab_ptr(fluxes, i, j, k, m);
+                *dst += dt * F[m] * area;
+            }
+        }
+        if (mass.p) {
+            *fab_ptr(mass, i, j, k, 0) = dt * F[URHO] * area;
+        }
+        if (qe.p) {
+            *fab_ptr(qe, i, j, k, GDU + RDir<N>::n) = f.ugd;
+            *fab_ptr(qe, i, j, k, GDU + RDir<N>::t) = f.ut;
+            *fab_ptr(qe, i, j, k, GDU + RDir<N>::tt) = f.utt;
+            *fab_ptr(qe, i, j, k, GDPRES) = f.pgd;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Castro::consup_hydro (Source/hydro/Castro_ctu.cpp:11-86), 3-D Cartesian
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_consup(Tile t, DevScratch S, DFab Uin, DFab Unew, double dt,
+                                                double area0, double area1, double area2, double vol,
+                                                int from_sborder)
+{
+    int lo[3] = { t.lo[0], t.lo[1], t.lo[2] };
+    int n[3] = { t.hi[0] - t.lo[0] + 1, t.hi[1] - t.lo[1] + 1, t.hi[2] - t.lo[2] + 1 };
+    int i, j, k;
+    if (!box_thread(lo, n, i, j, k)) return;
+    const long c = gidx(t, i, j, k);
+    const long sx = 1, sy = t.NX, sz = (long)t.NX * t.NY;
+    const long NC = t.NC;
+    const double volinv = 1.0 / vol;
+    const double* F0 = S.FL[0];
+    const double* F1 = S.FL[1];
+    const double* F2 = S.FL[2];
+
+    // record index of conserved component m in the FL arrays
+    constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
+
+#pragma unroll
+    for (int m = 0; m < NUM_STATE; ++m) {
+        double* dst = fab_ptr(Unew, i, j, k, m);
+        double u0 = from_sborder ? fab_get(Uin, i, j, k, m) : *dst;
+        if (m == UTEMP) {
+            // zero flux: U + dt*(0)*volinv == U
+            if (from_sborder) *dst = u0;
+            continue;
+        }
+        const long r = (long)rec[m] * NC;
+        double unew = u0 + dt *
+            ( F0[r + c] * area0
+            - F0[r + c + sx] * area0
+            + F1[r + c] * area1
+            - F1[r + c + sy] * area1
+            + F2[r + c] * area2
+            - F2[r + c + sz] * area2
+            ) * volinv;
+
+        if (m == UEINT) {
+            double pdu = (F0[GPG * NC + c + sx] + F0[GPG * NC + c]) *
+                (F0[GUG * NC + c + sx] * area0 - F0[GUG * NC + c] * area0);
+
+            pdu += (F1[GPG * NC + c + sy] + F1[GPG * NC + c]) *
+                (F1[GUG * NC + c + sy] * area1 - F1[GUG * NC + c] * area1);
+
+            pdu += (F2[GPG * NC + c + sz] + F2[GPG * NC + c]) *
+                (F2[GUG * NC + c + sz] * area2 - F2[GUG * NC + c] * area2);
+
+            pdu = 0.5 * pdu * volinv;
+
+            unew = unew - dt * pdu;
+        }
+        *dst = unew;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launcher
+// ---------------------------------------------------------------------------------------
+static inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
+
+#define KLAUNCH(name, kern, nthreads, ...)                                              \
+    do {                                                                                \
+        prof_begin(prof, name, stream);                                                 \
+        hipLaunchKernelGGL(kern, dim3(nblocks(nthreads)), dim3(256), 0, stream, __VA_ARGS__); \
+        prof_end(prof, stream);                                                         \
+    } while (0)
+
+int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Snew,
+                     const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
+                     const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
+                     int* d_status, hipStream_t stream, Profiler* prof)
+{
+    const long nx = t.hi[0] - t.lo[0] + 1, ny = t.hi[1] - t.lo[1] + 1, nz = t.hi[2] - t.lo[2] + 1;
+    const long ng = (long)t.NX * t.NY * t.NZ;
+    const long nobx = (nx + 2) * (ny + 2) * (nz + 2);
+
+    KLAUNCH("k_ctoprim", k_ctoprim, ng, t, Sborder, S.Q, P, d_status);
+    KLAUNCH("k_divu", k_divu, nobx, t, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+    KLAUNCH("k_trace", k_trace, nobx, t, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], P);
+
+    KLAUNCH("k_riemann1", k_riemann1<0>, (nx + 1) * (ny + 2) * (nz + 2), t, S.Q, S, g, P);
+    KLAUNCH("k_riemann1", k_riemann1<1>, (nx + 2) * (ny + 1) * (nz + 2), t, S.Q, S, g, P);
+    KLAUNCH("k_riemann1", k_riemann1<2>, (nx + 2) * (ny + 2) * (nz + 1), t, S.Q, S, g, P);
+
+    // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690)
+    const double cdtdx = dt / g.dx[0] / 3.0, cdtdy = dt / g.dx[1] / 3.0, cdtdz = dt / g.dx[2] / 3.0;
+    KLAUNCH("k_trans1", k_trans1<0>, (nx + 1) * (ny + 2) * (nz + 2), t, S.Q, S, g, cdtdy, cdtdz, P);
+    KLAUNCH("k_trans1", k_trans1<1>, (nx + 2) * (ny + 1) * (nz + 2), t, S.Q, S, g, cdtdx, cdtdz, P);
+    KLAUNCH("k_trans1", k_trans1<2>, (nx + 2) * (ny + 2) * (nz + 1), t, S.Q, S, g, cdtdx, cdtdy, P);
+
+    // hdtdx = 0.5*dt/dx (Castro_ctu_hydro.cpp:684-686)
+    const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
+    const double area0 = g.dx[1] * g.dx[2], area1 = g.dx[0] * g.dx[2], area2 = g.dx[0] * g.dx[1];
+    KLAUNCH("k_final", k_final<0>, (nx + 1) * ny * nz, t, S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
+            hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], P);
+    KLAUNCH("k_final", k_final<1>, nx * (ny + 1) * nz, t, S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
+            hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], P);
+    KLAUNCH("k_final", k_final<2>, nx * ny * (nz + 1), t, S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],
+            hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], P);
+
+    const double vol = g.dx[0] * g.dx[1] * g.dx[2];
+    KLAUNCH("k_consup", k_consup, nx * ny * nz, t, S, Sborder, Snew, dt, area0, area1, area2, vol,
+            (flags & 1) ? 1 : 0);
+
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+} // namespace cad

@@ -1,0 +1,703 @@
+// hydro_device.h -- per-zone / per-interface device functions of the MI355X CTU hydro path.
+//
+// Arithmetic follows BoxLib-Codes/Castro 21.07 expression by expression (files cited per
+// function) so that a build with -ffp-contract=off is bit-comparable with the reference's
+// CPU path; the structure (register-resident stencils, interface-local frames, fused
+// stages) is this project's own.  FP64 throughout, no MFMA: see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cad {
+
+// state / primitive indices of the Sedov build
+enum : int { URHO = 0, UMX = 1, UMY = 2, UMZ = 3, UEDEN = 4, UEINT = 5, UTEMP = 6, UFS = 7, NUM_STATE = 8 };
+enum : int { GDU = 0, GDV = 1, GDW = 2, GDPRES = 3, NGDNV = 4 };
+
+// compact primitive set carried between kernels (QTEMP is never read downstream of
+// ctoprim for a gamma-law gas, gamc == eos_gamma):
+enum : int { PRHO = 0, PU = 1, PV = 2, PW = 3, PP = 4, PRE = 5, PX = 6, PC = 7, NPRIM = 8 };
+// edge states: PRHO..PX
+enum : int { NEDGE = 7 };
+// transverse-stage flux record: rho, mx, my, mz, E, X fluxes + Godunov un and p
+enum : int { FRHO = 0, FMX = 1, FMY = 2, FMZ = 3, FE = 4, FX = 5, FUG = 6, FPG = 7, NF1 = 8 };
+// final flux record (unscaled): rho, mx, my, mz, E, eint, X  + Godunov un, p
+enum : int { GRHO = 0, GMX = 1, GMY = 2, GMZ = 3, GE = 4, GEI = 5, GX = 6, GUG = 7, GPG = 8, NFIN = 9 };
+
+// CODATA-2010 cgs constants of Microphysics' fundamental_constants (only Temp depends on them)
+constexpr double K_B = 1.3806488e-16;
+constexpr double M_U = 1.660538921e-24;
+
+struct DevParams {
+    double gamma;           // eos_gamma
+    double small_dens, small_pres, small_temp, small_ener;
+    double small_dens_ener; // small_dens * small_ener
+    double difmag;
+    double cg_tol;
+    double eta1, eta2;
+    double small_x;
+    double abar;
+    int riemann_solver, use_flattening, first_order_hydro, hybrid_riemann;
+    int cg_maxiter, cg_blend;
+    int reset_density, reset_rhoe, use_eos;
+    int ppm_temp_fix;
+};
+
+// amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument
+__device__ __forceinline__ double amin(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double amax(double a, double b) { return (a < b) ? b : a; }
+
+// ---------------------------------------------------------------------------------------
+// gamma-law EOS (Microphysics EOS/gamma_law restated)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double eos_e_of_T(const DevParams& P, double T)
+{
+    return K_B * T / ((P.gamma - 1.0) * (P.abar * M_U));
+}
+__device__ __forceinline__ double eos_T_of_e(const DevParams& P, double e)
+{
+    return (P.gamma - 1.0) * e * (P.abar * M_U) / K_B;
+}
+
+// ---------------------------------------------------------------------------------------
+// flattening along one direction (Source/hydro/flatten.cpp:29-70): p at offsets -3..3,
+// normal velocity at offsets -2..2, all in registers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double flatten_1d(const double p[7], const double u[5])
+{
+    constexpr double small_pres = 1.e-200;
+    constexpr double shktst = 0.33;
+    constexpr double zcut1 = 0.75;
+    constexpr double zcut2 = 0.85;
+    constexpr double dzcut = 1.0 / (zcut2 - zcut1);
+    // p[3] is the zone, u[2] is the zone
+    double dp = p[4] - p[2];
+    const bool up = dp > 0.0;                 // ishft = up ? 1 : -1
+
+    double denom = amax(small_pres, fabs(p[5] - p[1]));
+    double zeta = fabs(dp) / denom;
+    double z = amin(1.0, amax(0.0, dzcut * (zeta - zcut1)));
+
+    double tst = 0.0;
+    if (u[1] - u[3] >= 0.0) tst = 1.0;
+
+    double tmp = amin(p[4], p[2]);
+
+    double chi = 0.0;
+    if (fabs(dp) > shktst * tmp) chi = tst;
+
+    // shifted stencil: centre at -ishft
+    const double pp1 = up ? p[3] : p[5];      // p(+1-ishft)
+    const double pm1 = up ? p[1] : p[3];      // p(-1-ishft)
+    const double pp2 = up ? p[4] : p[6];      // p(+2-ishft)
+    const double pm2 = up ? p[0] : p[2];      // p(-2-ishft)
+    const double um1 = up ? u[0] : u[2];      // u(-1-ishft)
+    const double up1 = up ? u[2] : u[4];      // u(+1-ishft)
+
+    dp = pp1 - pm1;
+
+    denom = amax(small_pres, fabs(pp2 - pm2));
+    zeta = fabs(dp) / denom;
+    double z2 = amin(1.0, amax(0.0, dzcut * (zeta - zcut1)));
+
+    tst = 0.0;
+    if (um1 - up1 >= 0.0) tst = 1.0;
+
+    tmp = amin(pp1, pm1);
+
+    double chi2 = 0.0;
+    if (fabs(dp) > shktst * tmp) chi2 = tst;
+
+    return 1.0 - amax(chi2 * z2, chi * z);
+}
+
+// ---------------------------------------------------------------------------------------
+// PPM (Source/hydro/ppm.H)
+// ---------------------------------------------------------------------------------------
+// ppm.H:54-139; s[0..4] = zones i-2..i+2
+__device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn, double& sm, double& sp)
+{
+    double dsl = 2.0 * (s[1] - s[0]);
+    double dsr = 2.0 * (s[2] - s[1]);
+
+    double dsvl_l = 0.0;
+    if (dsl * dsr > 0.0) {
+        double dsc = 0.5 * (s[2] - s[0]);
+        dsvl_l = copysign(1.0, dsc) * amin(fabs(dsc), amin(fabs(dsl), fabs(dsr)));
+    }
+
+    dsl = 2.0 * (s[2] - s[1]);
+    dsr = 2.0 * (s[3] - s[2]);
+
+    double dsvl_r = 0.0;
+    if (dsl * dsr > 0.0) {
+        double dsc = 0.5 * (s[3] - s[1]);
+        dsvl_r = copysign(1.0, dsc) * amin(fabs(dsc), amin(fabs(dsl), fabs(dsr)));
+    }
+
+    sm = 0.5 * (s[2] + s[1]) - (1.0 / 6.0) * (dsvl_r - dsvl_l);
+
+    sm = amax(sm, amin(s[2], s[1]));
+    sm = amin(sm, amax(s[2], s[1]));
+
+    // the slope at zone i (dsvl_r above) is recomputed by the reference with identical
+    // operands: reuse it as the new "left" slope
+    dsvl_l = dsvl_r;
+
+    dsl = 2.0 * (s[3] - s[2]);
+    dsr = 2.0 * (s[4] - s[3]);
+
+    dsvl_r = 0.0;
+    if (dsl * dsr > 0.0) {
+        double dsc = 0.5 * (s[4] - s[2]);
+        dsvl_r = copysign(1.0, dsc) * amin(fabs(dsc), amin(fabs(dsl), fabs(dsr)));
+    }
+
+    sp = 0.5 * (s[3] + s[2]) - (1.0 / 6.0) * (dsvl_r - dsvl_l);
+
+    sp = amax(sp, amin(s[3], s[2]));
+    sp = amin(sp, amax(s[3], s[2]));
+
+    sm = flatn * sm + (1.0 - flatn) * s[2];
+    sp = flatn * sp + (1.0 - flatn) * s[2];
+
+    if ((sp - s[2]) * (s[2] - sm) <= 0.0) {
+        sp = s[2];
+        sm = s[2];
+    } else if (fabs(sp - s[2]) >= 2.0 * fabs(sm - s[2])) {
+        sp = 3.0 * s[2] - 2.0 * sm;
+    } else if (fabs(sm - s[2]) >= 2.0 * fabs(sp - s[2])) {
+        sm = 3.0 * s[2] - 2.0 * sp;
+    }
+}
+
+// ppm.H:225-252 (one wave); s6 is passed in because it is shared by the three waves
+__device__ __forceinline__ void ppm_int_wave(double sm, double sp, double s6, double lam, double dtdx,
+                                             double& Ip, double& Im)
+{
+    double sigma = fabs(lam) * dtdx;
+    if (lam <= 0.0) {
+        Ip = sp;
+        Im = sm + 0.5 * sigma * (sp - sm + (1.0 - (2.0 / 3.0) * sigma) * s6);
+    } else {
+        Ip = sp - 0.5 * sigma * (sp - sm - (1.0 - (2.0 / 3.0) * sigma) * s6);
+        Im = sm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Riemann problem in the interface-normal frame
+// ---------------------------------------------------------------------------------------
+struct RState { double rho, un, ut, utt, p, rhoe, gamc; };   // riemann.H:13-31
+struct RAux { double csmall, cavg, bnd_fac; };              // riemann.H:34-39
+
+// the "cleaning" tail of load_input_states (riemann.H:198-244)
+__device__ __forceinline__ void clean_input_state(RState& q, const DevParams& P)
+{
+    if (q.rhoe <= 0.0 || q.p < P.small_pres) {
+        double e = eos_e_of_T(P, P.small_temp);
+        q.rhoe = q.rho * e;
+        q.p = (P.gamma - 1.0) * q.rho * e;
+        q.gamc = P.gamma;
+    }
+}
+
+// riemann_solvers.H:597-820 -- Colella, Glaz & Ferguson (riemann_solver = 0, default)
+__device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, const RAux& raux,
+                                          RState& qint, const DevParams& P)
+{
+    constexpr double smallu = 1.e-12;
+    constexpr double small = 1.e-8;
+
+    double wsmall = P.small_dens * raux.csmall;
+
+    double wl = amax(wsmall, sqrt(fabs(ql.gamc * ql.p * ql.rho)));
+    double wr = amax(wsmall, sqrt(fabs(qr.gamc * qr.p * qr.rho)));
+
+    double wwinv = 1.0 / (wl + wr);
+    double pstar = ((wr * ql.p + wl * qr.p) + wl * wr * (ql.un - qr.un)) * wwinv;
+    double ustar = ((wl * ql.un + wr * qr.un) + (ql.p - qr.p)) * wwinv;
+
+    pstar = amax(pstar, P.small_pres);
+
+    if (fabs(ustar) < smallu * 0.5 * (fabs(ql.un) + fabs(qr.un))) {
+        ustar = 0.0;
+    }
+
+    double sgnm = copysign(1.0, ustar);
+    if (ustar == 0.0) sgnm = 0.0;
+
+    double fp = 0.5 * (1.0 + sgnm);
+    double fm = 0.5 * (1.0 - sgnm);
+
+    double ro = fp * ql.rho + fm * qr.rho;
+    double uo = fp * ql.un + fm * qr.un;
+    double po = fp * ql.p + fm * qr.p;
+    double reo = fp * ql.rhoe + fm * qr.rhoe;
+    double gamco = fp * ql.gamc + fm * qr.gamc;
+
+    ro = amax(P.small_dens, ro);
+
+    double roinv = 1.0 / ro;
+
+    double co = sqrt(fabs(gamco * po * roinv));
+    co = amax(raux.csmall, co);
+    double co2inv = 1.0 / (co * co);
+
+    qint.ut = fp * ql.ut + fm * qr.ut;
+    qint.utt = fp * ql.utt + fm * qr.utt;
+
+    double drho = (pstar - po) * co2inv;
+    double rstar = ro + drho;
+    rstar = amax(P.small_dens, rstar);
+
+    double entho = (reo + po) * roinv * co2inv;
+    double estar = reo + (pstar - po) * entho;
+
+    double cstar = sqrt(fabs(gamco * pstar / rstar));
+    cstar = amax(cstar, raux.csmall);
+
+    double spout = co - sgnm * uo;
+    double spin = cstar - sgnm * ustar;
+
+    double ushock = 0.5 * (spin + spout);
+
+    if (pstar - po > 0.0) {
+        spin = ushock;
+        spout = ushock;
+    }
+
+    double scr = spout - spin;
+    if (spout - spin == 0.0) {
+        scr = small * raux.cavg;
+    }
+
+    double frac = (1.0 + (spout + spin) / scr) * 0.5;
+    frac = amax(0.0, amin(1.0, frac));
+
+    qint.rho = frac * rstar + (1.0 - frac) * ro;
+    qint.un = frac * ustar + (1.0 - frac) * uo;
+    qint.p = frac * pstar + (1.0 - frac) * po;
+    double regdnv = frac * estar + (1.0 - frac) * reo;
+
+    if (spout < 0.0) {
+        qint.rho = ro;
+        qint.un = uo;
+        qint.p = po;
+        regdnv = reo;
+    }
+
+    if (spin >= 0.0) {
+        qint.rho = rstar;
+        qint.un = ustar;
+        qint.p = pstar;
+        regdnv = estar;
+    }
+
+    qint.p = amax(qint.p, P.small_pres);
+    qint.rhoe = regdnv;
+
+    qint.un = qint.un * raux.bnd_fac;
+}
+
+// riemann.H:248-282
+__device__ __forceinline__ void wsqge(double p, double v, double gam, double gdot, double& gstar,
+                                      double gmin, double gmax, double csq, double pstar, double& wsq)
+{
+    constexpr double smlp1 = 1.e-10;
+    gstar = (pstar - p) * gdot / (pstar + p) + gam;
+    gstar = amax(gmin, amin(gmax, gstar));
+
+    double alpha = pstar - (gstar - 1.0) * p / (gam - 1.0);
+    if (alpha == 0.0) {
+        alpha = smlp1 * (pstar + p);
+    }
+
+    double beta = pstar + 0.5 * (gstar - 1.0) * (pstar + p);
+
+    wsq = (pstar - p) * beta / (v * alpha);
+
+    if (fabs(pstar - p) < smlp1 * (pstar + p)) {
+        wsq = csq;
+    }
+    wsq = amax(wsq, (0.5 * (gam - 1.0) / gam) * csq);
+}
+
+// riemann_solvers.H:225-581 -- Colella & Glaz (riemann_solver = 1), the reference's GPU
+// semantics: no pstar history, so cg_blend = 2 cannot bisect and keeps the last iterate
+__device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, const RAux& raux,
+                                          RState& qint, const DevParams& P)
+{
+    constexpr double weakwv = 1.e-3;
+    constexpr double smallu = 1.e-12;
+    constexpr double small = 1.e-8;
+
+    double taul = 1.0 / ql.rho;
+    double taur = 1.0 / qr.rho;
+
+    double clsql = ql.gamc * ql.p * ql.rho;
+    double clsqr = qr.gamc * qr.p * qr.rho;
+
+    double gamel = ql.p / ql.rhoe + 1.0;
+    double gamer = qr.p / qr.rhoe + 1.0;
+
+    double gmin = amin(amin(gamel, gamer), 1.0);
+    double gmax = amax(amax(gamel, gamer), 2.0);
+
+    double game_bar = 0.5 * (gamel + gamer);
+    double gamc_bar = 0.5 * (ql.gamc + qr.gamc);
+
+    double gdot = 2.0 * (1.0 - game_bar / gamc_bar) * (game_bar - 1.0);
+
+    double wsmall = P.small_dens * raux.csmall;
+    double wl = amax(wsmall, sqrt(fabs(clsql)));
+    double wr = amax(wsmall, sqrt(fabs(clsqr)));
+
+    double pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    pstar = amax(pstar, P.small_pres);
+
+    double gamstar = 0.0;
+    double wlsq = 0.0;
+    wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
+    double wrsq = 0.0;
+    wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
+
+    double pstar_old = pstar;
+
+    wl = sqrt(wlsq);
+    wr = sqrt(wrsq);
+
+    double ustar_l = ql.un - (pstar - ql.p) / wl;
+    double ustar_r = qr.un + (pstar - qr.p) / wr;
+
+    pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    pstar = amax(pstar, P.small_pres);
+
+    bool converged = false;
+    int iter = 0;
+    while ((iter < P.cg_maxiter && !converged) || iter < 2) {
+        wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
+        wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
+
+        wl = 1.0 / sqrt(wlsq);
+        wr = 1.0 / sqrt(wrsq);
+
+        double ustar_r_old = ustar_r;
+        double ustar_l_old = ustar_l;
+
+        ustar_r = qr.un - (qr.p - pstar) * wr;
+        ustar_l = ql.un + (ql.p - pstar) * wl;
+
+        double dpditer = fabs(pstar_old - pstar);
+
+        double zp = fabs(ustar_l - ustar_l_old);
+        if (zp - weakwv * raux.cavg <= 0.0) zp = dpditer * wl;
+
+        double zm = fabs(ustar_r - ustar_r_old);
+        if (zm - weakwv * raux.cavg <= 0.0) zm = dpditer * wr;
+
+        double denom = dpditer / amax(zp + zm, small * raux.cavg);
+        pstar_old = pstar;
+        pstar = pstar - denom * (ustar_r - ustar_l);
+        pstar = amax(pstar, P.small_pres);
+
+        double err = fabs(pstar - pstar_old);
+        if (err < P.cg_tol * pstar) converged = true;
+
+        iter++;
+    }
+
+    if (!converged && P.cg_blend == 1) {
+        pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    }
+
+    ustar_r = qr.un - (qr.p - pstar) * wr;
+    ustar_l = ql.un + (ql.p - pstar) * wl;
+
+    double ustar = 0.5 * (ustar_l + ustar_r);
+
+    if (fabs(ustar) < smallu * 0.5 * (fabs(ql.un) + fabs(qr.un))) ustar = 0.0;
+
+    double ro, uo, po, tauo, gamco, gameo;
+    if (ustar > 0.0) {
+        ro = ql.rho; uo = ql.un; po = ql.p; tauo = taul; gamco = ql.gamc; gameo = gamel;
+    } else if (ustar < 0.0) {
+        ro = qr.rho; uo = qr.un; po = qr.p; tauo = taur; gamco = qr.gamc; gameo = gamer;
+    } else {
+        ro = 0.5 * (ql.rho + qr.rho);
+        uo = 0.5 * (ql.un + qr.un);
+        po = 0.5 * (ql.p + qr.p);
+        tauo = 0.5 * (taul + taur);
+        gamco = 0.5 * (ql.gamc + qr.gamc);
+        gameo = 0.5 * (gamel + gamer);
+    }
+
+    ro = amax(P.small_dens, 1.0 / tauo);
+    tauo = 1.0 / ro;
+
+    double co = sqrt(fabs(gamco * po * tauo));
+    co = amax(raux.csmall, co);
+    double clsq = (co * ro) * (co * ro);
+
+    double wosq = 0.0;
+    wsqge(po, tauo, gameo, gdot, gamstar, gmin, gmax, clsq, pstar, wosq);
+
+    double sgnm = copysign(1.0, ustar);
+
+    double wo = sqrt(wosq);
+    double dpjmp = pstar - po;
+
+    double rstar = 1.0 - ro * dpjmp / wosq;
+    rstar = ro / rstar;
+    rstar = amax(P.small_dens, rstar);
+
+    double cstar = sqrt(fabs(gamco * pstar / rstar));
+    cstar = amax(cstar, raux.csmall);
+
+    double spout = co - sgnm * uo;
+    double spin = cstar - sgnm * ustar;
+
+    double ushock = wo * tauo - sgnm * uo;
+
+    if (pstar - po >= 0.0) {
+        spin = ushock;
+        spout = ushock;
+    }
+
+    double frac = 0.5 * (1.0 + (spin + spout) / amax(amax(spout - spin, spin + spout), small * raux.cavg));
+
+    if (ustar > 0.0) {
+        qint.ut = ql.ut; qint.utt = ql.utt;
+    } else if (ustar < 0.0) {
+        qint.ut = qr.ut; qint.utt = qr.utt;
+    } else {
+        qint.ut = 0.5 * (ql.ut + qr.ut);
+        qint.utt = 0.5 * (ql.utt + qr.utt);
+    }
+
+    qint.rho = frac * rstar + (1.0 - frac) * ro;
+    qint.un = frac * ustar + (1.0 - frac) * uo;
+    qint.p = frac * pstar + (1.0 - frac) * po;
+    double game_int = frac * gamstar + (1.0 - frac) * gameo;
+
+    if (spout < 0.0) {
+        qint.rho = ro; qint.un = uo; qint.p = po; game_int = gameo;
+    }
+    if (spin >= 0.0) {
+        qint.rho = rstar; qint.un = ustar; qint.p = pstar; game_int = gamstar;
+    }
+
+    qint.p = amax(qint.p, P.small_pres);
+    qint.un = qint.un * raux.bnd_fac;
+    qint.rhoe = qint.p / (game_int - 1.0);
+}
+
+// One interface: riemann_state (riemann_solvers.H:1262-1388) + compute_flux_q (:14-211) +
+// the passive upwinding of cmpflx_plus_godunov (riemann.cpp:107-131), in the normal frame.
+//   ql/qr carry gamc already (= qaux(QGAMC) of the cells either side); cl, cr = qaux(QC)
+//   Xl, Xr = passive edge values.  Outputs: F = (rho, m_n, m_t, m_tt, E, eint, X) fluxes,
+//   ugd = Godunov normal velocity, pgd = Godunov pressure.
+struct IFlux { double rho, mn, mt, mtt, E, eint, X, ugd, ut, utt, pgd; };
+
+__device__ __forceinline__ void interface_flux(RState ql, RState qr, double Xl, double Xr,
+                                               double cl, double cr, double bnd_fac,
+                                               const DevParams& P, IFlux& F)
+{
+    constexpr double small = 1.e-8;
+    // riemann.H:70-71
+    ql.rho = amax(ql.rho, P.small_dens);
+    qr.rho = amax(qr.rho, P.small_dens);
+
+    RAux raux;
+    raux.csmall = amax(small, small * amax(cr, cl));
+    raux.cavg = 0.5 * (cr + cl);
+    raux.bnd_fac = bnd_fac;
+
+    clean_input_state(ql, P);
+    clean_input_state(qr, P);
+
+    RState qint;
+    if (P.riemann_solver == 0) {
+        riemannus(ql, qr, raux, qint, P);
+    } else {
+        riemanncg(ql, qr, raux, qint, P);
+    }
+
+    F.rho = qint.rho * qint.un;
+    F.mn = F.rho * qint.un;
+    F.mt = F.rho * qint.ut;
+    F.mtt = F.rho * qint.utt;
+    F.mn += qint.p;
+
+    double rhoetot = qint.rhoe + 0.5 * qint.rho * (qint.un * qint.un + qint.ut * qint.ut + qint.utt * qint.utt);
+
+    F.E = qint.un * (rhoetot + qint.p);
+    F.eint = qint.un * qint.rhoe;
+
+    F.ugd = qint.un;
+    F.ut = qint.ut;
+    F.utt = qint.utt;
+    F.pgd = qint.p;
+
+    double sgnm = copysign(1.0, qint.un);
+    if (qint.un == 0.0) sgnm = 0.0;
+
+    double fp = 0.5 * (1.0 + sgnm);
+    double fm = 0.5 * (1.0 - sgnm);
+
+    double X_int = fp * Xl + fm * Xr;
+    F.X = F.rho * X_int;
+}
+
+// direction maps of the Riemann solver (riemann.H:73-150): normal, first and second
+// transverse velocity component of direction D
+template <int D> struct RDir;
+template <> struct RDir<0> { static constexpr int n = 0, t = 1, tt = 2; };
+template <> struct RDir<1> { static constexpr int n = 1, t = 0, tt = 2; };
+template <> struct RDir<2> { static constexpr int n = 2, t = 0, tt = 1; };
+
+// ---------------------------------------------------------------------------------------
+// transverse corrections (Source/hydro/trans.cpp), operating on a register-resident edge
+// state q[NEDGE] = (rho,u,v,w,p,rhoe,X); flux differences are passed pre-loaded:
+//   fr/fl = flux record (FRHO..FPG) at the high/low transverse face
+// ---------------------------------------------------------------------------------------
+// actual_trans_single, trans.cpp:66-437 (3-D branch). TD = transverse direction.
+template <int TD>
+__device__ __forceinline__ void trans_single(const double q[NEDGE], const double fr[NF1], const double fl[NF1],
+                                             double gamc, double cdtdx, const DevParams& P, double qo[NEDGE])
+{
+    // passive :171-189
+    {
+        double rrnew = q[PRHO] - cdtdx * (fr[FRHO] - fl[FRHO]);
+        double compu = q[PRHO] * q[PX] - cdtdx * (fr[FX] - fl[FX]);
+        qo[PX] = compu / rrnew;
+    }
+
+    double pgp = fr[FPG];
+    double pgm = fl[FPG];
+    double ugp = fr[FUG];
+    double ugm = fl[FUG];
+
+    double dup = pgp * ugp - pgm * ugm;
+    double du = ugp - ugm;
+    double pav = 0.5 * (pgp + pgm);
+
+    double rrn = q[PRHO];
+    double run = rrn * q[PU];
+    double rvn = rrn * q[PV];
+    double rwn = rrn * q[PW];
+    double ekenn = 0.5 * rrn * (q[PU] * q[PU] + q[PV] * q[PV] + q[PW] * q[PW]);
+    double ren = q[PRE] + ekenn;
+
+    double rrnewn = rrn - cdtdx * (fr[FRHO] - fl[FRHO]);
+    double runewn = run - cdtdx * (fr[FMX] - fl[FMX]);
+    double rvnewn = rvn - cdtdx * (fr[FMY] - fl[FMY]);
+    double rwnewn = rwn - cdtdx * (fr[FMZ] - fl[FMZ]);
+    double renewn = ren - cdtdx * (fr[FE] - fl[FE]);
+
+    bool reset_state = false;
+    if (P.reset_density == 1 && rrnewn < 0.0) {
+        rrnewn = rrn;
+        runewn = run;
+        rvnewn = rvn;
+        rwnewn = rwn;
+        renewn = ren;
+        reset_state = true;
+    }
+
+    qo[PRHO] = rrnewn;
+    double rhoinv = 1.0 / rrnewn;
+    qo[PU] = runewn * rhoinv;
+    qo[PV] = rvnewn * rhoinv;
+    qo[PW] = rwnewn * rhoinv;
+
+    double rhoekenn = 0.5 * (runewn * runewn + rvnewn * rvnewn + rwnewn * rwnewn) * rhoinv;
+    qo[PRE] = renewn - rhoekenn;
+
+    if (!reset_state) {
+        // transverse_reset_rhoe == 1 needs the eint flux, which the transverse flux record
+        // does not carry: rejected on the host (CASTRO_AMD_ERR_UNSUPPORTED)
+        if (qo[PRE] <= 0.0) {
+            qo[PRE] = q[PRE];
+        }
+        double pnewn = q[PP] - cdtdx * (dup + pav * du * (gamc - 1.0));
+        qo[PP] = amax(pnewn, P.small_pres);
+    } else {
+        qo[PP] = q[PP];
+        qo[PRE] = q[PRE];
+    }
+}
+
+// actual_trans_final, trans.cpp:498-862 (no radiation)
+__device__ __forceinline__ void trans_final(const double q[NEDGE],
+                                            const double f1r[NF1], const double f1l[NF1],
+                                            const double f2r[NF1], const double f2l[NF1],
+                                            double gamc, double cdtdx_t1, double cdtdx_t2,
+                                            const DevParams& P, double qo[NEDGE])
+{
+    {
+        double rrn = q[PRHO];
+        double compn = rrn * q[PX];
+        double rrnewn = rrn - cdtdx_t1 * (f1r[FRHO] - f1l[FRHO]) - cdtdx_t2 * (f2r[FRHO] - f2l[FRHO]);
+        double compnn = compn - cdtdx_t1 * (f1r[FX] - f1l[FX]) - cdtdx_t2 * (f2r[FX] - f2l[FX]);
+        qo[PX] = compnn / rrnewn;
+    }
+
+    double pgt1p = f1r[FPG], pgt1m = f1l[FPG], ugt1p = f1r[FUG], ugt1m = f1l[FUG];
+    double pgt2p = f2r[FPG], pgt2m = f2l[FPG], ugt2p = f2r[FUG], ugt2m = f2l[FUG];
+
+    double dupt1 = pgt1p * ugt1p - pgt1m * ugt1m;
+    double pt1av = 0.5 * (pgt1p + pgt1m);
+    double dut1 = ugt1p - ugt1m;
+    double pt1new = cdtdx_t1 * (dupt1 + pt1av * dut1 * (gamc - 1.0));
+
+    double dupt2 = pgt2p * ugt2p - pgt2m * ugt2m;
+    double pt2av = 0.5 * (pgt2p + pgt2m);
+    double dut2 = ugt2p - ugt2m;
+    double pt2new = cdtdx_t2 * (dupt2 + pt2av * dut2 * (gamc - 1.0));
+
+    double rrn = q[PRHO];
+    double run = rrn * q[PU];
+    double rvn = rrn * q[PV];
+    double rwn = rrn * q[PW];
+    double ekenn = 0.5 * rrn * (q[PU] * q[PU] + q[PV] * q[PV] + q[PW] * q[PW]);
+    double ren = q[PRE] + ekenn;
+
+    double rrnewn = rrn - cdtdx_t1 * (f1r[FRHO] - f1l[FRHO]) - cdtdx_t2 * (f2r[FRHO] - f2l[FRHO]);
+    double runewn = run - cdtdx_t1 * (f1r[FMX] - f1l[FMX]) - cdtdx_t2 * (f2r[FMX] - f2l[FMX]);
+    double rvnewn = rvn - cdtdx_t1 * (f1r[FMY] - f1l[FMY]) - cdtdx_t2 * (f2r[FMY] - f2l[FMY]);
+    double rwnewn = rwn - cdtdx_t1 * (f1r[FMZ] - f1l[FMZ]) - cdtdx_t2 * (f2r[FMZ] - f2l[FMZ]);
+    double renewn = ren - cdtdx_t1 * (f1r[FE] - f1l[FE]) - cdtdx_t2 * (f2r[FE] - f2l[FE]);
+
+    bool reset_state = false;
+    if (P.reset_density == 1 && rrnewn < 0.0) {
+        rrnewn = rrn;
+        runewn = run;
+        rvnewn = rvn;
+        rwnewn = rwn;
+        renewn = ren;
+        reset_state = true;
+    }
+
+    qo[PRHO] = rrnewn;
+    qo[PU] = runewn / rrnewn;
+    qo[PV] = rvnewn / rrnewn;
+    qo[PW] = rwnewn / rrnewn;
+
+    double rhoekenn = 0.5 * (runewn * runewn + rvnewn * rvnewn + rwnewn * rwnewn) / rrnewn;
+    qo[PRE] = renewn - rhoekenn;
+
+    if (!reset_state) {
+        if (qo[PRE] <= 0.0) {
+            qo[PRE] = q[PRE];
+        }
+        double pnewn = q[PP] - pt1new - pt2new;
+        qo[PP] = pnewn;
+    } else {
+        qo[PP] = q[PP];
+        qo[PRE] = q[PRE];
+    }
+
+    qo[PP] = amax(qo[PP], P.small_pres);
+}
+
+} // namespace cad

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's hydro interface over the C ABI.
+
+`HipHydro` is the per-(device, stream) object whose methods carry the reference's names
+(`construct_ctu_hydro_source`, `clean_state`, `estdt_cfl`, ...) and take FABs as torch CUDA
+tensors shaped (ncomp, nz, ny, nx) plus their index box.  torch is used for device
+memory and streams only; every operation is a call into libcastro_hydro_amd.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+class HipHydro:
+    """One castro_amd_ctx.  No CPU fallback: constructing it without a HIP device raises."""
+
+    name = "hip"
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("castro_amd.HipHydro needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = L.load()
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        L.check(self.lib.castro_amd_ctx_create(C.byref(h), int(device)), "ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.castro_amd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory -------------------------------------------------------------------------
+    def alloc(self, ncomp, lo, hi, fill=0.0):
+        """A FAB for box [lo,hi] as a torch tensor (ncomp, nz, ny, nx), FP64, on the device."""
+        shape = (ncomp, hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
+        return torch.full(shape, fill, dtype=torch.float64, device=self.device)
+
+    def reserve(self, nx, ny, nz):
+        L.check(self.lib.castro_amd_ctx_reserve(self.h, nx, ny, nz), "ctx_reserve")
+
+    def scratch_bytes(self):
+        return int(self.lib.castro_amd_ctx_scratch_bytes(self.h))
+
+    def status(self, stream=None):
+        return int(self.lib.castro_amd_ctx_status(self.h, _stream_ptr(stream)))
+
+    # ---- the hot path: Castro::construct_ctu_hydro_source, one FAB/tile --------------------
+    def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
+                                   fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
+                                   update_from_sborder=False, src=None, src_box=None, stream=None):
+        bxlo, bxhi = bx
+        vlo, vhi = vbx if vbx is not None else bx
+        fb = (L.Fab * 3)()
+        mb = (L.Fab * 3)()
+        qb = (L.Fab * 3)()
+        for d in range(3):
+            if flux_boxes is not None:
+                flo, fhi = flux_boxes[d]
+            else:
+                flo, fhi = list(vlo), list(vhi)
+                fhi[d] += 1
+            fb[d] = L.fab_of(fluxes[d] if fluxes is not None else None, flo, fhi)
+            mb[d] = L.fab_of(mass_fluxes[d] if mass_fluxes is not None else None, flo, fhi)
+            qb[d] = L.fab_of(qe[d] if qe is not None else None, flo, fhi)
+        sfab = L.fab_of(src, *src_box) if src is not None else L.fab_desc(None, bxlo, bxhi, 0)
+        rc = self.lib.castro_amd_ctu_hydro_fab(
+            self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),
+            C.byref(L.fab_of(Sborder, *sb_box)), C.byref(sfab), C.byref(L.fab_of(S_new, *snew_box)),
+            fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt),
+            L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD, _stream_ptr(stream))
+        L.check(rc, "ctu_hydro_fab")
+
+    # ---- Castro::clean_state ---------------------------------------------------------------
+    def clean_state(self, state, box, lo, hi, params, ntimes=1, stream=None):
+        L.check(self.lib.castro_amd_clean_state_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                                    C.byref(params), int(ntimes), _stream_ptr(stream)), "clean_state_fab")
+
+    # ---- Castro::estdt_cfl + S_new.min(URHO) -------------------------------------------------
+    def estdt_cfl(self, state, box, lo, hi, geom, params, out, stream=None):
+        """Reduces into `out` (device tensor of 2 doubles: [min dx/(c+|u|), min rho]); the caller
+        initialises it (e.g. out.fill_(1e200))."""
+        L.check(self.lib.castro_amd_estdt_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                              C.byref(geom), C.byref(params), C.c_void_p(out.data_ptr()),
+                                              _stream_ptr(stream)), "estdt_fab")
+
+    # ---- FillPatch pieces --------------------------------------------------------------------
+    def bc_fill(self, state, box, geom, stream=None):
+        L.check(self.lib.castro_amd_bc_fill_fab(self.h, C.byref(L.fab_of(state, *box)), C.byref(geom),
+                                                _stream_ptr(stream)), "bc_fill_fab")
+
+    def copy(self, dst, dst_box, src, src_box, lo, hi, stream=None):
+        L.check(self.lib.castro_amd_copy_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), C.byref(L.fab_of(src, *src_box)),
+                                             L.i3(lo), L.i3(hi), _stream_ptr(stream)), "copy_fab")
+
+    def pack(self, state, box, lo, hi, buf, stream=None):
+        L.check(self.lib.castro_amd_pack_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                             C.c_void_p(buf.data_ptr()), _stream_ptr(stream)), "pack_fab")
+
+    def unpack(self, state, box, lo, hi, buf, stream=None):
+        L.check(self.lib.castro_amd_unpack_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                               C.c_void_p(buf.data_ptr()), _stream_ptr(stream)), "unpack_fab")
+
+    # ---- problem setups ----------------------------------------------------------------------
+    def sedov_init(self, state, box, lo, hi, geom, params, r_init=0.01, p_ambient=1.e-5, exp_energy=1.0,
+                   dens_ambient=1.0, nsub=10, stream=None):
+        L.check(self.lib.castro_amd_sedov_init_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                                   C.byref(geom), C.byref(params), r_init, p_ambient, exp_energy,
+                                                   dens_ambient, int(nsub), _stream_ptr(stream)), "sedov_init_fab")
+
+    def sod_init(self, state, box, lo, hi, geom, params, rho_l, u_l, p_l, rho_r, u_r, p_r, idir=1, frac=0.5,
+                 stream=None):
+        L.check(self.lib.castro_amd_sod_init_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                                 C.byref(geom), C.byref(params), rho_l, u_l, p_l, rho_r, u_r, p_r,
+                                                 int(idir), float(frac), _stream_ptr(stream)), "sod_init_fab")
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def profile(self, enable=True):
+        self.lib.castro_amd_ctx_profile(self.h, 1 if enable else 0)
+
+    def profile_reset(self):
+        self.lib.castro_amd_ctx_profile_reset(self.h)
+
+    def profile_report(self):
+        """{kernel name: (total_ms, launches)} measured with hipEvents on the launch stream."""
+        out = {}
+        n = self.lib.castro_amd_ctx_profile_count(self.h)
+        for i in range(n):
+            name = C.create_string_buffer(64)
+            ms = C.c_double()
+            cnt = C.c_longlong()
+            self.lib.castro_amd_ctx_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(cnt))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out

@@ -1,0 +1,209 @@
+/*
+ * castro_hydro_amd.h -- C ABI of the MI355X-native CTU hydro path for Castro.
+ *
+ * Drop-in boundary.  The reference has no FFI for this
+ * path: the seam is the C++ member
+ *     void Castro::construct_ctu_hydro_source(amrex::Real time, amrex::Real dt)
+ *     (Source/hydro/Castro_hydro.H:44, body Source/hydro/Castro_ctu_hydro.cpp:16-1528),
+ * called from Castro::do_advance_ctu (Source/driver/Castro_advance_ctu.cpp:156).
+ * castro_amd_ctu_hydro_fab() replaces the body of its MFIter loop
+ * (Castro_ctu_hydro.cpp:130-1480) for ONE FArrayBox / tile; the other entry
+ * points replace the per-FAB sweeps the driver runs either side of it.
+ *
+ * Conventions
+ *  - Arrays are AMReX FArrayBox memory: Fortran order, i fastest, component
+ *    slowest, described by (pointer, lo[3], hi[3], ncomp) exactly like the
+ *    reference's legacy BL_FORT_FAB_ARG_3D convention
+ *    (Source/driver/Castro_F.H:19-34).  All pointers are DEVICE pointers
+ *    (hipMalloc / AMReX The_Arena() on a HIP build).  FP64 only.
+ *  - State layout is the Sedov build's: NUM_STATE = 8
+ *    (URHO UMX UMY UMZ UEDEN UEINT UTEMP UFS), one species.
+ *  - The caller owns every array for the duration of the call AND until the
+ *    stream is synchronised (the AMReX analogue is Elixir,
+ *    Castro_ctu_hydro.cpp:79-82).  The callee owns its scratch (the context).
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *    NULL = the default stream).  No call allocates or synchronises once the
+ *    context has been reserved for the tile size.
+ *  - Error convention: the reference aborts on CPU and is silent on GPU
+ *    (advection_util.cpp:56-68); here every entry point returns an int status
+ *    (0 = ok, <0 = bad argument / unsupported option) and never aborts.
+ *    Data-dependent failures (rho <= 0 met in ctoprim) are latched in a device
+ *    flag readable with castro_amd_ctx_status().
+ *  - A context is bound to one device and must be used from one stream at a
+ *    time (re-entrant per (device, stream): create one context per stream).
+ */
+#ifndef CASTRO_HYDRO_AMD_H
+#define CASTRO_HYDRO_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASTRO_AMD_NUM_STATE 8
+#define CASTRO_AMD_NGDNV 4
+#define CASTRO_AMD_NUM_GROW 4
+
+#define CASTRO_AMD_OK 0
+#define CASTRO_AMD_ERR_ARG (-1)
+#define CASTRO_AMD_ERR_UNSUPPORTED (-2)
+#define CASTRO_AMD_ERR_NOMEM (-3)
+#define CASTRO_AMD_ERR_HIP (-4)
+
+/* FArrayBox descriptor: fab.dataPtr(), fab.loVect(), fab.hiVect(), fab.nComp() [AMReX] */
+typedef struct castro_amd_fab {
+    double *p;
+    int lo[3];
+    int hi[3];
+    int ncomp;
+} castro_amd_fab;
+
+/* geom.data() + phys_bc (Castro::geom, Castro::phys_bc) */
+typedef struct castro_amd_geom {
+    double dx[3];        /* geom.CellSize() */
+    double problo[3];    /* geom.ProbLo() */
+    double probhi[3];    /* geom.ProbHi() */
+    int domlo[3];        /* geom.Domain().loVect() */
+    int domhi[3];        /* geom.Domain().hiVect() */
+    int lo_bc[3];        /* phys_bc.lo(): 0 Interior 1 Inflow 2 Outflow 3 Symmetry 4 SlipWall 5 NoSlipWall */
+    int hi_bc[3];        /* phys_bc.hi() */
+    int coord;           /* geom.Coord(); only 0 (Cartesian) is supported */
+} castro_amd_geom;
+
+/* the castro:: runtime parameters the path reads (Source/driver/_cpp_parameters) */
+typedef struct castro_amd_params {
+    int ppm_type;                 /* 1 = PPM (supported); 0 = PLM (unsupported yet) */
+    int riemann_solver;           /* 0 CGF (default), 1 CG, 2 HLLC */
+    int use_flattening;
+    int hybrid_riemann;
+    int first_order_hydro;
+    int cg_maxiter;
+    int cg_blend;                 /* 2 degrades to "keep last iterate" like the reference's GPU build */
+    int transverse_use_eos;
+    int transverse_reset_density;
+    int transverse_reset_rhoe;
+    int ppm_temp_fix;
+    int reserved_i[3];
+    double difmag;
+    double small_dens, small_temp, small_pres, small_ener;
+    double cg_tol;
+    double dual_energy_eta1, dual_energy_eta2;
+    double cfl, init_shrink, change_max;
+    double eos_gamma;             /* gamma-law EOS (Microphysics EOS/gamma_law) */
+    double small_x;
+    double T_guess;
+    double abar;                  /* mean molecular weight with eos_assume_neutral = 1 */
+} castro_amd_params;
+
+typedef struct castro_amd_ctx castro_amd_ctx;
+
+/* Fill `p` with the reference defaults for the Sedov setup (see _cpp_parameters
+ * and Exec/hydro_tests/Sedov/inputs.3d.sph*) and derive small_pres/small_ener
+ * like Castro_setup.cpp:222-288. */
+void castro_amd_default_params(castro_amd_params *p);
+void castro_amd_finalize_params(castro_amd_params *p);
+
+/* Context = scratch arena + device status word for one (device, stream). */
+int castro_amd_ctx_create(castro_amd_ctx **ctx, int device);
+void castro_amd_ctx_destroy(castro_amd_ctx *ctx);
+/* Pre-allocate scratch for tiles up to nx*ny*nz valid cells (hipMalloc happens
+ * here, never inside the calls below once reserved). */
+int castro_amd_ctx_reserve(castro_amd_ctx *ctx, int nx, int ny, int nz);
+/* Bytes of scratch currently held. */
+long long castro_amd_ctx_scratch_bytes(const castro_amd_ctx *ctx);
+/* Synchronises `stream`, returns and clears the latched device status bits:
+ * bit0 = rho <= 0 or rho < small_dens met in ctoprim (advection_util.cpp:56-68). */
+int castro_amd_ctx_status(castro_amd_ctx *ctx, void *stream);
+
+/* flags for castro_amd_ctu_hydro_fab */
+#define CASTRO_AMD_UPDATE_ADD 0      /* S_new += dt*div(F)...   (reference semantics: S_new holds a copy of Sborder) */
+#define CASTRO_AMD_UPDATE_FROM_SBORDER 1 /* S_new = Sborder + ... (elides MultiFab::Copy, Castro_advance_ctu.cpp:94) */
+
+/*
+ * The hot path: replaces the MFIter-loop body of Castro::construct_ctu_hydro_source
+ * (Source/hydro/Castro_ctu_hydro.cpp:130-1480) for the tile bx = [bxlo, bxhi].
+ *   vbxlo/vbxhi : valid box of the FAB the tile belongs to (mfi.validbox()); decides
+ *                 mfi.nodaltilebox(d) (which shared faces this tile stores). Pass bx for whole-box calls.
+ *   Sborder     : in, ncomp 8, box must contain grow(bx, 4)           (Castro::Sborder)
+ *   src         : in, old_source (ncomp 7, box contains grow(bx,3)); p == NULL means identically zero
+ *   S_new       : in/out on bx, ncomp 8                               (get_new_data(State_Type))
+ *   flux_out[d] : in/out, += dt*area*flux on nodaltilebox(d), ncomp 8 (Castro::fluxes[d]); p NULL to skip
+ *   mass_flux_out[d] : out, = scaled density flux, ncomp 1            (Castro::mass_fluxes[d]); p NULL to skip
+ *   qe_out[d]   : out (optional, p NULL to skip), Godunov state u,v,w,p on the same faces, ncomp 4 (qe[d])
+ */
+int castro_amd_ctu_hydro_fab(castro_amd_ctx *ctx,
+                             const int bxlo[3], const int bxhi[3],
+                             const int vbxlo[3], const int vbxhi[3],
+                             const castro_amd_fab *Sborder,
+                             const castro_amd_fab *src,
+                             const castro_amd_fab *S_new,
+                             const castro_amd_fab flux_out[3],
+                             const castro_amd_fab mass_flux_out[3],
+                             const castro_amd_fab qe_out[3],
+                             const castro_amd_geom *geom,
+                             const castro_amd_params *params,
+                             double time, double dt, int flags, void *stream);
+
+/* Castro::clean_state on one FAB region (Source/driver/Castro.cpp:4238-4278):
+ * enforce_min_density, normalize_species, reset_internal_energy, computeTemp,
+ * applied `ntimes` times in a row to every zone of [lo,hi] (the reference runs it
+ * up to three times back to back on the same zones between two hydro updates). */
+int castro_amd_clean_state_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
+                               const int lo[3], const int hi[3],
+                               const castro_amd_params *params, int ntimes, void *stream);
+
+/* Castro::estdt_cfl (Source/driver/timestep.cpp:31-140) and S_new.min(URHO)
+ * (Castro_advance_ctu.cpp:168) fused: d_out[0] = min over [lo,hi] of dx/(c+|u|)
+ * (NOT yet multiplied by cfl), d_out[1] = min density.  d_out is a device
+ * pointer to 2 doubles that the CALLER initialises (e.g. to +huge) so several
+ * FABs can reduce into the same words. */
+int castro_amd_estdt_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
+                         const int lo[3], const int hi[3], const castro_amd_geom *geom,
+                         const castro_amd_params *params, double *d_out, void *stream);
+
+/* Physical-boundary ghost fill of a grown state FAB (the GpuBndryFuncFab /
+ * ca_statefill part of AmrLevel::FillPatch: Source/problems/Castro_bc_fill_nd.cpp:11-125,
+ * BC tables Source/driver/Castro_setup.cpp:40-53). Fills every zone of the FAB
+ * outside the problem domain; x, then y, then z. */
+int castro_amd_bc_fill_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
+                           const castro_amd_geom *geom, void *stream);
+
+/* dst(lo:hi, 0:ncomp) = src(lo:hi, 0:ncomp) between two FABs (MultiFab::Copy /
+ * the same-level copy part of FillPatch). */
+int castro_amd_copy_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, const castro_amd_fab *src,
+                        const int lo[3], const int hi[3], void *stream);
+
+/* Pack / unpack a sub-box of a FAB to / from a contiguous buffer (same FAB
+ * ordering restricted to the sub-box): the halo staging used by the RCCL
+ * FillBoundary replacement. */
+int castro_amd_pack_fab(castro_amd_ctx *ctx, const castro_amd_fab *fab, const int lo[3], const int hi[3],
+                        double *buf, void *stream);
+int castro_amd_unpack_fab(castro_amd_ctx *ctx, const castro_amd_fab *fab, const int lo[3], const int hi[3],
+                          const double *buf, void *stream);
+
+/* Problem initial data on [lo,hi] of `state` (ncomp 8):
+ * Exec/hydro_tests/Sedov/problem_initialize.H:8-113 + problem_initialize_state_data.H:8-148 */
+int castro_amd_sedov_init_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, const int lo[3], const int hi[3],
+                              const castro_amd_geom *geom, const castro_amd_params *params,
+                              double r_init, double p_ambient, double exp_energy, double dens_ambient,
+                              int nsub, void *stream);
+/* Exec/hydro_tests/Sod/problem_initialize*.H (use_Tinit = 0); idir is 1-based */
+int castro_amd_sod_init_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, const int lo[3], const int hi[3],
+                            const castro_amd_geom *geom, const castro_amd_params *params,
+                            double rho_l, double u_l, double p_l, double rho_r, double u_r, double p_r,
+                            int idir, double frac, void *stream);
+
+/* Library/version introspection */
+const char *castro_amd_version(void);
+/* Name and average device time (ms) of the most recent launch of each hot-path
+ * kernel when profiling is enabled with castro_amd_ctx_profile(ctx, 1): the
+ * library brackets every kernel with hipEvents on `stream`. */
+int castro_amd_ctx_profile(castro_amd_ctx *ctx, int enable);
+int castro_amd_ctx_profile_count(castro_amd_ctx *ctx);
+int castro_amd_ctx_profile_get(castro_amd_ctx *ctx, int idx, char *name, int name_len,
+                               double *total_ms, long long *launches);
+void castro_amd_ctx_profile_reset(castro_amd_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
