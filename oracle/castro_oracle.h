@@ -145,6 +145,10 @@ int ora_construct_ctu_hydro_source(const int bxlo[3], const int bxhi[3], ora_a4 
                                    ora_a4 qe_out[3], const ora_geom *G, const ora_params *P,
                                    double time, double dt, const int tile[3], int nthreads);
 
+int ora_ctu_hydro_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], const int vhi[3],
+                       ora_a4 Sborder, ora_a4 src, ora_a4 S_new, ora_a4 flux_out[3], ora_a4 mass_flux_out[3],
+                       ora_a4 qe_out[3], const ora_geom *G, const ora_params *P, double dt);
+
 /* ---------------- state maintenance (Source/driver) ---------------- */
 void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_params *P);
 double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P);

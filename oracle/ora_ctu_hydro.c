@@ -328,3 +328,16 @@ int ora_construct_ctu_hydro_source(const int bxlo[3], const int bxhi[3], ora_a4 
     }
     return bad;
 }
+
+/* One tile of a larger valid box (what one C-ABI call of the HIP path computes): bx = tile,
+ * [vlo,vhi] = valid box of the FAB (decides mfi.nodaltilebox). */
+int ora_ctu_hydro_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], const int vhi[3],
+                       ora_a4 Sborder, ora_a4 src, ora_a4 S_new, ora_a4 flux_out[3], ora_a4 mass_flux_out[3],
+                       ora_a4 qe_out[3], const ora_geom *G, const ora_params *P, double dt)
+{
+    scratch_t S;
+    memset(&S, 0, sizeof(S));
+    int bad = ctu_tile(bxlo, bxhi, vlo, vhi, Sborder, src, S_new, flux_out, mass_flux_out, qe_out, G, P, dt, &S);
+    scratch_free(&S);
+    return bad;
+}

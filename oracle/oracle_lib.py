@@ -61,6 +61,10 @@ def lib():
         L.ora_construct_ctu_hydro_source.argtypes = [
             I3, I3, A4, A4, A4, C.POINTER(A4), C.POINTER(A4), C.POINTER(A4),
             C.POINTER(Geom), C.POINTER(Params), C.c_double, C.c_double, I3, C.c_int]
+        L.ora_ctu_hydro_tile.restype = C.c_int
+        L.ora_ctu_hydro_tile.argtypes = [I3, I3, I3, I3, A4, A4, A4, C.POINTER(A4), C.POINTER(A4), C.POINTER(A4),
+                                         C.POINTER(Geom), C.POINTER(Params), C.c_double]
+        L.ora_fill_interior_copy.argtypes = [A4, A4, I3, I3]
         L.ora_clean_state.argtypes = [I3, I3, A4, C.POINTER(Params)]
         L.ora_estdt_cfl.restype = C.c_double
         L.ora_estdt_cfl.argtypes = [I3, I3, A4, C.POINTER(Geom), C.POINTER(Params)]

@@ -1,0 +1,99 @@
+"""CPU stand-in for castro_amd.hydro.HipHydro, used ONLY by the tests.
+
+It exposes the same method set as HipHydro but works on CPU torch tensors and calls the
+oracle, so the driver logic of castro_amd.Castro (decomposition, FillPatch halo exchange,
+dt control, tile/shell splitting) can be exercised without a GPU and with the gloo backend.
+The product never imports this file.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import oracle_lib as O
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, nthreads=1):
+        self.nthreads = nthreads
+        self.device = torch.device("cpu")
+
+    # geometry/params of the oracle flavour (same field layout for the shared fields)
+    make_geom = staticmethod(lambda n, plo, phi, lbc, hbc: O.make_geom(n, plo, phi, lbc, hbc))
+
+    def alloc(self, ncomp, lo, hi, fill=0.0):
+        shape = (ncomp, hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
+        return torch.full(shape, fill, dtype=torch.float64)
+
+    @staticmethod
+    def _a4(t, box):
+        if t is None:
+            return O.a4(None, box[0], box[1])
+        return O.a4(t.numpy(), box[0], box[1])
+
+    def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
+                                   fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
+                                   update_from_sborder=False, src=None, src_box=None, stream=None):
+        L = O.lib()
+        vlo, vhi = vbx if vbx is not None else bx
+        fa, ma, qa = (O.A4 * 3)(), (O.A4 * 3)(), (O.A4 * 3)()
+        for d in range(3):
+            fbox = flux_boxes[d] if flux_boxes is not None else None
+            fa[d] = self._a4(fluxes[d] if fluxes is not None else None, fbox or bx)
+            ma[d] = self._a4(mass_fluxes[d] if mass_fluxes is not None else None, fbox or bx)
+            qa[d] = self._a4(qe[d] if qe is not None else None, fbox or bx)
+        sb, sn = self._a4(Sborder, sb_box), self._a4(S_new, snew_box)
+        if update_from_sborder:
+            L.ora_fill_interior_copy(sn, sb, O.i3(bx[0]), O.i3(bx[1]))
+        st = L.ora_ctu_hydro_tile(O.i3(bx[0]), O.i3(bx[1]), O.i3(vlo), O.i3(vhi), sb, O.a4(None, bx[0], bx[1]), sn,
+                                  fa, ma, qa, C.byref(geom), C.byref(params), float(dt))
+        assert st == 0
+
+    def clean_state(self, state, box, lo, hi, params, ntimes=1, stream=None):
+        for _ in range(ntimes):
+            O.lib().ora_clean_state(O.i3(lo), O.i3(hi), self._a4(state, box), C.byref(params))
+
+    def estdt_cfl(self, state, box, lo, hi, geom, params, out, stream=None):
+        a = self._a4(state, box)
+        e = O.lib().ora_estdt_cfl(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))
+        r = O.lib().ora_min_density(O.i3(lo), O.i3(hi), a)
+        out[0] = min(out[0].item(), e)
+        out[1] = min(out[1].item(), r)
+
+    def bc_fill(self, state, box, geom, stream=None):
+        O.lib().ora_bc_fill(self._a4(state, box), C.byref(geom))
+
+    @staticmethod
+    def _slices(box, lo, hi):
+        return (slice(None),) + tuple(slice(lo[2 - a] - box[0][2 - a], hi[2 - a] - box[0][2 - a] + 1) for a in range(3))
+
+    def pack(self, state, box, lo, hi, buf, stream=None):
+        buf.copy_(state[self._slices(box, lo, hi)].reshape(-1))
+
+    def unpack(self, state, box, lo, hi, buf, stream=None):
+        sl = self._slices(box, lo, hi)
+        state[sl] = buf.reshape(state[sl].shape)
+
+    def copy(self, dst, dst_box, src, src_box, lo, hi, stream=None):
+        dst[self._slices(dst_box, lo, hi)] = src[self._slices(src_box, lo, hi)]
+
+    def sedov_init(self, state, box, lo, hi, geom, params, r_init=0.01, p_ambient=1.e-5, exp_energy=1.0,
+                   dens_ambient=1.0, nsub=10, stream=None):
+        O.lib().ora_sedov_init(O.i3(lo), O.i3(hi), self._a4(state, box), C.byref(geom), C.byref(params),
+                               r_init, p_ambient, exp_energy, dens_ambient, nsub)
+
+    def sod_init(self, state, box, lo, hi, geom, params, rho_l, u_l, p_l, rho_r, u_r, p_r, idir=1, frac=0.5,
+                 stream=None):
+        O.lib().ora_sod_init(O.i3(lo), O.i3(hi), self._a4(state, box), C.byref(geom), C.byref(params),
+                             rho_l, u_l, p_l, rho_r, u_r, p_r, idir, frac)
+
+    def profile(self, enable=True):
+        pass
+
+    def profile_reset(self):
+        pass
+
+    def profile_report(self):
+        return {}

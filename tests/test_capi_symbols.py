@@ -1,0 +1,76 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds/loads without a GPU, exports
+every symbol include/castro_hydro_amd.h declares, agrees with the oracle on the host-side
+parameter logic, and FAILS LOUDLY (no CPU fallback) when there is no HIP device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from castro_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    from castro_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "castro_hydro_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(castro_amd_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+
+
+def test_struct_layouts_match_header():
+    from castro_amd import _lib
+    # sizes implied by the header (LP64): fab = 8 + 12 + 12 + 4 (+4 pad) = 40
+    assert C.sizeof(_lib.Fab) == 40
+    assert C.sizeof(_lib.Geom) == 3 * 24 + 4 * 12 + 4 + 4
+    assert C.sizeof(_lib.Params) == 14 * 4 + 15 * 8
+
+
+def test_default_params_agree_with_oracle(lib, oracle):
+    from castro_amd import _lib
+    p = _lib.default_params()
+    o = oracle.default_params()
+    for f, _ in _lib.Params._fields_:
+        if f == "reserved_i":
+            continue
+        assert getattr(p, f) == getattr(o, f), f
+    p2 = _lib.default_params(eos_gamma=5.0 / 3.0, cfl=0.8)
+    o2 = oracle.default_params(eos_gamma=5.0 / 3.0, cfl=0.8)
+    assert p2.small_ener == o2.small_ener and p2.small_pres == o2.small_pres and p2.cfl == 0.8
+    with pytest.raises(AttributeError):
+        _lib.default_params(no_such_field=1)
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.castro_amd_ctx_create(C.byref(h), 0)
+    assert rc != 0 and not h.value          # CASTRO_AMD_ERR_HIP: the C ABI refuses to run
+    import castro_amd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        castro_amd.HipHydro(0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        castro_amd.Castro((16, 16, 16))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under castro_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "castro_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
