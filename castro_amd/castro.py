@@ -322,14 +322,16 @@ class Castro:
             self.expand_state(S)
             self.construct_ctu_hydro_source(time, dt)
 
-        # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216), on the un-cleaned update
-        _, rho_min = self._reduce()
+        # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
+        # (:221-225) and the estTimeStep validity check (:386-392): one fused pass + one 2-double allreduce
+        self.red.fill_(1.e200)
+        h.clean_state_reduce(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, self.red, ntimes=1)
+        self.comm.allreduce_min(self.red)
+        est, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:
             raise AdvanceFailure("negative/small density after the hydro update: %g (retry not implemented)" % rho_min)
-        self.clean_state(self.S_new_b, 1)                              # :221-225
-        est, _ = self._reduce()
         new_dt = min(1.e200, est * self.params.cfl)
-        if self.params.change_max * new_dt < dt:                       # :386-392
+        if self.params.change_max * new_dt < dt:
             raise AdvanceFailure("timestep validity check failed (retry not implemented)")
         return new_dt
 

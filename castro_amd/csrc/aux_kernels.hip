@@ -34,10 +34,48 @@ struct Box3 { int lo[3]; int n[3]; };
 // Every stage is zone-local, so running the whole chain per zone is identical to the
 // reference's stage-by-stage sweeps.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P, int ntimes)
+__device__ __forceinline__ void atomic_min_double(double* addr, double v)
 {
-    int i, j, k;
-    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    unsigned long long* a = (unsigned long long*)addr;
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        if (__longlong_as_double((long long)assumed) <= v) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+}
+
+// block-wide min of two values (wave shuffle -> LDS -> one atomic per block)
+__device__ __forceinline__ void block_min2_atomic(double a, double b, double* out)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fmin(a, __shfl_down(a, off, 64));
+        b = fmin(b, __shfl_down(b, off, 64));
+    }
+    __shared__ double sa[4], sb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_min_double(out, fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3])));
+        atomic_min_double(out + 1, fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3])));
+    }
+}
+
+// REDUCE: also return [min dx/(c+|u|) of the CLEANED state, min density of the RAW state]
+// (Castro::estdt_cfl, timestep.cpp:31-140, and S_new.min(URHO), Castro_advance_ctu.cpp:168)
+// through one atomic pair per block.  Grid-stride so the number of atomics stays small.
+template <bool REDUCE>
+__global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P, int ntimes,
+                                                     double dx0, double dx1, double dx2, double* red)
+{
+    double dtmin = 1.e200, rmin_raw = 1.e300;
+    const long total = (long)b.n[0] * b.n[1] * b.n[2];
+    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
+    const int i = b.lo[0] + (int)(tid % b.n[0]);
+    const long rr = tid / b.n[0];
+    const int j = b.lo[1] + (int)(rr % b.n[1]);
+    const int k = b.lo[2] + (int)(rr / b.n[1]);
     const long c = fidx(U, i, j, k, 0);
     double rho = U.p[c + U.sn * URHO];
     double mx = U.p[c + U.sn * UMX];
@@ -47,6 +85,7 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     double eint = U.p[c + U.sn * UEINT];
     double temp = U.p[c + U.sn * UTEMP];
     double rX = U.p[c + U.sn * UFS];
+    if (REDUCE) rmin_raw = fmin(rmin_raw, rho);
 
     for (int it = 0; it < ntimes; ++it) {
         // enforce_min_density
@@ -105,6 +144,20 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     U.p[c + U.sn * UEINT] = eint;
     U.p[c + U.sn * UTEMP] = temp;
     U.p[c + U.sn * UFS] = rX;
+
+    if (REDUCE) {
+        double rhoInv = 1.0 / rho;
+        double e = eint * rhoInv;
+        double p = (P.gamma - 1.0) * rho * e;
+        double cs = sqrt(P.gamma * p / rho);
+        double ux = mx * rhoInv, uy = my * rhoInv, uz = mz * rhoInv;
+        double dt1 = dx0 / (cs + fabs(ux));
+        double dt2 = dx1 / (cs + fabs(uy));
+        double dt3 = dx2 / (cs + fabs(uz));
+        dtmin = fmin(dtmin, amin(amin(dt1, dt2), dt3));
+    }
+    }
+    if (REDUCE) block_min2_atomic(dtmin, rmin_raw, red);
 }
 
 int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,
@@ -115,7 +168,24 @@ int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const De
     for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
     if (n <= 0) return 0;
     prof_begin(prof, "k_clean_state", stream);
-    hipLaunchKernelGGL(k_clean_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, b, P, ntimes);
+    hipLaunchKernelGGL(k_clean_state<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, b, P, ntimes,
+                       0.0, 0.0, 0.0, (double*)nullptr);
+    prof_end(prof, stream);
+    return 0;
+}
+
+int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
+                              int ntimes, double* d_out, hipStream_t stream, Profiler* prof)
+{
+    Box3 b;
+    long n = 1;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
+    if (n <= 0) return 0;
+    long nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;            // 256 CUs x 8 blocks; grid-stride the rest
+    prof_begin(prof, "k_clean_state_reduce", stream);
+    hipLaunchKernelGGL(k_clean_state<true>, dim3((unsigned)nb), dim3(256), 0, stream, U, b, P, ntimes,
+                       g.dx[0], g.dx[1], g.dx[2], d_out);
     prof_end(prof, stream);
     return 0;
 }
@@ -124,23 +194,16 @@ int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const De
 // Castro::estdt_cfl (Source/driver/timestep.cpp:31-140) + S_new.min(URHO)
 // (Castro_advance_ctu.cpp:168): wave shuffle -> LDS -> one atomic per block
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void atomic_min_double(double* addr, double v)
-{
-    unsigned long long* a = (unsigned long long*)addr;
-    unsigned long long old = *a, assumed;
-    do {
-        assumed = old;
-        if (__longlong_as_double((long long)assumed) <= v) break;
-        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    } while (assumed != old);
-}
-
 __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, double dx1, double dx2,
                                                DevParams P, double* out)
 {
-    int i, j, k;
     double dtmin = 1.e200, rmin = 1.e300;
-    if (box_thread3(b.lo, b.n, i, j, k)) {
+    const long total = (long)b.n[0] * b.n[1] * b.n[2];
+    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
+        const int i = b.lo[0] + (int)(tid % b.n[0]);
+        const long rr = tid / b.n[0];
+        const int j = b.lo[1] + (int)(rr % b.n[1]);
+        const int k = b.lo[2] + (int)(rr / b.n[1]);
         const long c = fidx(U, i, j, k, 0);
         const double rho = U.p[c + U.sn * URHO];
         double rhoInv = 1.0 / rho;
@@ -156,24 +219,10 @@ __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, doubl
         double dt2 = dx1 / (cs + fabs(uy));
         double dt3 = dx2 / (cs + fabs(uz));
 
-        dtmin = amin(amin(dt1, dt2), dt3);
-        rmin = rho;
+        dtmin = fmin(dtmin, amin(amin(dt1, dt2), dt3));
+        rmin = fmin(rmin, rho);
     }
-    // wavefront (64 lanes) reduction
-    for (int off = 32; off > 0; off >>= 1) {
-        dtmin = fmin(dtmin, __shfl_down(dtmin, off, 64));
-        rmin = fmin(rmin, __shfl_down(rmin, off, 64));
-    }
-    __shared__ double sdt[4], srho[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sdt[wave] = dtmin; srho[wave] = rmin; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = fmin(fmin(sdt[0], sdt[1]), fmin(sdt[2], sdt[3]));
-        double r = fmin(fmin(srho[0], srho[1]), fmin(srho[2], srho[3]));
-        atomic_min_double(out, a);
-        atomic_min_double(out + 1, r);
-    }
+    block_min2_atomic(dtmin, rmin, out);
 }
 
 int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
@@ -183,8 +232,10 @@ int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom&
     long n = 1;
     for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
     if (n <= 0) return 0;
+    long nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
     prof_begin(prof, "k_estdt", stream);
-    hipLaunchKernelGGL(k_estdt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, b,
+    hipLaunchKernelGGL(k_estdt, dim3((unsigned)nb), dim3(256), 0, stream, U, b,
                        g.dx[0], g.dx[1], g.dx[2], P, d_out);
     prof_end(prof, stream);
     return 0;

@@ -302,6 +302,18 @@ int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, c
     return launch_clean_state(to_dfab(state), lo, hi, to_devparams(params), ntimes, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_clean_state_reduce_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
+                                      const castro_amd_geom* geom, const castro_amd_params* params, int ntimes,
+                                      double* d_out, void* stream)
+{
+    if (!c || !state || !state->p || !geom || !params || !d_out || state->ncomp != NUM_STATE || ntimes < 1)
+        return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_clean_state_reduce(to_dfab(state), lo, hi, to_devgeom(geom), to_devparams(params), ntimes, d_out,
+                                     (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_estdt_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
                          const castro_amd_geom* geom, const castro_amd_params* params, double* d_out, void* stream)
 {

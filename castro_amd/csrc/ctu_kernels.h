@@ -62,6 +62,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 // auxiliary per-FAB kernels (aux_kernels.hip)
 int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,
                        hipStream_t stream, Profiler* prof);
+int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
+                              int ntimes, double* d_out, hipStream_t stream, Profiler* prof);
 int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
                  double* d_out, hipStream_t stream, Profiler* prof);
 int launch_bc_fill(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const DevGeom& g,

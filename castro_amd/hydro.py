@@ -90,6 +90,13 @@ class HipHydro:
         L.check(self.lib.castro_amd_clean_state_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
                                                     C.byref(params), int(ntimes), _stream_ptr(stream)), "clean_state_fab")
 
+    def clean_state_reduce(self, state, box, lo, hi, geom, params, out, ntimes=1, stream=None):
+        """min-density check + clean_state + estdt in one pass (see castro_amd_clean_state_reduce_fab)."""
+        L.check(self.lib.castro_amd_clean_state_reduce_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),
+                                                           C.byref(geom), C.byref(params), int(ntimes),
+                                                           C.c_void_p(out.data_ptr()), _stream_ptr(stream)),
+                "clean_state_reduce_fab")
+
     # ---- Castro::estdt_cfl + S_new.min(URHO) -------------------------------------------------
     def estdt_cfl(self, state, box, lo, hi, geom, params, out, stream=None):
         """Reduces into `out` (device tensor of 2 doubles: [min dx/(c+|u|), min rho]); the caller

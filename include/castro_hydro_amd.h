@@ -151,6 +151,15 @@ int castro_amd_clean_state_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
                                const int lo[3], const int hi[3],
                                const castro_amd_params *params, int ntimes, void *stream);
 
+/* The post-hydro sequence of Castro::do_advance_ctu fused into one pass over the zones of [lo,hi]:
+ *   d_out[1] = min(d_out[1], min density of the state AS GIVEN)   (S_new.min(URHO), Castro_advance_ctu.cpp:168)
+ *   clean_state applied `ntimes` times                            (Castro_advance_ctu.cpp:221-225)
+ *   d_out[0] = min(d_out[0], min dx/(c+|u|) of the cleaned state) (estTimeStep, Castro_advance_ctu.cpp:386)
+ * d_out: device pointer to 2 doubles initialised by the caller (see castro_amd_estdt_fab). */
+int castro_amd_clean_state_reduce_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
+                                      const int lo[3], const int hi[3], const castro_amd_geom *geom,
+                                      const castro_amd_params *params, int ntimes, double *d_out, void *stream);
+
 /* Castro::estdt_cfl (Source/driver/timestep.cpp:31-140) and S_new.min(URHO)
  * (Castro_advance_ctu.cpp:168) fused: d_out[0] = min over [lo,hi] of dx/(c+|u|)
  * (NOT yet multiplied by cfl), d_out[1] = min density.  d_out is a device

@@ -55,6 +55,14 @@ class OracleBackend:
         for _ in range(ntimes):
             O.lib().ora_clean_state(O.i3(lo), O.i3(hi), self._a4(state, box), C.byref(params))
 
+    def clean_state_reduce(self, state, box, lo, hi, geom, params, out, ntimes=1, stream=None):
+        a = self._a4(state, box)
+        r = O.lib().ora_min_density(O.i3(lo), O.i3(hi), a)
+        self.clean_state(state, box, lo, hi, params, ntimes=ntimes)
+        e = O.lib().ora_estdt_cfl(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))
+        out[0] = min(out[0].item(), e)
+        out[1] = min(out[1].item(), r)
+
     def estdt_cfl(self, state, box, lo, hi, geom, params, out, stream=None):
         a = self._a4(state, box)
         e = O.lib().ora_estdt_cfl(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))

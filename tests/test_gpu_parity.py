@@ -204,6 +204,16 @@ def test_clean_state_estdt_bcfill_pack(hip, oracle):
             assert ne == 0, "clean_state x%d + bc_fill %s: %d differ (max rel %.3e)" % (ntimes, bcs, ne, rd)
             assert red[0].item() == est_o and red[1].item() == rmin_o
 
+            # fused post-hydro pass: raw min density + clean + estdt
+            Ud2 = _to_dev(hip, U)
+            red2 = torch.full((2,), 1e200, dtype=torch.float64, device=hip.device)
+            hip.clean_state_reduce(Ud2, (glo, ghi), lo, hi, Gh, Ph, red2, ntimes=ntimes)
+            torch.cuda.synchronize()
+            raw_min = oracle.lib().ora_min_density(oracle.i3(lo), oracle.i3(hi), oracle.a4(U.copy(), glo, ghi))
+            sl_v = (slice(None),) + tuple(slice(lo[2 - a] - glo[2 - a], hi[2 - a] - glo[2 - a] + 1) for a in range(3))
+            assert np.array_equal(Ud2.cpu().numpy()[sl_v], Uo[sl_v])
+            assert red2[0].item() == est_o and red2[1].item() == raw_min
+
     # pack / unpack round trip and copy
     Ud = _to_dev(hip, U)
     slo, shi = (2, -4, 3), (9, 1, 8)
