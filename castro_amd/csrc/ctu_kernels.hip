@@ -16,43 +16,64 @@
 //                                                                                   normalize_species_fluxes, scale_flux]
 //   k_consup       S_new (+)= dt*div(F) - dt*p*div(u) term                         [consup_hydro]
 //
-// All scratch arrays share ONE index space: the tile grown by 4 (same as Sborder), unit
-// stride along x, one plane of NC doubles per component (SoA) so every load/store of a
-// wavefront is a contiguous 512-byte run along the x pencil.
+// Data layout.  All scratch arrays share ONE index space: the tile grown by 4 (same as
+// Sborder), unit stride along x, one plane of NC doubles per component (SoA), so every
+// load/store of a wavefront is a contiguous 512-byte run along the x pencil.
+//
+// Addressing.  Every access is `uniform plane base (SGPR pair) + 32-bit byte offset
+// (one VGPR)`: the global_load/store "saddr" form.  A thread carries ONE offset for its
+// zone in the scratch space and one for its zone in each caller FAB; neighbours are
+// offset +- stride.  (64-bit per-access pointers cost two VGPRs and a v_lshl_add_u64 each.)
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hydro_device.h"
 #include "ctu_kernels.h"
 
 namespace cad {
 
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ long gidx(const Tile& t, int i, int j, int k)
+// addressing helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double ldg(const double* base, unsigned boff)
 {
-    return (long)(i - t.glo[0]) + (long)t.NX * ((long)(j - t.glo[1]) + (long)t.NY * (long)(k - t.glo[2]));
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ __forceinline__ void stg(double* base, unsigned boff, double v)
+{
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
 }
 
-__device__ __forceinline__ double fab_get(const DFab& f, int i, int j, int k, int n)
+// byte offset of zone (i,j,k) in the scratch index space / in a caller FAB
+__device__ __forceinline__ unsigned goff(const Tile& t, int i, int j, int k)
 {
-    return f.p[(long)(i - f.lo[0]) + f.sy * (long)(j - f.lo[1]) + f.sz * (long)(k - f.lo[2]) + f.sn * (long)n];
+    return 8u * ((unsigned)(i - t.glo[0]) + (unsigned)t.NX * ((unsigned)(j - t.glo[1]) + (unsigned)t.NY * (unsigned)(k - t.glo[2])));
 }
-__device__ __forceinline__ double* fab_ptr(const DFab& f, int i, int j, int k, int n)
+__device__ __forceinline__ unsigned foff(const DFab& f, int i, int j, int k)
 {
-    return f.p + ((long)(i - f.lo[0]) + f.sy * (long)(j - f.lo[1]) + f.sz * (long)(k - f.lo[2]) + f.sn * (long)n);
+    return 8u * ((unsigned)(i - f.lo[0]) + (unsigned)f.sy * ((unsigned)(j - f.lo[1])) + (unsigned)f.sz * (unsigned)(k - f.lo[2]));
 }
+// byte strides of the scratch space
+struct Str { unsigned x, y, z; };
+__device__ __forceinline__ Str gstr(const Tile& t) { return Str{ 8u, 8u * (unsigned)t.NX, 8u * (unsigned)t.NX * (unsigned)t.NY }; }
+__device__ __forceinline__ unsigned dstr(const Str& s, int d) { return d == 0 ? s.x : d == 1 ? s.y : s.z; }
 
-// decompose a linear thread id into a box position (x fastest)
+// one zone (or face) per thread, x fastest over the whole box: a wavefront touches one contiguous
+// 512-byte run per array plane.  (Brick-shaped workgroups, XCD-contiguous workgroup ids and
+// marching workgroups were all measured slower on MI355X: DESIGN.md "Launch shape".)
 __device__ __forceinline__ bool box_thread(const int lo[3], const int n[3], int& i, int& j, int& k)
 {
-    long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)n[0] * n[1] * n[2];
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned total = (unsigned)n[0] * (unsigned)n[1] * (unsigned)n[2];
     if (tid >= total) return false;
-    int ii = (int)(tid % n[0]);
-    long r = tid / n[0];
-    int jj = (int)(r % n[1]);
-    int kk = (int)(r / n[1]);
-    i = lo[0] + ii; j = lo[1] + jj; k = lo[2] + kk;
+    const unsigned ii = tid % (unsigned)n[0];
+    const unsigned r = tid / (unsigned)n[0];
+    i = lo[0] + (int)ii;
+    j = lo[1] + (int)(r % (unsigned)n[1]);
+    k = lo[2] + (int)(r / (unsigned)n[1]);
     return true;
 }
+
+struct LinBox { int lo[3], n[3]; };
 
 // ---------------------------------------------------------------------------------------
 // Castro::ctoprim (Source/hydro/advection_util.cpp:26-200) with the gamma-law EOS inlined
@@ -63,74 +84,75 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, DFab U, double* __restr
     int n[3] = { t.NX, t.NY, t.NZ };
     int i, j, k;
     if (!box_thread(lo, n, i, j, k)) return;
-    const long c = gidx(t, i, j, k);
+    const unsigned c = goff(t, i, j, k);
+    const unsigned cu = foff(U, i, j, k);
+    const long NC = t.NC;
 
-    const double rho = fab_get(U, i, j, k, URHO);
+    const double rho = ldg(U.p + URHO * U.sn, cu);
     if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
 
     const double rhoinv = 1.0 / rho;
-    const double u = fab_get(U, i, j, k, UMX) * rhoinv;
-    const double v = fab_get(U, i, j, k, UMY) * rhoinv;
-    const double w = fab_get(U, i, j, k, UMZ) * rhoinv;
+    const double u = ldg(U.p + UMX * U.sn, cu) * rhoinv;
+    const double v = ldg(U.p + UMY * U.sn, cu) * rhoinv;
+    const double w = ldg(U.p + UMZ * U.sn, cu) * rhoinv;
 
     const double kineng = 0.5 * rho * (u * u + v * v + w * w);
-    const double eden = fab_get(U, i, j, k, UEDEN);
+    const double eden = ldg(U.p + UEDEN * U.sn, cu);
 
     double e;
     if ((eden - kineng) > P.eta1 * eden) {
         e = (eden - kineng) * rhoinv;
     } else {
-        e = fab_get(U, i, j, k, UEINT) * rhoinv;
+        e = ldg(U.p + UEINT * U.sn, cu) * rhoinv;
     }
 
-    const double X = fab_get(U, i, j, k, UFS) * rhoinv;
+    const double X = ldg(U.p + UFS * U.sn, cu) * rhoinv;
 
     // eos(eos_input_re): p = (gamma-1) rho e ; cs = sqrt(gamma p / rho)
     const double p = (P.gamma - 1.0) * rho * e;
     const double cs = sqrt(P.gamma * p / rho);
 
-    Q[PRHO * t.NC + c] = rho;
-    Q[PU * t.NC + c] = u;
-    Q[PV * t.NC + c] = v;
-    Q[PW * t.NC + c] = w;
-    Q[PP * t.NC + c] = p;
-    Q[PRE * t.NC + c] = e * rho;
-    Q[PX * t.NC + c] = X;
-    Q[PC * t.NC + c] = cs;
+    stg(Q + PRHO * NC, c, rho);
+    stg(Q + PU * NC, c, u);
+    stg(Q + PV * NC, c, v);
+    stg(Q + PW * NC, c, w);
+    stg(Q + PP * NC, c, p);
+    stg(Q + PRE * NC, c, e * rho);
+    stg(Q + PX * NC, c, X);
+    stg(Q + PC * NC, c, cs);
 }
 
 // ---------------------------------------------------------------------------------------
 // Castro::divu, 3-D branch (Source/hydro/advection_util.cpp:458-475), nodes of grow(bx,1)
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_divu(Tile t, const double* __restrict__ Q, double* __restrict__ DIV,
+__global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
                                               double dxinv, double dyinv, double dzinv)
 {
-    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
-    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
     int i, j, k;
-    if (!box_thread(lo, n, i, j, k)) return;
-    const long c = gidx(t, i, j, k);
-    const long sx = 1, sy = t.NX, sz = (long)t.NX * t.NY;
+    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    const unsigned c = goff(t, i, j, k);
+    const Str s = gstr(t);
+    const unsigned sx = s.x, sy = s.y, sz = s.z;
     const double* QU_ = Q + PU * t.NC;
     const double* QV_ = Q + PV * t.NC;
     const double* QW_ = Q + PW * t.NC;
 
-    double ux = 0.25 * (QU_[c] - QU_[c - sx] +
-                        QU_[c - sz] - QU_[c - sx - sz] +
-                        QU_[c - sy] - QU_[c - sx - sy] +
-                        QU_[c - sy - sz] - QU_[c - sx - sy - sz]) * dxinv;
+    double ux = 0.25 * (ldg(QU_, c) - ldg(QU_, c - sx) +
+                        ldg(QU_, c - sz) - ldg(QU_, c - sx - sz) +
+                        ldg(QU_, c - sy) - ldg(QU_, c - sx - sy) +
+                        ldg(QU_, c - sy - sz) - ldg(QU_, c - sx - sy - sz)) * dxinv;
 
-    double vy = 0.25 * (QV_[c] - QV_[c - sy] +
-                        QV_[c - sz] - QV_[c - sy - sz] +
-                        QV_[c - sx] - QV_[c - sx - sy] +
-                        QV_[c - sx - sz] - QV_[c - sx - sy - sz]) * dyinv;
+    double vy = 0.25 * (ldg(QV_, c) - ldg(QV_, c - sy) +
+                        ldg(QV_, c - sz) - ldg(QV_, c - sy - sz) +
+                        ldg(QV_, c - sx) - ldg(QV_, c - sx - sy) +
+                        ldg(QV_, c - sx - sz) - ldg(QV_, c - sx - sy - sz)) * dyinv;
 
-    double wz = 0.25 * (QW_[c] - QW_[c - sz] +
-                        QW_[c - sy] - QW_[c - sy - sz] +
-                        QW_[c - sx] - QW_[c - sx - sz] +
-                        QW_[c - sx - sy] - QW_[c - sx - sy - sz]) * dzinv;
+    double wz = 0.25 * (ldg(QW_, c) - ldg(QW_, c - sz) +
+                        ldg(QW_, c - sy) - ldg(QW_, c - sy - sz) +
+                        ldg(QW_, c - sx) - ldg(QW_, c - sx - sz) +
+                        ldg(QW_, c - sx - sy) - ldg(QW_, c - sx - sy - sz)) * dzinv;
 
-    DIV[c] = ux + vy + wz;
+    stg(DIV, c, ux + vy + wz);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -138,7 +160,7 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, const double* __restrict__
 // (trace_ppm.cpp:15-594, no sources) for the three directions of one zone of grow(bx,1).
 // ---------------------------------------------------------------------------------------
 template <int D>
-__device__ __forceinline__ void trace_dir(const Tile& t, const double* __restrict__ Q, long c, long sd,
+__device__ __forceinline__ void trace_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd,
                                           double flat, double dtdx, const DevParams& P,
                                           bool do_plus, bool do_minus,
                                           double* __restrict__ QMd, double* __restrict__ QPd)
@@ -149,13 +171,13 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
     constexpr int QUTT = (D == 0) ? PW : (D == 1) ? PU : PV;
 
     const long NC = t.NC;
-    const double cc = Q[PC * NC + c];
-    const double un = Q[QUN * NC + c];
+    const double cc = ldg(Q + PC * NC, c);
+    const double un = ldg(Q + QUN * NC, c);
 
     double s[5], sm, sp, s6;
 
-#define LOAD5(comp) { const double* a = Q + (long)(comp) * NC + c; \
-        s[0] = a[-2 * sd]; s[1] = a[-sd]; s[2] = a[0]; s[3] = a[sd]; s[4] = a[2 * sd]; }
+#define LOAD5(comp) { const double* a = Q + (long)(comp) * NC; \
+        s[0] = ldg(a, c - 2 * sd); s[1] = ldg(a, c - sd); s[2] = ldg(a, c); s[3] = ldg(a, c + sd); s[4] = ldg(a, c + 2 * sd); }
 
     // density: three waves
     double Ip_rho0, Im_rho0, Ip_rho1, Im_rho1, Ip_rho2, Im_rho2;
@@ -251,13 +273,13 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         alpha0r = un > 0.0 ? 0.0 : -alpha0r;
         alpha0e_g = un > 0.0 ? 0.0 : -alpha0e_g;
 
-        QPd[PRHO * NC + c] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
-        QPd[QUN * NC + c] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
-        QPd[PRE * NC + c] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
-        QPd[PP * NC + c] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
-        QPd[QUT * NC + c] = Im_ut;
-        QPd[QUTT * NC + c] = Im_utt;
-        QPd[PX * NC + c] = Im_X;
+        stg(QPd + PRHO * NC, c, amax(P.small_dens, rho_ref + alphap + alpham + alpha0r));
+        stg(QPd + QUN * NC, c, un_ref + (alphap - alpham) * cc_ref * rho_ref_inv);
+        stg(QPd + PRE * NC, c, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
+        stg(QPd + PP * NC, c, amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref));
+        stg(QPd + QUT * NC, c, Im_ut);
+        stg(QPd + QUTT * NC, c, Im_utt);
+        stg(QPd + PX * NC, c, Im_X);
     }
 
     if (do_minus) {
@@ -296,76 +318,80 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         alpha0r = un > 0.0 ? -alpha0r : 0.0;
         alpha0e_g = un > 0.0 ? -alpha0e_g : 0.0;
 
-        const long cp = c + sd;
-        QMd[PRHO * NC + cp] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
-        QMd[QUN * NC + cp] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
-        QMd[PRE * NC + cp] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
-        QMd[PP * NC + cp] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
-        QMd[QUT * NC + cp] = Ip_ut;
-        QMd[QUTT * NC + cp] = Ip_utt;
-        QMd[PX * NC + cp] = Ip_X;
+        const unsigned cp = c + sd;
+        stg(QMd + PRHO * NC, cp, amax(P.small_dens, rho_ref + alphap + alpham + alpha0r));
+        stg(QMd + QUN * NC, cp, un_ref + (alphap - alpham) * cc_ref * rho_ref_inv);
+        stg(QMd + PRE * NC, cp, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
+        stg(QMd + PP * NC, cp, amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref));
+        stg(QMd + QUT * NC, cp, Ip_ut);
+        stg(QMd + QUTT * NC, cp, Ip_utt);
+        stg(QMd + PX * NC, cp, Ip_X);
     }
 }
 
-__global__ void __launch_bounds__(256) k_trace(Tile t, const double* __restrict__ Q, DevScratch S,
+__global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
                                                double dtdx0, double dtdx1, double dtdx2, DevParams P)
 {
-    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
-    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
     int i, j, k;
-    if (!box_thread(lo, n, i, j, k)) return;
-    const long c = gidx(t, i, j, k);
-    const long sx = 1, sy = t.NX, sz = (long)t.NX * t.NY;
+    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    const unsigned c = goff(t, i, j, k);
+    const Str s = gstr(t);
 
     // flattening coefficient of this zone (Castro_ctu_hydro.cpp:228-266)
     double flat;
     if (P.first_order_hydro == 1) {
         flat = 0.0;
     } else if (P.use_flattening == 1) {
-        const double* Pp = Q + PP * t.NC + c;
+        const double* Pp = Q + PP * t.NC;
         double pv[7], uv[5];
         {
-            const double* Uu = Q + PU * t.NC + c;
-            for (int m = -3; m <= 3; ++m) pv[m + 3] = Pp[m * sx];
-            for (int m = -2; m <= 2; ++m) uv[m + 2] = Uu[m * sx];
+            const double* Uu = Q + PU * t.NC;
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) pv[m + 3] = ldg(Pp, c + m * s.x);
+#pragma unroll
+            for (int m = -2; m <= 2; ++m) uv[m + 2] = ldg(Uu, c + m * s.x);
             flat = flatten_1d(pv, uv);
         }
         {
-            const double* Uu = Q + PV * t.NC + c;
-            for (int m = -3; m <= 3; ++m) pv[m + 3] = Pp[m * sy];
-            for (int m = -2; m <= 2; ++m) uv[m + 2] = Uu[m * sy];
+            const double* Uu = Q + PV * t.NC;
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) pv[m + 3] = ldg(Pp, c + m * s.y);
+#pragma unroll
+            for (int m = -2; m <= 2; ++m) uv[m + 2] = ldg(Uu, c + m * s.y);
             flat = amin(flat, flatten_1d(pv, uv));
         }
         {
-            const double* Uu = Q + PW * t.NC + c;
-            for (int m = -3; m <= 3; ++m) pv[m + 3] = Pp[m * sz];
-            for (int m = -2; m <= 2; ++m) uv[m + 2] = Uu[m * sz];
+            const double* Uu = Q + PW * t.NC;
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) pv[m + 3] = ldg(Pp, c + m * s.z);
+#pragma unroll
+            for (int m = -2; m <= 2; ++m) uv[m + 2] = ldg(Uu, c + m * s.z);
             flat = amin(flat, flatten_1d(pv, uv));
         }
     } else {
         flat = 1.0;
     }
 
-    trace_dir<0>(t, Q, c, sx, flat, dtdx0, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
-    trace_dir<1>(t, Q, c, sy, flat, dtdx1, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
-    trace_dir<2>(t, Q, c, sz, flat, dtdx2, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+    trace_dir<0>(t, Q, c, s.x, flat, dtdx0, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+    trace_dir<1>(t, Q, c, s.y, flat, dtdx1, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+    trace_dir<2>(t, Q, c, s.z, flat, dtdx2, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
 }
 
 // ---------------------------------------------------------------------------------------
 // helpers shared by the Riemann stages
 // ---------------------------------------------------------------------------------------
 template <int D>
-__device__ __forceinline__ void load_rstate(const double* __restrict__ E, long NC, long c, double gamc,
+__device__ __forceinline__ void load_rstate(const double* __restrict__ E, long NC, unsigned c, double gamc,
                                             RState& q, double& X)
 {
-    q.rho = E[PRHO * NC + c];
-    q.un = E[(PU + RDir<D>::n) * NC + c];
-    q.ut = E[(PU + RDir<D>::t) * NC + c];
-    q.utt = E[(PU + RDir<D>::tt) * NC + c];
-    q.p = E[PP * NC + c];
-    q.rhoe = E[PRE * NC + c];
+    q.rho = ldg(E + PRHO * NC, c);
+    q.un = ldg(E + (PU + RDir<D>::n) * NC, c);
+    q.ut = ldg(E + (PU + RDir<D>::t) * NC, c);
+    q.utt = ldg(E + (PU + RDir<D>::tt) * NC, c);
+    q.p = ldg(E + PP * NC, c);
+    q.rhoe = ldg(E + PRE * NC, c);
     q.gamc = gamc;
-    X = E[PX * NC + c];
+    X = ldg(E + PX * NC, c);
 }
 
 template <int D>
@@ -388,54 +414,132 @@ __device__ __forceinline__ double wall_fac(const DevGeom& g, int idx)
     return ((idx == g.domlo[D] && g.wall_lo[D]) || (idx == g.domhi[D] + 1 && g.wall_hi[D])) ? 0.0 : 1.0;
 }
 
-// write a transverse-stage flux record at face index c (global component order)
+// write a transverse-stage flux record at face offset c (global component order)
 template <int D>
-__device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, long c, const IFlux& f)
+__device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsigned c, const IFlux& f)
 {
-    F[FRHO * NC + c] = f.rho;
-    F[(FMX + RDir<D>::n) * NC + c] = f.mn;
-    F[(FMX + RDir<D>::t) * NC + c] = f.mt;
-    F[(FMX + RDir<D>::tt) * NC + c] = f.mtt;
-    F[FE * NC + c] = f.E;
-    F[FX * NC + c] = f.X;
-    F[FUG * NC + c] = f.ugd;
-    F[FPG * NC + c] = f.pgd;
+    stg(F + FRHO * NC, c, f.rho);
+    stg(F + (FMX + RDir<D>::n) * NC, c, f.mn);
+    stg(F + (FMX + RDir<D>::t) * NC, c, f.mt);
+    stg(F + (FMX + RDir<D>::tt) * NC, c, f.mtt);
+    stg(F + FE * NC, c, f.E);
+    stg(F + FX * NC, c, f.X);
+    stg(F + FUG * NC, c, f.ugd);
+    stg(F + FPG * NC, c, f.pgd);
 }
 
-__device__ __forceinline__ void load_f1(const double* __restrict__ F, long NC, long c, double r[NF1])
+__device__ __forceinline__ void load_f1(const double* __restrict__ F, long NC, unsigned c, double r[NF1])
 {
 #pragma unroll
-    for (int n = 0; n < NF1; ++n) r[n] = F[(long)n * NC + c];
+    for (int n = 0; n < NF1; ++n) r[n] = ldg(F + (long)n * NC, c);
 }
+
+__device__ __forceinline__ void load_edge(const double* __restrict__ E, long NC, unsigned c, double q[NEDGE])
+{
+#pragma unroll
+    for (int n = 0; n < NEDGE; ++n) q[n] = ldg(E + (long)n * NC, c);
+}
+
+__host__ __device__ constexpr int f2_slot(int N, int T) { return N * 2 + ((T > N) ? T - 1 : T); }
 
 // ---------------------------------------------------------------------------------------
 // first Riemann solves: F^x, F^y, F^z on grow(nodal(bx,D), 1 in both transverse directions)
 // (Castro_ctu_hydro.cpp:719, :796, :875)
 // ---------------------------------------------------------------------------------------
 template <int D>
-__global__ void __launch_bounds__(256) k_riemann1(Tile t, const double* __restrict__ Q, DevScratch S,
+__global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
                                                   DevGeom g, DevParams P)
 {
-    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
-    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
-    lo[D] = t.lo[D];
-    n[D] = t.hi[D] - t.lo[D] + 2;
     int i, j, k;
-    if (!box_thread(lo, n, i, j, k)) return;
-    const long c = gidx(t, i, j, k);
-    const long sd = (D == 0) ? 1 : (D == 1) ? (long)t.NX : (long)t.NX * t.NY;
+    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    const unsigned c = goff(t, i, j, k);
+    const unsigned sd = dstr(gstr(t), D);
     const int idx = (D == 0) ? i : (D == 1) ? j : k;
 
     RState ql, qr;
     double Xl, Xr;
     load_rstate<D>(S.QM[D], t.NC, c, P.gamma, ql, Xl);
     load_rstate<D>(S.QP[D], t.NC, c, P.gamma, qr, Xr);
-    const double cl = Q[PC * t.NC + c - sd];
-    const double cr = Q[PC * t.NC + c];
+    const double cl = ldg(Q + PC * t.NC, c - sd);
+    const double cr = ldg(Q + PC * t.NC, c);
 
     IFlux f;
     interface_flux(ql, qr, Xl, Xr, cl, cr, wall_fac<D>(g, idx), P, f);
     store_f1<D>(S.F1[D], t.NC, c, f);
+}
+
+// shared tail of the final stage: flux in conserved order, artificial viscosity, species
+// normalisation, storage for consup, scaling and accumulation
+//   (Castro_ctu_hydro.cpp:1192-1243, 1322-1433; apply_av advection_util.cpp:482-528;
+//    normalize_species_fluxes :577-613; scale_flux :616-641)
+template <int N>
+__device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch& S, const IFlux& f, unsigned c,
+                                                unsigned s1, unsigned s2, const DFab& U, unsigned cu, unsigned un_,
+                                                const DFab& fluxes, const DFab& mass, const DFab& qe,
+                                                int i, int j, int k, int idxN, double dt, double area, double dxn,
+                                                int acc_hi, const DevParams& P)
+{
+    const long NC = t.NC;
+    double F[NUM_STATE];
+    F[URHO] = f.rho;
+    F[UMX + RDir<N>::n] = f.mn;
+    F[UMX + RDir<N>::t] = f.mt;
+    F[UMX + RDir<N>::tt] = f.mtt;
+    F[UEDEN] = f.E;
+    F[UEINT] = f.eint;
+    F[UTEMP] = 0.0;                       // Castro_ctu_hydro.cpp:1201
+    F[UFS] = f.X;
+
+    {
+        const double* DIV = S.DIV;
+        double div1 = 0.25 * (ldg(DIV, c) + ldg(DIV, c + s1) + ldg(DIV, c + s2) + ldg(DIV, c + s1 + s2));
+        div1 = P.difmag * amin(0.0, div1);
+#pragma unroll
+        for (int m = 0; m < NUM_STATE; ++m) {
+            if (m == UTEMP) continue;
+            double d1 = div1 * (ldg(U.p + m * U.sn, cu) - ldg(U.p + m * U.sn, cu - un_));
+            F[m] += dxn * d1;
+        }
+    }
+
+    {
+        double sum = 0.0;
+        sum += F[UFS];
+        double fac = 1.0;
+        if (fabs(sum) > 2.220446049250313e-16 * fabs(F[URHO])) fac = F[URHO] / sum;
+        F[UFS] = F[UFS] * fac;
+    }
+
+    double* FL = S.FL[N];
+    stg(FL + GRHO * NC, c, F[URHO]);
+    stg(FL + GMX * NC, c, F[UMX]);
+    stg(FL + GMY * NC, c, F[UMY]);
+    stg(FL + GMZ * NC, c, F[UMZ]);
+    stg(FL + GE * NC, c, F[UEDEN]);
+    stg(FL + GEI * NC, c, F[UEINT]);
+    stg(FL + GX * NC, c, F[UFS]);
+    stg(FL + GUG * NC, c, f.ugd);
+    stg(FL + GPG * NC, c, f.pgd);
+
+    if (idxN <= acc_hi) {
+        if (fluxes.p) {
+            const unsigned cf = foff(fluxes, i, j, k);
+#pragma unroll
+            for (int m = 0; m < NUM_STATE; ++m) {
+                if (m == UTEMP) continue;       // += dt*0*area leaves the register unchanged
+                double* dst = fluxes.p + m * fluxes.sn;
+                stg(dst, cf, ldg(dst, cf) + dt * F[m] * area);
+            }
+        }
+        if (mass.p) stg(mass.p, foff(mass, i, j, k), dt * F[URHO] * area);
+        if (qe.p) {
+            const unsigned cq = foff(qe, i, j, k);
+            stg(qe.p + (GDU + RDir<N>::n) * qe.sn, cq, f.ugd);
+            stg(qe.p + (GDU + RDir<N>::t) * qe.sn, cq, f.ut);
+            stg(qe.p + (GDU + RDir<N>::tt) * qe.sn, cq, f.utt);
+            stg(qe.p + GDPRES * qe.sn, cq, f.pgd);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -444,21 +548,19 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, const double* __restri
 //   F2 slot (N|T): flux in direction N from states corrected with the T-direction flux.
 // (Castro_ctu_hydro.cpp:724-945 for the corrections, :949-1135 for the six solves)
 // ---------------------------------------------------------------------------------------
-__host__ __device__ constexpr int f2_slot(int N, int T) { return N * 2 + ((T > N) ? T - 1 : T); }
-
 template <int N, int T>
-__device__ __forceinline__ void trans1_pair(const Tile& t, const double* __restrict__ Q, const DevScratch& S,
-                                            long c, long sn, long st, const double qm[NEDGE], const double qp[NEDGE],
+__device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, unsigned c, unsigned sn, unsigned st,
+                                            const double qm[NEDGE], const double qp[NEDGE],
                                             double cl, double cr, double bnd_fac, double cdtdx, const DevParams& P)
 {
     double fr[NF1], fl[NF1], qmo[NEDGE], qpo[NEDGE];
 
-    // minus state lives in cell c - sn; its T-faces are (c - sn) and (c - sn + st)
+    // minus state lives in zone c - sn; its T-faces are (c - sn) and (c - sn + st)
     load_f1(S.F1[T], t.NC, c - sn + st, fr);
     load_f1(S.F1[T], t.NC, c - sn, fl);
     trans_single<T>(qm, fr, fl, P.gamma, cdtdx, P, qmo);
 
-    // plus state lives in cell c
+    // plus state lives in zone c
     load_f1(S.F1[T], t.NC, c + st, fr);
     load_f1(S.F1[T], t.NC, c, fl);
     trans_single<T>(qp, fr, fl, P.gamma, cdtdx, P, qpo);
@@ -474,20 +576,16 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const double* __restr
 }
 
 template <int N>
-__global__ void __launch_bounds__(256) k_trans1(Tile t, const double* __restrict__ Q, DevScratch S, DevGeom g,
+__global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                 double cdtdx_t1, double cdtdx_t2, DevParams P)
 {
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
-    int lo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
-    int n[3] = { t.hi[0] - t.lo[0] + 3, t.hi[1] - t.lo[1] + 3, t.hi[2] - t.lo[2] + 3 };
-    lo[N] = t.lo[N];
-    n[N] = t.hi[N] - t.lo[N] + 2;
     int ijk[3];
-    if (!box_thread(lo, n, ijk[0], ijk[1], ijk[2])) return;
-    const long c = gidx(t, ijk[0], ijk[1], ijk[2]);
-    const long str[3] = { 1, (long)t.NX, (long)t.NX * t.NY };
-    const long sn = str[N];
+    if (!box_thread(b.lo, b.n, ijk[0], ijk[1], ijk[2])) return;
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    const Str s = gstr(t);
+    const unsigned sn = dstr(s, N);
 
     // the (N|T1) states exist where the T1 index is inside bx (T2 index may be in the 1-ring)
     const bool in_t1 = ijk[T1] >= t.lo[T1] && ijk[T1] <= t.hi[T1];
@@ -495,41 +593,29 @@ __global__ void __launch_bounds__(256) k_trans1(Tile t, const double* __restrict
     if (!in_t1 && !in_t2) return;
 
     double qm[NEDGE], qp[NEDGE];
-#pragma unroll
-    for (int m = 0; m < NEDGE; ++m) {
-        qm[m] = S.QM[N][(long)m * t.NC + c];
-        qp[m] = S.QP[N][(long)m * t.NC + c];
-    }
-    const double cl = Q[PC * t.NC + c - sn];
-    const double cr = Q[PC * t.NC + c];
+    load_edge(S.QM[N], t.NC, c, qm);
+    load_edge(S.QP[N], t.NC, c, qp);
+    const double cl = ldg(Q + PC * t.NC, c - sn);
+    const double cr = ldg(Q + PC * t.NC, c);
     const double bnd_fac = wall_fac<N>(g, ijk[N]);
 
-    if (in_t1) trans1_pair<N, T1>(t, Q, S, c, sn, str[T1], qm, qp, cl, cr, bnd_fac, cdtdx_t1, P);
-    if (in_t2) trans1_pair<N, T2>(t, Q, S, c, sn, str[T2], qm, qp, cl, cr, bnd_fac, cdtdx_t2, P);
+    if (in_t1) trans1_pair<N, T1>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, P);
+    if (in_t2) trans1_pair<N, T2>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, P);
 }
 
-// ---------------------------------------------------------------------------------------
-// final stage for normal direction N: trans_final on both edge states, final Riemann
-// solve, artificial viscosity, species-flux normalisation, flux scaling and accumulation.
-// (Castro_ctu_hydro.cpp:990-1026 / 1068-1106 / 1148-1186, 1192-1243, 1322-1433)
-// ---------------------------------------------------------------------------------------
 template <int N>
-__global__ void __launch_bounds__(256) k_final(Tile t, const double* __restrict__ Q, DevScratch S, DevGeom g,
+__global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
                                                int acc_hi, DevParams P)
 {
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
-    int lo[3] = { t.lo[0], t.lo[1], t.lo[2] };
-    int n[3] = { t.hi[0] - t.lo[0] + 1, t.hi[1] - t.lo[1] + 1, t.hi[2] - t.lo[2] + 1 };
-    n[N] += 1;
     int ijk[3];
-    if (!box_thread(lo, n, ijk[0], ijk[1], ijk[2])) return;
-    const int i = ijk[0], j = ijk[1], k = ijk[2];
-    const long c = gidx(t, i, j, k);
-    const long str[3] = { 1, (long)t.NX, (long)t.NX * t.NY };
-    const long sn = str[N], s1 = str[T1], s2 = str[T2];
+    if (!box_thread(b.lo, b.n, ijk[0], ijk[1], ijk[2])) return;
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    const Str s = gstr(t);
+    const unsigned sn = dstr(s, N), s1 = dstr(s, T1), s2 = dstr(s, T2);
     const long NC = t.NC;
 
     double q[NEDGE], ql[NEDGE], qr[NEDGE];
@@ -537,18 +623,16 @@ __global__ void __launch_bounds__(256) k_final(Tile t, const double* __restrict_
     const double* F12 = S.F2[f2_slot(T1, T2)];   // F^{T1|T2}: flux_t1
     const double* F21 = S.F2[f2_slot(T2, T1)];   // F^{T2|T1}: flux_t2
 
-    // minus state (cell c - sn)
-#pragma unroll
-    for (int m = 0; m < NEDGE; ++m) q[m] = S.QM[N][(long)m * NC + c];
+    // minus state (zone c - sn)
+    load_edge(S.QM[N], NC, c, q);
     load_f1(F12, NC, c - sn + s1, f1r);
     load_f1(F12, NC, c - sn, f1l);
     load_f1(F21, NC, c - sn + s2, f2r);
     load_f1(F21, NC, c - sn, f2l);
     trans_final(q, f1r, f1l, f2r, f2l, P.gamma, hdtdx_t1, hdtdx_t2, P, ql);
 
-    // plus state (cell c)
-#pragma unroll
-    for (int m = 0; m < NEDGE; ++m) q[m] = S.QP[N][(long)m * NC + c];
+    // plus state (zone c)
+    load_edge(S.QP[N], NC, c, q);
     load_f1(F12, NC, c + s1, f1r);
     load_f1(F12, NC, c, f1l);
     load_f1(F21, NC, c + s2, f2r);
@@ -559,139 +643,74 @@ __global__ void __launch_bounds__(256) k_final(Tile t, const double* __restrict_
     double Xl, Xr;
     rstate_from_edge<N>(ql, P.gamma, rl, Xl);
     rstate_from_edge<N>(qr, P.gamma, rr, Xr);
-    const double cl = Q[PC * NC + c - sn];
-    const double cr = Q[PC * NC + c];
+    const double cl = ldg(Q + PC * NC, c - sn);
+    const double cr = ldg(Q + PC * NC, c);
 
     IFlux f;
     interface_flux(rl, rr, Xl, Xr, cl, cr, wall_fac<N>(g, ijk[N]), P, f);
 
-    // flux in conserved-component order
-    double F[NUM_STATE];
-    F[URHO] = f.rho;
-    F[UMX + RDir<N>::n] = f.mn;
-    F[UMX + RDir<N>::t] = f.mt;
-    F[UMX + RDir<N>::tt] = f.mtt;
-    F[UEDEN] = f.E;
-    F[UEINT] = f.eint;
-    F[UTEMP] = 0.0;                       // Castro_ctu_hydro.cpp:1201
-    F[UFS] = f.X;
-
-    // apply_av (advection_util.cpp:482-528)
-    {
-        const double* DIV = S.DIV;
-        double div1 = 0.25 * (DIV[c] + DIV[c + s1] + DIV[c + s2] + DIV[c + s1 + s2]);
-        div1 = P.difmag * amin(0.0, div1);
-        const int im = i - (N == 0), jm = j - (N == 1), km = k - (N == 2);
-#pragma unroll
-        for (int m = 0; m < NUM_STATE; ++m) {
-            if (m == UTEMP) continue;
-            double d1 = div1 * (fab_get(U, i, j, k, m) - fab_get(U, im, jm, km, m));
-            F[m] += dxn * d1;
-        }
-    }
-
-    // normalize_species_fluxes (advection_util.cpp:577-613), NumSpec = 1
-    {
-        double sum = 0.0;
-        sum += F[UFS];
-        double fac = 1.0;
-        if (fabs(sum) > 2.220446049250313e-16 * fabs(F[URHO])) {
-            fac = F[URHO] / sum;
-        }
-        F[UFS] = F[UFS] * fac;
-    }
-
-    // keep the unscaled flux + Godunov (un, p) for consup_hydro
-    double* FL = S.FL[N];
-    FL[GRHO * NC + c] = F[URHO];
-    FL[GMX * NC + c] = F[UMX];
-    FL[GMY * NC + c] = F[UMY];
-    FL[GMZ * NC + c] = F[UMZ];
-    FL[GE * NC + c] = F[UEDEN];
-    FL[GEI * NC + c] = F[UEINT];
-    FL[GX * NC + c] = F[UFS];
-    FL[GUG * NC + c] = f.ugd;
-    FL[GPG * NC + c] = f.pgd;
-
-    // scale_flux (advection_util.cpp:616-641) and accumulation on mfi.nodaltilebox(N)
-    // (Castro_ctu_hydro.cpp:1379-1433)
-    if (ijk[N] <= acc_hi) {
-        if (fluxes.p) {
-#pragma unroll
-            for (int m = 0; m < NUM_STATE; ++m) {
-                if (m == UTEMP) continue;       // += dt*0*area leaves the register unchanged
-                double* dst = fab_ptr(fluxes, i, j, k, m);
-                *dst += dt * F[m] * area;
-            }
-        }
-        if (mass.p) {
-            *fab_ptr(mass, i, j, k, 0) = dt * F[URHO] * area;
-        }
-        if (qe.p) {
-            *fab_ptr(qe, i, j, k, GDU + RDir<N>::n) = f.ugd;
-            *fab_ptr(qe, i, j, k, GDU + RDir<N>::t) = f.ut;
-            *fab_ptr(qe, i, j, k, GDU + RDir<N>::tt) = f.utt;
-            *fab_ptr(qe, i, j, k, GDPRES) = f.pgd;
-        }
-    }
+    const unsigned usn = 8u * (N == 0 ? 1u : N == 1 ? (unsigned)U.sy : (unsigned)U.sz);
+    final_flux_tail<N>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
+                       ijk[0], ijk[1], ijk[2], ijk[N], dt, area, dxn, acc_hi, P);
 }
 
 // ---------------------------------------------------------------------------------------
 // Castro::consup_hydro (Source/hydro/Castro_ctu.cpp:11-86), 3-D Cartesian
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_consup(Tile t, DevScratch S, DFab Uin, DFab Unew, double dt,
+__global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, DFab Uin, DFab Unew, double dt,
                                                 double area0, double area1, double area2, double vol,
                                                 int from_sborder)
 {
-    int lo[3] = { t.lo[0], t.lo[1], t.lo[2] };
-    int n[3] = { t.hi[0] - t.lo[0] + 1, t.hi[1] - t.lo[1] + 1, t.hi[2] - t.lo[2] + 1 };
     int i, j, k;
-    if (!box_thread(lo, n, i, j, k)) return;
-    const long c = gidx(t, i, j, k);
-    const long sx = 1, sy = t.NX, sz = (long)t.NX * t.NY;
+    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    const unsigned c = goff(t, i, j, k);
+    const Str s = gstr(t);
+    const unsigned sx = s.x, sy = s.y, sz = s.z;
     const long NC = t.NC;
     const double volinv = 1.0 / vol;
     const double* F0 = S.FL[0];
     const double* F1 = S.FL[1];
     const double* F2 = S.FL[2];
+    const unsigned cn = foff(Unew, i, j, k);
+    const unsigned ci = foff(Uin, i, j, k);
 
     // record index of conserved component m in the FL arrays
     constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
 
 #pragma unroll
     for (int m = 0; m < NUM_STATE; ++m) {
-        double* dst = fab_ptr(Unew, i, j, k, m);
-        double u0 = from_sborder ? fab_get(Uin, i, j, k, m) : *dst;
+        double* dst = Unew.p + m * Unew.sn;
+        double u0 = from_sborder ? ldg(Uin.p + m * Uin.sn, ci) : ldg(dst, cn);
         if (m == UTEMP) {
             // zero flux: U + dt*(0)*volinv == U
-            if (from_sborder) *dst = u0;
+            if (from_sborder) stg(dst, cn, u0);
             continue;
         }
         const long r = (long)rec[m] * NC;
         double unew = u0 + dt *
-            ( F0[r + c] * area0
-            - F0[r + c + sx] * area0
-            + F1[r + c] * area1
-            - F1[r + c + sy] * area1
-            + F2[r + c] * area2
-            - F2[r + c + sz] * area2
+            ( ldg(F0 + r, c) * area0
+            - ldg(F0 + r, c + sx) * area0
+            + ldg(F1 + r, c) * area1
+            - ldg(F1 + r, c + sy) * area1
+            + ldg(F2 + r, c) * area2
+            - ldg(F2 + r, c + sz) * area2
             ) * volinv;
 
         if (m == UEINT) {
-            double pdu = (F0[GPG * NC + c + sx] + F0[GPG * NC + c]) *
-                (F0[GUG * NC + c + sx] * area0 - F0[GUG * NC + c] * area0);
+            double pdu = (ldg(F0 + GPG * NC, c + sx) + ldg(F0 + GPG * NC, c)) *
+                (ldg(F0 + GUG * NC, c + sx) * area0 - ldg(F0 + GUG * NC, c) * area0);
 
-            pdu += (F1[GPG * NC + c + sy] + F1[GPG * NC + c]) *
-                (F1[GUG * NC + c + sy] * area1 - F1[GUG * NC + c] * area1);
+            pdu += (ldg(F1 + GPG * NC, c + sy) + ldg(F1 + GPG * NC, c)) *
+                (ldg(F1 + GUG * NC, c + sy) * area1 - ldg(F1 + GUG * NC, c) * area1);
 
-            pdu += (F2[GPG * NC + c + sz] + F2[GPG * NC + c]) *
-                (F2[GUG * NC + c + sz] * area2 - F2[GUG * NC + c] * area2);
+            pdu += (ldg(F2 + GPG * NC, c + sz) + ldg(F2 + GPG * NC, c)) *
+                (ldg(F2 + GUG * NC, c + sz) * area2 - ldg(F2 + GUG * NC, c) * area2);
 
             pdu = 0.5 * pdu * volinv;
 
             unew = unew - dt * pdu;
         }
-        *dst = unew;
+        stg(dst, cn, unew);
     }
 }
 
@@ -700,11 +719,23 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, DevScratch S, DFab Uin, 
 // ---------------------------------------------------------------------------------------
 static inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
 
-#define KLAUNCH(name, kern, nthreads, ...)                                              \
-    do {                                                                                \
-        prof_begin(prof, name, stream);                                                 \
-        hipLaunchKernelGGL(kern, dim3(nblocks(nthreads)), dim3(256), 0, stream, __VA_ARGS__); \
-        prof_end(prof, stream);                                                         \
+static LinBox linbox(const int lo[3], const int hi[3], long& n)
+{
+    LinBox b;
+    n = 1;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
+    return b;
+}
+
+#define KL(name, kern, lo, hi, ...)                                                          \
+    do {                                                                                     \
+        long n_;                                                                             \
+        LinBox b_ = linbox(lo, hi, n_);                                                      \
+        if (n_ > 0) {                                                                        \
+            prof_begin(prof, name, stream);                                                  \
+            hipLaunchKernelGGL(kern, dim3(nblocks(n_)), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            prof_end(prof, stream);                                                          \
+        }                                                                                    \
     } while (0)
 
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Snew,
@@ -712,37 +743,46 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
                      int* d_status, hipStream_t stream, Profiler* prof)
 {
-    const long nx = t.hi[0] - t.lo[0] + 1, ny = t.hi[1] - t.lo[1] + 1, nz = t.hi[2] - t.lo[2] + 1;
-    const long ng = (long)t.NX * t.NY * t.NZ;
-    const long nobx = (nx + 2) * (ny + 2) * (nz + 2);
+    prof_begin(prof, "k_ctoprim", stream);
+    hipLaunchKernelGGL(k_ctoprim, dim3(nblocks((long)t.NX * t.NY * t.NZ)), dim3(256), 0, stream, t, Sborder, S.Q, P, d_status);
+    prof_end(prof, stream);
 
-    KLAUNCH("k_ctoprim", k_ctoprim, ng, t, Sborder, S.Q, P, d_status);
-    KLAUNCH("k_divu", k_divu, nobx, t, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
-    KLAUNCH("k_trace", k_trace, nobx, t, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], P);
+    // boxes
+    const int olo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
+    const int ohi[3] = { t.hi[0] + 1, t.hi[1] + 1, t.hi[2] + 1 };
+    int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
+    for (int d = 0; d < 3; ++d)
+        for (int e = 0; e < 3; ++e) {
+            flo[d][e] = (e == d) ? t.lo[e] : t.lo[e] - 1;      // faces of d, grown by 1 in the transverse dirs
+            fhi[d][e] = t.hi[e] + 1;
+            nlo[d][e] = t.lo[e];                               // faces of d of bx
+            nhi[d][e] = (e == d) ? t.hi[e] + 1 : t.hi[e];
+        }
 
-    KLAUNCH("k_riemann1", k_riemann1<0>, (nx + 1) * (ny + 2) * (nz + 2), t, S.Q, S, g, P);
-    KLAUNCH("k_riemann1", k_riemann1<1>, (nx + 2) * (ny + 1) * (nz + 2), t, S.Q, S, g, P);
-    KLAUNCH("k_riemann1", k_riemann1<2>, (nx + 2) * (ny + 2) * (nz + 1), t, S.Q, S, g, P);
+    KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+    KL("k_trace", k_trace, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], P);
 
-    // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690)
+    KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
+    KL("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
+    KL("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
+
+    // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690); hdtdx = 0.5*dt/dx (:684-686)
     const double cdtdx = dt / g.dx[0] / 3.0, cdtdy = dt / g.dx[1] / 3.0, cdtdz = dt / g.dx[2] / 3.0;
-    KLAUNCH("k_trans1", k_trans1<0>, (nx + 1) * (ny + 2) * (nz + 2), t, S.Q, S, g, cdtdy, cdtdz, P);
-    KLAUNCH("k_trans1", k_trans1<1>, (nx + 2) * (ny + 1) * (nz + 2), t, S.Q, S, g, cdtdx, cdtdz, P);
-    KLAUNCH("k_trans1", k_trans1<2>, (nx + 2) * (ny + 2) * (nz + 1), t, S.Q, S, g, cdtdx, cdtdy, P);
-
-    // hdtdx = 0.5*dt/dx (Castro_ctu_hydro.cpp:684-686)
     const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
     const double area0 = g.dx[1] * g.dx[2], area1 = g.dx[0] * g.dx[2], area2 = g.dx[0] * g.dx[1];
-    KLAUNCH("k_final", k_final<0>, (nx + 1) * ny * nz, t, S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
-            hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], P);
-    KLAUNCH("k_final", k_final<1>, nx * (ny + 1) * nz, t, S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
-            hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], P);
-    KLAUNCH("k_final", k_final<2>, nx * ny * (nz + 1), t, S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],
-            hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], P);
+
+    KL("k_trans1", k_trans1<0>, flo[0], fhi[0], S.Q, S, g, cdtdy, cdtdz, P);
+    KL("k_trans1", k_trans1<1>, flo[1], fhi[1], S.Q, S, g, cdtdx, cdtdz, P);
+    KL("k_trans1", k_trans1<2>, flo[2], fhi[2], S.Q, S, g, cdtdx, cdtdy, P);
+    KL("k_final", k_final<0>, nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
+       hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], P);
+    KL("k_final", k_final<1>, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
+       hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], P);
+    KL("k_final", k_final<2>, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],
+       hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], P);
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];
-    KLAUNCH("k_consup", k_consup, nx * ny * nz, t, S, Sborder, Snew, dt, area0, area1, area2, vol,
-            (flags & 1) ? 1 : 0);
+    KL("k_consup", k_consup, t.lo, t.hi, S, Sborder, Snew, dt, area0, area1, area2, vol, (flags & 1) ? 1 : 0);
 
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
