@@ -53,13 +53,30 @@ def kernel_units(name, n):
     }.get(name, nx * ny * nz)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC pass (profiles/*_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 correction on FETCH_SIZE).
+    Counters cannot be collected from inside this process, so None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["kernels"][kernel]["bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(ncell, steps):
     """The CPU oracle (a port organised like the reference's CPU path: ~75 sweeps per tile,
     tiles 1024x16x16, OpenMP over tiles) timed on this host on a bounded Sedov sample."""
     from oracle import oracle_lib as O
     n = (ncell, ncell, ncell)
     ntiles = max(1, (ncell // 16)) ** 2
-    threads = max(1, min(os.cpu_count() or 1, ntiles))
+    # one thread per tile at most; capped at 64 so the thread-private scratch (~220 MB per thread at
+    # 192^3) stays far below host memory
+    threads = max(1, min(os.cpu_count() or 1, ntiles, 64))
     lev = O.Level(n, O.make_geom(n), O.default_params(), nthreads=threads)
     lev.init_sedov()
     lev.step(0.01)                    # untimed first step (page faults, scratch allocation)
@@ -82,8 +99,8 @@ def main():
     ap.add_argument("--ncell", type=int, default=256, help="global zones per side (strong scaling: fixed as N grows)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: ncell^3 zones PER GPU (config 3: 512^3 on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-ncell", type=int, default=96)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-ncell", type=int, default=192)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-overlap", action="store_true")
     args = ap.parse_args()
 
@@ -149,8 +166,9 @@ def main():
         units = kernel_units(name, c.n)
         alg_bytes = KERNEL_BYTES_PER_UNIT.get(name, 0) * units
         achieved = alg_bytes / avg_s / 1e9
+        traffic, traffic_src = pmc_traffic(name)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": name, "avg_launch_ms": avg_s * 1e3, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes}
     hydro_ms = sum(v[0] for k, v in prof.items() if k in ("k_ctoprim", "k_divu", "k_trace", "k_riemann1", "k_trans1",
