@@ -124,7 +124,7 @@ static size_t plane_doubles(int nx, int ny, int nz)
 }
 
 // number of component planes in the scratch arena
-static constexpr int kPlanes = NPRIM + 1 + 6 * NEDGE + 3 * NF1 + 6 * NF1 + 3 * NFIN;
+static constexpr int kPlanes = NPRIM + 2 + 6 * NEDGE + 3 * NF1 + 6 * NF1 + 3 * NFIN;
 
 extern "C" {
 
@@ -234,9 +234,10 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
     if (Sborder->ncomp != NUM_STATE || S_new->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
     if (geom->coord != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
     if (params->ppm_type != 1) return CASTRO_AMD_ERR_UNSUPPORTED;                 // PLM: SURVEY 8(f-1)
-    if (params->riemann_solver < 0 || params->riemann_solver > 1) return CASTRO_AMD_ERR_UNSUPPORTED; // HLLC: next
-    if (params->hybrid_riemann != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
-    if (params->transverse_reset_rhoe != 0 || params->transverse_use_eos != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (params->riemann_solver < 0 || params->riemann_solver > 2) return CASTRO_AMD_ERR_ARG;
+    if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
+    // transverse_reset_rhoe needs the eint flux of the transverse solves, which the flux record does not carry
+    if (params->transverse_reset_rhoe != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
     if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
     if (src && src->p) return CASTRO_AMD_ERR_UNSUPPORTED;                         // source tracing: SURVEY 8(f-4)
 
@@ -264,6 +265,7 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
     const size_t NC = (size_t)t.NC;
     S.Q = p; p += NC * NPRIM;
     S.DIV = p; p += NC;
+    S.SHK = p; p += NC;
     for (int d = 0; d < 3; ++d) { S.QM[d] = p; p += NC * NEDGE; S.QP[d] = p; p += NC * NEDGE; }
     for (int d = 0; d < 3; ++d) { S.F1[d] = p; p += NC * NF1; }
     for (int d = 0; d < 6; ++d) { S.F2[d] = p; p += NC * NF1; }

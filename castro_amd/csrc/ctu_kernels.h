@@ -31,6 +31,7 @@ struct DevGeom {
 struct DevScratch {
     double* Q;        // NPRIM planes
     double* DIV;      // 1 plane
+    double* SHK;      // 1 plane (hybrid Riemann only)
     double* QM[3];    // NEDGE planes each
     double* QP[3];
     double* F1[3];    // NF1 planes each

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, DFab U, double* __restr
 // Castro::divu, 3-D branch (Source/hydro/advection_util.cpp:458-475), nodes of grow(bx,1)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
-                                              double dxinv, double dyinv, double dzinv)
+                                              double* __restrict__ SHK, double dxinv, double dyinv, double dzinv)
 {
     int i, j, k;
     if (!box_thread(b.lo, b.n, i, j, k)) return;
@@ -153,6 +153,43 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
                         ldg(QW_, c - sx - sy) - ldg(QW_, c - sx - sy - sz)) * dzinv;
 
     stg(DIV, c, ux + vy + wz);
+
+    // Castro::shock (Source/hydro/advection_util.cpp:203-363), 3-D Cartesian: only needed by the
+    // hybrid Riemann solver (Castro_ctu_hydro.cpp:294-303); the default zero-fill is elided
+    if (SHK) {
+        constexpr double small = 1.e-10;
+        constexpr double eps = 0.33e0;
+        const double* QP_ = Q + PP * t.NC;
+        double div_u = 0.0;
+        div_u += 0.5 * (ldg(QU_, c + sx) - ldg(QU_, c - sx)) * dxinv;
+        div_u += 0.5 * (ldg(QV_, c + sy) - ldg(QV_, c - sy)) * dyinv;
+        div_u += 0.5 * (ldg(QW_, c + sz) - ldg(QW_, c - sz)) * dzinv;
+
+        double px_pre, px_post, py_pre, py_post, pz_pre, pz_post;
+        if (ldg(QP_, c + sx) - ldg(QP_, c - sx) < 0.0) { px_pre = ldg(QP_, c + sx); px_post = ldg(QP_, c - sx); }
+        else { px_pre = ldg(QP_, c - sx); px_post = ldg(QP_, c + sx); }
+        double e_x = (ldg(QU_, c + sx) - ldg(QU_, c - sx)) * (ldg(QU_, c + sx) - ldg(QU_, c - sx));
+
+        if (ldg(QP_, c + sy) - ldg(QP_, c - sy) < 0.0) { py_pre = ldg(QP_, c + sy); py_post = ldg(QP_, c - sy); }
+        else { py_pre = ldg(QP_, c - sy); py_post = ldg(QP_, c + sy); }
+        double e_y = (ldg(QV_, c + sy) - ldg(QV_, c - sy)) * (ldg(QV_, c + sy) - ldg(QV_, c - sy));
+
+        if (ldg(QP_, c + sz) - ldg(QP_, c - sz) < 0.0) { pz_pre = ldg(QP_, c + sz); pz_post = ldg(QP_, c - sz); }
+        else { pz_pre = ldg(QP_, c - sz); pz_post = ldg(QP_, c + sz); }
+        double e_z = (ldg(QW_, c + sz) - ldg(QW_, c - sz)) * (ldg(QW_, c + sz) - ldg(QW_, c - sz));
+
+        double denom = 1.0 / (e_x + e_y + e_z + small);
+        e_x = e_x * denom;
+        e_y = e_y * denom;
+        e_z = e_z * denom;
+
+        double p_pre = e_x * px_pre + e_y * py_pre + e_z * pz_pre;
+        double p_post = e_x * px_post + e_y * py_post + e_z * pz_post;
+
+        double pjump = (p_pre == 0) ? 0.0 : eps - (p_post - p_pre) / p_pre;
+
+        stg(SHK, c, (pjump < 0.0 && div_u < 0.0) ? 1.0 : 0.0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -414,6 +451,13 @@ __device__ __forceinline__ double wall_fac(const DevGeom& g, int idx)
     return ((idx == g.domlo[D] && g.wall_lo[D]) || (idx == g.domhi[D] + 1 && g.wall_hi[D])) ? 0.0 : 1.0;
 }
 
+// is_shock of cmpflx_plus_godunov (riemann.cpp:155-163)
+__device__ __forceinline__ bool face_shock(const DevScratch& S, const DevParams& P, unsigned c, unsigned sd)
+{
+    if (P.hybrid_riemann != 1) return false;
+    return static_cast<int>(ldg(S.SHK, c - sd) + ldg(S.SHK, c)) >= 1;
+}
+
 // write a transverse-stage flux record at face offset c (global component order)
 template <int D>
 __device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsigned c, const IFlux& f)
@@ -464,7 +508,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
     const double cr = ldg(Q + PC * t.NC, c);
 
     IFlux f;
-    interface_flux(ql, qr, Xl, Xr, cl, cr, wall_fac<D>(g, idx), P, f);
+    interface_flux<D>(ql, qr, Xl, Xr, cl, cr, wall_fac<D>(g, idx), face_shock(S, P, c, sd), P, f);
     store_f1<D>(S.F1[D], t.NC, c, f);
 }
 
@@ -571,7 +615,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     rstate_from_edge<N>(qpo, P.gamma, qr, Xr);
 
     IFlux f;
-    interface_flux(ql, qr, Xl, Xr, cl, cr, bnd_fac, P, f);
+    interface_flux<N>(ql, qr, Xl, Xr, cl, cr, bnd_fac, face_shock(S, P, c, sn), P, f);
     store_f1<N>(S.F2[f2_slot(N, T)], t.NC, c, f);
 }
 
@@ -647,7 +691,7 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
     const double cr = ldg(Q + PC * NC, c);
 
     IFlux f;
-    interface_flux(rl, rr, Xl, Xr, cl, cr, wall_fac<N>(g, ijk[N]), P, f);
+    interface_flux<N>(rl, rr, Xl, Xr, cl, cr, wall_fac<N>(g, ijk[N]), face_shock(S, P, c, sn), P, f);
 
     const unsigned usn = 8u * (N == 0 ? 1u : N == 1 ? (unsigned)U.sy : (unsigned)U.sz);
     final_flux_tail<N>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
@@ -759,7 +803,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             nhi[d][e] = (e == d) ? t.hi[e] + 1 : t.hi[e];
         }
 
-    KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+    KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, (P.hybrid_riemann == 1) ? S.SHK : (double*)nullptr, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
     KL("k_trace", k_trace, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], P);
 
     KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);

@@ -491,63 +491,6 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     qint.rhoe = qint.p / (game_int - 1.0);
 }
 
-// One interface: riemann_state (riemann_solvers.H:1262-1388) + compute_flux_q (:14-211) +
-// the passive upwinding of cmpflx_plus_godunov (riemann.cpp:107-131), in the normal frame.
-//   ql/qr carry gamc already (= qaux(QGAMC) of the cells either side); cl, cr = qaux(QC)
-//   Xl, Xr = passive edge values.  Outputs: F = (rho, m_n, m_t, m_tt, E, eint, X) fluxes,
-//   ugd = Godunov normal velocity, pgd = Godunov pressure.
-struct IFlux { double rho, mn, mt, mtt, E, eint, X, ugd, ut, utt, pgd; };
-
-__device__ __forceinline__ void interface_flux(RState ql, RState qr, double Xl, double Xr,
-                                               double cl, double cr, double bnd_fac,
-                                               const DevParams& P, IFlux& F)
-{
-    constexpr double small = 1.e-8;
-    // riemann.H:70-71
-    ql.rho = amax(ql.rho, P.small_dens);
-    qr.rho = amax(qr.rho, P.small_dens);
-
-    RAux raux;
-    raux.csmall = amax(small, small * amax(cr, cl));
-    raux.cavg = 0.5 * (cr + cl);
-    raux.bnd_fac = bnd_fac;
-
-    clean_input_state(ql, P);
-    clean_input_state(qr, P);
-
-    RState qint;
-    if (P.riemann_solver == 0) {
-        riemannus(ql, qr, raux, qint, P);
-    } else {
-        riemanncg(ql, qr, raux, qint, P);
-    }
-
-    F.rho = qint.rho * qint.un;
-    F.mn = F.rho * qint.un;
-    F.mt = F.rho * qint.ut;
-    F.mtt = F.rho * qint.utt;
-    F.mn += qint.p;
-
-    double rhoetot = qint.rhoe + 0.5 * qint.rho * (qint.un * qint.un + qint.ut * qint.ut + qint.utt * qint.utt);
-
-    F.E = qint.un * (rhoetot + qint.p);
-    F.eint = qint.un * qint.rhoe;
-
-    F.ugd = qint.un;
-    F.ut = qint.ut;
-    F.utt = qint.utt;
-    F.pgd = qint.p;
-
-    double sgnm = copysign(1.0, qint.un);
-    if (qint.un == 0.0) sgnm = 0.0;
-
-    double fp = 0.5 * (1.0 + sgnm);
-    double fm = 0.5 * (1.0 - sgnm);
-
-    double X_int = fp * Xl + fm * Xr;
-    F.X = F.rho * X_int;
-}
-
 // direction maps of the Riemann solver (riemann.H:73-150): normal, first and second
 // transverse velocity component of direction D
 template <int D> struct RDir;
@@ -555,11 +498,314 @@ template <> struct RDir<0> { static constexpr int n = 0, t = 1, tt = 2; };
 template <> struct RDir<1> { static constexpr int n = 1, t = 0, tt = 2; };
 template <> struct RDir<2> { static constexpr int n = 2, t = 0, tt = 1; };
 
+// u*u + v*v + w*w summed in GLOBAL component order (cons_state / HLLC_state, riemann.H:379-440),
+// given the velocity in the normal frame of direction D
+template <int D>
+__device__ __forceinline__ double vsq_global(double un, double ut, double utt)
+{
+    if (D == 0) return un * un + ut * ut + utt * utt;      // (u,v,w) = (un,ut,utt)
+    if (D == 1) return ut * ut + un * un + utt * utt;      // (u,v,w) = (ut,un,utt)
+    return ut * ut + utt * utt + un * un;                  // (u,v,w) = (ut,utt,un)
+}
+
+struct IFlux { double rho, mn, mt, mtt, E, eint, X, ugd, ut, utt, pgd; };
+
+// riemann.H:442-501 compute_flux, normal frame, Cartesian (pressure in the normal momentum flux)
+struct CState { double rho, mn, mt, mtt, E, eint, X; };
+__device__ __forceinline__ void hllc_compute_flux(double bnd_fac, const CState& U, double p, CState& F)
+{
+    double u_flx = U.mn / U.rho;
+    if (bnd_fac == 0) u_flx = 0.0;
+    F.rho = U.rho * u_flx;
+    F.mn = U.mn * u_flx;
+    F.mt = U.mt * u_flx;
+    F.mtt = U.mtt * u_flx;
+    F.mn = F.mn + p;
+    F.eint = U.eint * u_flx;
+    F.E = (U.E + p) * u_flx;
+    F.X = U.X * u_flx;
+}
+
+// riemann_solvers.H:991-1258 -- HLLC (riemann_solver = 2).  q* are the RAW edge states.
+template <int D>
+__device__ __forceinline__ void hllc_flux(const RState& ql, const RState& qr, double Xl, double Xr,
+                                          double cl_zone, double cr_zone, double bnd_fac, const DevParams& P, IFlux& F)
+{
+    constexpr double small = 1.e-8;
+    constexpr double smallu = 1.e-12;
+
+    double rl = amax(ql.rho, P.small_dens);
+    double ul = ql.un;
+    double pl = amax(ql.p, P.small_pres);
+
+    double rr = amax(qr.rho, P.small_dens);
+    double ur = qr.un;
+    double pr = amax(qr.p, P.small_pres);
+
+    double csmall = amax(small, amax(small * cr_zone, small * cl_zone));
+    double cavg = 0.5 * (cr_zone + cl_zone);
+
+    double gamcl = ql.gamc;
+    double gamcr = qr.gamc;
+
+    double wsmall = P.small_dens * csmall;
+    double wl = amax(wsmall, sqrt(fabs(gamcl * pl * rl)));
+    double wr = amax(wsmall, sqrt(fabs(gamcr * pr * rr)));
+
+    double wwinv = 1.0 / (wl + wr);
+    double pstar = ((wr * pl + wl * pr) + wl * wr * (ul - ur)) * wwinv;
+    double ustar = ((wl * ul + wr * ur) + (pl - pr)) * wwinv;
+
+    pstar = amax(pstar, P.small_pres);
+
+    if (fabs(ustar) < smallu * 0.5 * (fabs(ul) + fabs(ur))) ustar = 0.0;
+
+    double ro, uo, po, gamco;
+    if (ustar > 0.0) { ro = rl; uo = ul; po = pl; gamco = gamcl; }
+    else if (ustar < 0.0) { ro = rr; uo = ur; po = pr; gamco = gamcr; }
+    else { ro = 0.5 * (rl + rr); uo = 0.5 * (ul + ur); po = 0.5 * (pl + pr); gamco = 0.5 * (gamcl + gamcr); }
+
+    ro = amax(P.small_dens, ro);
+
+    double roinv = 1.0 / ro;
+    double co = sqrt(fabs(gamco * po * roinv));
+    co = amax(csmall, co);
+    double co2inv = 1.0 / (co * co);
+
+    double rstar = ro + (pstar - po) * co2inv;
+    rstar = amax(P.small_dens, rstar);
+
+    double cstar = sqrt(fabs(gamco * pstar / rstar));
+    cstar = amax(cstar, csmall);
+
+    double sgnm = copysign(1.0, ustar);
+    double spout = co - sgnm * uo;
+    double spin = cstar - sgnm * ustar;
+    double ushock = 0.5 * (spin + spout);
+
+    if (pstar - po > 0.0) { spin = ushock; spout = ushock; }
+
+    double scr = spout - spin;
+    if (spout - spin == 0.0) scr = small * cavg;
+
+    double frac = (1.0 + (spout + spin) / scr) * 0.5;
+    frac = amax(0.0, amin(1.0, frac));
+
+    // Godunov state kept for the p div(u) term: only the normal velocity and the pressure are set
+    F.ugd = frac * ustar + (1.0 - frac) * uo;
+    F.ut = 0.0;
+    F.utt = 0.0;
+    F.pgd = frac * pstar + (1.0 - frac) * po;
+
+    double S_l = amin(ul - sqrt(gamcl * pl / rl), ur - sqrt(gamcr * pr / rr));
+    double S_r = amax(ul + sqrt(gamcl * pl / rl), ur + sqrt(gamcr * pr / rr));
+
+    double S_c = (pr - pl + rl * ul * (S_l - ul) - rr * ur * (S_r - ur)) /
+        (rl * (S_l - ul) - rr * (S_r - ur));
+
+    // cons_state / HLLC_state (riemann.H:379-440) of the RAW state q with passive X
+    auto cons = [&](const RState& q, double X, CState& U) {
+        U.rho = q.rho;
+        U.mn = q.rho * q.un;
+        U.mt = q.rho * q.ut;
+        U.mtt = q.rho * q.utt;
+        U.E = q.rhoe + 0.5 * q.rho * vsq_global<D>(q.un, q.ut, q.utt);
+        U.eint = q.rhoe;
+        U.X = q.rho * X;
+    };
+    auto hllc_state = [&](double S_k, const RState& q, double X, CState& U) {
+        double u_k = q.un;
+        double hllc_factor = q.rho * (S_k - u_k) / (S_k - S_c);
+        U.rho = hllc_factor;
+        U.mn = hllc_factor * S_c;
+        U.mt = hllc_factor * q.ut;
+        U.mtt = hllc_factor * q.utt;
+        U.E = hllc_factor * (q.rhoe / q.rho + 0.5 * vsq_global<D>(q.un, q.ut, q.utt) +
+                             (S_c - u_k) * (S_c + q.p / (q.rho * (S_k - u_k))));
+        U.eint = hllc_factor * q.rhoe / q.rho;
+        U.X = hllc_factor * X;
+    };
+
+    CState U, Uh, Fs;
+    if (S_r <= 0.0) {
+        cons(qr, Xr, U);
+        hllc_compute_flux(bnd_fac, U, pr, Fs);
+    } else if (S_r > 0.0 && S_c <= 0.0) {
+        cons(qr, Xr, U);
+        hllc_compute_flux(bnd_fac, U, pr, Fs);
+        hllc_state(S_r, qr, Xr, Uh);
+        Fs.rho = Fs.rho + S_r * (Uh.rho - U.rho);
+        Fs.mn = Fs.mn + S_r * (Uh.mn - U.mn);
+        Fs.mt = Fs.mt + S_r * (Uh.mt - U.mt);
+        Fs.mtt = Fs.mtt + S_r * (Uh.mtt - U.mtt);
+        Fs.E = Fs.E + S_r * (Uh.E - U.E);
+        Fs.eint = Fs.eint + S_r * (Uh.eint - U.eint);
+        Fs.X = Fs.X + S_r * (Uh.X - U.X);
+    } else if (S_c > 0.0 && S_l < 0.0) {
+        cons(ql, Xl, U);
+        hllc_compute_flux(bnd_fac, U, pl, Fs);
+        hllc_state(S_l, ql, Xl, Uh);
+        Fs.rho = Fs.rho + S_l * (Uh.rho - U.rho);
+        Fs.mn = Fs.mn + S_l * (Uh.mn - U.mn);
+        Fs.mt = Fs.mt + S_l * (Uh.mt - U.mt);
+        Fs.mtt = Fs.mtt + S_l * (Uh.mtt - U.mtt);
+        Fs.E = Fs.E + S_l * (Uh.E - U.E);
+        Fs.eint = Fs.eint + S_l * (Uh.eint - U.eint);
+        Fs.X = Fs.X + S_l * (Uh.X - U.X);
+    } else {
+        cons(ql, Xl, U);
+        hllc_compute_flux(bnd_fac, U, pl, Fs);
+    }
+    F.rho = Fs.rho; F.mn = Fs.mn; F.mt = Fs.mt; F.mtt = Fs.mtt; F.E = Fs.E; F.eint = Fs.eint; F.X = Fs.X;
+}
+
+// riemann_solvers.H:834-978 -- HLLE flux that overwrites the flux in shocked zones
+// (hybrid_riemann = 1, riemann.cpp:150-203).  q* are the RAW edge states.
+__device__ __forceinline__ void hll_flux(const RState& ql, const RState& qr, double Xl, double Xr,
+                                         double cl, double cr, IFlux& F)
+{
+    constexpr double small_hll = 1.e-10;
+
+    double rhol_sqrt = sqrt(ql.rho);
+    double rhor_sqrt = sqrt(qr.rho);
+    double rhod = 1.0 / (rhol_sqrt + rhor_sqrt);
+
+    double dv = qr.un - ql.un;
+    double cavg = sqrt((rhol_sqrt * cl * cl + rhor_sqrt * cr * cr) * rhod +
+                       0.5 * rhol_sqrt * rhor_sqrt * rhod * rhod * (dv * dv));
+
+    double uavg = (rhol_sqrt * ql.un + rhor_sqrt * qr.un) * rhod;
+    double a1 = uavg - cavg;
+    double a4 = uavg + cavg;
+
+    double bl = amin(a1, ql.un - cl);
+    double br = amax(a4, qr.un + cr);
+
+    double bm = amin(0.0, bl);
+    double bp = amax(0.0, br);
+
+    double bd = bp - bm;
+    if (fabs(bd) < small_hll * amax(fabs(bm), fabs(bp))) return;
+
+    bd = 1.0 / bd;
+
+    double fl_tmp = ql.rho * ql.un;
+    double fr_tmp = qr.rho * qr.un;
+    F.rho = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (qr.rho - ql.rho);
+
+    fl_tmp = ql.rho * ql.un * ql.un;
+    fr_tmp = qr.rho * qr.un * qr.un;
+    fl_tmp = fl_tmp + ql.p;
+    fr_tmp = fr_tmp + qr.p;
+    F.mn = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (qr.rho * qr.un - ql.rho * ql.un);
+
+    fl_tmp = ql.rho * ql.un * ql.ut;
+    fr_tmp = qr.rho * qr.un * qr.ut;
+    F.mt = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (qr.rho * qr.ut - ql.rho * ql.ut);
+
+    fl_tmp = ql.rho * ql.un * ql.utt;
+    fr_tmp = qr.rho * qr.un * qr.utt;
+    F.mtt = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (qr.rho * qr.utt - ql.rho * ql.utt);
+
+    double rhoEl = ql.rhoe + 0.5 * ql.rho * (ql.un * ql.un + ql.ut * ql.ut + ql.utt * ql.utt);
+    fl_tmp = ql.un * (rhoEl + ql.p);
+    double rhoEr = qr.rhoe + 0.5 * qr.rho * (qr.un * qr.un + qr.ut * qr.ut + qr.utt * qr.utt);
+    fr_tmp = qr.un * (rhoEr + qr.p);
+    F.E = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (rhoEr - rhoEl);
+
+    fl_tmp = ql.rhoe * ql.un;
+    fr_tmp = qr.rhoe * qr.un;
+    F.eint = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (qr.rhoe - ql.rhoe);
+
+    fl_tmp = ql.rho * Xl * ql.un;
+    fr_tmp = qr.rho * Xr * qr.un;
+    F.X = (bp * fl_tmp - bm * fr_tmp) * bd + bp * bm * bd * (qr.rho * Xr - ql.rho * Xl);
+}
+
+// One interface: riemann_state (riemann_solvers.H:1262-1388) + compute_flux_q (:14-211) +
+// the passive upwinding and the hybrid correction of cmpflx_plus_godunov (riemann.cpp:76-203),
+// in the normal frame of direction D.
+//   ql/qr carry gamc already (= qaux(QGAMC) of the zones either side); cl, cr = qaux(QC)
+//   Xl, Xr = passive edge values; is_shock = shk(left zone) + shk(right zone) >= 1.
+//   Outputs: F = (rho, m_n, m_t, m_tt, E, eint, X) fluxes, Godunov (un, ut, utt, p).
+template <int D>
+__device__ __forceinline__ void interface_flux(const RState& ql_raw, const RState& qr_raw, double Xl, double Xr,
+                                               double cl, double cr, double bnd_fac, bool is_shock,
+                                               const DevParams& P, IFlux& F)
+{
+    constexpr double small = 1.e-8;
+    if (P.riemann_solver == 2) {
+        hllc_flux<D>(ql_raw, qr_raw, Xl, Xr, cl, cr, bnd_fac, P, F);
+    } else {
+        RState ql = ql_raw, qr = qr_raw;
+        // riemann.H:70-71
+        ql.rho = amax(ql.rho, P.small_dens);
+        qr.rho = amax(qr.rho, P.small_dens);
+
+        RAux raux;
+        raux.csmall = amax(small, small * amax(cr, cl));
+        raux.cavg = 0.5 * (cr + cl);
+        raux.bnd_fac = bnd_fac;
+
+        clean_input_state(ql, P);
+        clean_input_state(qr, P);
+
+        RState qint;
+        if (P.riemann_solver == 0) {
+            riemannus(ql, qr, raux, qint, P);
+        } else {
+            riemanncg(ql, qr, raux, qint, P);
+        }
+
+        F.rho = qint.rho * qint.un;
+        F.mn = F.rho * qint.un;
+        F.mt = F.rho * qint.ut;
+        F.mtt = F.rho * qint.utt;
+        F.mn += qint.p;
+
+        double rhoetot = qint.rhoe + 0.5 * qint.rho * (qint.un * qint.un + qint.ut * qint.ut + qint.utt * qint.utt);
+
+        F.E = qint.un * (rhoetot + qint.p);
+        F.eint = qint.un * qint.rhoe;
+
+        F.ugd = qint.un;
+        F.ut = qint.ut;
+        F.utt = qint.utt;
+        F.pgd = qint.p;
+
+        double sgnm = copysign(1.0, qint.un);
+        if (qint.un == 0.0) sgnm = 0.0;
+
+        double fp = 0.5 * (1.0 + sgnm);
+        double fm = 0.5 * (1.0 - sgnm);
+
+        double X_int = fp * Xl + fm * Xr;
+        F.X = F.rho * X_int;
+    }
+
+    if (P.hybrid_riemann == 1 && is_shock) {
+        hll_flux(ql_raw, qr_raw, Xl, Xr, cl, cr, F);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // transverse corrections (Source/hydro/trans.cpp), operating on a register-resident edge
 // state q[NEDGE] = (rho,u,v,w,p,rhoe,X); flux differences are passed pre-loaded:
 //   fr/fl = flux record (FRHO..FPG) at the high/low transverse face
 // ---------------------------------------------------------------------------------------
+// Castro::reset_edge_state_thermo (Source/hydro/edge_util.cpp:6-76) with transverse_use_eos = 1:
+// make (rho e, p) of a corrected edge state EOS-consistent.  (transverse_reset_rhoe is rejected
+// on the host; with both flags 0 -- the default -- the reference's 18 launches are no-ops.)
+__device__ __forceinline__ void reset_edge_state_thermo(double q[NEDGE], const DevParams& P)
+{
+    if (P.use_eos == 1) {
+        double e = q[PRE] / q[PRHO];
+        double p = (P.gamma - 1.0) * q[PRHO] * e;
+        q[PRE] = e * q[PRHO];
+        q[PP] = amax(p, P.small_pres);
+    }
+}
+
 // actual_trans_single, trans.cpp:66-437 (3-D branch). TD = transverse direction.
 template <int TD>
 __device__ __forceinline__ void trans_single(const double q[NEDGE], const double fr[NF1], const double fl[NF1],
@@ -625,6 +871,7 @@ __device__ __forceinline__ void trans_single(const double q[NEDGE], const double
         qo[PP] = q[PP];
         qo[PRE] = q[PRE];
     }
+    reset_edge_state_thermo(qo, P);
 }
 
 // actual_trans_final, trans.cpp:498-862 (no radiation)
@@ -698,6 +945,7 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
     }
 
     qo[PP] = amax(qo[PP], P.small_pres);
+    reset_edge_state_thermo(qo, P);
 }
 
 } // namespace cad

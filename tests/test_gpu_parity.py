@@ -148,6 +148,21 @@ def test_ctu_hydro_walls_and_no_flattening(hip, oracle):
     _assert_exact(out, "walls")
 
 
+@pytest.mark.parametrize("pkw", [dict(riemann_solver=2), dict(hybrid_riemann=1), dict(riemann_solver=2, hybrid_riemann=1),
+                                 dict(transverse_use_eos=1), dict(first_order_hydro=1),
+                                 dict(riemann_solver=1, cg_blend=1, hybrid_riemann=1, transverse_use_eos=1)])
+def test_ctu_hydro_solver_options(hip, oracle, pkw):
+    """HLLC (riemann_solver=2), the hybrid solver (shock detection + HLL in shocked zones),
+    transverse_use_eos and first_order_hydro against the oracle: bit-exact."""
+    rng = np.random.default_rng(21)
+    bxlo, bxhi = (0, 0, 0), (13, 11, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (17, 15, 13)
+    U = physical_state(rng, sb_lo, sb_hi, vel=1.5)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), pkw=pkw,
+                    geom_kw=dict(lo_bc=(2, 4, 2), hi_bc=(3, 2, 2)))
+    _assert_exact(out, "options %s" % (pkw,))
+
+
 def test_unsupported_options_fail_loudly(hip):
     import castro_amd
     from castro_amd import _lib as L
@@ -155,7 +170,7 @@ def test_unsupported_options_fail_loudly(hip):
     G = castro_amd.make_geom(n)
     S = hip.alloc(8, (-4, -4, -4), (11, 11, 11), fill=1.0)
     N = hip.alloc(8, (0, 0, 0), (7, 7, 7), fill=1.0)
-    for kw in (dict(ppm_type=0), dict(riemann_solver=2), dict(hybrid_riemann=1), dict(transverse_reset_rhoe=1)):
+    for kw in (dict(ppm_type=0), dict(transverse_reset_rhoe=1), dict(ppm_temp_fix=2)):
         P = castro_amd.default_params(**kw)
         with pytest.raises(RuntimeError, match="unsupported"):
             hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
