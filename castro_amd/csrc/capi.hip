@@ -124,7 +124,7 @@ static size_t plane_doubles(int nx, int ny, int nz)
 }
 
 // number of component planes in the scratch arena
-static constexpr int kPlanes = NPRIM + 2 + 6 * NEDGE + 3 * NF1 + 6 * NF1 + 3 * NFIN;
+static constexpr int kPlanes = NPRIM + 2 + 6 + 6 * NEDGE + 3 * NF1 + 6 * NF1 + 3 * NFIN;
 
 extern "C" {
 
@@ -239,7 +239,6 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
     // transverse_reset_rhoe needs the eint flux of the transverse solves, which the flux record does not carry
     if (params->transverse_reset_rhoe != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
     if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
-    if (src && src->p) return CASTRO_AMD_ERR_UNSUPPORTED;                         // source tracing: SURVEY 8(f-4)
 
     Tile t;
     int glo[3], ghi[3];
@@ -255,6 +254,12 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
 
     if (!fab_contains(Sborder, glo, ghi)) return CASTRO_AMD_ERR_ARG;
     if (!fab_contains(S_new, bxlo, bxhi)) return CASTRO_AMD_ERR_ARG;
+    if (src && src->p) {
+        // old_source: NSRC = 7 components, NUM_GROW_SRC = 3 ghost zones (Castro_setup.cpp:317-327)
+        int s3lo[3], s3hi[3];
+        for (int d = 0; d < 3; ++d) { s3lo[d] = bxlo[d] - 3; s3hi[d] = bxhi[d] + 3; }
+        if (src->ncomp < 6 || !fab_contains(src, s3lo, s3hi)) return CASTRO_AMD_ERR_ARG;
+    }
 
     hipSetDevice(c->device);
     int rc = castro_amd_ctx_reserve(c, nx, ny, nz);
@@ -266,6 +271,7 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
     S.Q = p; p += NC * NPRIM;
     S.DIV = p; p += NC;
     S.SHK = p; p += NC;
+    S.SRCQ = p; p += NC * 6;
     for (int d = 0; d < 3; ++d) { S.QM[d] = p; p += NC * NEDGE; S.QP[d] = p; p += NC * NEDGE; }
     for (int d = 0; d < 3; ++d) { S.F1[d] = p; p += NC * NF1; }
     for (int d = 0; d < 6; ++d) { S.F2[d] = p; p += NC * NF1; }
@@ -291,7 +297,7 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
         dF[d] = to_dfab(f); dM[d] = to_dfab(m); dQ[d] = to_dfab(q);
     }
 
-    return launch_ctu_hydro(t, S, dS, dN, dF, dM, dQ, to_devgeom(geom), to_devparams(params), dt, flags,
+    return launch_ctu_hydro(t, S, dS, to_dfab(src), dN, dF, dM, dQ, to_devgeom(geom), to_devparams(params), dt, flags,
                             acc_hi, c->d_status, (hipStream_t)stream, &c->prof);
 }
 

@@ -32,6 +32,7 @@ struct DevScratch {
     double* Q;        // NPRIM planes
     double* DIV;      // 1 plane
     double* SHK;      // 1 plane (hybrid Riemann only)
+    double* SRCQ;     // 6 planes (rho,u,v,w,p,rhoe primitive sources; only with a source FAB)
     double* QM[3];    // NEDGE planes each
     double* QP[3];
     double* F1[3];    // NF1 planes each
@@ -55,7 +56,7 @@ void prof_begin(Profiler* p, const char* name, hipStream_t s);
 void prof_end(Profiler* p, hipStream_t s);
 void prof_collect(Profiler* p);
 
-int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Snew,
+int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
                      int* d_status, hipStream_t stream, Profiler* prof);

@@ -123,6 +123,41 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, DFab U, double* __restr
 }
 
 // ---------------------------------------------------------------------------------------
+// Castro::src_to_prim (Source/hydro/Castro_ctu.cpp:468-545) on grow(bx,3): conserved old-time
+// sources -> primitive sources (CTU, source_term_predictor = 0: srcU = old_source)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const double* __restrict__ Q, DFab SRC,
+                                                     double* __restrict__ SQ, DevParams P)
+{
+    int i, j, k;
+    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    const unsigned c = goff(t, i, j, k);
+    const unsigned cs = foff(SRC, i, j, k);
+    const long NC = t.NC;
+
+    const double s_rho = 0.0 + ldg(SRC.p + URHO * SRC.sn, cs);
+    const double s_mx = 0.0 + ldg(SRC.p + UMX * SRC.sn, cs);
+    const double s_my = 0.0 + ldg(SRC.p + UMY * SRC.sn, cs);
+    const double s_mz = 0.0 + ldg(SRC.p + UMZ * SRC.sn, cs);
+    const double s_ei = 0.0 + ldg(SRC.p + UEINT * SRC.sn, cs);
+
+    const double rho = ldg(Q + PRHO * NC, c);
+    const double rhoinv = 1.0 / rho;
+    const double qre = ldg(Q + PRE * NC, c);
+    const double e = qre * rhoinv;
+    const double dpde = (P.gamma - 1.0) * rho;
+    const double dpdr_e = (P.gamma - 1.0) * e;
+
+    const double q_rho = s_rho;
+    stg(SQ + PRHO * NC, c, q_rho);
+    stg(SQ + PU * NC, c, (s_mx - ldg(Q + PU * NC, c) * q_rho) * rhoinv);
+    stg(SQ + PV * NC, c, (s_my - ldg(Q + PV * NC, c) * q_rho) * rhoinv);
+    stg(SQ + PW * NC, c, (s_mz - ldg(Q + PW * NC, c) * q_rho) * rhoinv);
+    stg(SQ + PRE * NC, c, s_ei);
+    stg(SQ + PP * NC, c, dpde * (s_ei - qre * q_rho * rhoinv) * rhoinv + dpdr_e * q_rho);
+}
+
+// ---------------------------------------------------------------------------------------
 // Castro::divu, 3-D branch (Source/hydro/advection_util.cpp:458-475), nodes of grow(bx,1)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
@@ -196,9 +231,40 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
 // flattening + PPM + tracing.  Castro::uflatten (flatten.cpp:12-166) and Castro::trace_ppm
 // (trace_ppm.cpp:15-594, no sources) for the three directions of one zone of grow(bx,1).
 // ---------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void trace_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd,
-                                          double flat, double dtdx, const DevParams& P,
+// one source component: trace under it only if its 5-point stencil is not identically zero
+// (check_trace_source, ppm.H:11-41 -- the reference's GPU form; the CPU form pre-scans the
+// tile, trace_ppm.cpp:66-93, and gives the same numbers because an all-zero stencil integrates
+// to exactly zero)
+template <int NW>
+__device__ __forceinline__ void trace_source(const double* __restrict__ a, unsigned c, unsigned sd, double flat,
+                                             double un, double cc, double dtdx, double Ip[3], double Im[3])
+{
+    double s[5];
+    s[0] = ldg(a, c - 2 * sd); s[1] = ldg(a, c - sd); s[2] = ldg(a, c); s[3] = ldg(a, c + sd); s[4] = ldg(a, c + 2 * sd);
+    Ip[0] = Ip[1] = Ip[2] = 0.0;
+    Im[0] = Im[1] = Im[2] = 0.0;
+    const bool do_trace = fabs(s[0]) > 0.0 || fabs(s[1]) > 0.0 || fabs(s[2]) > 0.0 || fabs(s[3]) > 0.0 || fabs(s[4]) > 0.0;
+    if (do_trace) {
+        double sm, sp;
+        ppm_reconstruct(s, flat, sm, sp);
+        const double s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+        if (NW == 3) {            // rho, p, rho e: all three waves
+            ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip[0], Im[0]);
+            ppm_int_wave(sm, sp, s6, un, dtdx, Ip[1], Im[1]);
+            ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip[2], Im[2]);
+        } else if (NW == 2) {     // normal velocity: u-c and u+c
+            ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip[0], Im[0]);
+            ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip[2], Im[2]);
+        } else {                  // transverse velocities: contact only
+            ppm_int_wave(sm, sp, s6, un, dtdx, Ip[1], Im[1]);
+        }
+    }
+}
+
+template <int D, bool SRC>
+__device__ __forceinline__ void trace_dir(const Tile& t, const double* __restrict__ Q, const double* __restrict__ SQ,
+                                          unsigned c, unsigned sd,
+                                          double flat, double dtdx, double hdt, const DevParams& P,
                                           bool do_plus, bool do_minus,
                                           double* __restrict__ QMd, double* __restrict__ QPd)
 {
@@ -269,6 +335,20 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
     ppm_int_wave(sm, sp, s6, un, dtdx, Ip_X, Im_X);
 #undef LOAD5
 
+    // source terms (trace_ppm.cpp:226-330); SQ planes are indexed like the primitive components
+    double Ips_rho[3], Ims_rho[3], Ips_un[3], Ims_un[3], Ips_p[3], Ims_p[3], Ips_re[3], Ims_re[3];
+    double Ips_ut[3], Ims_ut[3], Ips_utt[3], Ims_utt[3];
+    if (SRC) {
+        trace_source<3>(SQ + PRHO * NC, c, sd, flat, un, cc, dtdx, Ips_rho, Ims_rho);
+        trace_source<2>(SQ + (long)QUN * NC, c, sd, flat, un, cc, dtdx, Ips_un, Ims_un);
+        trace_source<3>(SQ + PP * NC, c, sd, flat, un, cc, dtdx, Ips_p, Ims_p);
+        trace_source<3>(SQ + PRE * NC, c, sd, flat, un, cc, dtdx, Ips_re, Ims_re);
+        trace_source<1>(SQ + (long)QUT * NC, c, sd, flat, un, cc, dtdx, Ips_ut, Ims_ut);
+        trace_source<1>(SQ + (long)QUTT * NC, c, sd, flat, un, cc, dtdx, Ips_utt, Ims_utt);
+    }
+#define SADD(x, sv) (SRC ? ((x) + hdt * (sv)) : (x))
+#define SSUB(x, sv) (SRC ? ((x) - hdt * (sv)) : (x))
+
     // gamma_c is the constant eos_gamma for a gamma-law gas: its parabola is flat and
     // Ip = Im = gamma exactly (sm == sp == s0 => quadratic limiter resets, s6 == 0), so the
     // reference's QGAMC reconstruction (trace_ppm.cpp:212-223) is elided bit-for-bit.
@@ -276,10 +356,10 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
 
     if (do_plus) {
         // plus state on face i, trace_ppm.cpp:382-466 (source integrals are zero)
-        double rho_ref = Im_rho0;
-        double un_ref = Im_un_0;
-        double p_ref = Im_p0;
-        double rhoe_g_ref = Im_re0;
+        double rho_ref = SADD(Im_rho0, Ims_rho[0]);
+        double un_ref = SADD(Im_un_0, Ims_un[0]);
+        double p_ref = SADD(Im_p0, Ims_p[0]);
+        double rhoe_g_ref = SADD(Im_re0, Ims_re[0]);
 
         rho_ref = amax(rho_ref, P.small_dens);
         double rho_ref_inv = 1.0 / rho_ref;
@@ -290,15 +370,15 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         double cc_ref_inv = 1.0 / cc_ref;
         double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
 
-        double dum = un_ref - Im_un_0;
-        double dptotm = p_ref - Im_p0;
+        double dum = SSUB(un_ref - Im_un_0, Ims_un[0]);
+        double dptotm = SSUB(p_ref - Im_p0, Ims_p[0]);
 
-        double drho = rho_ref - Im_rho1;
-        double dptot = p_ref - Im_p1;
-        double drhoe_g = rhoe_g_ref - Im_re1;
+        double drho = SSUB(rho_ref - Im_rho1, Ims_rho[1]);
+        double dptot = SSUB(p_ref - Im_p1, Ims_p[1]);
+        double drhoe_g = SSUB(rhoe_g_ref - Im_re1, Ims_re[1]);
 
-        double dup = un_ref - Im_un_2;
-        double dptotp = p_ref - Im_p2;
+        double dup = SSUB(un_ref - Im_un_2, Ims_un[2]);
+        double dptotp = SSUB(p_ref - Im_p2, Ims_p[2]);
 
         double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
         double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
@@ -314,17 +394,17 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         stg(QPd + QUN * NC, c, un_ref + (alphap - alpham) * cc_ref * rho_ref_inv);
         stg(QPd + PRE * NC, c, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
         stg(QPd + PP * NC, c, amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref));
-        stg(QPd + QUT * NC, c, Im_ut);
-        stg(QPd + QUTT * NC, c, Im_utt);
+        stg(QPd + QUT * NC, c, SADD(Im_ut, Ims_ut[1]));
+        stg(QPd + QUTT * NC, c, SADD(Im_utt, Ims_utt[1]));
         stg(QPd + PX * NC, c, Im_X);
     }
 
     if (do_minus) {
         // minus state on face i+1, trace_ppm.cpp:470-561
-        double rho_ref = Ip_rho2;
-        double un_ref = Ip_un_2;
-        double p_ref = Ip_p2;
-        double rhoe_g_ref = Ip_re2;
+        double rho_ref = SADD(Ip_rho2, Ips_rho[2]);
+        double un_ref = SADD(Ip_un_2, Ips_un[2]);
+        double p_ref = SADD(Ip_p2, Ips_p[2]);
+        double rhoe_g_ref = SADD(Ip_re2, Ips_re[2]);
 
         rho_ref = amax(rho_ref, P.small_dens);
         double rho_ref_inv = 1.0 / rho_ref;
@@ -335,15 +415,15 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         double cc_ref_inv = 1.0 / cc_ref;
         double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
 
-        double dum = un_ref - Ip_un_0;
-        double dptotm = p_ref - Ip_p0;
+        double dum = SSUB(un_ref - Ip_un_0, Ips_un[0]);
+        double dptotm = SSUB(p_ref - Ip_p0, Ips_p[0]);
 
-        double drho = rho_ref - Ip_rho1;
-        double dptot = p_ref - Ip_p1;
-        double drhoe_g = rhoe_g_ref - Ip_re1;
+        double drho = SSUB(rho_ref - Ip_rho1, Ips_rho[1]);
+        double dptot = SSUB(p_ref - Ip_p1, Ips_p[1]);
+        double drhoe_g = SSUB(rhoe_g_ref - Ip_re1, Ips_re[1]);
 
-        double dup = un_ref - Ip_un_2;
-        double dptotp = p_ref - Ip_p2;
+        double dup = SSUB(un_ref - Ip_un_2, Ips_un[2]);
+        double dptotp = SSUB(p_ref - Ip_p2, Ips_p[2]);
 
         double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
         double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
@@ -360,14 +440,17 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         stg(QMd + QUN * NC, cp, un_ref + (alphap - alpham) * cc_ref * rho_ref_inv);
         stg(QMd + PRE * NC, cp, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
         stg(QMd + PP * NC, cp, amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref));
-        stg(QMd + QUT * NC, cp, Ip_ut);
-        stg(QMd + QUTT * NC, cp, Ip_utt);
+        stg(QMd + QUT * NC, cp, SADD(Ip_ut, Ips_ut[1]));
+        stg(QMd + QUTT * NC, cp, SADD(Ip_utt, Ips_utt[1]));
         stg(QMd + PX * NC, cp, Ip_X);
     }
+#undef SADD
+#undef SSUB
 }
 
+template <bool SRC>
 __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
-                                               double dtdx0, double dtdx1, double dtdx2, DevParams P)
+                                               double dtdx0, double dtdx1, double dtdx2, double hdt, DevParams P)
 {
     int i, j, k;
     if (!box_thread(b.lo, b.n, i, j, k)) return;
@@ -409,9 +492,9 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
         flat = 1.0;
     }
 
-    trace_dir<0>(t, Q, c, s.x, flat, dtdx0, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
-    trace_dir<1>(t, Q, c, s.y, flat, dtdx1, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
-    trace_dir<2>(t, Q, c, s.z, flat, dtdx2, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+    trace_dir<0, SRC>(t, Q, S.SRCQ, c, s.x, flat, dtdx0, hdt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+    trace_dir<1, SRC>(t, Q, S.SRCQ, c, s.y, flat, dtdx1, hdt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+    trace_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, flat, dtdx2, hdt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -782,7 +865,7 @@ static LinBox linbox(const int lo[3], const int hi[3], long& n)
         }                                                                                    \
     } while (0)
 
-int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Snew,
+int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
                      int* d_status, hipStream_t stream, Profiler* prof)
@@ -804,7 +887,14 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         }
 
     KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, (P.hybrid_riemann == 1) ? S.SHK : (double*)nullptr, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
-    KL("k_trace", k_trace, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], P);
+    if (Src.p) {
+        const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
+        const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
+        KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P);
+        KL("k_trace", k_trace<true>, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], 0.5 * dt, P);
+    } else {
+        KL("k_trace", k_trace<false>, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], 0.5 * dt, P);
+    }
 
     KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
     KL("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);

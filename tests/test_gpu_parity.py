@@ -31,7 +31,7 @@ def _to_dev(h, a):
 
 
 def _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, pkw=None, geom_kw=None, tile=(0, 0, 0),
-              hip_tiles=None, dx=None):
+              hip_tiles=None, dx=None, src=None, src_box=None):
     """One construct_ctu_hydro_source call on both paths; returns dict of (hip, oracle) arrays."""
     import torch
     import castro_amd
@@ -48,12 +48,15 @@ def _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, pkw=None, geom_kw=No
     g = 4
     sl = (slice(None),) + tuple(slice(bxlo[2 - a] - sb_lo[2 - a], bxhi[2 - a] - sb_lo[2 - a] + 1) for a in range(3))
     Snew_o = np.ascontiguousarray(U[sl])
-    st, fl_o, mf_o, qe_o = oracle.ctu_hydro(bxlo, bxhi, U, sb_lo, sb_hi, Snew_o, Go, Po, dt, tile=tile, want_qe=True)
+    st, fl_o, mf_o, qe_o = oracle.ctu_hydro(bxlo, bxhi, U, sb_lo, sb_hi, Snew_o, Go, Po, dt, tile=tile, want_qe=True,
+                                            src=src, src_lo=src_box[0] if src is not None else None,
+                                            src_hi=src_box[1] if src is not None else None)
     assert st == 0
 
     # HIP
     Ud = _to_dev(hip, U)
     Snew_d = _to_dev(hip, U[sl])
+    src_d = _to_dev(hip, src) if src is not None else None
     fl_d, mf_d, qe_d, fboxes = [], [], [], []
     for d in range(3):
         fhi = list(bxhi)
@@ -65,7 +68,8 @@ def _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, pkw=None, geom_kw=No
     for bx in (hip_tiles or [(tuple(bxlo), tuple(bxhi))]):
         hip.construct_ctu_hydro_source(bx, Ud, (sb_lo, sb_hi), Snew_d, (bxlo, bxhi), Gh, Ph, 0.0, dt,
                                        fluxes=fl_d, flux_boxes=fboxes, mass_fluxes=mf_d, qe=qe_d,
-                                       vbx=(tuple(bxlo), tuple(bxhi)), update_from_sborder=False)
+                                       vbx=(tuple(bxlo), tuple(bxhi)), update_from_sborder=False,
+                                       src=src_d, src_box=src_box)
     torch.cuda.synchronize()
     assert hip.status() == 0
     out = {"S_new": (Snew_d.cpu().numpy(), Snew_o)}
@@ -161,6 +165,35 @@ def test_ctu_hydro_solver_options(hip, oracle, pkw):
     out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), pkw=pkw,
                     geom_kw=dict(lo_bc=(2, 4, 2), hi_bc=(3, 2, 2)))
     _assert_exact(out, "options %s" % (pkw,))
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_ctu_hydro_with_old_sources(hip, oracle, sparse):
+    """Non-zero old_source (gravity-like momentum/energy sources): src_to_prim + source tracing in
+    trace_ppm.  `sparse` leaves most stencils identically zero, which exercises the per-stencil
+    check of the GPU form against the oracle's tile-wide pre-scan (the reference's CPU form)."""
+    rng = np.random.default_rng(33)
+    bxlo, bxhi = (0, 0, 0), (11, 13, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (15, 17, 13)
+    s_lo, s_hi = (-3, -3, -3), (14, 16, 12)
+    U = physical_state(rng, sb_lo, sb_hi)
+    nz, ny, nx = (s_hi[2] - s_lo[2] + 1, s_hi[1] - s_lo[1] + 1, s_hi[0] - s_lo[0] + 1)
+    rho = U[0][1:-1, 1:-1, 1:-1]
+    gvec = np.array([0.3, -9.8, 1.7])
+    src = np.zeros((7, nz, ny, nx))
+    for d in range(3):
+        src[1 + d] = rho * gvec[d]
+        src[4] += U[1 + d][1:-1, 1:-1, 1:-1] * gvec[d]
+    src[0] = 0.01 * rho * rng.uniform(-1, 1, size=rho.shape)
+    src[5] = 0.05 * rng.uniform(-1, 1, size=rho.shape)
+    if sparse:
+        mask = np.zeros_like(rho)
+        mask[5:8, 6:9, 4:7] = 1.0
+        src *= mask
+    src = np.ascontiguousarray(src)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02),
+                    src=src, src_box=(s_lo, s_hi))
+    _assert_exact(out, "sources sparse=%s" % sparse)
 
 
 def test_unsupported_options_fail_loudly(hip):
