@@ -102,6 +102,8 @@ static DevParams to_devparams(const castro_amd_params* p)
     P.reset_density = p->transverse_reset_density; P.reset_rhoe = p->transverse_reset_rhoe;
     P.use_eos = p->transverse_use_eos;
     P.ppm_temp_fix = p->ppm_temp_fix;
+    P.ppm_type = p->ppm_type; P.plm_iorder = p->plm_iorder; P.plm_limiter = p->plm_limiter; P.use_pslope = p->use_pslope;
+    P.pslope_cutoff_density = p->pslope_cutoff_density;
     return P;
 }
 
@@ -113,6 +115,8 @@ static DevGeom to_devgeom(const castro_amd_geom* g)
         G.domlo[d] = g->domlo[d]; G.domhi[d] = g->domhi[d];
         G.wall_lo[d] = (g->lo_bc[d] >= 3) ? 1 : 0;
         G.wall_hi[d] = (g->hi_bc[d] >= 3) ? 1 : 0;
+        G.sym_lo[d] = (g->lo_bc[d] == 3) ? 1 : 0;
+        G.sym_hi[d] = (g->hi_bc[d] == 3) ? 1 : 0;
     }
     return G;
 }
@@ -138,6 +142,7 @@ void castro_amd_default_params(castro_amd_params* p)
     p->first_order_hydro = 0; p->cg_maxiter = 12; p->cg_blend = 2;
     p->transverse_use_eos = 0; p->transverse_reset_density = 1; p->transverse_reset_rhoe = 0;
     p->ppm_temp_fix = 0;
+    p->plm_iorder = 2; p->plm_limiter = 2; p->use_pslope = 1; p->pslope_cutoff_density = -1.e20;
     p->difmag = 0.1;
     p->small_dens = -1.e200; p->small_temp = -1.e200; p->small_pres = -1.e200; p->small_ener = -1.e200;
     p->cg_tol = 1.0e-5;
@@ -233,7 +238,7 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
         return CASTRO_AMD_ERR_ARG;
     if (Sborder->ncomp != NUM_STATE || S_new->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
     if (geom->coord != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
-    if (params->ppm_type != 1) return CASTRO_AMD_ERR_UNSUPPORTED;                 // PLM: SURVEY 8(f-1)
+    if (params->ppm_type != 0 && params->ppm_type != 1) return CASTRO_AMD_ERR_ARG;
     if (params->riemann_solver < 0 || params->riemann_solver > 2) return CASTRO_AMD_ERR_ARG;
     if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
     // transverse_reset_rhoe needs the eint flux of the transverse solves, which the flux record does not carry

@@ -26,6 +26,7 @@ struct DevGeom {
     double dx[3];
     int domlo[3], domhi[3];
     int wall_lo[3], wall_hi[3];   // Symmetry / SlipWall / NoSlipWall: zero normal flux (riemann.cpp:53-59)
+    int sym_lo[3], sym_hi[3];     // Symmetry only: PLM reflecting treatment (trace_plm.cpp:39-40, Castro_ctu.cpp:293-294)
 };
 
 struct DevScratch {

@@ -448,9 +448,215 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
 #undef SSUB
 }
 
-template <bool SRC>
-__global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
-                                               double dtdx0, double dtdx1, double dtdx2, double hdt, DevParams P)
+
+// ---------------------------------------------------------------------------------------
+// PLM characteristic tracing (ppm_type = 0), Castro::trace_plm, trace_plm.cpp:17-339, fused with the
+// reflecting-boundary fix-up of Castro::ctu_plm_states (Castro_ctu.cpp:287-433): at a Symmetry
+// face the zone inside the domain writes both edge states and the ghost zone writes neither.
+// ---------------------------------------------------------------------------------------
+template <int D, bool SRC>
+__device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __restrict__ Q, const double* __restrict__ SQ,
+                                              unsigned c, unsigned sd, int idx, const DevGeom& g,
+                                              double flat, double dt, const DevParams& P,
+                                              bool do_plus, bool do_minus,
+                                              double* __restrict__ QMd, double* __restrict__ QPd)
+{
+    constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
+    constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
+    constexpr int QUTT = (D == 0) ? PW : (D == 1) ? PU : PV;
+
+    const long NC = t.NC;
+    const double dtdx = dt / g.dx[D];
+    const bool lo_bc_test = g.sym_lo[D] && idx == g.domlo[D];
+    const bool hi_bc_test = g.sym_hi[D] && idx == g.domhi[D];
+    // ghost zones just outside a Symmetry face leave that face to the zone inside
+    if (g.sym_lo[D] && idx == g.domlo[D] - 1) do_minus = false;
+    if (g.sym_hi[D] && idx == g.domhi[D] + 1) do_plus = false;
+
+#define LOAD5(arr, comp, dst) { const double* a = (arr) + (long)(comp) * NC; \
+        dst[0] = ldg(a, c - 2 * sd); dst[1] = ldg(a, c - sd); dst[2] = ldg(a, c); dst[3] = ldg(a, c + sd); dst[4] = ldg(a, c + 2 * sd); }
+
+    double srho[5], sp[5], s[5];
+    LOAD5(Q, PRHO, srho);
+    LOAD5(Q, PP, sp);
+
+    const double cc = ldg(Q + PC * NC, c);
+    const double csq = cc * cc;
+    const double rho = srho[2];
+    const double p = sp[2];
+    const double enth_rhoe = ldg(Q + PRE * NC, c);
+
+    const double dq_rho = uslope(srho, flat, false, false, P);
+    LOAD5(Q, QUN, s);
+    const double un = s[2];
+    const double dq_un = uslope(s, flat, lo_bc_test, hi_bc_test, P);
+    LOAD5(Q, QUT, s);
+    const double ut = s[2];
+    const double dq_ut = uslope(s, flat, false, false, P);
+    LOAD5(Q, QUTT, s);
+    const double utt = s[2];
+    const double dq_utt = uslope(s, flat, false, false, P);
+    double dq_p = uslope(sp, flat, false, false, P);
+    LOAD5(Q, PRE, s);
+    const double rhoe = enth_rhoe;
+    const double dq_re = uslope(s, flat, false, false, P);
+    LOAD5(Q, PX, s);
+    const double X = s[2];
+    const double dX = uslope(s, flat, false, false, P);
+
+    const double enth = (rhoe + p) / (rho * csq);
+
+    if (P.use_pslope == 1) {
+        double src[5];
+        if (SRC) { LOAD5(SQ, QUN, src); }
+        else { src[0] = src[1] = src[2] = src[3] = src[4] = 0.0; }
+        pslope(srho, sp, src, flat, lo_bc_test, hi_bc_test, g.dx[D], dq_p, P);
+    }
+#undef LOAD5
+
+    // old-time sources at the zone centre (zero planes when the caller passes no source)
+    double sq_rho = 0.0, sq_un = 0.0, sq_ut = 0.0, sq_utt = 0.0, sq_p = 0.0, sq_re = 0.0;
+    if (SRC) {
+        sq_rho = ldg(SQ + PRHO * NC, c);
+        sq_un = ldg(SQ + (long)QUN * NC, c);
+        sq_ut = ldg(SQ + (long)QUT * NC, c);
+        sq_utt = ldg(SQ + (long)QUTT * NC, c);
+        sq_p = ldg(SQ + PP * NC, c);
+        sq_re = ldg(SQ + PRE * NC, c);
+    }
+
+    const double alpham = 0.5 * (dq_p / (rho * cc) - dq_un) * (rho / cc);
+    const double alphap = 0.5 * (dq_p / (rho * cc) + dq_un) * (rho / cc);
+    const double alpha0r = dq_rho - dq_p / csq;
+    const double alpha0e = dq_re - dq_p * enth;
+    const double alpha0ut = dq_ut;
+    const double alpha0utt = dq_utt;
+
+    const double e0 = un - cc, e1 = un, e2 = un + cc;
+
+    if (do_plus) {
+        // right state on the i interface, trace_plm.cpp:183-236
+        double ref_fac = 0.5 * (1.0 + dtdx * amin(e0, 0.0));
+        double rho_ref = rho - ref_fac * dq_rho;
+        double un_ref = un - ref_fac * dq_un;
+        double ut_ref = ut - ref_fac * dq_ut;
+        double utt_ref = utt - ref_fac * dq_utt;
+        double p_ref = p - ref_fac * dq_p;
+        double rhoe_ref = rhoe - ref_fac * dq_re;
+
+        double trace_fac0 = 0.0;
+        double trace_fac1 = 0.25 * dtdx * (e0 - e1) * (1.0 - copysign(1.0, e1));
+        double trace_fac2 = 0.25 * dtdx * (e0 - e2) * (1.0 - copysign(1.0, e2));
+
+        double apright = trace_fac2 * alphap;
+        double amright = trace_fac0 * alpham;
+
+        double azrright = trace_fac1 * alpha0r;
+        double azeright = trace_fac1 * alpha0e;
+        double azut1rght = trace_fac1 * alpha0ut;
+        double azutt1rght = trace_fac1 * alpha0utt;
+
+        double o_rho = amax(P.small_dens, rho_ref + apright + amright + azrright);
+        double o_un = un_ref + (apright - amright) * cc / rho;
+        double o_ut = ut_ref + azut1rght;
+        double o_utt = utt_ref + azutt1rght;
+        double o_p = amax(P.small_pres, p_ref + (apright + amright) * csq);
+        double o_re = rhoe_ref + (apright + amright) * enth * csq + azeright;
+
+        o_rho = o_rho + 0.5 * dt * sq_rho;
+        o_rho = amax(P.small_dens, o_rho);
+        o_un = o_un + 0.5 * dt * sq_un;
+        o_ut = o_ut + 0.5 * dt * sq_ut;
+        o_utt = o_utt + 0.5 * dt * sq_utt;
+        o_re = o_re + 0.5 * dt * sq_re;
+        o_p = o_p + 0.5 * dt * sq_p;
+
+        double spzero = un >= 0.0 ? -1.0 : un * dtdx;
+        double o_X = X + 0.5 * (-1.0 - spzero) * dX;
+
+        stg(QPd + PRHO * NC, c, o_rho);
+        stg(QPd + QUN * NC, c, o_un);
+        stg(QPd + QUT * NC, c, o_ut);
+        stg(QPd + QUTT * NC, c, o_utt);
+        stg(QPd + PP * NC, c, o_p);
+        stg(QPd + PRE * NC, c, o_re);
+        stg(QPd + PX * NC, c, o_X);
+        if (lo_bc_test) {
+            // Castro_ctu.cpp:293-318: the left state on the Symmetry face mirrors the right one
+            stg(QMd + PRHO * NC, c, o_rho);
+            stg(QMd + QUN * NC, c, -o_un);
+            stg(QMd + QUT * NC, c, o_ut);
+            stg(QMd + QUTT * NC, c, o_utt);
+            stg(QMd + PP * NC, c, o_p);
+            stg(QMd + PRE * NC, c, o_re);
+            stg(QMd + PX * NC, c, o_X);
+        }
+    }
+
+    if (do_minus) {
+        // left state on the i+1 interface, trace_plm.cpp:238-300
+        double ref_fac = 0.5 * (1.0 - dtdx * amax(e2, 0.0));
+        double rho_ref = rho + ref_fac * dq_rho;
+        double un_ref = un + ref_fac * dq_un;
+        double ut_ref = ut + ref_fac * dq_ut;
+        double utt_ref = utt + ref_fac * dq_utt;
+        double p_ref = p + ref_fac * dq_p;
+        double rhoe_ref = rhoe + ref_fac * dq_re;
+
+        double trace_fac0 = 0.25 * dtdx * (e2 - e0) * (1.0 + copysign(1.0, e0));
+        double trace_fac1 = 0.25 * dtdx * (e2 - e1) * (1.0 + copysign(1.0, e1));
+        double trace_fac2 = 0.0;
+
+        double apleft = trace_fac2 * alphap;
+        double amleft = trace_fac0 * alpham;
+
+        double azrleft = trace_fac1 * alpha0r;
+        double azeleft = trace_fac1 * alpha0e;
+        double azut1left = trace_fac1 * alpha0ut;
+        double azutt1left = trace_fac1 * alpha0utt;
+
+        double o_rho = amax(P.small_dens, rho_ref + apleft + amleft + azrleft);
+        double o_un = un_ref + (apleft - amleft) * cc / rho;
+        double o_ut = ut_ref + azut1left;
+        double o_utt = utt_ref + azutt1left;
+        double o_p = amax(P.small_pres, p_ref + (apleft + amleft) * csq);
+        double o_re = rhoe_ref + (apleft + amleft) * enth * csq + azeleft;
+
+        o_rho = amax(P.small_dens, o_rho + 0.5 * dt * sq_rho);
+        o_un = o_un + 0.5 * dt * sq_un;
+        o_ut = o_ut + 0.5 * dt * sq_ut;
+        o_utt = o_utt + 0.5 * dt * sq_utt;
+        o_re = o_re + 0.5 * dt * sq_re;
+        o_p = o_p + 0.5 * dt * sq_p;
+
+        double spzero = un >= 0.0 ? un * dtdx : 1.0;
+        double acmpleft = 0.5 * (1.0 - spzero) * dX;
+        double o_X = X + acmpleft;
+
+        const unsigned cp = c + sd;
+        stg(QMd + PRHO * NC, cp, o_rho);
+        stg(QMd + QUN * NC, cp, o_un);
+        stg(QMd + QUT * NC, cp, o_ut);
+        stg(QMd + QUTT * NC, cp, o_utt);
+        stg(QMd + PP * NC, cp, o_p);
+        stg(QMd + PRE * NC, cp, o_re);
+        stg(QMd + PX * NC, cp, o_X);
+        if (hi_bc_test) {
+            // Castro_ctu.cpp:320-345
+            stg(QPd + PRHO * NC, cp, o_rho);
+            stg(QPd + QUN * NC, cp, -o_un);
+            stg(QPd + QUT * NC, cp, o_ut);
+            stg(QPd + QUTT * NC, cp, o_utt);
+            stg(QPd + PP * NC, cp, o_p);
+            stg(QPd + PRE * NC, cp, o_re);
+            stg(QPd + PX * NC, cp, o_X);
+        }
+    }
+}
+
+template <bool SRC, bool PLM>
+__global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                               double dt, DevParams P)
 {
     int i, j, k;
     if (!box_thread(b.lo, b.n, i, j, k)) return;
@@ -492,9 +698,16 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
         flat = 1.0;
     }
 
-    trace_dir<0, SRC>(t, Q, S.SRCQ, c, s.x, flat, dtdx0, hdt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
-    trace_dir<1, SRC>(t, Q, S.SRCQ, c, s.y, flat, dtdx1, hdt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
-    trace_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, flat, dtdx2, hdt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+    if (PLM) {
+        trace_plm_dir<0, SRC>(t, Q, S.SRCQ, c, s.x, i, g, flat, dt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+        trace_plm_dir<1, SRC>(t, Q, S.SRCQ, c, s.y, j, g, flat, dt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+        trace_plm_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, k, g, flat, dt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+    } else {
+        const double hdt = 0.5 * dt;
+        trace_dir<0, SRC>(t, Q, S.SRCQ, c, s.x, flat, dt / g.dx[0], hdt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+        trace_dir<1, SRC>(t, Q, S.SRCQ, c, s.y, flat, dt / g.dx[1], hdt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+        trace_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, flat, dt / g.dx[2], hdt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -891,9 +1104,11 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
         KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P);
-        KL("k_trace", k_trace<true>, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], 0.5 * dt, P);
+        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P); }
+        else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
-        KL("k_trace", k_trace<false>, olo, ohi, S.Q, S, dt / g.dx[0], dt / g.dx[1], dt / g.dx[2], 0.5 * dt, P);
+        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
+        else { KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P); }
     }
 
     KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);

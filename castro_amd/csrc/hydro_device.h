@@ -40,6 +40,8 @@ struct DevParams {
     int cg_maxiter, cg_blend;
     int reset_density, reset_rhoe, use_eos;
     int ppm_temp_fix;
+    int ppm_type, plm_iorder, plm_limiter, use_pslope;
+    double pslope_cutoff_density;
 };
 
 // amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument
@@ -181,6 +183,114 @@ __device__ __forceinline__ void ppm_int_wave(double sm, double sp, double s6, do
     } else {
         Ip = sp - 0.5 * sigma * (sp - sm - (1.0 - (2.0 / 3.0) * sigma) * s6);
         Im = sm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// PLM slopes (Source/hydro/slope.H); q[0..4] = zones i-2..i+2
+// ---------------------------------------------------------------------------------------
+// slope.H:27-121
+__device__ __forceinline__ double uslope(const double q[5], double flatn, bool bnd_lo_reflect, bool bnd_hi_reflect,
+                                         const DevParams& P)
+{
+    double dq;
+    if (P.plm_iorder == 1) {
+        dq = 0.0;
+    } else if (P.plm_limiter == 1) {
+        double dlft = 2.0 * (q[2] - q[1]);
+        double drgt = 2.0 * (q[3] - q[2]);
+        double dcen = 0.25 * (dlft + drgt);
+        double dsgn = copysign(1.0, dcen);
+        double slop = amin(fabs(dlft), fabs(drgt));
+        double dlim = dlft * drgt >= 0.0 ? slop : 0.0;
+        dq = flatn * dsgn * amin(dlim, fabs(dcen));
+    } else {
+        double qm2 = q[0], qm1 = q[1], q0 = q[2], qp1 = q[3], qp2 = q[4];
+        if (bnd_lo_reflect) {
+            qm2 = -qp1;
+            qm1 = -3.0 * q0 + qp1 - 0.125 * (qp2 + qp1);
+        }
+        if (bnd_hi_reflect) {
+            qp2 = -qm1;
+            qp1 = -3.0 * q0 + qm1 - 0.125 * (qm2 + qm1);
+        }
+
+        double dlftp1 = 2.0 * (qp1 - q0);
+        double drgtp1 = 2.0 * (qp2 - qp1);
+        double dcen = 0.25 * (dlftp1 + drgtp1);
+        double dsgn = copysign(1.0, dcen);
+        double slop = amin(fabs(dlftp1), fabs(drgtp1));
+        double dlim = dlftp1 * drgtp1 >= 0.0 ? slop : 0.0;
+        double dfp1 = dsgn * amin(dlim, fabs(dcen));
+
+        double dlftm1 = 2.0 * (qm1 - qm2);
+        double drgtm1 = 2.0 * (q0 - qm1);
+        dcen = 0.25 * (dlftm1 + drgtm1);
+        dsgn = copysign(1.0, dcen);
+        slop = amin(fabs(dlftm1), fabs(drgtm1));
+        dlim = dlftm1 * drgtm1 >= 0.0 ? slop : 0.0;
+        double dfm1 = dsgn * amin(dlim, fabs(dcen));
+
+        double dlft = drgtm1;
+        double drgt = dlftp1;
+        dcen = 0.25 * (dlft + drgt);
+        dsgn = copysign(1.0, dcen);
+        slop = amin(fabs(dlft), fabs(drgt));
+        dlim = dlft * drgt >= 0.0 ? slop : 0.0;
+
+        double dq1 = (4.0 / 3.0) * dcen - (1.0 / 6.0) * (dfp1 + dfm1);
+        dq = flatn * dsgn * amin(dlim, fabs(dq1));
+    }
+    return dq;
+}
+
+// slope.H:137-241
+__device__ __forceinline__ void pslope(const double rho[5], const double p[5], const double src[5], double flatn,
+                                       bool lo_bc_test, bool hi_bc_test, double dx, double& dp, const DevParams& P)
+{
+    if (P.plm_iorder == 1) {
+        dp = 0.0;
+    } else {
+        if (rho[2] < P.pslope_cutoff_density) return;
+
+        double p0_hse = p[2];
+        double pp1_hse = p0_hse + 0.25 * dx * (rho[2] + rho[3]) * (src[2] + src[3]);
+        double pp2_hse = pp1_hse + 0.25 * dx * (rho[3] + rho[4]) * (src[3] + src[4]);
+        double pm1_hse = p0_hse - 0.25 * dx * (rho[2] + rho[1]) * (src[2] + src[1]);
+        double pm2_hse = pm1_hse - 0.25 * dx * (rho[1] + rho[0]) * (src[1] + src[0]);
+
+        double p0 = 0.0;
+        double pp1 = p[3] - pp1_hse;
+        double pp2 = p[4] - pp2_hse;
+        double pm1 = p[1] - pm1_hse;
+        double pm2 = p[0] - pm2_hse;
+
+        if (lo_bc_test) { pm1 = 0.0; pm2 = 0.0; }
+        if (hi_bc_test) { pp1 = 0.0; pp2 = 0.0; }
+
+        double dlftp1 = pp1 - p0;
+        double drgtp1 = pp2 - pp1;
+        double dcen = 0.5 * (dlftp1 + drgtp1);
+        double dsgn = copysign(1.0, dcen);
+        double dlim = dlftp1 * drgtp1 >= 0.0 ? 2.0 * amin(fabs(dlftp1), fabs(drgtp1)) : 0.0;
+        double dfp1 = dsgn * amin(dlim, fabs(dcen));
+
+        double dlftm1 = pm1 - pm2;
+        double drgtm1 = p0 - pm1;
+        dcen = 0.5 * (dlftm1 + drgtm1);
+        dsgn = copysign(1.0, dcen);
+        dlim = dlftm1 * drgtm1 >= 0.0 ? 2.0 * amin(fabs(dlftm1), fabs(drgtm1)) : 0.0;
+        double dfm1 = dsgn * amin(dlim, fabs(dcen));
+
+        double dlft = drgtm1;
+        double drgt = dlftp1;
+        dcen = 0.5 * (dlft + drgt);
+        dsgn = copysign(1.0, dcen);
+        dlim = dlft * drgt >= 0.0 ? 2.0 * amin(fabs(dlft), fabs(drgt)) : 0.0;
+
+        double dp1 = (4.0 / 3.0) * dcen - (1.0 / 6.0) * (dfp1 + dfm1);
+        dp = flatn * dsgn * amin(dlim, fabs(dp1));
+        dp += rho[2] * src[2] * dx;
     }
 }
 

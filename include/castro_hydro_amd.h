@@ -71,7 +71,7 @@ typedef struct castro_amd_geom {
 
 /* the castro:: runtime parameters the path reads (Source/driver/_cpp_parameters) */
 typedef struct castro_amd_params {
-    int ppm_type;                 /* 1 = PPM (supported); 0 = PLM (unsupported yet) */
+    int ppm_type;                 /* 1 = PPM (default), 0 = PLM */
     int riemann_solver;           /* 0 CGF (default), 1 CG, 2 HLLC */
     int use_flattening;
     int hybrid_riemann;
@@ -82,7 +82,9 @@ typedef struct castro_amd_params {
     int transverse_reset_density;
     int transverse_reset_rhoe;
     int ppm_temp_fix;
-    int reserved_i[3];
+    int plm_iorder;               /* 2 (default) or 1 */
+    int plm_limiter;              /* 2 = 4th-order MC (default), 1 = 2nd-order MC */
+    int use_pslope;               /* 1 (default): well-balanced pressure slope in PLM */
     double difmag;
     double small_dens, small_temp, small_pres, small_ener;
     double cg_tol;
@@ -92,6 +94,7 @@ typedef struct castro_amd_params {
     double small_x;
     double T_guess;
     double abar;                  /* mean molecular weight with eos_assume_neutral = 1 */
+    double pslope_cutoff_density;
 } castro_amd_params;
 
 typedef struct castro_amd_ctx castro_amd_ctx;

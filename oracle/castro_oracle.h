@@ -67,7 +67,7 @@ typedef struct {
     int ppm_temp_fix;
     int plm_iorder;
     int plm_limiter;
-    int plm_well_balanced;
+    int use_pslope;               /* :161 */
     double difmag;                /* :40  */
     double small_dens, small_temp, small_pres, small_ener; /* :43-54 */
     double cg_tol;                /* :121 */
@@ -78,6 +78,7 @@ typedef struct {
     double small_x;               /* network small_x */
     double T_guess;
     double abar;                  /* species A (eos_assume_neutral=1 => mu = abar) */
+    double pslope_cutoff_density; /* :165 */
 } ora_params;
 
 typedef struct {
@@ -109,6 +110,10 @@ void ora_divu(const int lo[3], const int hi[3], ora_a4 q, ora_a4 div, const ora_
 void ora_trace_ppm(const int lo[3], const int hi[3], int idir, ora_a4 q, ora_a4 qaux, ora_a4 srcQ,
                    ora_a4 flatn, ora_a4 qm, ora_a4 qp, const int vlo[3], const int vhi[3],
                    double dt, const ora_geom *G, const ora_params *P);
+void ora_trace_plm(const int lo[3], const int hi[3], int idir, ora_a4 q, ora_a4 qaux, ora_a4 srcQ,
+                   ora_a4 flatn, ora_a4 qm, ora_a4 qp, const int vlo[3], const int vhi[3],
+                   double dt, const ora_geom *G, const ora_params *P);
+void ora_plm_reflect_fix(const int lo[3], const int hi[3], int idir, ora_a4 qm, ora_a4 qp, const ora_geom *G);
 void ora_cmpflx_plus_godunov(const int lo[3], const int hi[3], ora_a4 qm, ora_a4 qp, ora_a4 flx,
                              ora_a4 qgdnv, ora_a4 qaux, ora_a4 shk, int idir,
                              const ora_geom *G, const ora_params *P);

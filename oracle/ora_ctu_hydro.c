@@ -96,8 +96,13 @@ static int ctu_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], cons
     fab_resize(&S->qzm, obxlo, obxhi, NQ); fab_resize(&S->qzp, obxlo, obxhi, NQ);
 
     if (P->ppm_type == 0) {
-        /* PLM (trace_plm.cpp, slope.H) is SURVEY.md 8(f-1) 'next': not restated yet */
-        return 2;
+        /* Castro::ctu_plm_states, Castro_ctu.cpp:216-434: trace, then the reflecting-BC fix-up */
+        ora_trace_plm(obxlo, obxhi, 0, S->q.a, S->qaux.a, S->src_q.a, S->flatn.a, S->qxm.a, S->qxp.a, bxlo, bxhi, dt, G, P);
+        ora_plm_reflect_fix(obxlo, obxhi, 0, S->qxm.a, S->qxp.a, G);
+        ora_trace_plm(obxlo, obxhi, 1, S->q.a, S->qaux.a, S->src_q.a, S->flatn.a, S->qym.a, S->qyp.a, bxlo, bxhi, dt, G, P);
+        ora_plm_reflect_fix(obxlo, obxhi, 1, S->qym.a, S->qyp.a, G);
+        ora_trace_plm(obxlo, obxhi, 2, S->q.a, S->qaux.a, S->src_q.a, S->flatn.a, S->qzm.a, S->qzp.a, bxlo, bxhi, dt, G, P);
+        ora_plm_reflect_fix(obxlo, obxhi, 2, S->qzm.a, S->qzp.a, G);
     } else {
         /* Castro::ctu_ppm_states, Castro_ctu.cpp:112-149 */
         ora_trace_ppm(obxlo, obxhi, 0, S->q.a, S->qaux.a, S->src_q.a, S->flatn.a, S->qxm.a, S->qxp.a, bxlo, bxhi, dt, G, P);

@@ -31,7 +31,8 @@ void ora_default_params(ora_params *p)
     p->ppm_temp_fix = 0;
     p->plm_iorder = 2;
     p->plm_limiter = 2;
-    p->plm_well_balanced = 0;
+    p->use_pslope = 1;
+    p->pslope_cutoff_density = -1.e20;
     p->difmag = 0.1;
     p->small_dens = -1.e200;
     p->small_temp = -1.e200;

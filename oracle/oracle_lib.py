@@ -21,11 +21,11 @@ class Params(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "ppm_type", "riemann_solver", "use_flattening", "hybrid_riemann", "first_order_hydro",
         "cg_maxiter", "cg_blend", "transverse_use_eos", "transverse_reset_density",
-        "transverse_reset_rhoe", "ppm_temp_fix", "plm_iorder", "plm_limiter", "plm_well_balanced")] + \
+        "transverse_reset_rhoe", "ppm_temp_fix", "plm_iorder", "plm_limiter", "use_pslope")] + \
         [(n, C.c_double) for n in (
             "difmag", "small_dens", "small_temp", "small_pres", "small_ener", "cg_tol",
             "dual_energy_eta1", "dual_energy_eta2", "cfl", "init_shrink", "change_max",
-            "eos_gamma", "small_x", "T_guess", "abar")]
+            "eos_gamma", "small_x", "T_guess", "abar", "pslope_cutoff_density")]
 
 
 class Geom(C.Structure):

@@ -196,6 +196,45 @@ def test_ctu_hydro_with_old_sources(hip, oracle, sparse):
     _assert_exact(out, "sources sparse=%s" % sparse)
 
 
+@pytest.mark.parametrize("pkw", [dict(), dict(plm_limiter=1), dict(plm_iorder=1), dict(use_pslope=0),
+                                 dict(riemann_solver=2, hybrid_riemann=1), dict(pslope_cutoff_density=1.0)])
+@pytest.mark.parametrize("with_src", [False, True])
+def test_ctu_hydro_plm(hip, oracle, pkw, with_src):
+    """ppm_type = 0: trace_plm (slope.H uslope/pslope) with Symmetry faces on three sides (reflecting
+    slopes + the ctu_plm_states edge fix-up), with and without old-time sources: bit-exact."""
+    rng = np.random.default_rng(44)
+    bxlo, bxhi = (0, 0, 0), (12, 10, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (16, 14, 13)
+    s_lo, s_hi = (-3, -3, -3), (15, 13, 12)
+    U = physical_state(rng, sb_lo, sb_hi, vel=1.2)
+    src = None
+    if with_src:
+        rho = U[0][1:-1, 1:-1, 1:-1]
+        src = np.zeros((7,) + rho.shape)
+        for d, gd in enumerate((0.3, -9.8, 1.7)):
+            src[1 + d] = rho * gd
+            src[4] += U[1 + d][1:-1, 1:-1, 1:-1] * gd
+        src[0] = 0.01 * rho * rng.uniform(-1, 1, size=rho.shape)
+        src = np.ascontiguousarray(src)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02),
+                    pkw=dict(ppm_type=0, **pkw), geom_kw=dict(lo_bc=(3, 2, 3), hi_bc=(2, 3, 4)),
+                    src=src, src_box=(s_lo, s_hi) if with_src else None)
+    _assert_exact(out, "PLM %s src=%s" % (pkw, with_src))
+
+
+def test_ctu_hydro_plm_tiles_with_symmetry(hip, oracle):
+    """PLM on tiles: the Symmetry fix-up only acts on tiles that touch the domain face."""
+    rng = np.random.default_rng(45)
+    bxlo, bxhi = (0, 0, 0), (15, 11, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (19, 15, 13)
+    U = physical_state(rng, sb_lo, sb_hi, vel=1.2)
+    tiles = [((0, 0, 0), (0, 11, 9)), ((1, 0, 0), (7, 5, 9)), ((1, 6, 0), (7, 11, 9)), ((8, 0, 0), (14, 11, 4)),
+             ((8, 0, 5), (14, 11, 9)), ((15, 0, 0), (15, 11, 9))]
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), pkw=dict(ppm_type=0),
+                    geom_kw=dict(lo_bc=(3, 3, 3), hi_bc=(3, 3, 3)), hip_tiles=tiles)
+    _assert_exact(out, "PLM tiles")
+
+
 def test_unsupported_options_fail_loudly(hip):
     import castro_amd
     from castro_amd import _lib as L
@@ -203,7 +242,7 @@ def test_unsupported_options_fail_loudly(hip):
     G = castro_amd.make_geom(n)
     S = hip.alloc(8, (-4, -4, -4), (11, 11, 11), fill=1.0)
     N = hip.alloc(8, (0, 0, 0), (7, 7, 7), fill=1.0)
-    for kw in (dict(ppm_type=0), dict(transverse_reset_rhoe=1), dict(ppm_temp_fix=2)):
+    for kw in (dict(transverse_reset_rhoe=1), dict(ppm_temp_fix=2)):
         P = castro_amd.default_params(**kw)
         with pytest.raises(RuntimeError, match="unsupported"):
             hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
@@ -309,15 +348,17 @@ def test_sedov_driver_matches_oracle(oracle):
         assert rd <= 1e-13, "fluxes[%d] deviate: max rel %.3e" % (d, rd)
 
 
-def test_sod_driver_with_walls_matches_oracle_and_exact(oracle):
-    """Sod along y with SlipWall transverse BCs (reflecting ghost fill + zero wall flux): HIP == oracle,
-    and both close to the reference's exact-solution table."""
+@pytest.mark.parametrize("ppm_type,wall", [(1, 4), (0, 3)])
+def test_sod_driver_with_walls_matches_oracle_and_exact(oracle, ppm_type, wall):
+    """Sod along y with SlipWall (PPM) or Symmetry (PLM) transverse BCs (reflecting ghost fill + zero
+    wall flux, and for PLM the reflecting slope treatment): HIP == oracle, and both close to the
+    reference's exact-solution table."""
     import os
     import torch
     import castro_amd
     n = (4, 64, 4)
-    kw = dict(cfl=0.9, init_shrink=0.1, change_max=1.05)
-    lo_bc, hi_bc = (4, 2, 4), (4, 2, 4)
+    kw = dict(cfl=0.9, init_shrink=0.1, change_max=1.05, ppm_type=ppm_type)
+    lo_bc, hi_bc = (wall, 2, wall), (wall, 2, wall)
     prob_hi = (4 / 64, 1.0, 4 / 64)
     c = castro_amd.Castro(n, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=castro_amd.default_params(**kw))
     c.initData("sod", rho_l=1.0, u_l=0.0, p_l=1.0, rho_r=0.125, u_r=0.0, p_r=0.1, idir=2)
