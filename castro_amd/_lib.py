@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
     "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status",
-    "castro_amd_ctu_hydro_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
+    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
@@ -79,6 +79,9 @@ def load():
     L.castro_amd_ctu_hydro_fab.argtypes = [
         C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
         C.c_double, C.c_double, C.c_int, C.c_void_p]
+    L.castro_amd_ctu_hydro_clean_fab.argtypes = [
+        C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
+        C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.castro_amd_clean_state_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]
     L.castro_amd_clean_state_reduce_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params),
                                                     C.c_int, C.c_void_p, C.c_void_p]

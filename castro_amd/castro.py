@@ -91,7 +91,7 @@ class AdvanceFailure(RuntimeError):
 # --------------------------------------------------------------------------------------------
 class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
-                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None):
+                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -138,6 +138,7 @@ class Castro:
 
         self.neighbors = self._build_neighbors()
         self.overlap = (self.comm.size > 1) if overlap is None else bool(overlap)
+        self.fuse_clean = bool(fuse_clean)
         self._comm_stream = None
         if self.overlap and self.S_new_b.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
@@ -266,12 +267,16 @@ class Castro:
         return dt_0
 
     # ---- Castro::construct_ctu_hydro_source over this rank's box ------------------------------
-    def construct_ctu_hydro_source(self, time, dt, tiles=None):
+    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False):
+        """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
+        and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
+        self.red, which the caller has initialised."""
         h = self.hydro
         for bx in (tiles or [self.bx]):
             h.construct_ctu_hydro_source(bx, self.S_old_b, self.gbox, self.S_new_b, self.gbox, self.geom,
                                          self.params, time, dt, fluxes=self.fluxes, flux_boxes=self.flux_boxes,
-                                         mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=True)
+                                         mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=True,
+                                         clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None)
 
     def _shell_tiles(self):
         """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
@@ -306,8 +311,13 @@ class Castro:
             self.fluxes[d].zero_()          # Castro_advance.cpp:391-394
             self.mass_fluxes[d].zero_()
 
+        # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
+        # (:221-225) and the estTimeStep validity check (:386-392) are fused into the update pass
+        # (no new-time source terms on this path) + one 2-double allreduce
+        fuse = self.fuse_clean
+        self.red.fill_(1.e200)
+
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
-        t0 = None
         if use_overlap:
             interior, shells = self._shell_tiles()
             cur = torch.cuda.current_stream()
@@ -315,17 +325,15 @@ class Castro:
             with torch.cuda.stream(self._comm_stream):
                 self.expand_state(S)                                   # halo exchange + BC fill
             if interior is not None:
-                self.construct_ctu_hydro_source(time, dt, tiles=[interior])   # overlapped: needs no ghost data
+                self.construct_ctu_hydro_source(time, dt, tiles=[interior], fuse_clean=fuse)   # overlapped: needs no ghost data
             cur.wait_stream(self._comm_stream)
-            self.construct_ctu_hydro_source(time, dt, tiles=shells)
+            self.construct_ctu_hydro_source(time, dt, tiles=shells, fuse_clean=fuse)
         else:
             self.expand_state(S)
-            self.construct_ctu_hydro_source(time, dt)
+            self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse)
 
-        # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
-        # (:221-225) and the estTimeStep validity check (:386-392): one fused pass + one 2-double allreduce
-        self.red.fill_(1.e200)
-        h.clean_state_reduce(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, self.red, ntimes=1)
+        if not fuse:
+            h.clean_state_reduce(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, self.red, ntimes=1)
         self.comm.allreduce_min(self.red)
         est, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:

@@ -34,34 +34,6 @@ struct Box3 { int lo[3]; int n[3]; };
 // Every stage is zone-local, so running the whole chain per zone is identical to the
 // reference's stage-by-stage sweeps.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void atomic_min_double(double* addr, double v)
-{
-    unsigned long long* a = (unsigned long long*)addr;
-    unsigned long long old = *a, assumed;
-    do {
-        assumed = old;
-        if (__longlong_as_double((long long)assumed) <= v) break;
-        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    } while (assumed != old);
-}
-
-// block-wide min of two values (wave shuffle -> LDS -> one atomic per block)
-__device__ __forceinline__ void block_min2_atomic(double a, double b, double* out)
-{
-    for (int off = 32; off > 0; off >>= 1) {
-        a = fmin(a, __shfl_down(a, off, 64));
-        b = fmin(b, __shfl_down(b, off, 64));
-    }
-    __shared__ double sa[4], sb[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sa[wave] = a; sb[wave] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomic_min_double(out, fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3])));
-        atomic_min_double(out + 1, fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3])));
-    }
-}
-
 // REDUCE: also return [min dx/(c+|u|) of the CLEANED state, min density of the RAW state]
 // (Castro::estdt_cfl, timestep.cpp:31-140, and S_new.min(URHO), Castro_advance_ctu.cpp:168)
 // through one atomic pair per block.  Grid-stride so the number of atomics stays small.
@@ -87,54 +59,7 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     double rX = U.p[c + U.sn * UFS];
     if (REDUCE) rmin_raw = fmin(rmin_raw, rho);
 
-    for (int it = 0; it < ntimes; ++it) {
-        // enforce_min_density
-        if (rho < P.small_dens) {
-            rX *= (P.small_dens / rho);
-            double e = eos_e_of_T(P, P.small_temp);
-            rho = P.small_dens;
-            temp = P.small_temp;
-            mx = 0.0; my = 0.0; mz = 0.0;
-            eint = rho * e;
-            eden = eint;
-        }
-
-        // normalize_species (NumSpec = 1)
-        {
-            rX = amax(P.small_x * rho, amin(rho, rX));
-            double rhoX_sum = 0.0;
-            rhoX_sum += rX;
-            double fac = rho / rhoX_sum;
-            rX *= fac;
-        }
-
-        // reset_internal_energy
-        {
-            double rhoInv = 1.0 / rho;
-            double Up = mx * rhoInv;
-            double Vp = my * rhoInv;
-            double Wp = mz * rhoInv;
-            double ke = 0.5 * (Up * Up + Vp * Vp + Wp * Wp);
-
-            double small_e = eos_e_of_T(P, P.small_temp);
-
-            eint = amax(eint, rho * small_e);
-            eden = amax(eden, rho * (small_e + ke) + 0.0);
-
-            double rho_eint = eden - rho * ke - 0.0;
-
-            if (rho_eint > P.eta2 * eden) {
-                eint = rho_eint;
-            }
-        }
-
-        // computeTemp
-        {
-            double rhoInv = 1.0 / rho;
-            double e = eint * rhoInv;
-            temp = eos_T_of_e(P, e);
-        }
-    }
+    clean_zone(P, ntimes, rho, mx, my, mz, eden, eint, temp, rX);
 
     U.p[c + U.sn * URHO] = rho;
     U.p[c + U.sn * UMX] = mx;
@@ -145,17 +70,7 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     U.p[c + U.sn * UTEMP] = temp;
     U.p[c + U.sn * UFS] = rX;
 
-    if (REDUCE) {
-        double rhoInv = 1.0 / rho;
-        double e = eint * rhoInv;
-        double p = (P.gamma - 1.0) * rho * e;
-        double cs = sqrt(P.gamma * p / rho);
-        double ux = mx * rhoInv, uy = my * rhoInv, uz = mz * rhoInv;
-        double dt1 = dx0 / (cs + fabs(ux));
-        double dt2 = dx1 / (cs + fabs(uy));
-        double dt3 = dx2 / (cs + fabs(uz));
-        dtmin = fmin(dtmin, amin(amin(dt1, dt2), dt3));
-    }
+    if (REDUCE) dtmin = fmin(dtmin, zone_dt_cfl(P, dx0, dx1, dx2, rho, mx, my, mz, eint));
     }
     if (REDUCE) block_min2_atomic(dtmin, rmin_raw, red);
 }

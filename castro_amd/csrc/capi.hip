@@ -6,7 +6,9 @@
 #include <cstring>
 #include <new>
 #include "../../include/castro_hydro_amd.h"
+#include <cstdlib>
 #include "ctu_kernels.h"
+namespace cad { extern int g_tile_rows; }
 
 using namespace cad;
 
@@ -124,7 +126,8 @@ static DevGeom to_devgeom(const castro_amd_geom* g)
 static size_t plane_doubles(int nx, int ny, int nz)
 {
     size_t n = (size_t)(nx + 8) * (ny + 8) * (nz + 8);
-    return (n + 31) & ~(size_t)31;     // keep every component plane 256-byte aligned
+    static const long pad = std::getenv("CASTRO_AMD_PLANE_PAD") ? std::atol(std::getenv("CASTRO_AMD_PLANE_PAD")) : 0;
+    return ((n + 31) & ~(size_t)31) + (size_t)pad;     // keep every component plane 256-byte aligned
 }
 
 // number of component planes in the scratch arena
@@ -182,6 +185,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (hipMalloc(&c->d_status, sizeof(int)) != hipSuccess) { delete c; return CASTRO_AMD_ERR_NOMEM; }
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
+    if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
     *out = c;
     return CASTRO_AMD_OK;
 }
@@ -233,7 +237,20 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
                              const castro_amd_geom* geom, const castro_amd_params* params,
                              double time, double dt, int flags, void* stream)
 {
+    return castro_amd_ctu_hydro_clean_fab(c, bxlo, bxhi, vbxlo, vbxhi, Sborder, src, S_new, flux_out, mass_flux_out, qe_out,
+                                          geom, params, time, dt, flags, 0, nullptr, stream);
+}
+
+int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3],
+                                   const int vbxlo[3], const int vbxhi[3],
+                                   const castro_amd_fab* Sborder, const castro_amd_fab* src,
+                                   const castro_amd_fab* S_new, const castro_amd_fab flux_out[3],
+                                   const castro_amd_fab mass_flux_out[3], const castro_amd_fab qe_out[3],
+                                   const castro_amd_geom* geom, const castro_amd_params* params,
+                                   double time, double dt, int flags, int clean_ntimes, double* d_out, void* stream)
+{
     (void)time;
+    if (clean_ntimes < 0) return CASTRO_AMD_ERR_ARG;
     if (!c || !bxlo || !bxhi || !Sborder || !Sborder->p || !S_new || !S_new->p || !geom || !params)
         return CASTRO_AMD_ERR_ARG;
     if (Sborder->ncomp != NUM_STATE || S_new->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
@@ -303,7 +320,7 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx* c, const int bxlo[3], const int bxh
     }
 
     return launch_ctu_hydro(t, S, dS, to_dfab(src), dN, dF, dM, dQ, to_devgeom(geom), to_devparams(params), dt, flags,
-                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof);
+                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof, clean_ntimes, d_out);
 }
 
 int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],

@@ -43,6 +43,23 @@ __device__ __forceinline__ void stg(double* base, unsigned boff, double v)
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
 }
 
+// Two x-adjacent zones per thread.  The stencil kernels issue ~100 vector-memory instructions per
+// zone and are bound by the rate at which a CU can issue them (TA busy 70-90 %, tools/ta_bench.hip),
+// not by bytes: a 16-byte access moves two zones per instruction.  8-byte alignment is enough
+// (unaligned 16-byte global accesses run at full rate on gfx950, same benchmark).
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+struct D2 { double a, b; };
+__device__ __forceinline__ D2 ldg2(const double* base, unsigned boff)
+{
+    const d2u v = *reinterpret_cast<const d2u*>(reinterpret_cast<const char*>(base) + boff);
+    return D2{ v.x, v.y };
+}
+__device__ __forceinline__ void stg2(double* base, unsigned boff, double a, double b)
+{
+    d2u v; v.x = a; v.y = b;
+    *reinterpret_cast<d2u*>(reinterpret_cast<char*>(base) + boff) = v;
+}
+
 // byte offset of zone (i,j,k) in the scratch index space / in a caller FAB
 __device__ __forceinline__ unsigned goff(const Tile& t, int i, int j, int k)
 {
@@ -60,30 +77,48 @@ __device__ __forceinline__ unsigned dstr(const Str& s, int d) { return d == 0 ? 
 // one zone (or face) per thread, x fastest over the whole box: a wavefront touches one contiguous
 // 512-byte run per array plane.  (Brick-shaped workgroups, XCD-contiguous workgroup ids and
 // marching workgroups were all measured slower on MI355X: DESIGN.md "Launch shape".)
-__device__ __forceinline__ bool box_thread(const int lo[3], const int n[3], int& i, int& j, int& k)
+// `ty` > 0 selects the XCD-tiled order: workgroup ids are dealt round-robin to the 8 XCDs by the
+// dispatcher, so id -> (id % 8) * (nb / 8) + id / 8 hands each XCD one contiguous run of rows, and
+// the rows are enumerated y-tile by y-tile (ty rows), z-plane by z-plane inside a tile, so that the
+// workgroups resident on one XCD at a time share their y and z stencil neighbours through that XCD's L2.
+struct LinBox { int lo[3], n[3]; int ty; unsigned nb; int w, hi0; };   // w zones per thread along x (n[0] counts threads)
+
+__device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int& k)
 {
-    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned total = (unsigned)n[0] * (unsigned)n[1] * (unsigned)n[2];
+    unsigned bid = blockIdx.x;
+    if (b.ty > 0) {
+        const unsigned per = b.nb >> 3;          // nb is a multiple of 8 in this mode
+        bid = (bid & 7u) * per + (bid >> 3);
+    }
+    const unsigned tid = bid * blockDim.x + threadIdx.x;
+    const unsigned total = (unsigned)b.n[0] * (unsigned)b.n[1] * (unsigned)b.n[2];
     if (tid >= total) return false;
-    const unsigned ii = tid % (unsigned)n[0];
-    const unsigned r = tid / (unsigned)n[0];
-    i = lo[0] + (int)ii;
-    j = lo[1] + (int)(r % (unsigned)n[1]);
-    k = lo[2] + (int)(r / (unsigned)n[1]);
+    const unsigned ii = tid % (unsigned)b.n[0];
+    const unsigned r = tid / (unsigned)b.n[0];
+    i = b.lo[0] + b.w * (int)ii;
+    if (b.ty > 0) {
+        const unsigned rpt = (unsigned)b.ty * (unsigned)b.n[2];
+        const unsigned yt = r / rpt;
+        const unsigned rem = r - yt * rpt;
+        const unsigned left = (unsigned)b.n[1] - yt * (unsigned)b.ty;
+        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
+        const unsigned kk = rem / tyh;
+        j = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - kk * tyh));
+        k = b.lo[2] + (int)kk;
+    } else {
+        j = b.lo[1] + (int)(r % (unsigned)b.n[1]);
+        k = b.lo[2] + (int)(r / (unsigned)b.n[1]);
+    }
     return true;
 }
-
-struct LinBox { int lo[3], n[3]; };
 
 // ---------------------------------------------------------------------------------------
 // Castro::ctoprim (Source/hydro/advection_util.cpp:26-200) with the gamma-law EOS inlined
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ctoprim(Tile t, DFab U, double* __restrict__ Q, DevParams P, int* status)
+__global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status)
 {
-    int lo[3] = { t.glo[0], t.glo[1], t.glo[2] };
-    int n[3] = { t.NX, t.NY, t.NZ };
     int i, j, k;
-    if (!box_thread(lo, n, i, j, k)) return;
+    if (!box_thread(b, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const unsigned cu = foff(U, i, j, k);
     const long NC = t.NC;
@@ -130,7 +165,7 @@ __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const dou
                                                      double* __restrict__ SQ, DevParams P)
 {
     int i, j, k;
-    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    if (!box_thread(b, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const unsigned cs = foff(SRC, i, j, k);
     const long NC = t.NC;
@@ -164,7 +199,7 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
                                               double* __restrict__ SHK, double dxinv, double dyinv, double dzinv)
 {
     int i, j, k;
-    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    if (!box_thread(b, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const unsigned sx = s.x, sy = s.y, sz = s.z;
@@ -659,7 +694,7 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
                                                double dt, DevParams P)
 {
     int i, j, k;
-    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    if (!box_thread(b, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
 
@@ -791,7 +826,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
                                                   DevGeom g, DevParams P)
 {
     int i, j, k;
-    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    if (!box_thread(b, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const unsigned sd = dstr(gstr(t), D);
     const int idx = (D == 0) ? i : (D == 1) ? j : k;
@@ -888,31 +923,69 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 //   F2 slot (N|T): flux in direction N from states corrected with the T-direction flux.
 // (Castro_ctu_hydro.cpp:724-945 for the corrections, :949-1135 for the six solves)
 // ---------------------------------------------------------------------------------------
+// pair (two x-adjacent faces) forms of the record loads / stores
+__device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC, unsigned c, double r[2][NF1])
+{
+#pragma unroll
+    for (int n = 0; n < NF1; ++n) { const D2 v = ldg2(F + (long)n * NC, c); r[0][n] = v.a; r[1][n] = v.b; }
+}
+
+__device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long NC, unsigned c, double q[2][NEDGE])
+{
+#pragma unroll
+    for (int n = 0; n < NEDGE; ++n) { const D2 v = ldg2(E + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b; }
+}
+
+template <int D>
+__device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1)
+{
+    if (m0 && m1) {
+        stg2(F + FRHO * NC, c, f[0].rho, f[1].rho);
+        stg2(F + (FMX + RDir<D>::n) * NC, c, f[0].mn, f[1].mn);
+        stg2(F + (FMX + RDir<D>::t) * NC, c, f[0].mt, f[1].mt);
+        stg2(F + (FMX + RDir<D>::tt) * NC, c, f[0].mtt, f[1].mtt);
+        stg2(F + FE * NC, c, f[0].E, f[1].E);
+        stg2(F + FX * NC, c, f[0].X, f[1].X);
+        stg2(F + FUG * NC, c, f[0].ugd, f[1].ugd);
+        stg2(F + FPG * NC, c, f[0].pgd, f[1].pgd);
+    } else if (m0) {
+        store_f1<D>(F, NC, c, f[0]);
+    } else if (m1) {
+        store_f1<D>(F, NC, c + 8u, f[1]);
+    }
+}
+
 template <int N, int T>
 __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, unsigned c, unsigned sn, unsigned st,
-                                            const double qm[NEDGE], const double qp[NEDGE],
-                                            double cl, double cr, double bnd_fac, double cdtdx, const DevParams& P)
+                                            const double qm[2][NEDGE], const double qp[2][NEDGE],
+                                            const D2& cl, const D2& cr, const double bnd_fac[2], double cdtdx,
+                                            bool m0, bool m1, const DevParams& P)
 {
-    double fr[NF1], fl[NF1], qmo[NEDGE], qpo[NEDGE];
+    double fr[2][NF1], fl[2][NF1], qmo[2][NEDGE], qpo[2][NEDGE];
 
-    // minus state lives in zone c - sn; its T-faces are (c - sn) and (c - sn + st)
-    load_f1(S.F1[T], t.NC, c - sn + st, fr);
-    load_f1(S.F1[T], t.NC, c - sn, fl);
-    trans_single<T>(qm, fr, fl, P.gamma, cdtdx, P, qmo);
+    // minus states live in zones c - sn; their T-faces are (c - sn) and (c - sn + st)
+    load_f1_2(S.F1[T], t.NC, c - sn + st, fr);
+    load_f1_2(S.F1[T], t.NC, c - sn, fl);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) trans_single<T>(qm[w], fr[w], fl[w], P.gamma, cdtdx, P, qmo[w]);
 
-    // plus state lives in zone c
-    load_f1(S.F1[T], t.NC, c + st, fr);
-    load_f1(S.F1[T], t.NC, c, fl);
-    trans_single<T>(qp, fr, fl, P.gamma, cdtdx, P, qpo);
+    // plus states live in zones c
+    load_f1_2(S.F1[T], t.NC, c + st, fr);
+    load_f1_2(S.F1[T], t.NC, c, fl);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) trans_single<T>(qp[w], fr[w], fl[w], P.gamma, cdtdx, P, qpo[w]);
 
-    RState ql, qr;
-    double Xl, Xr;
-    rstate_from_edge<N>(qmo, P.gamma, ql, Xl);
-    rstate_from_edge<N>(qpo, P.gamma, qr, Xr);
-
-    IFlux f;
-    interface_flux<N>(ql, qr, Xl, Xr, cl, cr, bnd_fac, face_shock(S, P, c, sn), P, f);
-    store_f1<N>(S.F2[f2_slot(N, T)], t.NC, c, f);
+    IFlux f[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState ql, qr;
+        double Xl, Xr;
+        rstate_from_edge<N>(qmo[w], P.gamma, ql, Xl);
+        rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
+        interface_flux<N>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
+                          face_shock(S, P, c + 8u * w, sn), P, f[w]);
+    }
+    store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1);
 }
 
 template <int N>
@@ -922,25 +995,35 @@ __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* 
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
     int ijk[3];
-    if (!box_thread(b.lo, b.n, ijk[0], ijk[1], ijk[2])) return;
+    if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
+    const bool v1 = ijk[0] + 1 <= b.hi0;          // second zone of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const Str s = gstr(t);
     const unsigned sn = dstr(s, N);
 
     // the (N|T1) states exist where the T1 index is inside bx (T2 index may be in the 1-ring)
-    const bool in_t1 = ijk[T1] >= t.lo[T1] && ijk[T1] <= t.hi[T1];
-    const bool in_t2 = ijk[T2] >= t.lo[T2] && ijk[T2] <= t.hi[T2];
-    if (!in_t1 && !in_t2) return;
+    bool in_t1[2], in_t2[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int i1 = ijk[T1] + (T1 == 0 ? w : 0), i2 = ijk[T2] + (T2 == 0 ? w : 0);
+        const bool v = (w == 0) || v1;
+        in_t1[w] = v && i1 >= t.lo[T1] && i1 <= t.hi[T1];
+        in_t2[w] = v && i2 >= t.lo[T2] && i2 <= t.hi[T2];
+    }
+    const bool any1 = in_t1[0] || in_t1[1], any2 = in_t2[0] || in_t2[1];
+    if (!any1 && !any2) return;
 
-    double qm[NEDGE], qp[NEDGE];
-    load_edge(S.QM[N], t.NC, c, qm);
-    load_edge(S.QP[N], t.NC, c, qp);
-    const double cl = ldg(Q + PC * t.NC, c - sn);
-    const double cr = ldg(Q + PC * t.NC, c);
-    const double bnd_fac = wall_fac<N>(g, ijk[N]);
+    double qm[2][NEDGE], qp[2][NEDGE];
+    load_edge_2(S.QM[N], t.NC, c, qm);
+    load_edge_2(S.QP[N], t.NC, c, qp);
+    const D2 cl = ldg2(Q + PC * t.NC, c - sn);
+    const D2 cr = ldg2(Q + PC * t.NC, c);
+    double bnd_fac[2];
+    bnd_fac[0] = wall_fac<N>(g, ijk[N]);
+    bnd_fac[1] = wall_fac<N>(g, ijk[N] + (N == 0 ? 1 : 0));
 
-    if (in_t1) trans1_pair<N, T1>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, P);
-    if (in_t2) trans1_pair<N, T2>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, P);
+    if (any1) trans1_pair<N, T1>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, in_t1[0], in_t1[1], P);
+    if (any2) trans1_pair<N, T2>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
 }
 
 template <int N>
@@ -952,7 +1035,7 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
     int ijk[3];
-    if (!box_thread(b.lo, b.n, ijk[0], ijk[1], ijk[2])) return;
+    if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const Str s = gstr(t);
     const unsigned sn = dstr(s, N), s1 = dstr(s, T1), s2 = dstr(s, T2);
@@ -997,12 +1080,19 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
 // ---------------------------------------------------------------------------------------
 // Castro::consup_hydro (Source/hydro/Castro_ctu.cpp:11-86), 3-D Cartesian
 // ---------------------------------------------------------------------------------------
+// CLEAN: the post-update sequence of do_advance_ctu fused in (Castro_advance_ctu.cpp:168-225, 386):
+// raw minimum density, clean_state `ntimes` times, CFL time step of the cleaned zone, both minima
+// reduced into red[0..1] (see castro_amd_clean_state_reduce_fab).
+template <bool CLEAN>
 __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, DFab Uin, DFab Unew, double dt,
                                                 double area0, double area1, double area2, double vol,
-                                                int from_sborder)
+                                                int from_sborder, DevParams P, int ntimes,
+                                                double dx0, double dx1, double dx2, double* red)
 {
     int i, j, k;
-    if (!box_thread(b.lo, b.n, i, j, k)) return;
+    const bool valid = box_thread(b, i, j, k);
+    double dtmin = 1.e200, rmin_raw = 1.e300;
+    if (valid) {
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const unsigned sx = s.x, sy = s.y, sz = s.z;
@@ -1016,6 +1106,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 
     // record index of conserved component m in the FL arrays
     constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
+    double un[NUM_STATE];
 
 #pragma unroll
     for (int m = 0; m < NUM_STATE; ++m) {
@@ -1023,7 +1114,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
         double u0 = from_sborder ? ldg(Uin.p + m * Uin.sn, ci) : ldg(dst, cn);
         if (m == UTEMP) {
             // zero flux: U + dt*(0)*volinv == U
-            if (from_sborder) stg(dst, cn, u0);
+            un[m] = u0;
             continue;
         }
         const long r = (long)rec[m] * NC;
@@ -1050,22 +1141,63 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 
             unew = unew - dt * pdu;
         }
-        stg(dst, cn, unew);
+        un[m] = unew;
     }
+
+    if (CLEAN) {
+        rmin_raw = un[URHO];
+        clean_zone(P, ntimes, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEDEN], un[UEINT], un[UTEMP], un[UFS]);
+        dtmin = zone_dt_cfl(P, dx0, dx1, dx2, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEINT]);
+    }
+#pragma unroll
+    for (int m = 0; m < NUM_STATE; ++m) {
+        if (m == UTEMP && !CLEAN && !from_sborder) continue;     // unchanged in place
+        stg(Unew.p + m * Unew.sn, cn, un[m]);
+    }
+    }
+    if (CLEAN && red) block_min2_atomic(dtmin, rmin_raw, red);
 }
 
 // ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
-static inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
+int g_tile_rows = 0;      // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
 
 static LinBox linbox(const int lo[3], const int hi[3], long& n)
 {
     LinBox b;
     n = 1;
     for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
+    b.ty = g_tile_rows;
+    b.w = 1;
+    b.hi0 = hi[0];
+    b.nb = (unsigned)((n + 255) / 256);
+    if (b.ty > 0) b.nb = (b.nb + 7u) & ~7u;
     return b;
 }
+
+// pairs of x-adjacent zones: thread ii of a row handles lo[0] + 2 ii and, if <= hi0, the next one
+static LinBox linbox2(const int lo[3], const int hi[3], long& n)
+{
+    LinBox b = linbox(lo, hi, n);
+    b.w = 2;
+    b.n[0] = (b.n[0] + 1) / 2;
+    n = (long)b.n[0] * b.n[1] * b.n[2];
+    b.nb = (unsigned)((n + 255) / 256);
+    if (b.ty > 0) b.nb = (b.nb + 7u) & ~7u;
+    return b;
+}
+
+#define KL2(name, kern, lo, hi, ...)                                                         \
+    do {                                                                                     \
+        long n_;                                                                             \
+        LinBox b_ = linbox2(lo, hi, n_);                                                     \
+        if (n_ > 0) {                                                                        \
+            prof_begin(prof, name, stream);                                                  \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            prof_end(prof, stream);                                                          \
+        }                                                                                    \
+    } while (0)
 
 #define KL(name, kern, lo, hi, ...)                                                          \
     do {                                                                                     \
@@ -1073,7 +1205,7 @@ static LinBox linbox(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox(lo, hi, n_);                                                      \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(nblocks(n_)), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)
@@ -1081,11 +1213,12 @@ static LinBox linbox(const int lo[3], const int hi[3], long& n)
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
-                     int* d_status, hipStream_t stream, Profiler* prof)
+                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red)
 {
-    prof_begin(prof, "k_ctoprim", stream);
-    hipLaunchKernelGGL(k_ctoprim, dim3(nblocks((long)t.NX * t.NY * t.NZ)), dim3(256), 0, stream, t, Sborder, S.Q, P, d_status);
-    prof_end(prof, stream);
+    {
+        const int qhi[3] = { t.glo[0] + t.NX - 1, t.glo[1] + t.NY - 1, t.glo[2] + t.NZ - 1 };
+        KL("k_ctoprim", k_ctoprim, t.glo, qhi, Sborder, S.Q, P, d_status);
+    }
 
     // boxes
     const int olo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
@@ -1120,9 +1253,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
     const double area0 = g.dx[1] * g.dx[2], area1 = g.dx[0] * g.dx[2], area2 = g.dx[0] * g.dx[1];
 
-    KL("k_trans1", k_trans1<0>, flo[0], fhi[0], S.Q, S, g, cdtdy, cdtdz, P);
-    KL("k_trans1", k_trans1<1>, flo[1], fhi[1], S.Q, S, g, cdtdx, cdtdz, P);
-    KL("k_trans1", k_trans1<2>, flo[2], fhi[2], S.Q, S, g, cdtdx, cdtdy, P);
+    KL2("k_trans1", k_trans1<0>, flo[0], fhi[0], S.Q, S, g, cdtdy, cdtdz, P);
+    KL2("k_trans1", k_trans1<1>, flo[1], fhi[1], S.Q, S, g, cdtdx, cdtdz, P);
+    KL2("k_trans1", k_trans1<2>, flo[2], fhi[2], S.Q, S, g, cdtdx, cdtdy, P);
     KL("k_final", k_final<0>, nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
        hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], P);
     KL("k_final", k_final<1>, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
@@ -1131,7 +1264,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
        hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], P);
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];
-    KL("k_consup", k_consup, t.lo, t.hi, S, Sborder, Snew, dt, area0, area1, area2, vol, (flags & 1) ? 1 : 0);
+    if (clean_ntimes > 0) {
+        KL("k_consup_clean", k_consup<true>, t.lo, t.hi, S, Sborder, Snew, dt, area0, area1, area2, vol, (flags & 1) ? 1 : 0,
+           P, clean_ntimes, g.dx[0], g.dx[1], g.dx[2], red);
+    } else {
+        KL("k_consup", k_consup<false>, t.lo, t.hi, S, Sborder, Snew, dt, area0, area1, area2, vol, (flags & 1) ? 1 : 0,
+           P, 0, 0.0, 0.0, 0.0, (double*)nullptr);
+    }
 
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -187,6 +187,110 @@ __device__ __forceinline__ void ppm_int_wave(double sm, double sp, double s6, do
 }
 
 // ---------------------------------------------------------------------------------------
+// Castro::clean_state for one zone, applied `ntimes` in a row (Source/driver/Castro.cpp:4238-4278):
+//   do_enforce_minimum_density  Source/hydro/advection_util.cpp:1080-1172
+//   normalize_species           Source/driver/Castro.cpp:2902-2948
+//   reset_internal_energy       Source/driver/Castro.cpp:3353-3414
+//   computeTemp (EOS re -> T)   Source/driver/Castro.cpp:3682-3707
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, double& rho, double& mx, double& my, double& mz,
+                                           double& eden, double& eint, double& temp, double& rX)
+{
+    for (int it = 0; it < ntimes; ++it) {
+        // enforce_min_density
+        if (rho < P.small_dens) {
+            rX *= (P.small_dens / rho);
+            double e = eos_e_of_T(P, P.small_temp);
+            rho = P.small_dens;
+            temp = P.small_temp;
+            mx = 0.0; my = 0.0; mz = 0.0;
+            eint = rho * e;
+            eden = eint;
+        }
+
+        // normalize_species (NumSpec = 1)
+        {
+            rX = amax(P.small_x * rho, amin(rho, rX));
+            double rhoX_sum = 0.0;
+            rhoX_sum += rX;
+            double fac = rho / rhoX_sum;
+            rX *= fac;
+        }
+
+        // reset_internal_energy
+        {
+            double rhoInv = 1.0 / rho;
+            double Up = mx * rhoInv;
+            double Vp = my * rhoInv;
+            double Wp = mz * rhoInv;
+            double ke = 0.5 * (Up * Up + Vp * Vp + Wp * Wp);
+
+            double small_e = eos_e_of_T(P, P.small_temp);
+
+            eint = amax(eint, rho * small_e);
+            eden = amax(eden, rho * (small_e + ke) + 0.0);
+
+            double rho_eint = eden - rho * ke - 0.0;
+
+            if (rho_eint > P.eta2 * eden) {
+                eint = rho_eint;
+            }
+        }
+
+        // computeTemp
+        {
+            double rhoInv = 1.0 / rho;
+            double e = eint * rhoInv;
+            temp = eos_T_of_e(P, e);
+        }
+    }
+
+}
+
+// zone term of Castro::estdt_cfl (Source/driver/timestep.cpp:31-140)
+__device__ __forceinline__ double zone_dt_cfl(const DevParams& P, double dx0, double dx1, double dx2,
+                                              double rho, double mx, double my, double mz, double eint)
+{
+    double rhoInv = 1.0 / rho;
+    double e = eint * rhoInv;
+    double p = (P.gamma - 1.0) * rho * e;
+    double cs = sqrt(P.gamma * p / rho);
+    double ux = mx * rhoInv, uy = my * rhoInv, uz = mz * rhoInv;
+    double dt1 = dx0 / (cs + fabs(ux));
+    double dt2 = dx1 / (cs + fabs(uy));
+    double dt3 = dx2 / (cs + fabs(uz));
+    return amin(amin(dt1, dt2), dt3);
+}
+
+// global_atomic_min_f64: one fire-and-forget L2 atomic (a CAS loop here serialises the ~65k
+// workgroups of a 256^3 launch on one address: measured 4 ms)
+__device__ __forceinline__ void atomic_min_double(double* addr, double v)
+{
+    // the minimum only ever decreases, so a (possibly stale) read that is already <= v makes the
+    // atomic unnecessary; same-address atomics cost ~5 ns each at L2
+    if (__hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= v) return;
+    __hip_atomic_fetch_min(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// block-wide min of two values (wave shuffle -> LDS -> one atomic per block)
+__device__ __forceinline__ void block_min2_atomic(double a, double b, double* out)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fmin(a, __shfl_down(a, off, 64));
+        b = fmin(b, __shfl_down(b, off, 64));
+    }
+    __shared__ double sa[4], sb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_min_double(out, fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3])));
+        atomic_min_double(out + 1, fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3])));
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
 // PLM slopes (Source/hydro/slope.H); q[0..4] = zones i-2..i+2
 // ---------------------------------------------------------------------------------------
 // slope.H:27-121

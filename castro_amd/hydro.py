@@ -62,7 +62,10 @@ class HipHydro:
     # ---- the hot path: Castro::construct_ctu_hydro_source, one FAB/tile --------------------
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
-                                   update_from_sborder=False, src=None, src_box=None, stream=None):
+                                   update_from_sborder=False, src=None, src_box=None, stream=None,
+                                   clean_ntimes=0, red=None):
+        """clean_ntimes > 0 selects castro_amd_ctu_hydro_clean_fab: the update is followed, in the same
+        pass, by S_new.min(URHO), clean_state x clean_ntimes and the CFL estimate, reduced into `red`."""
         bxlo, bxhi = bx
         vlo, vhi = vbx if vbx is not None else bx
         fb = (L.Fab * 3)()
@@ -78,11 +81,19 @@ class HipHydro:
             mb[d] = L.fab_of(mass_fluxes[d] if mass_fluxes is not None else None, flo, fhi)
             qb[d] = L.fab_of(qe[d] if qe is not None else None, flo, fhi)
         sfab = L.fab_of(src, *src_box) if src is not None else L.fab_desc(None, bxlo, bxhi, 0)
+        flags = L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD
+        if clean_ntimes > 0:
+            rc = self.lib.castro_amd_ctu_hydro_clean_fab(
+                self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),
+                C.byref(L.fab_of(Sborder, *sb_box)), C.byref(sfab), C.byref(L.fab_of(S_new, *snew_box)),
+                fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt), flags,
+                int(clean_ntimes), C.c_void_p(red.data_ptr()) if red is not None else None, _stream_ptr(stream))
+            L.check(rc, "ctu_hydro_clean_fab")
+            return
         rc = self.lib.castro_amd_ctu_hydro_fab(
             self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),
             C.byref(L.fab_of(Sborder, *sb_box)), C.byref(sfab), C.byref(L.fab_of(S_new, *snew_box)),
-            fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt),
-            L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD, _stream_ptr(stream))
+            fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt), flags, _stream_ptr(stream))
         L.check(rc, "ctu_hydro_fab")
 
     # ---- Castro::clean_state ---------------------------------------------------------------

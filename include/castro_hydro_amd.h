@@ -146,6 +146,31 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx *ctx,
                              const castro_amd_params *params,
                              double time, double dt, int flags, void *stream);
 
+/*
+ * castro_amd_ctu_hydro_fab followed, zone by zone and before S_new is written, by the sequence
+ * do_advance_ctu runs on the updated state when no new-time source intervenes
+ * (Source/driver/Castro_advance_ctu.cpp:168-225, 386-392):
+ *   d_out[1] = min(d_out[1], density of the updated zone)         (S_new.min(URHO))
+ *   clean_state applied `clean_ntimes` (>= 1) times               (Castro::clean_state)
+ *   d_out[0] = min(d_out[0], dx/(c+|u|) of the cleaned zone)      (Castro::estdt_cfl)
+ * The result equals castro_amd_ctu_hydro_fab + castro_amd_clean_state_reduce_fab on bx, without the
+ * second pass over S_new.  clean_ntimes == 0 is exactly castro_amd_ctu_hydro_fab; d_out may be NULL
+ * (no reduction) and otherwise points to 2 device doubles initialised by the caller.
+ */
+int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx *ctx,
+                                   const int bxlo[3], const int bxhi[3],
+                                   const int vbxlo[3], const int vbxhi[3],
+                                   const castro_amd_fab *Sborder,
+                                   const castro_amd_fab *src,
+                                   const castro_amd_fab *S_new,
+                                   const castro_amd_fab flux_out[3],
+                                   const castro_amd_fab mass_flux_out[3],
+                                   const castro_amd_fab qe_out[3],
+                                   const castro_amd_geom *geom,
+                                   const castro_amd_params *params,
+                                   double time, double dt, int flags,
+                                   int clean_ntimes, double *d_out, void *stream);
+
 /* Castro::clean_state on one FAB region (Source/driver/Castro.cpp:4238-4278):
  * enforce_min_density, normalize_species, reset_internal_energy, computeTemp,
  * applied `ntimes` times in a row to every zone of [lo,hi] (the reference runs it

@@ -35,7 +35,8 @@ class OracleBackend:
 
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
-                                   update_from_sborder=False, src=None, src_box=None, stream=None):
+                                   update_from_sborder=False, src=None, src_box=None, stream=None,
+                                   clean_ntimes=0, red=None):
         L = O.lib()
         vlo, vhi = vbx if vbx is not None else bx
         fa, ma, qa = (O.A4 * 3)(), (O.A4 * 3)(), (O.A4 * 3)()
@@ -50,6 +51,8 @@ class OracleBackend:
         st = L.ora_ctu_hydro_tile(O.i3(bx[0]), O.i3(bx[1]), O.i3(vlo), O.i3(vhi), sb, O.a4(None, bx[0], bx[1]), sn,
                                   fa, ma, qa, C.byref(geom), C.byref(params), float(dt))
         assert st == 0
+        if clean_ntimes > 0:      # castro_amd_ctu_hydro_clean_fab == the update followed by the separate pass
+            self.clean_state_reduce(S_new, snew_box, bx[0], bx[1], geom, params, red, ntimes=clean_ntimes)
 
     def clean_state(self, state, box, lo, hi, params, ntimes=1, stream=None):
         for _ in range(ntimes):

@@ -235,6 +235,44 @@ def test_ctu_hydro_plm_tiles_with_symmetry(hip, oracle):
     _assert_exact(out, "PLM tiles")
 
 
+def test_ctu_hydro_clean_fab_equals_two_passes(hip, oracle):
+    """castro_amd_ctu_hydro_clean_fab (update + S_new.min + clean_state + CFL estimate in one pass) against
+    the oracle's update followed by its separate min-density / clean_state / estdt sweeps: bit-exact,
+    including a zone driven below small_dens (enforce_min_density branch) and tiles sharing one reduction."""
+    import torch
+    import castro_amd
+    rng = np.random.default_rng(61)
+    bxlo, bxhi = (0, 0, 0), (15, 11, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (19, 15, 13)
+    U = physical_state(rng, sb_lo, sb_hi, vel=1.0)
+    n = [bxhi[d] - bxlo[d] + 1 for d in range(3)]
+    probhi = [n[d] * 0.02 for d in range(3)]
+    pkw = dict(small_dens=0.45, small_temp=1.e-2)
+    Po, Go = oracle.default_params(**pkw), oracle.make_geom(n, probhi=probhi, domlo=bxlo)
+    Ph, Gh = castro_amd.default_params(**pkw), castro_amd.make_geom(n, prob_hi=probhi, domlo=bxlo)
+    dt = 8.0e-4
+    sl = (slice(None),) + tuple(slice(4, 4 + n[2 - a]) for a in range(3))
+    Snew_o = np.ascontiguousarray(U[sl])
+    st, _, _, _ = oracle.ctu_hydro(bxlo, bxhi, U, sb_lo, sb_hi, Snew_o, Go, Po, dt)
+    assert st == 0 or st == 1          # rho < small_dens met in ctoprim is only a status bit
+    L = oracle.lib()
+    a = oracle.a4(Snew_o, bxlo, bxhi)
+    rmin = L.ora_min_density(oracle.i3(bxlo), oracle.i3(bxhi), a)
+    L.ora_clean_state(oracle.i3(bxlo), oracle.i3(bxhi), a, Po)
+    est = L.ora_estdt_cfl(oracle.i3(bxlo), oracle.i3(bxhi), a, Go, Po)
+
+    Ud, Snew_d = _to_dev(hip, U), _to_dev(hip, U[sl])
+    red = torch.full((2,), 1.e200, dtype=torch.float64, device=hip.device)
+    for bx in [((0, 0, 0), (7, 11, 9)), ((8, 0, 0), (15, 11, 4)), ((8, 0, 5), (15, 11, 9))]:
+        hip.construct_ctu_hydro_source(bx, Ud, (sb_lo, sb_hi), Snew_d, (bxlo, bxhi), Gh, Ph, 0.0, dt,
+                                       vbx=(bxlo, bxhi), clean_ntimes=1, red=red)
+    torch.cuda.synchronize()
+    hip.status()
+    assert (Snew_o[0] == 0.45).any(), "test does not reach the enforce_min_density branch"
+    _assert_exact({"S_new": (Snew_d.cpu().numpy(), Snew_o)}, "fused clean")
+    assert red.tolist() == [est, rmin]
+
+
 def test_unsupported_options_fail_loudly(hip):
     import castro_amd
     from castro_amd import _lib as L
