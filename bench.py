@@ -21,7 +21,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PATH_BYTES_PER_CELL = 600.0    # contract traffic of construct_ctu_hydro_source
+# contract traffic of construct_ctu_hydro_source per cell-update, 8 B x
+#   (8 Sborder read + 8 S_new read + 8 S_new write + 3*8*2 fluxes read-modify-write + 3 mass_fluxes write) = 600 B.
+# The default bench mode elides bytes the single-level driver does not need (declared, as 8(d) requires):
+#   S_new = Sborder + ... (no S_new read) and fluxes[d] = ... instead of zero-fill + "+=" (no fluxes read):
+#   8 B x (8 + 8 + 3*8 + 3) = 344 B.  --reference-contract runs the 600-B form.
+PATH_BYTES_CONTRACT = 600.0
+PATH_BYTES_ASSIGN = 344.0
 
 # algorithmic (compulsory) bytes per processed unit of each hot-path kernel: every input and
 # output array element exactly once (DESIGN.md "Kernels").  Unit = one zone/face of the kernel's box.
@@ -31,8 +37,10 @@ KERNEL_BYTES_PER_UNIT = {
     "k_trace": 8 * (8 + 42),
     "k_riemann1": 8 * (14 + 1 + 8),
     "k_trans1": 8 * (14 + 16 + 1 + 16),
-    "k_final": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),
+    "k_final": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),        # fluxes read-modify-write (8 read + 8 write + mass)
+    "k_final_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 9),  # fluxes written only
     "k_consup": 8 * (27 + 8 + 8),
+    "k_consup_clean": 8 * (27 + 8 + 8),
     "k_clean_state": 8 * (8 + 8),
     "k_estdt": 8 * 5,
 }
@@ -48,6 +56,7 @@ def kernel_units(name, n):
         "k_trans1": ((nx + 1) * (ny + 2) * (nz + 2) + (nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 3.0,
         "k_final": ((nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + 1)) / 3.0,
         "k_consup": nx * ny * nz,
+        "k_consup_clean": nx * ny * nz,
         "k_clean_state": nx * ny * nz,
         "k_estdt": nx * ny * nz,
     }.get(name, nx * ny * nz)
@@ -102,6 +111,8 @@ def main():
     ap.add_argument("--cpu-ncell", type=int, default=192)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--reference-contract", action="store_true",
+                    help="zero-fill + accumulate fluxes and run clean_state/estdt as separate passes (600 B/cell form)")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +139,10 @@ def main():
     else:
         n_cell = (args.ncell,) * 3
 
-    c = castro_amd.Castro(n_cell, comm=comm, grid=grid, overlap=(False if args.no_overlap else None))
+    contract = args.reference_contract
+    c = castro_amd.Castro(n_cell, comm=comm, grid=grid, overlap=(False if args.no_overlap else None),
+                          fuse_clean=not contract, flux_assign=not contract)
+    PATH_BYTES_PER_CELL = PATH_BYTES_CONTRACT if contract else PATH_BYTES_ASSIGN
     c.initData("sedov")                      # synthetic input, generated on the device
     for _ in range(args.warmup):
         c.step()
@@ -164,7 +178,7 @@ def main():
         name, (tot_ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_s = tot_ms / launches / 1e3
         units = kernel_units(name, c.n)
-        alg_bytes = KERNEL_BYTES_PER_UNIT.get(name, 0) * units
+        alg_bytes = KERNEL_BYTES_PER_UNIT.get(name + "_assign" if (name == "k_final" and not contract) else name, 0) * units
         achieved = alg_bytes / avg_s / 1e9
         traffic, traffic_src = pmc_traffic(name)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -172,7 +186,7 @@ def main():
                 "kernel": name, "avg_launch_ms": avg_s * 1e3, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes}
     hydro_ms = sum(v[0] for k, v in prof.items() if k in ("k_ctoprim", "k_divu", "k_trace", "k_riemann1", "k_trans1",
-                                                          "k_final", "k_consup")) / max(args.steps, 1)
+                                                          "k_final", "k_consup", "k_consup_clean")) / max(args.steps, 1)
     path = {"bytes_per_cell_update": PATH_BYTES_PER_CELL,
             "achieved_GBs_per_gpu": value / world * PATH_BYTES_PER_CELL / 1e9,
             "frac_of_hbm_peak": value / world * PATH_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS,
@@ -187,7 +201,9 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Sedov 3D %dx%dx%d single level, gamma-law EOS, PPM + CGF Riemann, CTU" % n_cell,
                    "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": c.n[0] * c.n[1] * c.n[2],
-                   "overlap_halo": bool(c.overlap), "sim_time": c.time, "nstep": c.nstep},
+                   "overlap_halo": bool(c.overlap), "sim_time": c.time, "nstep": c.nstep,
+                   "flux_mode": "accumulate (600 B/cell contract)" if contract else "assign (344 B/cell, declared)",
+                   "fused_clean_state": not contract},
         "roofline": roof,
         "path_roofline": path,
     }

@@ -14,7 +14,7 @@ NUM_STATE, NGDNV, NUM_GROW = 8, 4, 4
 URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
-UPDATE_ADD, UPDATE_FROM_SBORDER = 0, 1
+UPDATE_ADD, UPDATE_FROM_SBORDER, FLUX_ASSIGN = 0, 1, 2
 
 # every symbol include/castro_hydro_amd.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (

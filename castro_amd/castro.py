@@ -91,7 +91,7 @@ class AdvanceFailure(RuntimeError):
 # --------------------------------------------------------------------------------------------
 class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
-                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True):
+                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -139,6 +139,8 @@ class Castro:
         self.neighbors = self._build_neighbors()
         self.overlap = (self.comm.size > 1) if overlap is None else bool(overlap)
         self.fuse_clean = bool(fuse_clean)
+        # one hydro call per step: "zero fluxes, then +=" (Castro_advance.cpp:391-394) is an assignment
+        self.flux_assign = bool(flux_assign)
         self._comm_stream = None
         if self.overlap and self.S_new_b.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
@@ -276,7 +278,8 @@ class Castro:
             h.construct_ctu_hydro_source(bx, self.S_old_b, self.gbox, self.S_new_b, self.gbox, self.geom,
                                          self.params, time, dt, fluxes=self.fluxes, flux_boxes=self.flux_boxes,
                                          mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=True,
-                                         clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None)
+                                         clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None,
+                                         flux_assign=self.flux_assign)
 
     def _shell_tiles(self):
         """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
@@ -307,9 +310,10 @@ class Castro:
         # "clean twice"; ghost zones are copies (or sign-reflected copies) of twice-cleaned
         # valid zones, so they are filled AFTER the cleaning.  See DESIGN.md "clean_state order".
         self.clean_state(S, 2)
-        for d in range(3):
-            self.fluxes[d].zero_()          # Castro_advance.cpp:391-394
-            self.mass_fluxes[d].zero_()
+        if not self.flux_assign:
+            for d in range(3):
+                self.fluxes[d].zero_()          # Castro_advance.cpp:391-394
+                self.mass_fluxes[d].zero_()
 
         # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
         # (:221-225) and the estTimeStep validity check (:386-392) are fused into the update pass

@@ -8,7 +8,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; }
+namespace cad { extern int g_tile_rows; extern int g_lds_pad; }
 
 using namespace cad;
 
@@ -185,6 +185,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (hipMalloc(&c->d_status, sizeof(int)) != hipSuccess) { delete c; return CASTRO_AMD_ERR_NOMEM; }
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
+    if (const char* e = std::getenv("CASTRO_AMD_LDS_PAD")) g_lds_pad = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
     *out = c;
     return CASTRO_AMD_OK;

@@ -485,6 +485,270 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
 
 
 // ---------------------------------------------------------------------------------------
+// PPM tracing without source terms, two x-adjacent zones per thread (the benchmark path).
+// Same arithmetic as trace_dir<D, false>: the stencils of both zones come from shared 16-byte loads.
+// ---------------------------------------------------------------------------------------
+struct TraceW {        // parabola integrals under the u-c, u, u+c waves for one zone and one direction
+    double Ip_rho[3], Im_rho[3], Ip_un[3], Im_un[3], Ip_p[3], Im_p[3], Ip_re[3], Im_re[3];
+    double Ip_ut[3], Im_ut[3], Ip_utt[3], Im_utt[3], Ip_X[3], Im_X[3];   // [1] only
+};
+
+template <int NW>
+__device__ __forceinline__ void ppm_waves(const double s[5], double flat, double un, double cc, double dtdx,
+                                          double Ip[3], double Im[3])
+{
+    double sm, sp;
+    ppm_reconstruct(s, flat, sm, sp);
+    const double s6 = 6.0 * s[2] - 3.0 * (sm + sp);
+    if (NW == 3) {
+        ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip[0], Im[0]);
+        ppm_int_wave(sm, sp, s6, un, dtdx, Ip[1], Im[1]);
+        ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip[2], Im[2]);
+    } else if (NW == 2) {
+        ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip[0], Im[0]);
+        ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip[2], Im[2]);
+    } else {
+        ppm_int_wave(sm, sp, s6, un, dtdx, Ip[1], Im[1]);
+    }
+}
+
+// characteristic projection of trace_ppm.cpp:382-561 with zero source integrals
+template <int D>
+__device__ __forceinline__ void trace_finish(const TraceW& w, double un, double cc, const DevParams& P,
+                                             double qp[NEDGE], double qm[NEDGE])
+{
+    constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
+    constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
+    constexpr int QUTT = (D == 0) ? PW : (D == 1) ? PU : PV;
+    const double gam = P.gamma;
+    {
+        // plus state on face i, trace_ppm.cpp:382-466
+        double rho_ref = w.Im_rho[0];
+        double un_ref = w.Im_un[0];
+        double p_ref = w.Im_p[0];
+        double rhoe_g_ref = w.Im_re[0];
+
+        rho_ref = amax(rho_ref, P.small_dens);
+        double rho_ref_inv = 1.0 / rho_ref;
+        p_ref = amax(p_ref, P.small_pres);
+
+        double csq_ref = gam * p_ref * rho_ref_inv;
+        double cc_ref = sqrt(csq_ref);
+        double cc_ref_inv = 1.0 / cc_ref;
+        double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
+
+        double dum = un_ref - w.Im_un[0];
+        double dptotm = p_ref - w.Im_p[0];
+
+        double drho = rho_ref - w.Im_rho[1];
+        double dptot = p_ref - w.Im_p[1];
+        double drhoe_g = rhoe_g_ref - w.Im_re[1];
+
+        double dup = un_ref - w.Im_un[2];
+        double dptotp = p_ref - w.Im_p[2];
+
+        double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
+        double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
+        double alpha0r = drho - dptot / csq_ref;
+        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+
+        alpham = un - cc > 0.0 ? 0.0 : -alpham;
+        alphap = un + cc > 0.0 ? 0.0 : -alphap;
+        alpha0r = un > 0.0 ? 0.0 : -alpha0r;
+        alpha0e_g = un > 0.0 ? 0.0 : -alpha0e_g;
+
+        qp[PRHO] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
+        qp[QUN] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
+        qp[PRE] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
+        qp[PP] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        qp[QUT] = w.Im_ut[1];
+        qp[QUTT] = w.Im_utt[1];
+        qp[PX] = w.Im_X[1];
+    }
+    {
+        // minus state on face i+1, trace_ppm.cpp:470-561
+        double rho_ref = w.Ip_rho[2];
+        double un_ref = w.Ip_un[2];
+        double p_ref = w.Ip_p[2];
+        double rhoe_g_ref = w.Ip_re[2];
+
+        rho_ref = amax(rho_ref, P.small_dens);
+        double rho_ref_inv = 1.0 / rho_ref;
+        p_ref = amax(p_ref, P.small_pres);
+
+        double csq_ref = gam * p_ref * rho_ref_inv;
+        double cc_ref = sqrt(csq_ref);
+        double cc_ref_inv = 1.0 / cc_ref;
+        double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
+
+        double dum = un_ref - w.Ip_un[0];
+        double dptotm = p_ref - w.Ip_p[0];
+
+        double drho = rho_ref - w.Ip_rho[1];
+        double dptot = p_ref - w.Ip_p[1];
+        double drhoe_g = rhoe_g_ref - w.Ip_re[1];
+
+        double dup = un_ref - w.Ip_un[2];
+        double dptotp = p_ref - w.Ip_p[2];
+
+        double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
+        double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
+        double alpha0r = drho - dptot / csq_ref;
+        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+
+        alpham = un - cc > 0.0 ? -alpham : 0.0;
+        alphap = un + cc > 0.0 ? -alphap : 0.0;
+        alpha0r = un > 0.0 ? -alpha0r : 0.0;
+        alpha0e_g = un > 0.0 ? -alpha0e_g : 0.0;
+
+        qm[PRHO] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
+        qm[QUN] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
+        qm[PRE] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
+        qm[PP] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        qm[QUT] = w.Ip_ut[1];
+        qm[QUTT] = w.Ip_utt[1];
+        qm[PX] = w.Ip_X[1];
+    }
+}
+
+__device__ __forceinline__ void store_edge_2(double* __restrict__ E, long NC, unsigned c, const double q[2][NEDGE], bool m0, bool m1)
+{
+    if (m0 && m1) {
+#pragma unroll
+        for (int n = 0; n < NEDGE; ++n) stg2(E + (long)n * NC, c, q[0][n], q[1][n]);
+    } else if (m0) {
+#pragma unroll
+        for (int n = 0; n < NEDGE; ++n) stg(E + (long)n * NC, c, q[0][n]);
+    } else if (m1) {
+#pragma unroll
+        for (int n = 0; n < NEDGE; ++n) stg(E + (long)n * NC, c + 8u, q[1][n]);
+    }
+}
+
+// five-point stencils of two x-adjacent zones along direction D
+template <int D>
+__device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, unsigned c, unsigned sd, double sA[5], double sB[5])
+{
+    if (D == 0) {
+        const D2 l = ldg2(a, c - 16u), m = ldg2(a, c), r = ldg2(a, c + 16u);
+        sA[0] = l.a; sA[1] = l.b; sA[2] = m.a; sA[3] = m.b; sA[4] = r.a;
+        sB[0] = l.b; sB[1] = m.a; sB[2] = m.b; sB[3] = r.a; sB[4] = r.b;
+    } else {
+#pragma unroll
+        for (int m = -2; m <= 2; ++m) { const D2 v = ldg2(a, c + m * sd); sA[m + 2] = v.a; sB[m + 2] = v.b; }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd,
+                                               const double flat[2], double dtdx, const DevParams& P,
+                                               const bool do_plus[2], const bool do_minus[2],
+                                               double* __restrict__ QMd, double* __restrict__ QPd)
+{
+    constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
+    constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
+    constexpr int QUTT = (D == 0) ? PW : (D == 1) ? PU : PV;
+    const long NC = t.NC;
+    const D2 ccv = ldg2(Q + PC * NC, c);
+    const double cc[2] = { ccv.a, ccv.b };
+
+    TraceW w[2];
+    double sA[5], sB[5];
+    double un[2];
+
+    load_stencil_2<D>(Q + (long)QUN * NC, c, sd, sA, sB);
+    un[0] = sA[2]; un[1] = sB[2];
+    ppm_waves<2>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_un, w[0].Im_un);
+    ppm_waves<2>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
+
+    load_stencil_2<D>(Q + (long)PRHO * NC, c, sd, sA, sB);
+    ppm_waves<3>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
+    ppm_waves<3>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
+
+    load_stencil_2<D>(Q + (long)PP * NC, c, sd, sA, sB);
+    ppm_waves<3>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
+    ppm_waves<3>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
+
+    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, sA, sB);
+    ppm_waves<3>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_re, w[0].Im_re);
+    ppm_waves<3>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_re, w[1].Im_re);
+
+    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, sA, sB);
+    ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
+    ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
+
+    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, sA, sB);
+    ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
+    ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
+
+    load_stencil_2<D>(Q + (long)PX * NC, c, sd, sA, sB);
+    ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_X, w[0].Im_X);
+    ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_X, w[1].Im_X);
+
+    double qp[2][NEDGE], qm[2][NEDGE];
+    trace_finish<D>(w[0], un[0], cc[0], P, qp[0], qm[0]);
+    trace_finish<D>(w[1], un[1], cc[1], P, qp[1], qm[1]);
+
+    store_edge_2(QPd, NC, c, qp, do_plus[0], do_plus[1]);
+    store_edge_2(QMd, NC, c + sd, qm, do_minus[0], do_minus[1]);
+}
+
+__global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                    double dt, DevParams P)
+{
+    int i, j, k;
+    if (!box_thread(b, i, j, k)) return;
+    const bool v1 = i + 1 <= b.hi0;
+    const unsigned c = goff(t, i, j, k);
+    const Str s = gstr(t);
+    const long NC = t.NC;
+
+    // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
+    double flat[2];
+    if (P.first_order_hydro == 1) {
+        flat[0] = flat[1] = 0.0;
+    } else if (P.use_flattening == 1) {
+        const double* Pp = Q + PP * NC;
+        double pA[7], pB[7], uA[5], uB[5];
+        {
+            const D2 p0 = ldg2(Pp, c - 24u), p1 = ldg2(Pp, c - 8u), p2 = ldg2(Pp, c + 8u), p3 = ldg2(Pp, c + 24u);
+            pA[0] = p0.a; pA[1] = p0.b; pA[2] = p1.a; pA[3] = p1.b; pA[4] = p2.a; pA[5] = p2.b; pA[6] = p3.a;
+            pB[0] = p0.b; pB[1] = p1.a; pB[2] = p1.b; pB[3] = p2.a; pB[4] = p2.b; pB[5] = p3.a; pB[6] = p3.b;
+            load_stencil_2<0>(Q + PU * NC, c, s.x, uA, uB);
+            flat[0] = flatten_1d(pA, uA);
+            flat[1] = flatten_1d(pB, uB);
+        }
+        {
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.y); pA[m + 3] = v.a; pB[m + 3] = v.b; }
+            load_stencil_2<1>(Q + PV * NC, c, s.y, uA, uB);
+            flat[0] = amin(flat[0], flatten_1d(pA, uA));
+            flat[1] = amin(flat[1], flatten_1d(pB, uB));
+        }
+        {
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.z); pA[m + 3] = v.a; pB[m + 3] = v.b; }
+            load_stencil_2<2>(Q + PW * NC, c, s.z, uA, uB);
+            flat[0] = amin(flat[0], flatten_1d(pA, uA));
+            flat[1] = amin(flat[1], flatten_1d(pB, uB));
+        }
+    } else {
+        flat[0] = flat[1] = 1.0;
+    }
+
+    bool dp[2], dm[2];
+    dp[0] = i >= t.lo[0]; dp[1] = v1 && i + 1 >= t.lo[0];
+    dm[0] = i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
+    trace_pair_dir<0>(t, Q, c, s.x, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0]);
+    dp[0] = j >= t.lo[1]; dp[1] = v1 && dp[0];
+    dm[0] = j <= t.hi[1]; dm[1] = v1 && dm[0];
+    trace_pair_dir<1>(t, Q, c, s.y, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1]);
+    dp[0] = k >= t.lo[2]; dp[1] = v1 && dp[0];
+    dm[0] = k <= t.hi[2]; dm[1] = v1 && dm[0];
+    trace_pair_dir<2>(t, Q, c, s.z, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2]);
+}
+
+// ---------------------------------------------------------------------------------------
 // PLM characteristic tracing (ppm_type = 0), Castro::trace_plm, trace_plm.cpp:17-339, fused with the
 // reflecting-boundary fix-up of Castro::ctu_plm_states (Castro_ctu.cpp:287-433): at a Symmetry
 // face the zone inside the domain writes both edge states and the ghost zone writes neither.
@@ -843,76 +1107,114 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
     store_f1<D>(S.F1[D], t.NC, c, f);
 }
 
-// shared tail of the final stage: flux in conserved order, artificial viscosity, species
-// normalisation, storage for consup, scaling and accumulation
+// shared tail of the final stage for a pair of x-adjacent faces: flux in conserved order, artificial
+// viscosity, species normalisation, record for consup, scaling and accumulation
 //   (Castro_ctu_hydro.cpp:1192-1243, 1322-1433; apply_av advection_util.cpp:482-528;
 //    normalize_species_fluxes :577-613; scale_flux :616-641)
 template <int N>
-__device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch& S, const IFlux& f, unsigned c,
+__device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch& S, const IFlux f[2], unsigned c,
                                                 unsigned s1, unsigned s2, const DFab& U, unsigned cu, unsigned un_,
                                                 const DFab& fluxes, const DFab& mass, const DFab& qe,
-                                                int i, int j, int k, int idxN, double dt, double area, double dxn,
-                                                int acc_hi, const DevParams& P)
+                                                int i, int j, int k, double dt, double area, double dxn,
+                                                int acc_hi, bool assign, bool v1, const DevParams& P, double R[2][NFIN])
 {
-    const long NC = t.NC;
-    double F[NUM_STATE];
-    F[URHO] = f.rho;
-    F[UMX + RDir<N>::n] = f.mn;
-    F[UMX + RDir<N>::t] = f.mt;
-    F[UMX + RDir<N>::tt] = f.mtt;
-    F[UEDEN] = f.E;
-    F[UEINT] = f.eint;
-    F[UTEMP] = 0.0;                       // Castro_ctu_hydro.cpp:1201
-    F[UFS] = f.X;
+    double F[2][NUM_STATE];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        F[w][URHO] = f[w].rho;
+        F[w][UMX + RDir<N>::n] = f[w].mn;
+        F[w][UMX + RDir<N>::t] = f[w].mt;
+        F[w][UMX + RDir<N>::tt] = f[w].mtt;
+        F[w][UEDEN] = f[w].E;
+        F[w][UEINT] = f[w].eint;
+        F[w][UTEMP] = 0.0;                       // Castro_ctu_hydro.cpp:1201
+        F[w][UFS] = f[w].X;
+    }
 
     {
         const double* DIV = S.DIV;
-        double div1 = 0.25 * (ldg(DIV, c) + ldg(DIV, c + s1) + ldg(DIV, c + s2) + ldg(DIV, c + s1 + s2));
-        div1 = P.difmag * amin(0.0, div1);
+        const D2 d00 = ldg2(DIV, c), d10 = ldg2(DIV, c + s1), d01 = ldg2(DIV, c + s2), d11 = ldg2(DIV, c + s1 + s2);
+        double div1[2];
+        div1[0] = 0.25 * (d00.a + d10.a + d01.a + d11.a);
+        div1[1] = 0.25 * (d00.b + d10.b + d01.b + d11.b);
+        div1[0] = P.difmag * amin(0.0, div1[0]);
+        div1[1] = P.difmag * amin(0.0, div1[1]);
 #pragma unroll
         for (int m = 0; m < NUM_STATE; ++m) {
             if (m == UTEMP) continue;
-            double d1 = div1 * (ldg(U.p + m * U.sn, cu) - ldg(U.p + m * U.sn, cu - un_));
-            F[m] += dxn * d1;
+            const D2 uc = ldg2(U.p + m * U.sn, cu), ul = ldg2(U.p + m * U.sn, cu - un_);
+            double d1 = div1[0] * (uc.a - ul.a);
+            F[0][m] += dxn * d1;
+            d1 = div1[1] * (uc.b - ul.b);
+            F[1][m] += dxn * d1;
         }
     }
 
-    {
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
         double sum = 0.0;
-        sum += F[UFS];
+        sum += F[w][UFS];
         double fac = 1.0;
-        if (fabs(sum) > 2.220446049250313e-16 * fabs(F[URHO])) fac = F[URHO] / sum;
-        F[UFS] = F[UFS] * fac;
+        if (fabs(sum) > 2.220446049250313e-16 * fabs(F[w][URHO])) fac = F[w][URHO] / sum;
+        F[w][UFS] = F[w][UFS] * fac;
+
+        // record for consup (stored by the caller, two faces per store)
+        R[w][GRHO] = F[w][URHO]; R[w][GMX] = F[w][UMX]; R[w][GMY] = F[w][UMY]; R[w][GMZ] = F[w][UMZ];
+        R[w][GE] = F[w][UEDEN]; R[w][GEI] = F[w][UEINT]; R[w][GX] = F[w][UFS]; R[w][GUG] = f[w].ugd; R[w][GPG] = f[w].pgd;
     }
 
-    double* FL = S.FL[N];
-    stg(FL + GRHO * NC, c, F[URHO]);
-    stg(FL + GMX * NC, c, F[UMX]);
-    stg(FL + GMY * NC, c, F[UMY]);
-    stg(FL + GMZ * NC, c, F[UMZ]);
-    stg(FL + GE * NC, c, F[UEDEN]);
-    stg(FL + GEI * NC, c, F[UEINT]);
-    stg(FL + GX * NC, c, F[UFS]);
-    stg(FL + GUG * NC, c, f.ugd);
-    stg(FL + GPG * NC, c, f.pgd);
-
-    if (idxN <= acc_hi) {
+    const int idx0 = (N == 0) ? i : (N == 1) ? j : k;
+    const int idx1 = (N == 0) ? i + 1 : idx0;
+    const bool m0 = idx0 <= acc_hi, m1 = v1 && idx1 <= acc_hi;
+    if (m0 && m1) {
         if (fluxes.p) {
             const unsigned cf = foff(fluxes, i, j, k);
 #pragma unroll
             for (int m = 0; m < NUM_STATE; ++m) {
-                if (m == UTEMP) continue;       // += dt*0*area leaves the register unchanged
                 double* dst = fluxes.p + m * fluxes.sn;
-                stg(dst, cf, ldg(dst, cf) + dt * F[m] * area);
+                if (assign) {
+                    // fluxes[d] was going to be zeroed by the caller (Castro_advance.cpp:391-394): 0 + x
+                    stg2(dst, cf, 0.0 + dt * F[0][m] * area, 0.0 + dt * F[1][m] * area);
+                } else {
+                    if (m == UTEMP) continue;       // += dt*0*area leaves the register unchanged
+                    const D2 old = ldg2(dst, cf);
+                    stg2(dst, cf, old.a + dt * F[0][m] * area, old.b + dt * F[1][m] * area);
+                }
             }
         }
-        if (mass.p) stg(mass.p, foff(mass, i, j, k), dt * F[URHO] * area);
+        if (mass.p) stg2(mass.p, foff(mass, i, j, k), dt * F[0][URHO] * area, dt * F[1][URHO] * area);
         if (qe.p) {
             const unsigned cq = foff(qe, i, j, k);
-            stg(qe.p + (GDU + RDir<N>::n) * qe.sn, cq, f.ugd);
-            stg(qe.p + (GDU + RDir<N>::t) * qe.sn, cq, f.ut);
-            stg(qe.p + (GDU + RDir<N>::tt) * qe.sn, cq, f.utt);
-            stg(qe.p + GDPRES * qe.sn, cq, f.pgd);
+            stg2(qe.p + (GDU + RDir<N>::n) * qe.sn, cq, f[0].ugd, f[1].ugd);
+            stg2(qe.p + (GDU + RDir<N>::t) * qe.sn, cq, f[0].ut, f[1].ut);
+            stg2(qe.p + (GDU + RDir<N>::tt) * qe.sn, cq, f[0].utt, f[1].utt);
+            stg2(qe.p + GDPRES * qe.sn, cq, f[0].pgd, f[1].pgd);
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            if (!(w ? m1 : m0)) continue;
+            if (fluxes.p) {
+                const unsigned cf = foff(fluxes, i + w, j, k);
+#pragma unroll
+                for (int m = 0; m < NUM_STATE; ++m) {
+                    double* dst = fluxes.p + m * fluxes.sn;
+                    if (assign) {
+                        stg(dst, cf, 0.0 + dt * F[w][m] * area);
+                    } else {
+                        if (m == UTEMP) continue;
+                        stg(dst, cf, ldg(dst, cf) + dt * F[w][m] * area);
+                    }
+                }
+            }
+            if (mass.p) stg(mass.p, foff(mass, i + w, j, k), dt * F[w][URHO] * area);
+            if (qe.p) {
+                const unsigned cq = foff(qe, i + w, j, k);
+                stg(qe.p + (GDU + RDir<N>::n) * qe.sn, cq, f[w].ugd);
+                stg(qe.p + (GDU + RDir<N>::t) * qe.sn, cq, f[w].ut);
+                stg(qe.p + (GDU + RDir<N>::tt) * qe.sn, cq, f[w].utt);
+                stg(qe.p + GDPRES * qe.sn, cq, f[w].pgd);
+            }
         }
     }
 }
@@ -1030,51 +1332,67 @@ template <int N>
 __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
-                                               int acc_hi, DevParams P)
+                                               int acc_hi, int assign, DevParams P)
 {
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
     int ijk[3];
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
+    const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const Str s = gstr(t);
     const unsigned sn = dstr(s, N), s1 = dstr(s, T1), s2 = dstr(s, T2);
     const long NC = t.NC;
 
-    double q[NEDGE], ql[NEDGE], qr[NEDGE];
-    double f1r[NF1], f1l[NF1], f2r[NF1], f2l[NF1];
+    double q[2][NEDGE], ql[2][NEDGE], qr[2][NEDGE];
+    double f1r[2][NF1], f1l[2][NF1], f2r[2][NF1], f2l[2][NF1];
     const double* F12 = S.F2[f2_slot(T1, T2)];   // F^{T1|T2}: flux_t1
     const double* F21 = S.F2[f2_slot(T2, T1)];   // F^{T2|T1}: flux_t2
 
-    // minus state (zone c - sn)
-    load_edge(S.QM[N], NC, c, q);
-    load_f1(F12, NC, c - sn + s1, f1r);
-    load_f1(F12, NC, c - sn, f1l);
-    load_f1(F21, NC, c - sn + s2, f2r);
-    load_f1(F21, NC, c - sn, f2l);
-    trans_final(q, f1r, f1l, f2r, f2l, P.gamma, hdtdx_t1, hdtdx_t2, P, ql);
+    // minus states (zones c - sn)
+    load_edge_2(S.QM[N], NC, c, q);
+    load_f1_2(F12, NC, c - sn + s1, f1r);
+    load_f1_2(F12, NC, c - sn, f1l);
+    load_f1_2(F21, NC, c - sn + s2, f2r);
+    load_f1_2(F21, NC, c - sn, f2l);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) trans_final(q[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[w]);
 
-    // plus state (zone c)
-    load_edge(S.QP[N], NC, c, q);
-    load_f1(F12, NC, c + s1, f1r);
-    load_f1(F12, NC, c, f1l);
-    load_f1(F21, NC, c + s2, f2r);
-    load_f1(F21, NC, c, f2l);
-    trans_final(q, f1r, f1l, f2r, f2l, P.gamma, hdtdx_t1, hdtdx_t2, P, qr);
+    // plus states (zones c)
+    load_edge_2(S.QP[N], NC, c, q);
+    load_f1_2(F12, NC, c + s1, f1r);
+    load_f1_2(F12, NC, c, f1l);
+    load_f1_2(F21, NC, c + s2, f2r);
+    load_f1_2(F21, NC, c, f2l);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) trans_final(q[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[w]);
 
-    RState rl, rr;
-    double Xl, Xr;
-    rstate_from_edge<N>(ql, P.gamma, rl, Xl);
-    rstate_from_edge<N>(qr, P.gamma, rr, Xr);
-    const double cl = ldg(Q + PC * NC, c - sn);
-    const double cr = ldg(Q + PC * NC, c);
-
-    IFlux f;
-    interface_flux<N>(rl, rr, Xl, Xr, cl, cr, wall_fac<N>(g, ijk[N]), face_shock(S, P, c, sn), P, f);
-
+    const D2 cl = ldg2(Q + PC * NC, c - sn);
+    const D2 cr = ldg2(Q + PC * NC, c);
     const unsigned usn = 8u * (N == 0 ? 1u : N == 1 ? (unsigned)U.sy : (unsigned)U.sz);
+
+    double R[2][NFIN];
+    IFlux f[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState rl, rr;
+        double Xl, Xr;
+        rstate_from_edge<N>(ql[w], P.gamma, rl, Xl);
+        rstate_from_edge<N>(qr[w], P.gamma, rr, Xr);
+        const int idxN = (N == 0) ? ijk[0] + w : ijk[N];
+        interface_flux<N>(rl, rr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
+                          face_shock(S, P, c + 8u * w, sn), P, f[w]);
+    }
     final_flux_tail<N>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
-                       ijk[0], ijk[1], ijk[2], ijk[N], dt, area, dxn, acc_hi, P);
+                       ijk[0], ijk[1], ijk[2], dt, area, dxn, acc_hi, assign != 0, v1, P, R);
+    double* FL = S.FL[N];
+    if (v1) {
+#pragma unroll
+        for (int n = 0; n < NFIN; ++n) stg2(FL + (long)n * NC, c, R[0][n], R[1][n]);
+    } else {
+#pragma unroll
+        for (int n = 0; n < NFIN; ++n) stg(FL + (long)n * NC, c, R[0][n]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1161,6 +1479,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 // ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
+int g_lds_pad = 0;        // experiment knob: dynamic LDS bytes per workgroup (caps occupancy)
 int g_tile_rows = 0;      // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
 
 static LinBox linbox(const int lo[3], const int hi[3], long& n)
@@ -1194,7 +1513,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox2(lo, hi, n_);                                                     \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), g_lds_pad, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)
@@ -1205,7 +1524,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox(lo, hi, n_);                                                      \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), g_lds_pad, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)
@@ -1241,7 +1560,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
-        else { KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P); }
+        else { KL2("k_trace", k_trace_pair, olo, ohi, S.Q, S, g, dt, P); }
     }
 
     KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
@@ -1256,12 +1575,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     KL2("k_trans1", k_trans1<0>, flo[0], fhi[0], S.Q, S, g, cdtdy, cdtdz, P);
     KL2("k_trans1", k_trans1<1>, flo[1], fhi[1], S.Q, S, g, cdtdx, cdtdz, P);
     KL2("k_trans1", k_trans1<2>, flo[2], fhi[2], S.Q, S, g, cdtdx, cdtdy, P);
-    KL("k_final", k_final<0>, nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
-       hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], P);
-    KL("k_final", k_final<1>, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
-       hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], P);
-    KL("k_final", k_final<2>, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],
-       hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], P);
+    KL2("k_final", k_final<0>, nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
+       hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P);
+    KL2("k_final", k_final<1>, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
+       hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
+    KL2("k_final", k_final<2>, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],
+       hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];
     if (clean_ntimes > 0) {

@@ -63,7 +63,7 @@ class HipHydro:
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
                                    update_from_sborder=False, src=None, src_box=None, stream=None,
-                                   clean_ntimes=0, red=None):
+                                   clean_ntimes=0, red=None, flux_assign=False):
         """clean_ntimes > 0 selects castro_amd_ctu_hydro_clean_fab: the update is followed, in the same
         pass, by S_new.min(URHO), clean_state x clean_ntimes and the CFL estimate, reduced into `red`."""
         bxlo, bxhi = bx
@@ -82,6 +82,8 @@ class HipHydro:
             qb[d] = L.fab_of(qe[d] if qe is not None else None, flo, fhi)
         sfab = L.fab_of(src, *src_box) if src is not None else L.fab_desc(None, bxlo, bxhi, 0)
         flags = L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD
+        if flux_assign:
+            flags |= L.FLUX_ASSIGN
         if clean_ntimes > 0:
             rc = self.lib.castro_amd_ctu_hydro_clean_fab(
                 self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),

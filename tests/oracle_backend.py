@@ -36,7 +36,7 @@ class OracleBackend:
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
                                    update_from_sborder=False, src=None, src_box=None, stream=None,
-                                   clean_ntimes=0, red=None):
+                                   clean_ntimes=0, red=None, flux_assign=False):
         L = O.lib()
         vlo, vhi = vbx if vbx is not None else bx
         fa, ma, qa = (O.A4 * 3)(), (O.A4 * 3)(), (O.A4 * 3)()
@@ -46,6 +46,14 @@ class OracleBackend:
             ma[d] = self._a4(mass_fluxes[d] if mass_fluxes is not None else None, fbox or bx)
             qa[d] = self._a4(qe[d] if qe is not None else None, fbox or bx)
         sb, sn = self._a4(Sborder, sb_box), self._a4(S_new, snew_box)
+        if flux_assign:           # the oracle accumulates: zero this tile's faces first
+            vh = list(vhi)
+            for d in range(3):
+                hi = list(bx[1])
+                hi[d] += 1 if bx[1][d] == vh[d] else 0
+                for arr in ((fluxes[d] if fluxes is not None else None), (mass_fluxes[d] if mass_fluxes is not None else None)):
+                    if arr is not None:
+                        arr[self._slices(flux_boxes[d] if flux_boxes is not None else bx, bx[0], hi)] = 0.0
         if update_from_sborder:
             L.ora_fill_interior_copy(sn, sb, O.i3(bx[0]), O.i3(bx[1]))
         st = L.ora_ctu_hydro_tile(O.i3(bx[0]), O.i3(bx[1]), O.i3(vlo), O.i3(vhi), sb, O.a4(None, bx[0], bx[1]), sn,

@@ -31,7 +31,7 @@ def _to_dev(h, a):
 
 
 def _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, pkw=None, geom_kw=None, tile=(0, 0, 0),
-              hip_tiles=None, dx=None, src=None, src_box=None):
+              hip_tiles=None, dx=None, src=None, src_box=None, flux_assign=False):
     """One construct_ctu_hydro_source call on both paths; returns dict of (hip, oracle) arrays."""
     import torch
     import castro_amd
@@ -62,14 +62,14 @@ def _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, pkw=None, geom_kw=No
         fhi = list(bxhi)
         fhi[d] += 1
         fboxes.append((tuple(bxlo), tuple(fhi)))
-        fl_d.append(hip.alloc(8, bxlo, fhi))
+        fl_d.append(hip.alloc(8, bxlo, fhi, fill=float("nan") if flux_assign else 0.0))
         mf_d.append(hip.alloc(1, bxlo, fhi))
         qe_d.append(hip.alloc(4, bxlo, fhi))
     for bx in (hip_tiles or [(tuple(bxlo), tuple(bxhi))]):
         hip.construct_ctu_hydro_source(bx, Ud, (sb_lo, sb_hi), Snew_d, (bxlo, bxhi), Gh, Ph, 0.0, dt,
                                        fluxes=fl_d, flux_boxes=fboxes, mass_fluxes=mf_d, qe=qe_d,
                                        vbx=(tuple(bxlo), tuple(bxhi)), update_from_sborder=False,
-                                       src=src_d, src_box=src_box)
+                                       src=src_d, src_box=src_box, flux_assign=flux_assign)
     torch.cuda.synchronize()
     assert hip.status() == 0
     out = {"S_new": (Snew_d.cpu().numpy(), Snew_o)}
@@ -127,6 +127,19 @@ def test_ctu_hydro_tiles_equal_whole_box(hip, oracle):
     out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02),
                     tile=(1024, 8, 8), hip_tiles=tiles)
     _assert_exact(out, "tiled")
+
+
+def test_ctu_hydro_flux_assign(hip, oracle):
+    """CASTRO_AMD_FLUX_ASSIGN: fluxes[d] = dt*A*F written over garbage equals the reference's
+    zero-then-accumulate (Castro_advance.cpp:391-394), tile by tile."""
+    rng = np.random.default_rng(12)
+    bxlo, bxhi = (0, 0, 0), (15, 9, 11)
+    sb_lo, sb_hi = (-4, -4, -4), (19, 13, 15)
+    U = physical_state(rng, sb_lo, sb_hi)
+    tiles = [((0, 0, 0), (7, 9, 11)), ((8, 0, 0), (15, 9, 5)), ((8, 0, 6), (15, 9, 11))]
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), hip_tiles=tiles,
+                    flux_assign=True)
+    _assert_exact(out, "flux assign")
 
 
 def test_ctu_hydro_cg_solver(hip, oracle):
