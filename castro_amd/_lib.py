@@ -15,13 +15,17 @@ URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
 UPDATE_ADD, UPDATE_FROM_SBORDER, FLUX_ASSIGN = 0, 1, 2
+# CASTRO_AMD_DER_* ids, in the order the reference registers the fields (Castro_setup.cpp:756-960)
+DERIVE_IDS = {"pressure": 0, "kineng": 1, "soundspeed": 2, "Gamma_1": 3, "MachNumber": 4, "magvort": 5, "divu": 6,
+              "eint_E": 7, "eint_e": 8, "logden": 9, "X(X)": 10, "abar": 11, "x_velocity": 12, "y_velocity": 13,
+              "z_velocity": 14, "magvel": 15, "radvel": 16, "magmom": 17}
 
 # every symbol include/castro_hydro_amd.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
     "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status",
-    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
+    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
@@ -87,6 +91,8 @@ def load():
                                                     C.c_int, C.c_void_p, C.c_void_p]
     L.castro_amd_estdt_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params),
                                        C.c_void_p, C.c_void_p]
+    L.castro_amd_derive_fab.argtypes = [C.c_void_p, C.c_int, PF, PF, C.c_int, I3, I3, C.POINTER(Geom), C.POINTER(Params),
+                                        C.POINTER(C.c_double * 3), C.c_void_p]
     L.castro_amd_bc_fill_fab.argtypes = [C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
     L.castro_amd_copy_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_void_p]
     L.castro_amd_pack_fab.argtypes = [C.c_void_p, PF, I3, I3, C.c_void_p, C.c_void_p]

@@ -40,6 +40,9 @@ class SingleComm:
     def barrier(self):
         pass
 
+    def gather_objects(self, obj):
+        return [obj]
+
 
 class DistComm:
     """torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" on CPU for tests)."""
@@ -70,6 +73,12 @@ class DistComm:
 
     def barrier(self):
         self.dist.barrier(group=self.group)
+
+    def gather_objects(self, obj):
+        """every rank's (small, picklable) object, in rank order, on all ranks"""
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj, group=self.group)
+        return out
 
 
 def default_grid(size):
@@ -349,6 +358,11 @@ class Castro:
 
     def advance(self, time, dt):
         return self.do_advance_ctu(time, dt)
+
+    # ---- Castro::writePlotFile (Source/driver/Castro_io.cpp:853) ------------------------------
+    def writePlotFile(self, dirname, derive=None):
+        from .plotfile import write_plotfile
+        return write_plotfile(dirname, self, derive=derive)
 
     # ---- Amr::coarseTimeStep loop -----------------------------------------------------------
     def step(self, stop_time=-1.0):

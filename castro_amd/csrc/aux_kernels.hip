@@ -157,6 +157,96 @@ int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom&
 }
 
 // ---------------------------------------------------------------------------------------
+// derived plotfile fields (Source/driver/Derive.cpp); ids = CASTRO_AMD_DER_*
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_derive(DFab U, DFab D, int dcomp, Box3 b, int which, DevParams P,
+                                                double dx0, double dx1, double dx2,
+                                                double plo0, double plo1, double plo2, double c0, double c1, double c2)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+#define UU(ii, jj, kk, n) U.p[fidx(U, ii, jj, kk, n)]
+    const double rho = UU(i, j, k, URHO);
+    // the eos_input_re call of the EOS-based derives (Derive.cpp:37-50)
+    const double rhoInv = 1.0 / rho;
+    const double e = UU(i, j, k, UEINT) * rhoInv;
+    const double p = (P.gamma - 1.0) * rho * e;
+    const double cs = sqrt(P.gamma * p / rho);
+    const double mx = UU(i, j, k, UMX), my = UU(i, j, k, UMY), mz = UU(i, j, k, UMZ);
+    double v = 0.0;
+    switch (which) {
+    case 0: v = p; break;
+    case 1: v = 0.5 / rho * (mx * mx + my * my + mz * mz); break;
+    case 2: v = cs; break;
+    case 3: v = P.gamma; break;
+    case 4: v = sqrt(mx * mx + my * my + mz * mz) / rho / cs; break;
+    case 5: {
+        double vx = 0.5 * (UU(i + 1, j, k, UMY) / UU(i + 1, j, k, URHO) - UU(i - 1, j, k, UMY) / UU(i - 1, j, k, URHO)) / dx0;
+        double wx = 0.5 * (UU(i + 1, j, k, UMZ) / UU(i + 1, j, k, URHO) - UU(i - 1, j, k, UMZ) / UU(i - 1, j, k, URHO)) / dx0;
+        double uy = 0.5 * (UU(i, j + 1, k, UMX) / UU(i, j + 1, k, URHO) - UU(i, j - 1, k, UMX) / UU(i, j - 1, k, URHO)) / dx1;
+        double wy = 0.5 * (UU(i, j + 1, k, UMZ) / UU(i, j + 1, k, URHO) - UU(i, j - 1, k, UMZ) / UU(i, j - 1, k, URHO)) / dx1;
+        double uz = 0.5 * (UU(i, j, k + 1, UMX) / UU(i, j, k + 1, URHO) - UU(i, j, k - 1, UMX) / UU(i, j, k - 1, URHO)) / dx2;
+        double vz = 0.5 * (UU(i, j, k + 1, UMY) / UU(i, j, k + 1, URHO) - UU(i, j, k - 1, UMY) / UU(i, j, k - 1, URHO)) / dx2;
+        double v1 = wy - vz, v2 = uz - wx, v3 = vx - uy;
+        v = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+        break; }
+    case 6: {
+        double uhi = UU(i + 1, j, k, UMX) / UU(i + 1, j, k, URHO);
+        double ulo = UU(i - 1, j, k, UMX) / UU(i - 1, j, k, URHO);
+        double vhi = UU(i, j + 1, k, UMY) / UU(i, j + 1, k, URHO);
+        double vlo = UU(i, j - 1, k, UMY) / UU(i, j - 1, k, URHO);
+        double whi = UU(i, j, k + 1, UMZ) / UU(i, j, k + 1, URHO);
+        double wlo = UU(i, j, k - 1, UMZ) / UU(i, j, k - 1, URHO);
+        v = 0.5 * (uhi - ulo) / dx0;
+        v += 0.5 * (vhi - vlo) / dx1;
+        v += 0.5 * (whi - wlo) / dx2;
+        break; }
+    case 7: {
+        double ux = mx * rhoInv, uy = my * rhoInv, uz = mz * rhoInv;
+        v = UU(i, j, k, UEDEN) * rhoInv - 0.5 * (ux * ux + uy * uy + uz * uz);
+        break; }
+    case 8: v = UU(i, j, k, UEINT) / rho; break;
+    case 9: v = log10(rho); break;
+    case 10: v = UU(i, j, k, UFS) / rho; break;
+    case 11: {
+        double sum = 0.0;
+        double xn = UU(i, j, k, UFS) / rho;
+        sum += xn / P.abar;
+        v = 1.0 / sum;
+        break; }
+    case 12: v = mx / rho; break;
+    case 13: v = my / rho; break;
+    case 14: v = mz / rho; break;
+    case 15: v = sqrt((mx * mx + my * my + mz * mz)) * rhoInv; break;
+    case 16: {
+        double x = plo0 + ((double)i + 0.5) * dx0 - c0;
+        double y = plo1 + ((double)j + 0.5) * dx1 - c1;
+        double z = plo2 + ((double)k + 0.5) * dx2 - c2;
+        double r = sqrt(x * x + y * y + z * z);
+        v = (mx * x + my * y + mz * z) / (rho * r);
+        break; }
+    case 17: v = sqrt(mx * mx + my * my + mz * mz); break;
+    }
+#undef UU
+    D.p[fidx(D, i, j, k, dcomp)] = v;
+}
+
+int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int lo[3], const int hi[3],
+                  const double dx[3], const double problo[3], const DevParams& P, const double center[3],
+                  hipStream_t stream, Profiler* prof)
+{
+    Box3 b;
+    long n = 1;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_derive", stream);
+    hipLaunchKernelGGL(k_derive, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, D, dcomp, b, which, P,
+                       dx[0], dx[1], dx[2], problo[0], problo[1], problo[2], center[0], center[1], center[2]);
+    prof_end(prof, stream);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // physical-boundary ghost fill (AMReX GpuBndryFuncFab semantics [3P], SURVEY.md D.2;
 // Castro BC tables Source/driver/Castro_setup.cpp:40-53; EXT_DIR -> FOEXTRAP per
 // Source/problems/Castro_bc_fill_nd.cpp:26-39).  One launch per (direction, side).

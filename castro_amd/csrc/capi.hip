@@ -354,6 +354,23 @@ int castro_amd_estdt_fab(castro_amd_ctx* c, const castro_amd_fab* state, const i
     return launch_estdt(to_dfab(state), lo, hi, to_devgeom(geom), to_devparams(params), d_out, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_derive_fab(castro_amd_ctx* c, int which, const castro_amd_fab* state, const castro_amd_fab* der, int dcomp,
+                          const int lo[3], const int hi[3], const castro_amd_geom* geom, const castro_amd_params* params,
+                          const double center[3], void* stream)
+{
+    if (!c || !state || !state->p || !der || !der->p || !geom || !params || !center) return CASTRO_AMD_ERR_ARG;
+    if (which < 0 || which >= CASTRO_AMD_DER_COUNT || state->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
+    if (dcomp < 0 || dcomp >= der->ncomp || !fab_contains(der, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    if (geom->coord != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    int slo[3], shi[3];
+    const int g1 = (which == CASTRO_AMD_DER_MAGVORT || which == CASTRO_AMD_DER_DIVU) ? 1 : 0;   // grow_box_by_one
+    for (int d = 0; d < 3; ++d) { slo[d] = lo[d] - g1; shi[d] = hi[d] + g1; }
+    if (!fab_contains(state, slo, shi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_derive(which, to_dfab(state), to_dfab(der), dcomp, lo, hi, geom->dx, geom->problo,
+                         to_devparams(params), center, (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_bc_fill_fab(castro_amd_ctx* c, const castro_amd_fab* state, const castro_amd_geom* geom, void* stream)
 {
     if (!c || !state || !state->p || !geom) return CASTRO_AMD_ERR_ARG;

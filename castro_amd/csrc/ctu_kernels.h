@@ -69,6 +69,9 @@ int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], c
                               int ntimes, double* d_out, hipStream_t stream, Profiler* prof);
 int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
                  double* d_out, hipStream_t stream, Profiler* prof);
+int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int lo[3], const int hi[3],
+                  const double dx[3], const double problo[3], const DevParams& P, const double center[3],
+                  hipStream_t stream, Profiler* prof);
 int launch_bc_fill(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const DevGeom& g,
                    const int lo_bc[3], const int hi_bc[3], hipStream_t stream, Profiler* prof);
 int launch_copy(const DFab& dst, const DFab& src, const int lo[3], const int hi[3], int ncomp,

@@ -1480,7 +1480,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 // host-side launcher
 // ---------------------------------------------------------------------------------------
 int g_lds_pad = 0;        // experiment knob: dynamic LDS bytes per workgroup (caps occupancy)
-int g_tile_rows = 0;      // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
+int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
 
 static LinBox linbox(const int lo[3], const int hi[3], long& n)
 {

@@ -98,6 +98,14 @@ class HipHydro:
             fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt), flags, _stream_ptr(stream))
         L.check(rc, "ctu_hydro_fab")
 
+    # ---- derived plotfile fields (Source/driver/Derive.cpp) ---------------------------------
+    def derive(self, name, state, box, der, der_box, dcomp, lo, hi, geom, params, center, stream=None):
+        ctr = (C.c_double * 3)(*[float(x) for x in center])
+        L.check(self.lib.castro_amd_derive_fab(self.h, L.DERIVE_IDS[name], C.byref(L.fab_of(state, *box)),
+                                               C.byref(L.fab_of(der, *der_box)), int(dcomp), L.i3(lo), L.i3(hi),
+                                               C.byref(geom), C.byref(params), C.byref(ctr), _stream_ptr(stream)),
+                "derive_fab")
+
     # ---- Castro::clean_state ---------------------------------------------------------------
     def clean_state(self, state, box, lo, hi, params, ntimes=1, stream=None):
         L.check(self.lib.castro_amd_clean_state_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),

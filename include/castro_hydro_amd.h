@@ -191,6 +191,36 @@ int castro_amd_clean_state_reduce_fab(castro_amd_ctx *ctx, const castro_amd_fab 
                                       const int lo[3], const int hi[3], const castro_amd_geom *geom,
                                       const castro_amd_params *params, int ntimes, double *d_out, void *stream);
 
+/* Derived plotfile fields (Source/driver/Derive.cpp, registered in Castro_setup.cpp:756-960) for the
+ * 3-D Cartesian gamma-law build.  Not provided: entropy (needs the Microphysics entropy formula),
+ * StateErr, circvel, angular_momentum_{x,y,z}. */
+enum {
+    CASTRO_AMD_DER_PRESSURE = 0,   /* ca_derpres         Derive.cpp:24   */
+    CASTRO_AMD_DER_KINENG,         /* ca_derkineng       :860 */
+    CASTRO_AMD_DER_SOUNDSPEED,     /* ca_dersoundspeed   :180 */
+    CASTRO_AMD_DER_GAMMA_1,        /* ca_dergamma1       :216 */
+    CASTRO_AMD_DER_MACHNUMBER,     /* ca_dermachnumber   :251 */
+    CASTRO_AMD_DER_MAGVORT,        /* ca_dermagvort      :929  (needs 1 ghost zone of state) */
+    CASTRO_AMD_DER_DIVU,           /* ca_derdivu         :1021 (needs 1 ghost zone of state) */
+    CASTRO_AMD_DER_EINT_E1,        /* eint_E, ca_dereint1 :57 */
+    CASTRO_AMD_DER_EINT_E2,        /* eint_e, ca_dereint2 :79 */
+    CASTRO_AMD_DER_LOGDEN,         /* ca_derlogden       :95 */
+    CASTRO_AMD_DER_SPEC,           /* X(spec), ca_derspec :891 */
+    CASTRO_AMD_DER_ABAR,           /* ca_derabar         :907 */
+    CASTRO_AMD_DER_X_VELOCITY,     /* ca_dervel          :516 */
+    CASTRO_AMD_DER_Y_VELOCITY,
+    CASTRO_AMD_DER_Z_VELOCITY,
+    CASTRO_AMD_DER_MAGVEL,         /* ca_dermagvel       :532 */
+    CASTRO_AMD_DER_RADVEL,         /* ca_derradialvel    :572 (about `center`) */
+    CASTRO_AMD_DER_MAGMOM,         /* ca_dermagmom       :692 */
+    CASTRO_AMD_DER_COUNT
+};
+/* der(:,:,:,dcomp) = derived field `which` of `state` on [lo,hi]; `center` = problem::center (radvel only). */
+int castro_amd_derive_fab(castro_amd_ctx *ctx, int which, const castro_amd_fab *state,
+                          const castro_amd_fab *der, int dcomp, const int lo[3], const int hi[3],
+                          const castro_amd_geom *geom, const castro_amd_params *params,
+                          const double center[3], void *stream);
+
 /* Castro::estdt_cfl (Source/driver/timestep.cpp:31-140) and S_new.min(URHO)
  * (Castro_advance_ctu.cpp:168) fused: d_out[0] = min over [lo,hi] of dx/(c+|u|)
  * (NOT yet multiplied by cfl), d_out[1] = min density.  d_out is a device

@@ -98,6 +98,9 @@ ora_a4 ora_make_a4(double *p, const int lo[3], const int hi[3], int nc);
 /* ---------------- EOS (Microphysics gamma_law restated) -------- */
 typedef struct { double rho, T, e, p, gam1, cs, dpde, dpdr_e; } ora_eos_t;
 void ora_eos_re(const ora_params *P, ora_eos_t *s);
+/* Source/driver/Derive.cpp; `which` uses the CASTRO_AMD_DER_* numbering */
+int ora_derive(int which, const int lo[3], const int hi[3], ora_a4 dat, ora_a4 der, const ora_geom *G,
+               const ora_params *P, const double center[3]);
 void ora_eos_rt(const ora_params *P, ora_eos_t *s);
 void ora_eos_rp(const ora_params *P, ora_eos_t *s);
 

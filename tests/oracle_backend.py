@@ -62,6 +62,14 @@ class OracleBackend:
         if clean_ntimes > 0:      # castro_amd_ctu_hydro_clean_fab == the update followed by the separate pass
             self.clean_state_reduce(S_new, snew_box, bx[0], bx[1], geom, params, red, ntimes=clean_ntimes)
 
+    def derive(self, name, state, box, der, der_box, dcomp, lo, hi, geom, params, center, stream=None):
+        from castro_amd._lib import DERIVE_IDS
+        ctr = (C.c_double * 3)(*[float(x) for x in center])
+        d = der[dcomp:dcomp + 1]
+        rc = O.lib().ora_derive(DERIVE_IDS[name], O.i3(lo), O.i3(hi), self._a4(state, box), self._a4(d, der_box),
+                                C.byref(geom), C.byref(params), C.byref(ctr))
+        assert rc == 0
+
     def clean_state(self, state, box, lo, hi, params, ntimes=1, stream=None):
         for _ in range(ntimes):
             O.lib().ora_clean_state(O.i3(lo), O.i3(hi), self._a4(state, box), C.byref(params))

@@ -427,3 +427,51 @@ def test_sod_driver_with_walls_matches_oracle_and_exact(oracle, ppm_type, wall):
     xs = (np.arange(64) + 0.5) / 64
     rho_ex = np.interp(xs, ex[:, 0], ex[:, 1])
     assert np.abs(rho - rho_ex).mean() / rho_ex.mean() < 0.02
+
+
+def test_plotfile_state_and_derived_fields_match_oracle(tmp_path, oracle):
+    """SURVEY.md 8 f-2 / north-star tolerance: every field of the plotfile written from the HIP run agrees with
+    the oracle run to rtol 1e-10 (state and algebraic derives are expected bit-exact; logden goes through the
+    device log10)."""
+    import ctypes as C
+    import torch
+    import castro_amd
+    from castro_amd import plotfile as pf
+    from castro_amd._lib import DERIVE_IDS
+    n = (16, 16, 16)
+    c = castro_amd.Castro(n)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    G, P = oracle.make_geom(n), oracle.default_params()
+    lev = oracle.Level(n, G, P, nthreads=8)
+    lev.init_sedov(r_init=0.1, nsub=4)
+    for _ in range(5):
+        c.step(0.01)
+        lev.step(0.01)
+    d = str(tmp_path / "plt00005")
+    names = c.writePlotFile(d)
+    torch.cuda.synchronize()
+    r = pf.read_plotfile(d)
+    assert r["nstep"] == 5 and r["time"] == lev.time
+    got = dict(zip(names, r["data"]))
+
+    S = lev.state()
+    lo1, hi1 = (-1, -1, -1), (16, 16, 16)
+    Sg = np.zeros((8, 18, 18, 18))
+    Sg[:, 1:-1, 1:-1, 1:-1] = S
+    oracle.lib().ora_bc_fill(oracle.a4(Sg, lo1, hi1), C.byref(G))
+    ctr = (C.c_double * 3)(0.5, 0.5, 0.5)
+    worst = 0.0
+    for m, nm in enumerate(pf.STATE_NAMES):
+        assert np.array_equal(got[nm], S[m]), nm
+    for nm in pf.DERIVE_NAMES:
+        want = np.zeros((1, 16, 16, 16))
+        rc = oracle.lib().ora_derive(DERIVE_IDS[nm], oracle.i3((0, 0, 0)), oracle.i3((15, 15, 15)), oracle.a4(Sg, lo1, hi1),
+                                     oracle.a4(want, (0, 0, 0), (15, 15, 15)), C.byref(G), C.byref(P), C.byref(ctr))
+        assert rc == 0
+        assert np.allclose(got[nm], want[0], rtol=1e-10, atol=0.0), nm
+        ne, ad, rd = ulp_report(got[nm], want[0])
+        worst = max(worst, rd)
+        if nm != "logden":
+            assert ne == 0, "%s: %d entries differ (max rel %.3e)" % (nm, ne, rd)
+    assert worst <= 1e-14
+    lev.close()
