@@ -100,7 +100,8 @@ class AdvanceFailure(RuntimeError):
 # --------------------------------------------------------------------------------------------
 class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
-                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True):
+                 params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
+                 use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -150,6 +151,11 @@ class Castro:
         self.fuse_clean = bool(fuse_clean)
         # one hydro call per step: "zero fluxes, then +=" (Castro_advance.cpp:391-394) is an assignment
         self.flux_assign = bool(flux_assign)
+        self._flux_clear = False
+        # castro.use_retry, retry_subcycle_factor, max_subcycles, dt_cutoff (_cpp_parameters:311-354)
+        self.use_retry, self.retry_subcycle_factor = bool(use_retry), float(retry_subcycle_factor)
+        self.max_subcycles, self.dt_cutoff = int(max_subcycles), float(dt_cutoff)
+        self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
         self._comm_stream = None
         if self.overlap and self.S_new_b.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
@@ -288,7 +294,7 @@ class Castro:
                                          self.params, time, dt, fluxes=self.fluxes, flux_boxes=self.flux_boxes,
                                          mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=True,
                                          clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None,
-                                         flux_assign=self.flux_assign)
+                                         flux_assign=self.flux_assign and self._flux_clear)
 
     def _shell_tiles(self):
         """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
@@ -308,21 +314,17 @@ class Castro:
         shells.append(((ihi[0] + 1, ilo[1], ilo[2]), (hi[0], ihi[1], ihi[2])))
         return (ilo, ihi), shells
 
-    # ---- Castro::do_advance_ctu -------------------------------------------------------------
+    # ---- Castro::do_advance_ctu (Source/driver/Castro_advance_ctu.cpp:15-397) -----------------
     def do_advance_ctu(self, time, dt):
+        """One attempt at advancing S_old -> S_new by dt on the current time levels.
+        Returns (success, reason, new_dt) like the reference's advance_status."""
         h = self.hydro
-        # initialize_advance: swap_state_time_levels
-        self.S_old_b, self.S_new_b = self.S_new_b, self.S_old_b
         S = self.S_old_b
         # clean_state(S_old) [Castro_advance.cpp:311] and clean_state(Sborder, 4 ghosts)
         # [Castro_advance.cpp:186] are both zone-local: on the valid zones they compose to
         # "clean twice"; ghost zones are copies (or sign-reflected copies) of twice-cleaned
         # valid zones, so they are filled AFTER the cleaning.  See DESIGN.md "clean_state order".
         self.clean_state(S, 2)
-        if not self.flux_assign:
-            for d in range(3):
-                self.fluxes[d].zero_()          # Castro_advance.cpp:391-394
-                self.mass_fluxes[d].zero_()
 
         # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
         # (:221-225) and the estTimeStep validity check (:386-392) are fused into the update pass
@@ -344,20 +346,87 @@ class Castro:
         else:
             self.expand_state(S)
             self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse)
+        self._flux_clear = False
 
         if not fuse:
             h.clean_state_reduce(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, self.red, ntimes=1)
         self.comm.allreduce_min(self.red)
         est, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:
-            raise AdvanceFailure("negative/small density after the hydro update: %g (retry not implemented)" % rho_min)
+            # retry_small_density_cutoff keeps its default (-1e200): every such step is rejected
+            return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         new_dt = min(1.e200, est * self.params.cfl)
         if self.params.change_max * new_dt < dt:
-            raise AdvanceFailure("timestep validity check failed (retry not implemented)")
-        return new_dt
+            return False, "timestep validity check failed", None
+        return True, "", new_dt
 
+    def _swap_state_time_levels(self):
+        self.S_old_b, self.S_new_b = self.S_new_b, self.S_old_b
+
+    def _zero_fluxes(self):
+        """fluxes[d].setVal(0) (Castro_advance.cpp:391-394, Castro_advance_ctu.cpp:455-461).  In flux-assign mode
+        the fill is not executed: the next hydro call overwrites every face instead of accumulating."""
+        self._flux_clear = True
+        if not self.flux_assign:
+            for d in range(3):
+                self.fluxes[d].zero_()
+                self.mass_fluxes[d].zero_()
+
+    # ---- Castro::advance (Source/driver/Castro_advance.cpp:19-121) ------------------------------
     def advance(self, time, dt):
-        return self.do_advance_ctu(time, dt)
+        # initialize_advance: swap_state_time_levels, zero the flux registers, dt_subcycle = 1e200
+        self._swap_state_time_levels()
+        self._zero_fluxes()
+        self.nsubcycles, self.nretries = 1, 0
+        if not self.use_retry:
+            ok, reason, new_dt = self.do_advance_ctu(time, dt)
+            if not ok:
+                raise AdvanceFailure("Advance was unsuccessful: " + reason)      # amrex::Abort in the reference
+            return new_dt
+        return self.subcycle_advance_ctu(time, dt)
+
+    # ---- Castro::subcycle_advance_ctu + retry_advance_ctu (Castro_advance_ctu.cpp:403-768) ------
+    def subcycle_advance_ctu(self, time, dt):
+        dt_subcycle = 1.e200
+        if dt_subcycle == 1.e200:
+            dt_subcycle = dt
+        subcycle_time = time
+        sub_iteration = 0
+        eps = 1.0e-14
+        do_swap = False
+        prev_old = None
+        new_dt = None
+        self.nretries = 0
+        while subcycle_time < (1.0 - eps) * (time + dt):
+            # shorten the last subcycle so that it lands on time + dt
+            if subcycle_time + dt_subcycle > (1.0 - self.dt_cutoff) * (time + dt):
+                dt_subcycle = (time + dt) - subcycle_time
+            if dt_subcycle <= self.dt_cutoff * time:
+                raise AdvanceFailure("Error: subcycled timesteps too short.")
+            num_subcycles_remaining = int(round(((time + dt) - subcycle_time) / dt_subcycle))
+            if num_subcycles_remaining > self.max_subcycles:
+                raise AdvanceFailure("Error: too many subcycles.")
+            if do_swap:
+                self._swap_state_time_levels()
+            else:
+                do_swap = True
+            ok, reason, new_dt = self.do_advance_ctu(subcycle_time, dt_subcycle)
+            if not ok:
+                # retry_advance_ctu: halve the subcycle, keep the original old data, clear the fluxes
+                dt_subcycle = min(dt_subcycle, dt_subcycle) * self.retry_subcycle_factor
+                if prev_old is None:
+                    prev_old = self.S_old_b.clone()
+                self._zero_fluxes()
+                do_swap = False
+                self.nretries += 1
+                self.last_failure = reason
+                continue
+            subcycle_time += dt_subcycle
+            sub_iteration += 1
+        if sub_iteration > 1 and prev_old is not None:
+            self.S_old_b.copy_(prev_old)          # state[k].replaceOldData(*prev_state[k])
+        self.nsubcycles = sub_iteration
+        return new_dt
 
     # ---- Castro::writePlotFile (Source/driver/Castro_io.cpp:853) ------------------------------
     def writePlotFile(self, dirname, derive=None):

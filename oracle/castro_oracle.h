@@ -184,6 +184,12 @@ double ora_level_est_time_step(ora_level *L);
 double ora_level_initial_dt(ora_level *L, double stop_time);
 double ora_level_new_dt(ora_level *L, double dt_old, double cur_time, double stop_time);
 int  ora_level_advance(ora_level *L, double time, double dt);   /* 0 ok, 1 density failure, 2 dt check failed */
+/* Castro::advance with castro.use_retry = 1 (Castro_advance_ctu.cpp:403-768): 0 ok, -1 / -2 = the reference's aborts */
+int  ora_level_advance_retry(ora_level *L, double time, double dt, double retry_subcycle_factor,
+                             int max_subcycles, double dt_cutoff);
+int  ora_level_nsubcycles(ora_level *L);
+int  ora_level_nretries(ora_level *L);
+double *ora_level_old_state(ora_level *L);
 double ora_level_last_hydro_seconds(ora_level *L);
 
 #ifdef __cplusplus

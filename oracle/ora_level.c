@@ -4,6 +4,7 @@
  * the hot path:
  *   Castro::advance / initialize_advance    Source/driver/Castro_advance.cpp:19-121,232-410
  *   Castro::do_advance_ctu                  Source/driver/Castro_advance_ctu.cpp:15-397
+ *   retry_advance_ctu / subcycle_advance_ctu Source/driver/Castro_advance_ctu.cpp:403-768
  *   initialize_do_advance (FillPatch+clean) Source/driver/Castro_advance.cpp:124-209
  *   estTimeStep / computeNewDt / computeInitialDt / initialTimeStep
  *                                           Source/driver/Castro.cpp:1490-1866
@@ -24,6 +25,8 @@ struct ora_level {
     double *S_new, *S_old, *Sborder;
     double *fluxes[3], *mass_fluxes[3];
     double hydro_seconds;
+    double *prev_old;       /* prev_state old data kept across a retry (Castro_advance_ctu.cpp:430-451) */
+    int nsubcycles, nretries;
 };
 
 static double now_s(void)
@@ -65,7 +68,7 @@ ora_level *ora_level_create(const int n[3], const ora_geom *G, const ora_params 
 void ora_level_destroy(ora_level *L)
 {
     if (!L) return;
-    free(L->S_new); free(L->S_old); free(L->Sborder);
+    free(L->S_new); free(L->S_old); free(L->Sborder); free(L->prev_old);
     for (int d = 0; d < 3; ++d) { free(L->fluxes[d]); free(L->mass_fluxes[d]); }
     free(L);
 }
@@ -119,30 +122,42 @@ double ora_level_new_dt(ora_level *L, double dt_old, double cur_time, double sto
 }
 
 /* One level advance.  0 ok; 1 = density failure; 2 = dt validity check failed */
-int ora_level_advance(ora_level *L, double time, double dt)
+static void level_fabs(ora_level *L, ora_a4 fl[3], ora_a4 mf[3], ora_a4 qe[3])
 {
-    const ora_params *P = &L->P;
-    size_t nv = (size_t)L->n[0] * L->n[1] * L->n[2];
-
-    /* initialize_advance: swap_state_time_levels; clean_state(S_old) */
-    { double *t = L->S_old; L->S_old = L->S_new; L->S_new = t; }
-    ora_a4 S_old = ora_make_a4(L->S_old, L->lo, L->hi, NUM_STATE);
-    ora_a4 S_new = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
-    ora_clean_state(L->lo, L->hi, S_old, P);
-
-    /* zero the flux registers (Castro_advance.cpp:391-394) */
-    ora_a4 fl[3], mf[3], qe[3];
     for (int d = 0; d < 3; ++d) {
         int fhi[3] = { L->hi[0], L->hi[1], L->hi[2] };
         fhi[d] += 1;
         fl[d] = ora_make_a4(L->fluxes[d], L->lo, fhi, NUM_STATE);
         mf[d] = ora_make_a4(L->mass_fluxes[d], L->lo, fhi, 1);
-        memset(L->fluxes[d], 0, sizeof(double) * (size_t)fl[d].sn * NUM_STATE);
-        memset(L->mass_fluxes[d], 0, sizeof(double) * (size_t)mf[d].sn);
         qe[d].p = NULL;
     }
+}
 
-    /* initialize_do_advance: Sborder = FillPatch(S_old, 4 ghosts); clean_state(Sborder, 4) */
+static void level_swap(ora_level *L) { double *t = L->S_old; L->S_old = L->S_new; L->S_new = t; }
+
+/* zero the flux registers (Castro_advance.cpp:391-394; retry: Castro_advance_ctu.cpp:455-461) */
+static void level_zero_fluxes(ora_level *L)
+{
+    ora_a4 fl[3], mf[3], qe[3];
+    level_fabs(L, fl, mf, qe);
+    for (int d = 0; d < 3; ++d) {
+        memset(L->fluxes[d], 0, sizeof(double) * (size_t)fl[d].sn * NUM_STATE);
+        memset(L->mass_fluxes[d], 0, sizeof(double) * (size_t)mf[d].sn);
+    }
+}
+
+/* Castro::do_advance_ctu (Castro_advance_ctu.cpp:15-397) on the current time levels.
+ * Returns 0, 1 (small/negative density) or 2 (timestep validity check failed). */
+static int level_do_advance(ora_level *L, double time, double dt)
+{
+    const ora_params *P = &L->P;
+    ora_a4 S_old = ora_make_a4(L->S_old, L->lo, L->hi, NUM_STATE);
+    ora_a4 S_new = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
+    ora_a4 fl[3], mf[3], qe[3];
+    level_fabs(L, fl, mf, qe);
+
+    /* initialize_do_advance: clean_state(S_old); Sborder = FillPatch(S_old, 4 ghosts); clean_state(Sborder, 4) */
+    ora_clean_state(L->lo, L->hi, S_old, P);
     ora_a4 Sb = ora_make_a4(L->Sborder, L->glo, L->ghi, NUM_STATE);
     ora_fill_interior_copy(Sb, S_old, L->lo, L->hi);
     ora_bc_fill(Sb, &L->G);
@@ -159,7 +174,7 @@ int ora_level_advance(ora_level *L, double time, double dt)
     L->hydro_seconds = now_s() - t0;
     (void)bad;
 
-    /* small/negative density check (:168-216) */
+    /* small/negative density check (:168-216); retry_small_density_cutoff keeps its default (-1e200) */
     if (ora_min_density(L->lo, L->hi, S_new) < P->small_dens) return 1;
 
     /* clean_state(S_new) (:221-225) */
@@ -168,10 +183,76 @@ int ora_level_advance(ora_level *L, double time, double dt)
     /* timestep validity check (:386-392) */
     double new_dt = ora_level_est_time_step(L);
     if (P->change_max * new_dt < dt) return 2;
-
-    (void)nv;
     return 0;
 }
+
+/* Castro::advance without retries: one do_advance_ctu over the whole step */
+int ora_level_advance(ora_level *L, double time, double dt)
+{
+    level_swap(L);
+    level_zero_fluxes(L);
+    return level_do_advance(L, time, dt);
+}
+
+/* Castro::advance with castro.use_retry = 1: initialize_advance + subcycle_advance_ctu
+ * (Castro_advance_ctu.cpp:507-768) + retry_advance_ctu (:403-503).
+ * Returns 0, or -1 "subcycled timesteps too short", -2 "too many subcycles" (amrex::Abort in the reference). */
+int ora_level_advance_retry(ora_level *L, double time, double dt, double retry_subcycle_factor,
+                            int max_subcycles, double dt_cutoff)
+{
+    const size_t nv = (size_t)L->n[0] * L->n[1] * L->n[2] * NUM_STATE;
+    /* initialize_advance */
+    level_swap(L);
+    level_zero_fluxes(L);
+    double dt_subcycle = 1.e200;
+    int have_prev = 0;
+
+    if (dt_subcycle == 1.e200) dt_subcycle = dt;
+    double subcycle_time = time;
+    int sub_iteration = 0;
+    const double eps = 1.0e-14;
+    int do_swap = 0;
+    L->nsubcycles = 0; L->nretries = 0;
+
+    while (subcycle_time < (1.0 - eps) * (time + dt)) {
+        if (subcycle_time + dt_subcycle > (1.0 - dt_cutoff) * (time + dt)) {
+            dt_subcycle = (time + dt) - subcycle_time;
+        }
+        if (dt_subcycle <= dt_cutoff * time) return -1;
+        int num_subcycles_remaining = (int)round(((time + dt) - subcycle_time) / dt_subcycle);
+        if (num_subcycles_remaining > max_subcycles) return -2;
+
+        if (do_swap) level_swap(L); else do_swap = 1;
+
+        int status = level_do_advance(L, subcycle_time, dt_subcycle);
+
+        if (status != 0) {
+            /* retry_advance_ctu */
+            dt_subcycle = amin(dt_subcycle, dt_subcycle) * retry_subcycle_factor;
+            if (!have_prev) {
+                if (!L->prev_old) L->prev_old = (double *)malloc(sizeof(double) * nv);
+                memcpy(L->prev_old, L->S_old, sizeof(double) * nv);
+                have_prev = 1;
+            }
+            level_zero_fluxes(L);
+            do_swap = 0;
+            L->nretries += 1;
+            continue;
+        }
+        subcycle_time += dt_subcycle;
+        sub_iteration += 1;
+    }
+    if (sub_iteration > 1 && have_prev) {
+        /* state[k].replaceOldData(*prev_state[k]) (:716-726) */
+        memcpy(L->S_old, L->prev_old, sizeof(double) * nv);
+    }
+    L->nsubcycles = sub_iteration;
+    return 0;
+}
+
+int ora_level_nsubcycles(ora_level *L) { return L->nsubcycles; }
+int ora_level_nretries(ora_level *L) { return L->nretries; }
+double *ora_level_old_state(ora_level *L) { return L->S_old; }
 
 /* ------------------------------------------------------------------ */
 /* Exec/hydro_tests/Sod/problem_initialize.H + problem_initialize_state_data.H

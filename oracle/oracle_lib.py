@@ -109,6 +109,12 @@ def lib():
         L.ora_level_new_dt.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.ora_level_advance.restype = C.c_int
         L.ora_level_advance.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ora_level_advance_retry.restype = C.c_int
+        L.ora_level_advance_retry.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+        L.ora_level_nsubcycles.argtypes = [C.c_void_p]
+        L.ora_level_nretries.argtypes = [C.c_void_p]
+        L.ora_level_old_state.restype = C.POINTER(C.c_double)
+        L.ora_level_old_state.argtypes = [C.c_void_p]
         L.ora_level_last_hydro_seconds.restype = C.c_double
         L.ora_level_last_hydro_seconds.argtypes = [C.c_void_p]
         _lib = L
@@ -207,7 +213,11 @@ def ctu_hydro(bxlo, bxhi, Sborder, sb_lo, sb_hi, S_new, geom, params, dt, time=0
 class Level:
     """Single-box level driver (oracle mirror of Castro::advance for max_level=0)."""
 
-    def __init__(self, n, geom, params, nthreads=0):
+    def __init__(self, n, geom, params, nthreads=0, use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10,
+                 dt_cutoff=1.e-12):
+        self.use_retry, self.retry_subcycle_factor = bool(use_retry), float(retry_subcycle_factor)
+        self.max_subcycles, self.dt_cutoff = int(max_subcycles), float(dt_cutoff)
+        self.nsubcycles = self.nretries = 0
         self.n = tuple(int(x) for x in n)
         self.geom = geom
         self.params = params
@@ -232,6 +242,11 @@ class Level:
     def state(self):
         """View of S_new as (NUM_STATE, nz, ny, nx). Re-fetch after every advance (buffers swap)."""
         p = lib().ora_level_state(self.h)
+        nx, ny, nz = self.n
+        return np.ctypeslib.as_array(p, shape=(NUM_STATE, nz, ny, nx))
+
+    def old_state(self):
+        p = lib().ora_level_old_state(self.h)
         nx, ny, nz = self.n
         return np.ctypeslib.as_array(p, shape=(NUM_STATE, nz, ny, nx))
 
@@ -266,9 +281,14 @@ class Level:
             self.dt = L.ora_level_initial_dt(self.h, stop_time)
         else:
             self.dt = L.ora_level_new_dt(self.h, self.dt, self.time, stop_time)
-        st = L.ora_level_advance(self.h, self.time, self.dt)
+        if self.use_retry:
+            st = L.ora_level_advance_retry(self.h, self.time, self.dt, self.retry_subcycle_factor, self.max_subcycles,
+                                           self.dt_cutoff)
+            self.nsubcycles, self.nretries = L.ora_level_nsubcycles(self.h), L.ora_level_nretries(self.h)
+        else:
+            st = L.ora_level_advance(self.h, self.time, self.dt)
         if st != 0:
-            raise RuntimeError("oracle advance failed with status %d (retry logic not restated)" % st)
+            raise RuntimeError("oracle advance failed with status %d" % st)
         self.time += self.dt
         self.nstep += 1
         return self.dt

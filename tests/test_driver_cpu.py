@@ -147,3 +147,42 @@ def test_decomposed_run_is_bitwise_identical_gloo(tmp_path, oracle, world, n, bc
     want_S, want_dts = _single(n, bcs, nsteps, oracle)
     assert np.array_equal(got["dts"], want_dts)
     assert np.array_equal(got["S"], want_S)
+
+
+def test_retry_and_subcycling_match_the_oracle_driver(oracle):
+    """castro.use_retry (Castro_advance_ctu.cpp:403-768): a step that fails the timestep-validity check is redone
+    as two half steps; state, old state, accumulated fluxes and step sizes equal the oracle's C restatement."""
+    import castro_amd
+    n = (16, 16, 16)
+    kw = dict(cfl=0.9, init_shrink=1.0, change_max=1.02)
+    c = _make(n, oracle, **kw)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    lev = oracle.Level(n, oracle.make_geom(n), oracle.default_params(**kw), nthreads=4)
+    lev.init_sedov(r_init=0.1, nsub=4)
+    seen_retry = False
+    for _ in range(4):
+        c.step(0.05)
+        lev.step(0.05)
+        assert (c.dt, c.nsubcycles, c.nretries) == (lev.dt, lev.nsubcycles, lev.nretries)
+        seen_retry |= c.nretries > 0
+        assert np.array_equal(c.S_new().numpy(), lev.state())
+        g = 4
+        assert np.array_equal(c.S_old_b[:, g:-g, g:-g, g:-g].numpy(), lev.old_state())
+        for d in range(3):
+            assert np.array_equal(c.fluxes[d].numpy(), lev.flux(d))
+    assert seen_retry and "timestep validity" in c.last_failure
+    lev.close()
+
+    # without retries the same step aborts (amrex::Abort("Advance was unsuccessful.") in the reference)
+    c = castro_amd.Castro(n, params=oracle.default_params(**kw), hydro=OracleBackend(), use_retry=False)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    with pytest.raises(castro_amd.AdvanceFailure, match="timestep validity"):
+        c.step(0.05)
+
+    # small-density failures halve the step until max_subcycles is exceeded
+    c = _make(n, oracle, small_dens=0.9, init_shrink=1.0)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    with pytest.raises(castro_amd.AdvanceFailure, match="too many subcycles"):
+        for _ in range(12):
+            c.step(0.05)
+    assert "density" in c.last_failure
