@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--cpu-ncell", type=int, default=192)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--periodic", action="store_true", help="periodic instead of outflow boundaries (exercises the halo "
+                    "pack/exchange/unpack path even on one GPU)")
+    ap.add_argument("--force-overlap", action="store_true", help="interior + 6 shell tiles with the halo exchange on the "
+                    "communication stream, as every rank of a multi-GPU run does")
     ap.add_argument("--reference-contract", action="store_true",
                     help="zero-fill + accumulate fluxes and run clean_state/estdt as separate passes (600 B/cell form)")
     args = ap.parse_args()
@@ -140,7 +144,9 @@ def main():
         n_cell = (args.ncell,) * 3
 
     contract = args.reference_contract
-    c = castro_amd.Castro(n_cell, comm=comm, grid=grid, overlap=(False if args.no_overlap else None),
+    bc = (0, 0, 0) if args.periodic else (2, 2, 2)
+    c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc,
+                          overlap=(False if args.no_overlap else (True if args.force_overlap else None)),
                           fuse_clean=not contract, flux_assign=not contract)
     PATH_BYTES_PER_CELL = PATH_BYTES_CONTRACT if contract else PATH_BYTES_ASSIGN
     c.initData("sedov")                      # synthetic input, generated on the device

@@ -147,7 +147,10 @@ class Castro:
         self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)   # [min dt, min rho]
 
         self.neighbors = self._build_neighbors()
-        self.overlap = (self.comm.size > 1) if overlap is None else bool(overlap)
+        # Overlapping the halo exchange with an interior tile costs more than it hides on MI355X: the six
+        # 4-zone boundary slabs re-do ctoprim/trace on 3x their volume (+18 % at 256^3, +44 % at 128^3 per
+        # rank, tools/overlap_cost.sh) while the exchange itself is ~1-3 % of a step.  Off by default.
+        self.overlap = False if overlap is None else bool(overlap)
         self.fuse_clean = bool(fuse_clean)
         # one hydro call per step: "zero fluxes, then +=" (Castro_advance.cpp:391-394) is an assignment
         self.flux_assign = bool(flux_assign)

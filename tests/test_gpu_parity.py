@@ -103,6 +103,29 @@ def test_ctu_hydro_fab_bit_exact(hip, oracle, shape, seed):
     _assert_exact(out, "ctu_hydro_fab %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 1, 3), (3, 5, 2), (7, 3, 1), (1, 9, 4), (515, 3, 2)])
+def test_ctu_hydro_ragged_and_minimal_boxes(hip, oracle, shape):
+    """Degenerate extents: single zones, odd x extents (the kernels process x-pairs with a scalar tail),
+    rows longer than two workgroups; anisotropic dx."""
+    rng = np.random.default_rng(100 + shape[0])
+    bxlo = (3, -2, 5)
+    bxhi = tuple(bxlo[d] + shape[d] - 1 for d in range(3))
+    sb_lo = tuple(x - 4 for x in bxlo)
+    sb_hi = tuple(x + 4 for x in bxhi)
+    U = physical_state(rng, sb_lo, sb_hi)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 5.0e-4, dx=(0.02, 0.013, 0.031))
+    _assert_exact(out, "shape %s" % (shape,))
+
+
+def test_empty_box_is_rejected(hip):
+    import castro_amd
+    S = hip.alloc(8, (-4, -4, -4), (11, 11, 11), fill=1.0)
+    N = hip.alloc(8, (0, 0, 0), (7, 7, 7), fill=1.0)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        hip.construct_ctu_hydro_source(((0, 0, 0), (-1, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N, ((0, 0, 0), (7, 7, 7)),
+                                       castro_amd.make_geom((8, 8, 8)), castro_amd.default_params(), 0.0, 1e-3)
+
+
 def test_ctu_hydro_fab_larger_sborder_and_noisy(hip, oracle):
     """Sborder FAB larger than grow(bx,4) (tile of a bigger FAB) and cell-to-cell noise."""
     rng = np.random.default_rng(7)
