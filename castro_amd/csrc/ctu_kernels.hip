@@ -83,14 +83,13 @@ __device__ __forceinline__ unsigned dstr(const Str& s, int d) { return d == 0 ? 
 // workgroups resident on one XCD at a time share their y and z stencil neighbours through that XCD's L2.
 struct LinBox { int lo[3], n[3]; int ty; unsigned nb; int w, hi0; };   // w zones per thread along x (n[0] counts threads)
 
-__device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int& k)
+__device__ __forceinline__ bool box_thread_at(const LinBox& b, unsigned bid, unsigned thr, int& i, int& j, int& k)
 {
-    unsigned bid = blockIdx.x;
     if (b.ty > 0) {
         const unsigned per = b.nb >> 3;          // nb is a multiple of 8 in this mode
         bid = (bid & 7u) * per + (bid >> 3);
     }
-    const unsigned tid = bid * blockDim.x + threadIdx.x;
+    const unsigned tid = bid * 256u + thr;
     const unsigned total = (unsigned)b.n[0] * (unsigned)b.n[1] * (unsigned)b.n[2];
     if (tid >= total) return false;
     const unsigned ii = tid % (unsigned)b.n[0];
@@ -110,6 +109,11 @@ __device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int&
         k = b.lo[2] + (int)(r / (unsigned)b.n[1]);
     }
     return true;
+}
+
+__device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int& k)
+{
+    return box_thread_at(b, blockIdx.x, threadIdx.x, i, j, k);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -643,7 +647,8 @@ template <int D>
 __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd,
                                                const double flat[2], double dtdx, const DevParams& P,
                                                const bool do_plus[2], const bool do_minus[2],
-                                               double* __restrict__ QMd, double* __restrict__ QPd)
+                                               double* __restrict__ QMd, double* __restrict__ QPd,
+                                               double qp[2][NEDGE], double qm[2][NEDGE])
 {
     constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
     constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
@@ -685,67 +690,11 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_X, w[0].Im_X);
     ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_X, w[1].Im_X);
 
-    double qp[2][NEDGE], qm[2][NEDGE];
     trace_finish<D>(w[0], un[0], cc[0], P, qp[0], qm[0]);
     trace_finish<D>(w[1], un[1], cc[1], P, qp[1], qm[1]);
 
     store_edge_2(QPd, NC, c, qp, do_plus[0], do_plus[1]);
     store_edge_2(QMd, NC, c + sd, qm, do_minus[0], do_minus[1]);
-}
-
-__global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                    double dt, DevParams P)
-{
-    int i, j, k;
-    if (!box_thread(b, i, j, k)) return;
-    const bool v1 = i + 1 <= b.hi0;
-    const unsigned c = goff(t, i, j, k);
-    const Str s = gstr(t);
-    const long NC = t.NC;
-
-    // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
-    double flat[2];
-    if (P.first_order_hydro == 1) {
-        flat[0] = flat[1] = 0.0;
-    } else if (P.use_flattening == 1) {
-        const double* Pp = Q + PP * NC;
-        double pA[7], pB[7], uA[5], uB[5];
-        {
-            const D2 p0 = ldg2(Pp, c - 24u), p1 = ldg2(Pp, c - 8u), p2 = ldg2(Pp, c + 8u), p3 = ldg2(Pp, c + 24u);
-            pA[0] = p0.a; pA[1] = p0.b; pA[2] = p1.a; pA[3] = p1.b; pA[4] = p2.a; pA[5] = p2.b; pA[6] = p3.a;
-            pB[0] = p0.b; pB[1] = p1.a; pB[2] = p1.b; pB[3] = p2.a; pB[4] = p2.b; pB[5] = p3.a; pB[6] = p3.b;
-            load_stencil_2<0>(Q + PU * NC, c, s.x, uA, uB);
-            flat[0] = flatten_1d(pA, uA);
-            flat[1] = flatten_1d(pB, uB);
-        }
-        {
-#pragma unroll
-            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.y); pA[m + 3] = v.a; pB[m + 3] = v.b; }
-            load_stencil_2<1>(Q + PV * NC, c, s.y, uA, uB);
-            flat[0] = amin(flat[0], flatten_1d(pA, uA));
-            flat[1] = amin(flat[1], flatten_1d(pB, uB));
-        }
-        {
-#pragma unroll
-            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.z); pA[m + 3] = v.a; pB[m + 3] = v.b; }
-            load_stencil_2<2>(Q + PW * NC, c, s.z, uA, uB);
-            flat[0] = amin(flat[0], flatten_1d(pA, uA));
-            flat[1] = amin(flat[1], flatten_1d(pB, uB));
-        }
-    } else {
-        flat[0] = flat[1] = 1.0;
-    }
-
-    bool dp[2], dm[2];
-    dp[0] = i >= t.lo[0]; dp[1] = v1 && i + 1 >= t.lo[0];
-    dm[0] = i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
-    trace_pair_dir<0>(t, Q, c, s.x, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0]);
-    dp[0] = j >= t.lo[1]; dp[1] = v1 && dp[0];
-    dm[0] = j <= t.hi[1]; dm[1] = v1 && dm[0];
-    trace_pair_dir<1>(t, Q, c, s.y, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1]);
-    dp[0] = k >= t.lo[2]; dp[1] = v1 && dp[0];
-    dm[0] = k <= t.hi[2]; dm[1] = v1 && dm[0];
-    trace_pair_dir<2>(t, Q, c, s.z, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1257,6 +1206,125 @@ __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsi
     }
 }
 
+__global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                    double dt, DevParams P)
+{
+    int i, j, k;
+    const bool valid = box_thread(b, i, j, k);     // no early exit: the block synchronises below
+    if (!valid) { i = b.lo[0]; j = b.lo[1]; k = b.lo[2]; }
+    const bool v1 = valid && i + 1 <= b.hi0;
+    const unsigned c = goff(t, i, j, k);
+    const Str s = gstr(t);
+    const long NC = t.NC;
+
+    // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
+    double flat[2];
+    if (P.first_order_hydro == 1) {
+        flat[0] = flat[1] = 0.0;
+    } else if (P.use_flattening == 1) {
+        const double* Pp = Q + PP * NC;
+        double pA[7], pB[7], uA[5], uB[5];
+        {
+            const D2 p0 = ldg2(Pp, c - 24u), p1 = ldg2(Pp, c - 8u), p2 = ldg2(Pp, c + 8u), p3 = ldg2(Pp, c + 24u);
+            pA[0] = p0.a; pA[1] = p0.b; pA[2] = p1.a; pA[3] = p1.b; pA[4] = p2.a; pA[5] = p2.b; pA[6] = p3.a;
+            pB[0] = p0.b; pB[1] = p1.a; pB[2] = p1.b; pB[3] = p2.a; pB[4] = p2.b; pB[5] = p3.a; pB[6] = p3.b;
+            load_stencil_2<0>(Q + PU * NC, c, s.x, uA, uB);
+            flat[0] = flatten_1d(pA, uA);
+            flat[1] = flatten_1d(pB, uB);
+        }
+        {
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.y); pA[m + 3] = v.a; pB[m + 3] = v.b; }
+            load_stencil_2<1>(Q + PV * NC, c, s.y, uA, uB);
+            flat[0] = amin(flat[0], flatten_1d(pA, uA));
+            flat[1] = amin(flat[1], flatten_1d(pB, uB));
+        }
+        {
+#pragma unroll
+            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.z); pA[m + 3] = v.a; pB[m + 3] = v.b; }
+            load_stencil_2<2>(Q + PW * NC, c, s.z, uA, uB);
+            flat[0] = amin(flat[0], flatten_1d(pA, uA));
+            flat[1] = amin(flat[1], flatten_1d(pB, uB));
+        }
+    } else {
+        flat[0] = flat[1] = 1.0;
+    }
+
+    bool dp[2], dm[2];
+    double qp[2][NEDGE], qm[2][NEDGE];
+    dp[0] = valid && i >= t.lo[0]; dp[1] = v1 && i + 1 >= t.lo[0];
+    dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
+    trace_pair_dir<0>(t, Q, c, s.x, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm);
+
+    // ---- first Riemann solve in x (Castro_ctu_hydro.cpp:719) on the two faces of this thread:
+    //      face i+1 lies between its two zones; face i needs the minus state of the zone to the left, which
+    //      the neighbouring lane (or, across a wavefront boundary, LDS) hands over.  The first thread of a
+    //      workgroup has no left neighbour here: k_riemann1_blockstart does those faces from QM/QP.
+    {
+        double qmL[NEDGE];
+        __shared__ double xch[4][NEDGE];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int n = 0; n < NEDGE; ++n) qmL[n] = __shfl_up(qm[1][n], 1, 64);
+        if (lane == 63) {
+#pragma unroll
+            for (int n = 0; n < NEDGE; ++n) xch[wave][n] = qm[1][n];
+        }
+        __syncthreads();
+        if (lane == 0 && wave > 0) {
+#pragma unroll
+            for (int n = 0; n < NEDGE; ++n) qmL[n] = xch[wave - 1][n];
+        }
+        const bool mA = valid && i >= t.lo[0] && threadIdx.x > 0;     // face i   (plus state: zone i)
+        const bool mB = v1;                                            // face i+1 (needed: i+1 >= lo always)
+        if (mA || mB) {
+            const double* Cp = Q + PC * NC;
+            const double cm1 = ldg(Cp, c - 8u);
+            const D2 cc01 = ldg2(Cp, c);
+            IFlux f[2];
+            RState ql, qr;
+            double Xl, Xr;
+            rstate_from_edge<0>(qmL, P.gamma, ql, Xl);
+            rstate_from_edge<0>(qp[0], P.gamma, qr, Xr);
+            interface_flux<0>(ql, qr, Xl, Xr, cm1, cc01.a, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f[0]);
+            rstate_from_edge<0>(qm[0], P.gamma, ql, Xl);
+            rstate_from_edge<0>(qp[1], P.gamma, qr, Xr);
+            interface_flux<0>(ql, qr, Xl, Xr, cc01.a, cc01.b, wall_fac<0>(g, i + 1), face_shock(S, P, c + 8u, 8u), P, f[1]);
+            store_f1_2<0>(S.F1[0], NC, c, f, mA, mB);
+        }
+    }
+
+    dp[0] = valid && j >= t.lo[1]; dp[1] = v1 && dp[0];
+    dm[0] = valid && j <= t.hi[1]; dm[1] = v1 && dm[0];
+    trace_pair_dir<1>(t, Q, c, s.y, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm);
+    dp[0] = valid && k >= t.lo[2]; dp[1] = v1 && dp[0];
+    dm[0] = valid && k <= t.hi[2]; dm[1] = v1 && dm[0];
+    trace_pair_dir<2>(t, Q, c, s.z, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm);
+}
+
+// the x-faces k_trace_pair leaves out: face i of the first thread of every workgroup of that launch
+__global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
+                                                             DevGeom g, DevParams P)
+{
+    const unsigned blk = blockIdx.x * blockDim.x + threadIdx.x;      // workgroup index of the k_trace_pair launch
+    if (blk >= b.nb) return;
+    int i, j, k;
+    if (!box_thread_at(b, blk, 0u, i, j, k)) return;
+    if (i < t.lo[0]) return;
+    const unsigned c = goff(t, i, j, k);
+    RState ql, qr;
+    double Xl, Xr;
+    load_rstate<0>(S.QM[0], t.NC, c, P.gamma, ql, Xl);
+    load_rstate<0>(S.QP[0], t.NC, c, P.gamma, qr, Xr);
+    const double cl = ldg(Q + PC * t.NC, c - 8u);
+    const double cr = ldg(Q + PC * t.NC, c);
+    IFlux f;
+    interface_flux<0>(ql, qr, Xl, Xr, cl, cr, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f);
+    store_f1<0>(S.F1[0], t.NC, c, f);
+}
+
+
+
 template <int N, int T>
 __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, unsigned c, unsigned sn, unsigned st,
                                             const double qm[2][NEDGE], const double qp[2][NEDGE],
@@ -1584,6 +1652,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         }
 
     KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, (P.hybrid_riemann == 1) ? S.SHK : (double*)nullptr, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+    bool x_done = false;      // first x Riemann solve already done inside the trace kernel
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
@@ -1592,10 +1661,19 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
-        else { KL2("k_trace", k_trace_pair, olo, ohi, S.Q, S, g, dt, P); }
+        else {
+            KL2("k_trace", k_trace_pair, olo, ohi, S.Q, S, g, dt, P);
+            // x-faces at the workgroup starts of that launch (one thread per workgroup)
+            long n_;
+            LinBox b_ = linbox2(olo, ohi, n_);
+            prof_begin(prof, "k_riemann1", stream);
+            hipLaunchKernelGGL(k_riemann1_blockstart, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
+            prof_end(prof, stream);
+            x_done = true;
+        }
     }
 
-    KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
+    if (!x_done) KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
     KL("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
     KL("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
 
