@@ -34,9 +34,9 @@ PATH_BYTES_ASSIGN = 344.0
 KERNEL_BYTES_PER_UNIT = {
     "k_ctoprim": 8 * (8 + 8),
     "k_divu": 8 * (3 + 1),
-    "k_trace": 8 * (8 + 42),
+    "k_trace": 8 * (8 + 42 + 8),                          # + F1[x]: the first x Riemann solve is fused in
     "k_riemann1": 8 * (14 + 1 + 8),
-    "k_trans1": 8 * (14 + 16 + 1 + 16),
+    "k_trans1": 8 * (42 + 24 + 1 + 48),                   # all three normal directions in one launch
     "k_final": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),        # fluxes read-modify-write (8 read + 8 write + mass)
     "k_final_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 9),  # fluxes written only
     "k_consup": 8 * (27 + 8 + 8),
@@ -53,7 +53,7 @@ def kernel_units(name, n):
         "k_divu": (nx + 2) * (ny + 2) * (nz + 2),
         "k_trace": (nx + 2) * (ny + 2) * (nz + 2),
         "k_riemann1": ((nx + 1) * (ny + 2) * (nz + 2) + (nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 3.0,
-        "k_trans1": ((nx + 1) * (ny + 2) * (nz + 2) + (nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 3.0,
+        "k_trans1": (nx + 2) * (ny + 2) * (nz + 2),
         "k_final": ((nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + 1)) / 3.0,
         "k_consup": nx * ny * nz,
         "k_consup_clean": nx * ny * nz,
@@ -72,7 +72,9 @@ def pmc_traffic(kernel):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        return d["kernels"][kernel]["bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup"}       # hipEvent label -> kernel symbol
+        k = d["kernels"].get(kernel) or d["kernels"][alias[kernel]]
+        return k["bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     except (KeyError, ValueError):
         return None, None
 

@@ -1030,6 +1030,38 @@ __device__ __forceinline__ void load_edge(const double* __restrict__ E, long NC,
 
 __host__ __device__ constexpr int f2_slot(int N, int T) { return N * 2 + ((T > N) ? T - 1 : T); }
 
+// pair (two x-adjacent faces) forms of the record loads / stores
+__device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC, unsigned c, double r[2][NF1])
+{
+#pragma unroll
+    for (int n = 0; n < NF1; ++n) { const D2 v = ldg2(F + (long)n * NC, c); r[0][n] = v.a; r[1][n] = v.b; }
+}
+
+__device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long NC, unsigned c, double q[2][NEDGE])
+{
+#pragma unroll
+    for (int n = 0; n < NEDGE; ++n) { const D2 v = ldg2(E + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b; }
+}
+
+template <int D>
+__device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1)
+{
+    if (m0 && m1) {
+        stg2(F + FRHO * NC, c, f[0].rho, f[1].rho);
+        stg2(F + (FMX + RDir<D>::n) * NC, c, f[0].mn, f[1].mn);
+        stg2(F + (FMX + RDir<D>::t) * NC, c, f[0].mt, f[1].mt);
+        stg2(F + (FMX + RDir<D>::tt) * NC, c, f[0].mtt, f[1].mtt);
+        stg2(F + FE * NC, c, f[0].E, f[1].E);
+        stg2(F + FX * NC, c, f[0].X, f[1].X);
+        stg2(F + FUG * NC, c, f[0].ugd, f[1].ugd);
+        stg2(F + FPG * NC, c, f[0].pgd, f[1].pgd);
+    } else if (m0) {
+        store_f1<D>(F, NC, c, f[0]);
+    } else if (m1) {
+        store_f1<D>(F, NC, c + 8u, f[1]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // first Riemann solves: F^x, F^y, F^z on grow(nodal(bx,D), 1 in both transverse directions)
 // (Castro_ctu_hydro.cpp:719, :796, :875)
@@ -1040,20 +1072,28 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
 {
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
+    const bool v1 = i + 1 <= b.hi0;               // two x-adjacent faces per thread
     const unsigned c = goff(t, i, j, k);
     const unsigned sd = dstr(gstr(t), D);
-    const int idx = (D == 0) ? i : (D == 1) ? j : k;
 
-    RState ql, qr;
-    double Xl, Xr;
-    load_rstate<D>(S.QM[D], t.NC, c, P.gamma, ql, Xl);
-    load_rstate<D>(S.QP[D], t.NC, c, P.gamma, qr, Xr);
-    const double cl = ldg(Q + PC * t.NC, c - sd);
-    const double cr = ldg(Q + PC * t.NC, c);
+    double qm[2][NEDGE], qp[2][NEDGE];
+    load_edge_2(S.QM[D], t.NC, c, qm);
+    load_edge_2(S.QP[D], t.NC, c, qp);
+    const D2 cl = ldg2(Q + PC * t.NC, c - sd);
+    const D2 cr = ldg2(Q + PC * t.NC, c);
 
-    IFlux f;
-    interface_flux<D>(ql, qr, Xl, Xr, cl, cr, wall_fac<D>(g, idx), face_shock(S, P, c, sd), P, f);
-    store_f1<D>(S.F1[D], t.NC, c, f);
+    IFlux f[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState ql, qr;
+        double Xl, Xr;
+        rstate_from_edge<D>(qm[w], P.gamma, ql, Xl);
+        rstate_from_edge<D>(qp[w], P.gamma, qr, Xr);
+        const int idx = (D == 0) ? i + w : (D == 1) ? j : k;
+        interface_flux<D>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<D>(g, idx),
+                          face_shock(S, P, c + 8u * w, sd), P, f[w]);
+    }
+    store_f1_2<D>(S.F1[D], t.NC, c, f, true, v1);
 }
 
 // shared tail of the final stage for a pair of x-adjacent faces: flux in conserved order, artificial
@@ -1174,38 +1214,6 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 //   F2 slot (N|T): flux in direction N from states corrected with the T-direction flux.
 // (Castro_ctu_hydro.cpp:724-945 for the corrections, :949-1135 for the six solves)
 // ---------------------------------------------------------------------------------------
-// pair (two x-adjacent faces) forms of the record loads / stores
-__device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC, unsigned c, double r[2][NF1])
-{
-#pragma unroll
-    for (int n = 0; n < NF1; ++n) { const D2 v = ldg2(F + (long)n * NC, c); r[0][n] = v.a; r[1][n] = v.b; }
-}
-
-__device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long NC, unsigned c, double q[2][NEDGE])
-{
-#pragma unroll
-    for (int n = 0; n < NEDGE; ++n) { const D2 v = ldg2(E + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b; }
-}
-
-template <int D>
-__device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1)
-{
-    if (m0 && m1) {
-        stg2(F + FRHO * NC, c, f[0].rho, f[1].rho);
-        stg2(F + (FMX + RDir<D>::n) * NC, c, f[0].mn, f[1].mn);
-        stg2(F + (FMX + RDir<D>::t) * NC, c, f[0].mt, f[1].mt);
-        stg2(F + (FMX + RDir<D>::tt) * NC, c, f[0].mtt, f[1].mtt);
-        stg2(F + FE * NC, c, f[0].E, f[1].E);
-        stg2(F + FX * NC, c, f[0].X, f[1].X);
-        stg2(F + FUG * NC, c, f[0].ugd, f[1].ugd);
-        stg2(F + FPG * NC, c, f[0].pgd, f[1].pgd);
-    } else if (m0) {
-        store_f1<D>(F, NC, c, f[0]);
-    } else if (m1) {
-        store_f1<D>(F, NC, c + 8u, f[1]);
-    }
-}
-
 __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P)
 {
@@ -1673,9 +1681,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         }
     }
 
-    if (!x_done) KL("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
-    KL("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
-    KL("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
+    if (!x_done) KL2("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
+    KL2("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
+    KL2("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
 
     // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690); hdtdx = 0.5*dt/dx (:684-686)
     const double cdtdx = dt / g.dx[0] / 3.0, cdtdy = dt / g.dx[1] / 3.0, cdtdz = dt / g.dx[2] / 3.0;
