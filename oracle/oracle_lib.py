@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcastro_oracle.so")
+_SO = os.environ.get("CASTRO_ORACLE_SO", _SO)      # e.g. a sanitizer build of the same sources
 
 URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
 QRHO, QU, QV, QW, QPRES, QREINT, QTEMP, QFS = range(8)
