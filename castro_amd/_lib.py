@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
     "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status",
-    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
+    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab",
+    "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
@@ -93,6 +94,11 @@ def load():
                                        C.c_void_p, C.c_void_p]
     L.castro_amd_derive_fab.argtypes = [C.c_void_p, C.c_int, PF, PF, C.c_int, I3, I3, C.POINTER(Geom), C.POINTER(Params),
                                         C.POINTER(C.c_double * 3), C.c_void_p]
+    D3 = C.POINTER(C.c_double * 3)
+    L.castro_amd_old_gravity_source_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, D3, C.c_int, C.c_double, C.c_void_p]
+    L.castro_amd_new_gravity_source_fab.argtypes = [C.c_void_p, PF, PF, PF, PF, I3, I3, D3, C.c_int, C.c_double,
+                                                    C.POINTER(Geom), C.c_void_p]
+    L.castro_amd_saxpy_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]
     L.castro_amd_bc_fill_fab.argtypes = [C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
     L.castro_amd_copy_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_void_p]
     L.castro_amd_pack_fab.argtypes = [C.c_void_p, PF, I3, I3, C.c_void_p, C.c_void_p]

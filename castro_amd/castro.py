@@ -101,7 +101,8 @@ class AdvanceFailure(RuntimeError):
 class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
-                 use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12):
+                 use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
+                 do_grav=False, const_grav=0.0, grav_source_type=4):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -159,6 +160,14 @@ class Castro:
         self.use_retry, self.retry_subcycle_factor = bool(use_retry), float(retry_subcycle_factor)
         self.max_subcycles, self.dt_cutoff = int(max_subcycles), float(dt_cutoff)
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
+        # castro.do_grav with gravity.gravity_type = "ConstantGrav": g along the last dimension (Gravity.cpp:860-866)
+        self.do_grav, self.grav, self.grav_source_type = bool(do_grav), (0.0, 0.0, float(const_grav)), int(grav_source_type)
+        if self.do_grav:
+            NSRC, NGS = 7, 3            # NSRC, NUM_GROW_SRC (Castro_setup.cpp:317-327)
+            self.sbox = (tuple(x - NGS for x in self.lo), tuple(x + NGS for x in self.hi))
+            self.old_source = hydro.alloc(NSRC, *self.sbox)
+            self.new_source = hydro.alloc(NSRC, self.lo, self.hi)
+            self.src_neighbors = self._build_neighbors(NGS, NSRC)
         self._comm_stream = None
         if self.overlap and self.S_new_b.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
@@ -177,8 +186,9 @@ class Castro:
         return self.S_new_b[:, g:-g, g:-g, g:-g]
 
     # ----------------------------------------------------------------------------------------
-    def _build_neighbors(self):
-        """[(peer_rank, send_tag, recv_tag, send_box, recv_box)] for the up-to-26 neighbours."""
+    def _build_neighbors(self, ng=NUM_GROW, ncomp=NUM_STATE):
+        """[(peer_rank, send_tag, recv_tag, send_box, recv_box)] for the up-to-26 neighbours (ng ghost layers of
+        an ncomp-component FAB)."""
         out = []
         for off in itertools.product((-1, 0, 1), repeat=3):      # (ox, oy, oz)
             if off == (0, 0, 0):
@@ -200,11 +210,11 @@ class Castro:
             slo, shi, rlo, rhi = [], [], [], []
             for d in range(3):
                 if off[d] == -1:
-                    slo.append(self.lo[d]); shi.append(self.lo[d] + NUM_GROW - 1)
-                    rlo.append(self.lo[d] - NUM_GROW); rhi.append(self.lo[d] - 1)
+                    slo.append(self.lo[d]); shi.append(self.lo[d] + ng - 1)
+                    rlo.append(self.lo[d] - ng); rhi.append(self.lo[d] - 1)
                 elif off[d] == 1:
-                    slo.append(self.hi[d] - NUM_GROW + 1); shi.append(self.hi[d])
-                    rlo.append(self.hi[d] + 1); rhi.append(self.hi[d] + NUM_GROW)
+                    slo.append(self.hi[d] - ng + 1); shi.append(self.hi[d])
+                    rlo.append(self.hi[d] + 1); rhi.append(self.hi[d] + ng)
                 else:
                     slo.append(self.lo[d]); shi.append(self.hi[d])
                     rlo.append(self.lo[d]); rhi.append(self.hi[d])
@@ -217,17 +227,20 @@ class Castro:
             n = 1
             for d in range(3):
                 n *= nbr["sbox"][1][d] - nbr["sbox"][0][d] + 1
-            nbr["sbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * NUM_STATE - 1, 0, 0)).reshape(-1)
-            nbr["rbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * NUM_STATE - 1, 0, 0)).reshape(-1)
+            nbr["sbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * ncomp - 1, 0, 0)).reshape(-1)
+            nbr["rbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * ncomp - 1, 0, 0)).reshape(-1)
         return out
 
     # ---- AmrLevel::FillPatch at a single level: same-level copy + physical BCs ----
-    def expand_state(self, S):
+    def expand_state(self, S, box=None, neighbors=None):
+        """box / neighbors default to the state's (NUM_GROW ghosts); the Source_Type FillPatch passes its own."""
         h = self.hydro
+        box = self.gbox if box is None else box
+        neighbors = self.neighbors if neighbors is None else neighbors
         sends, recvs, local = [], [], []
-        for nb in self.neighbors:
-            h.pack(S, self.gbox, nb["sbox"][0], nb["sbox"][1], nb["sbuf"])
-        for nb in self.neighbors:
+        for nb in neighbors:
+            h.pack(S, box, nb["sbox"][0], nb["sbox"][1], nb["sbuf"])
+        for nb in neighbors:
             if nb["peer"] == self.comm.rank:
                 local.append(nb)
             else:
@@ -238,9 +251,9 @@ class Castro:
             src = next(x for x in local if x["send_tag"] == nb["recv_tag"])
             nb["rbuf"].copy_(src["sbuf"])
         self.comm.exchange(sends, recvs)
-        for nb in self.neighbors:
-            h.unpack(S, self.gbox, nb["rbox"][0], nb["rbox"][1], nb["rbuf"])
-        h.bc_fill(S, self.gbox, self.geom)
+        for nb in neighbors:
+            h.unpack(S, box, nb["rbox"][0], nb["rbox"][1], nb["rbuf"])
+        h.bc_fill(S, box, self.geom)
 
     # ---- Castro::clean_state ---------------------------------------------------------------
     def clean_state(self, S, ntimes=1):
@@ -256,6 +269,15 @@ class Castro:
         else:
             raise ValueError(problem)
         self.clean_state(self.S_new_b, 1)      # Castro.cpp:1100-1160
+        self.time, self.nstep, self.dt = 0.0, 0, 0.0
+
+    def set_state(self, full_state):
+        """Initial data from a host array (NUM_STATE, nz, ny, nx) covering the whole domain (a custom
+        problem_initialize_state_data); followed by the post-init clean_state like initData."""
+        g, lo, n = NUM_GROW, self.lo, self.n
+        part = torch.as_tensor(full_state[:, lo[2]:lo[2] + n[2], lo[1]:lo[1] + n[1], lo[0]:lo[0] + n[0]])
+        self.S_new_b[:, g:g + n[2], g:g + n[1], g:g + n[0]] = part.to(self.S_new_b.device, self.S_new_b.dtype)
+        self.clean_state(self.S_new_b, 1)
         self.time, self.nstep, self.dt = 0.0, 0, 0.0
 
     # ---- Castro::estTimeStep (hydro limiter) -------------------------------------------------
@@ -287,7 +309,7 @@ class Castro:
         return dt_0
 
     # ---- Castro::construct_ctu_hydro_source over this rank's box ------------------------------
-    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False):
+    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None):
         """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
         and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
         self.red, which the caller has initialised."""
@@ -295,7 +317,8 @@ class Castro:
         for bx in (tiles or [self.bx]):
             h.construct_ctu_hydro_source(bx, self.S_old_b, self.gbox, self.S_new_b, self.gbox, self.geom,
                                          self.params, time, dt, fluxes=self.fluxes, flux_boxes=self.flux_boxes,
-                                         mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=True,
+                                         mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=src is None,
+                                         src=src, src_box=self.sbox if src is not None else None,
                                          clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None,
                                          flux_assign=self.flux_assign and self._flux_clear)
 
@@ -332,8 +355,10 @@ class Castro:
         # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
         # (:221-225) and the estTimeStep validity check (:386-392) are fused into the update pass
         # (no new-time source terms on this path) + one 2-double allreduce
-        fuse = self.fuse_clean
+        fuse = self.fuse_clean and not self.do_grav
         self.red.fill_(1.e200)
+        if self.do_grav:
+            return self._do_advance_with_sources(time, dt, S)
 
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
         if use_overlap:
@@ -358,6 +383,41 @@ class Castro:
         if rho_min < self.params.small_dens:
             # retry_small_density_cutoff keeps its default (-1e200): every such step is rejected
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
+        new_dt = min(1.e200, est * self.params.cfl)
+        if self.params.change_max * new_dt < dt:
+            return False, "timestep validity check failed", None
+        return True, "", new_dt
+
+    def _do_advance_with_sources(self, time, dt, S):
+        """do_advance_ctu with old- and new-time gravity sources (Castro_advance_ctu.cpp:94-143, 156-274)."""
+        h = self.hydro
+        lo, hi = self.lo, self.hi
+        self.expand_state(S)
+        # MultiFab::Copy(S_new, Sborder) (:94)
+        h.copy(self.S_new_b, self.gbox, S, self.gbox, lo, hi)
+        # do_old_sources (:127-131): construct at t^n, apply with the full dt, clean_state; FillPatch the source
+        self.old_source.zero_()
+        h.old_gravity_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.grav, self.grav_source_type, dt)
+        h.saxpy(self.S_new_b, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi)
+        h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+        self.expand_state(self.old_source, self.sbox, self.src_neighbors)
+        # hydro with the old source traced in the predictor; S_new += (it already holds the old source)
+        self.construct_ctu_hydro_source(time, dt, src=self.old_source)
+        self._flux_clear = False
+        # S_new.min(URHO) (:168-216), clean_state(S_new) (:221-225)
+        h.clean_state_reduce(self.S_new_b, self.gbox, lo, hi, self.geom, self.params, self.red, ntimes=1)
+        self.comm.allreduce_min(self.red)
+        _, rho_min = self.red.tolist()
+        if rho_min < self.params.small_dens:
+            return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
+        # do_new_sources (:262-268): corrector from the new state, apply, clean_state
+        self.new_source.zero_()
+        h.new_gravity_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
+                             self.flux_boxes, lo, hi, self.grav, self.grav_source_type, dt, self.geom)
+        h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
+        h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+        # timestep validity check (:386-392)
+        est, _ = self._reduce()
         new_dt = min(1.e200, est * self.params.cfl)
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None

@@ -157,6 +157,176 @@ int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom&
 }
 
 // ---------------------------------------------------------------------------------------
+// constant-gravity source terms (Source/gravity/Castro_gravity.cpp:234-614; gravity.gravity_type =
+// "ConstantGrav": the same vector in every zone, ghost zones included, Gravity.cpp:860-866) and
+// Castro::apply_source_to_state (Source/sources/Castro_sources.cpp:10-19)
+// ---------------------------------------------------------------------------------------
+constexpr int NSRC = 7;
+
+__global__ void __launch_bounds__(256) k_old_grav_source(DFab U, DFab SRC, Box3 b, double g0, double g1, double g2,
+                                                         int type, double dt)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const double grav[3] = { g0, g1, g2 };
+    double snew[NUM_STATE], src[NSRC];
+    for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
+    const long c = fidx(U, i, j, k, 0);
+    double rho = U.p[c + U.sn * URHO];
+    double rhoInv = 1.0 / rho;
+    for (int n = 0; n < NUM_STATE; ++n) snew[n] = U.p[c + U.sn * n];
+    const double u_mx = snew[UMX], u_my = snew[UMY], u_mz = snew[UMZ];
+
+    double old_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoInv;
+
+    double Sr[3];
+    for (int n = 0; n < 3; ++n) {
+        Sr[n] = rho * grav[n];
+        src[UMX + n] = Sr[n];
+        snew[UMX + n] += dt * src[UMX + n];
+    }
+
+    double SrE;
+    if (type == 1 || type == 2) {
+        SrE = (u_mx * Sr[0] + u_my * Sr[1] + u_mz * Sr[2]) * rhoInv;
+    } else if (type == 3) {
+        double new_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoInv;
+        SrE = new_ke - old_ke;
+    } else {
+        SrE = (u_mx * Sr[0] + u_my * Sr[1] + u_mz * Sr[2]) * rhoInv;
+    }
+    src[UEDEN] = SrE;
+
+    const long cs = fidx(SRC, i, j, k, 0);
+    for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
+}
+
+__global__ void __launch_bounds__(256) k_new_grav_source(DFab UO, DFab UN, DFab SRC, DFab M0, DFab M1, DFab M2, Box3 b,
+                                                         double g0, double g1, double g2, int type, double dt,
+                                                         double dx0, double dx1, double dx2)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const double grav[3] = { g0, g1, g2 };
+    const double vol = dx0 * dx1 * dx2;
+    double src[NSRC];
+    for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
+    double hdtInv = 0.5 / dt;
+
+    const long co = fidx(UO, i, j, k, 0), cn = fidx(UN, i, j, k, 0);
+    double rhoo = UO.p[co + UO.sn * URHO];
+    double rhooinv = 1.0 / UO.p[co + UO.sn * URHO];
+    double rhon = UN.p[cn + UN.sn * URHO];
+    double rhoninv = 1.0 / UN.p[cn + UN.sn * URHO];
+
+    double snew[NUM_STATE];
+    for (int n = 0; n < NUM_STATE; ++n) snew[n] = UN.p[cn + UN.sn * n];
+
+    double old_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoninv;
+
+    double vold[3], Sr_old[3], vnew[3], Sr_new[3];
+    for (int n = 0; n < 3; ++n) vold[n] = UO.p[co + UO.sn * (UMX + n)] * rhooinv;
+    for (int n = 0; n < 3; ++n) Sr_old[n] = rhoo * grav[n];
+    double SrE_old = vold[0] * Sr_old[0] + vold[1] * Sr_old[1] + vold[2] * Sr_old[2];
+
+    for (int n = 0; n < 3; ++n) vnew[n] = snew[UMX + n] * rhoninv;
+    for (int n = 0; n < 3; ++n) Sr_new[n] = rhon * grav[n];
+    double SrE_new = vnew[0] * Sr_new[0] + vnew[1] * Sr_new[1] + vnew[2] * Sr_new[2];
+
+    double Srcorr[3];
+    for (int n = 0; n < 3; ++n) Srcorr[n] = 0.5 * (Sr_new[n] - Sr_old[n]);
+    for (int n = 0; n < 3; ++n) {
+        src[UMX + n] = Srcorr[n];
+        snew[UMX + n] += dt * src[UMX + n];
+    }
+
+    double SrEcorr;
+    if (type == 1) {
+        SrEcorr = 0.5 * (SrE_new - SrE_old);
+    } else if (type == 2) {
+        for (int n = 0; n < 3; ++n) vnew[n] = snew[UMX + n] * rhoninv;
+        SrE_new = vnew[0] * Sr_new[0] + vnew[1] * Sr_new[1] + vnew[2] * Sr_new[2];
+        SrEcorr = 0.5 * (SrE_new - SrE_old);
+    } else if (type == 3) {
+        double new_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoninv;
+        SrEcorr = new_ke - old_ke;
+    } else {
+        SrEcorr = -SrE_old;
+        // time-averaged edge-centred gravity; gold == gnew == grav in every zone
+        double g[3];
+        for (int n = 0; n < 3; ++n) g[n] = 0.5 * (grav[n] + grav[n]);
+        double gxl = 0.5 * (g[0] + 0.5 * (grav[0] + grav[0]));
+        double gxr = 0.5 * (g[0] + 0.5 * (grav[0] + grav[0]));
+        double gyl = 0.5 * (g[1] + 0.5 * (grav[1] + grav[1]));
+        double gyr = 0.5 * (g[1] + 0.5 * (grav[1] + grav[1]));
+        double gzl = 0.5 * (g[2] + 0.5 * (grav[2] + grav[2]));
+        double gzr = 0.5 * (g[2] + 0.5 * (grav[2] + grav[2]));
+
+        SrEcorr += hdtInv * (M0.p[fidx(M0, i, j, k, 0)] * gxl * dx0 +
+                             M0.p[fidx(M0, i + 1, j, k, 0)] * gxr * dx0 +
+                             M1.p[fidx(M1, i, j, k, 0)] * gyl * dx1 +
+                             M1.p[fidx(M1, i, j + 1, k, 0)] * gyr * dx1 +
+                             M2.p[fidx(M2, i, j, k, 0)] * gzl * dx2 +
+                             M2.p[fidx(M2, i, j, k + 1, 0)] * gzr * dx2) / vol;
+    }
+    src[UEDEN] = SrEcorr;
+
+    const long cs = fidx(SRC, i, j, k, 0);
+    for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
+}
+
+__global__ void __launch_bounds__(256) k_saxpy(DFab D, DFab S, Box3 b, double a, int ncomp)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const long cd = fidx(D, i, j, k, 0), cs = fidx(S, i, j, k, 0);
+    for (int n = 0; n < ncomp; ++n) D.p[cd + D.sn * n] += a * S.p[cs + S.sn * n];
+}
+
+static Box3 make_box3(const int lo[3], const int hi[3], long& n)
+{
+    Box3 b;
+    n = 1;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
+    return b;
+}
+
+int launch_old_grav_source(const DFab& U, const DFab& SRC, const int lo[3], const int hi[3], const double grav[3],
+                           int type, double dt, hipStream_t stream, Profiler* prof)
+{
+    long n; Box3 b = make_box3(lo, hi, n);
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_old_grav_source", stream);
+    hipLaunchKernelGGL(k_old_grav_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, SRC, b,
+                       grav[0], grav[1], grav[2], type, dt);
+    prof_end(prof, stream);
+    return 0;
+}
+
+int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
+                           const double grav[3], int type, double dt, const double dx[3], hipStream_t stream, Profiler* prof)
+{
+    long n; Box3 b = make_box3(lo, hi, n);
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_new_grav_source", stream);
+    hipLaunchKernelGGL(k_new_grav_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, UO, UN, SRC, M[0], M[1], M[2], b,
+                       grav[0], grav[1], grav[2], type, dt, dx[0], dx[1], dx[2]);
+    prof_end(prof, stream);
+    return 0;
+}
+
+int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
+                 hipStream_t stream, Profiler* prof)
+{
+    long n; Box3 b = make_box3(lo, hi, n);
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_saxpy", stream);
+    hipLaunchKernelGGL(k_saxpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, D, S, b, a, ncomp);
+    prof_end(prof, stream);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // derived plotfile fields (Source/driver/Derive.cpp); ids = CASTRO_AMD_DER_*
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_derive(DFab U, DFab D, int dcomp, Box3 b, int which, DevParams P,

@@ -354,6 +354,48 @@ int castro_amd_estdt_fab(castro_amd_ctx* c, const castro_amd_fab* state, const i
     return launch_estdt(to_dfab(state), lo, hi, to_devgeom(geom), to_devparams(params), d_out, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_old_gravity_source_fab(castro_amd_ctx* c, const castro_amd_fab* state, const castro_amd_fab* source,
+                                      const int lo[3], const int hi[3], const double grav[3], int grav_source_type,
+                                      double dt, void* stream)
+{
+    if (!c || !state || !state->p || !source || !source->p || !grav) return CASTRO_AMD_ERR_ARG;
+    if (state->ncomp != NUM_STATE || source->ncomp < 7 || grav_source_type < 1 || grav_source_type > 4) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state, lo, hi) || !fab_contains(source, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_old_grav_source(to_dfab(state), to_dfab(source), lo, hi, grav, grav_source_type, dt, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_new_gravity_source_fab(castro_amd_ctx* c, const castro_amd_fab* state_old, const castro_amd_fab* state_new,
+                                      const castro_amd_fab* source, const castro_amd_fab mass_fluxes[3],
+                                      const int lo[3], const int hi[3], const double grav[3], int grav_source_type,
+                                      double dt, const castro_amd_geom* geom, void* stream)
+{
+    if (!c || !state_old || !state_old->p || !state_new || !state_new->p || !source || !source->p || !mass_fluxes || !grav || !geom)
+        return CASTRO_AMD_ERR_ARG;
+    if (state_old->ncomp != NUM_STATE || state_new->ncomp != NUM_STATE || source->ncomp < 7) return CASTRO_AMD_ERR_ARG;
+    if (grav_source_type < 1 || grav_source_type > 4 || geom->coord != 0) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state_old, lo, hi) || !fab_contains(state_new, lo, hi) || !fab_contains(source, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    DFab M[3];
+    for (int d = 0; d < 3; ++d) {
+        int fhi[3] = { hi[0], hi[1], hi[2] };
+        fhi[d] += 1;
+        if (!mass_fluxes[d].p || mass_fluxes[d].ncomp != 1 || !fab_contains(&mass_fluxes[d], lo, fhi)) return CASTRO_AMD_ERR_ARG;
+        M[d] = to_dfab(&mass_fluxes[d]);
+    }
+    hipSetDevice(c->device);
+    return launch_new_grav_source(to_dfab(state_old), to_dfab(state_new), to_dfab(source), M, lo, hi, grav, grav_source_type,
+                                  dt, geom->dx, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_saxpy_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a, const castro_amd_fab* src, int ncomp,
+                         const int lo[3], const int hi[3], void* stream)
+{
+    if (!c || !dst || !dst->p || !src || !src->p || ncomp < 1 || ncomp > dst->ncomp || ncomp > src->ncomp) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(dst, lo, hi) || !fab_contains(src, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_saxpy(to_dfab(dst), to_dfab(src), lo, hi, a, ncomp, (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_derive_fab(castro_amd_ctx* c, int which, const castro_amd_fab* state, const castro_amd_fab* der, int dcomp,
                           const int lo[3], const int hi[3], const castro_amd_geom* geom, const castro_amd_params* params,
                           const double center[3], void* stream)

@@ -69,6 +69,12 @@ int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], c
                               int ntimes, double* d_out, hipStream_t stream, Profiler* prof);
 int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
                  double* d_out, hipStream_t stream, Profiler* prof);
+int launch_old_grav_source(const DFab& U, const DFab& SRC, const int lo[3], const int hi[3], const double grav[3],
+                           int type, double dt, hipStream_t stream, Profiler* prof);
+int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
+                           const double grav[3], int type, double dt, const double dx[3], hipStream_t stream, Profiler* prof);
+int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
+                 hipStream_t stream, Profiler* prof);
 int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int lo[3], const int hi[3],
                   const double dx[3], const double problo[3], const DevParams& P, const double center[3],
                   hipStream_t stream, Profiler* prof);

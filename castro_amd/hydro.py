@@ -98,6 +98,30 @@ class HipHydro:
             fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt), flags, _stream_ptr(stream))
         L.check(rc, "ctu_hydro_fab")
 
+    # ---- gravity source terms (Source/gravity/Castro_gravity.cpp) and apply_source_to_state ----------
+    def old_gravity_source(self, state, box, source, src_box, lo, hi, grav, grav_source_type, dt, stream=None):
+        g = (C.c_double * 3)(*[float(x) for x in grav])
+        L.check(self.lib.castro_amd_old_gravity_source_fab(self.h, C.byref(L.fab_of(state, *box)), C.byref(L.fab_of(source, *src_box)),
+                                                           L.i3(lo), L.i3(hi), C.byref(g), int(grav_source_type), float(dt),
+                                                           _stream_ptr(stream)), "old_gravity_source_fab")
+
+    def new_gravity_source(self, state_old, old_box, state_new, new_box, source, src_box, mass_fluxes, flux_boxes, lo, hi,
+                           grav, grav_source_type, dt, geom, stream=None):
+        g = (C.c_double * 3)(*[float(x) for x in grav])
+        mb = (L.Fab * 3)()
+        for d in range(3):
+            mb[d] = L.fab_of(mass_fluxes[d], *flux_boxes[d])
+        L.check(self.lib.castro_amd_new_gravity_source_fab(self.h, C.byref(L.fab_of(state_old, *old_box)),
+                                                           C.byref(L.fab_of(state_new, *new_box)),
+                                                           C.byref(L.fab_of(source, *src_box)), mb, L.i3(lo), L.i3(hi), C.byref(g),
+                                                           int(grav_source_type), float(dt), C.byref(geom), _stream_ptr(stream)),
+                "new_gravity_source_fab")
+
+    def saxpy(self, dst, dst_box, a, src, src_box, ncomp, lo, hi, stream=None):
+        """dst[:ncomp] += a * src[:ncomp] on [lo,hi] (Castro::apply_source_to_state)."""
+        L.check(self.lib.castro_amd_saxpy_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(src, *src_box)),
+                                              int(ncomp), L.i3(lo), L.i3(hi), _stream_ptr(stream)), "saxpy_fab")
+
     # ---- derived plotfile fields (Source/driver/Derive.cpp) ---------------------------------
     def derive(self, name, state, box, der, der_box, dcomp, lo, hi, geom, params, center, stream=None):
         ctr = (C.c_double * 3)(*[float(x) for x in center])

@@ -191,6 +191,22 @@ int castro_amd_clean_state_reduce_fab(castro_amd_ctx *ctx, const castro_amd_fab 
                                       const int lo[3], const int hi[3], const castro_amd_geom *geom,
                                       const castro_amd_params *params, int ntimes, double *d_out, void *stream);
 
+/* Gravity source terms for gravity.gravity_type = "ConstantGrav" (grav[] is the same in every zone,
+ * Source/gravity/Gravity.cpp:860-866), castro.grav_source_type 1..4 (default 4):
+ *   castro_amd_old_gravity_source_fab  Castro::construct_old_gravity_source, Source/gravity/Castro_gravity.cpp:234-362
+ *   castro_amd_new_gravity_source_fab  Castro::construct_new_gravity_source, :384-596 (needs mass_fluxes[d] of the hydro call)
+ *   castro_amd_saxpy_fab               Castro::apply_source_to_state (MultiFab::Saxpy), Source/sources/Castro_sources.cpp:10-19
+ * `source` has NSRC = 7 components and is accumulated into (+=), as in the reference. */
+int castro_amd_old_gravity_source_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, const castro_amd_fab *source,
+                                      const int lo[3], const int hi[3], const double grav[3], int grav_source_type,
+                                      double dt, void *stream);
+int castro_amd_new_gravity_source_fab(castro_amd_ctx *ctx, const castro_amd_fab *state_old, const castro_amd_fab *state_new,
+                                      const castro_amd_fab *source, const castro_amd_fab mass_fluxes[3],
+                                      const int lo[3], const int hi[3], const double grav[3], int grav_source_type,
+                                      double dt, const castro_amd_geom *geom, void *stream);
+int castro_amd_saxpy_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double a, const castro_amd_fab *src, int ncomp,
+                         const int lo[3], const int hi[3], void *stream);
+
 /* Derived plotfile fields (Source/driver/Derive.cpp, registered in Castro_setup.cpp:756-960) for the
  * 3-D Cartesian gamma-law build.  Not provided: entropy (needs the Microphysics entropy formula),
  * StateErr, circvel, angular_momentum_{x,y,z}. */

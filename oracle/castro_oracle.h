@@ -98,6 +98,13 @@ ora_a4 ora_make_a4(double *p, const int lo[3], const int hi[3], int nc);
 /* ---------------- EOS (Microphysics gamma_law restated) -------- */
 typedef struct { double rho, T, e, p, gam1, cs, dpde, dpdr_e; } ora_eos_t;
 void ora_eos_re(const ora_params *P, ora_eos_t *s);
+/* constant-gravity source terms (Source/gravity/Castro_gravity.cpp:234-614) and Saxpy */
+void ora_old_gravity_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a4 source, const double grav[3],
+                            int grav_source_type, double dt);
+void ora_new_gravity_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a4 unew, ora_a4 source,
+                            const ora_a4 mflux[3], const double grav[3], int grav_source_type, double dt,
+                            const double dx[3]);
+void ora_saxpy(const int lo[3], const int hi[3], ora_a4 dst, double a, ora_a4 src, int ncomp);
 /* Source/driver/Derive.cpp; `which` uses the CASTRO_AMD_DER_* numbering */
 int ora_derive(int which, const int lo[3], const int hi[3], ora_a4 dat, ora_a4 der, const ora_geom *G,
                const ora_params *P, const double center[3]);
@@ -190,6 +197,8 @@ int  ora_level_advance_retry(ora_level *L, double time, double dt, double retry_
 int  ora_level_nsubcycles(ora_level *L);
 int  ora_level_nretries(ora_level *L);
 double *ora_level_old_state(ora_level *L);
+/* castro.do_grav with gravity.gravity_type = ConstantGrav: sources in do_advance_ctu (Castro_advance_ctu.cpp:113-143,256-274) */
+void ora_level_set_gravity(ora_level *L, int do_grav, double const_grav, int grav_source_type);
 double ora_level_last_hydro_seconds(ora_level *L);
 
 #ifdef __cplusplus

@@ -27,6 +27,9 @@ struct ora_level {
     double hydro_seconds;
     double *prev_old;       /* prev_state old data kept across a retry (Castro_advance_ctu.cpp:430-451) */
     int nsubcycles, nretries;
+    int do_grav, grav_source_type;   /* castro.do_grav, castro.grav_source_type; gravity.const_grav along z */
+    double grav[3];
+    double *old_source, *new_source; /* Source_Type old (NUM_GROW_SRC ghosts) / new data */
 };
 
 static double now_s(void)
@@ -68,7 +71,7 @@ ora_level *ora_level_create(const int n[3], const ora_geom *G, const ora_params 
 void ora_level_destroy(ora_level *L)
 {
     if (!L) return;
-    free(L->S_new); free(L->S_old); free(L->Sborder); free(L->prev_old);
+    free(L->S_new); free(L->S_old); free(L->Sborder); free(L->prev_old); free(L->old_source); free(L->new_source);
     for (int d = 0; d < 3; ++d) { free(L->fluxes[d]); free(L->mass_fluxes[d]); }
     free(L);
 }
@@ -166,10 +169,32 @@ static int level_do_advance(ora_level *L, double time, double dt)
     /* MultiFab::Copy(S_new, Sborder) (Castro_advance_ctu.cpp:94) */
     ora_fill_interior_copy(S_new, Sb, L->lo, L->hi);
 
+    /* old-time sources (:113-143): do_old_sources = construct, apply to S_new with full dt, clean_state;
+     * then FillPatch the ghost zones of old_source for the tracing */
+    ora_a4 src; memset(&src, 0, sizeof(src));
+    ora_a4 osrc, nsrc;
+    int slo[3], shi[3];
+    if (L->do_grav) {
+        size_t ns = 1, nv1 = 1;
+        for (int d = 0; d < 3; ++d) {
+            slo[d] = L->lo[d] - NUM_GROW_SRC; shi[d] = L->hi[d] + NUM_GROW_SRC;
+            ns *= (size_t)(L->n[d] + 2 * NUM_GROW_SRC); nv1 *= (size_t)L->n[d];
+        }
+        if (!L->old_source) L->old_source = (double *)malloc(sizeof(double) * ns * NSRC);
+        if (!L->new_source) L->new_source = (double *)malloc(sizeof(double) * nv1 * NSRC);
+        memset(L->old_source, 0, sizeof(double) * ns * NSRC);
+        osrc = ora_make_a4(L->old_source, slo, shi, NSRC);
+        nsrc = ora_make_a4(L->new_source, L->lo, L->hi, NSRC);
+        ora_old_gravity_source(L->lo, L->hi, Sb, osrc, L->grav, L->grav_source_type, dt);
+        ora_saxpy(L->lo, L->hi, S_new, dt, osrc, NSRC);
+        ora_clean_state(L->lo, L->hi, S_new, P);
+        ora_bc_fill(osrc, &L->G);
+        src = osrc;
+    }
+
     /* construct_ctu_hydro_source (:156) */
-    ora_a4 nosrc; memset(&nosrc, 0, sizeof(nosrc));
     double t0 = now_s();
-    int bad = ora_construct_ctu_hydro_source(L->lo, L->hi, Sb, nosrc, S_new, fl, mf, qe, &L->G, P,
+    int bad = ora_construct_ctu_hydro_source(L->lo, L->hi, Sb, src, S_new, fl, mf, qe, &L->G, P,
                                              time, dt, L->tile, L->nthreads);
     L->hydro_seconds = now_s() - t0;
     (void)bad;
@@ -179,6 +204,14 @@ static int level_do_advance(ora_level *L, double time, double dt)
 
     /* clean_state(S_new) (:221-225) */
     ora_clean_state(L->lo, L->hi, S_new, P);
+
+    /* new-time sources (:256-274): do_new_sources = construct the corrector, apply, clean_state */
+    if (L->do_grav) {
+        memset(L->new_source, 0, sizeof(double) * (size_t)nsrc.sn * NSRC);
+        ora_new_gravity_source(L->lo, L->hi, Sb, S_new, nsrc, mf, L->grav, L->grav_source_type, dt, L->G.dx);
+        ora_saxpy(L->lo, L->hi, S_new, dt, nsrc, NSRC);
+        ora_clean_state(L->lo, L->hi, S_new, P);
+    }
 
     /* timestep validity check (:386-392) */
     double new_dt = ora_level_est_time_step(L);
@@ -248,6 +281,12 @@ int ora_level_advance_retry(ora_level *L, double time, double dt, double retry_s
     }
     L->nsubcycles = sub_iteration;
     return 0;
+}
+
+void ora_level_set_gravity(ora_level *L, int do_grav, double const_grav, int grav_source_type)
+{
+    L->do_grav = do_grav; L->grav_source_type = grav_source_type;
+    L->grav[0] = 0.0; L->grav[1] = 0.0; L->grav[2] = const_grav;     /* Gravity.cpp:860-866 */
 }
 
 int ora_level_nsubcycles(ora_level *L) { return L->nsubcycles; }

@@ -112,6 +112,11 @@ def lib():
         L.ora_level_advance.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.ora_level_advance_retry.restype = C.c_int
         L.ora_level_advance_retry.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+        L.ora_level_set_gravity.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+        L.ora_saxpy.argtypes = [I3, I3, A4, C.c_double, A4, C.c_int]
+        L.ora_old_gravity_source.argtypes = [I3, I3, A4, A4, C.POINTER(C.c_double * 3), C.c_int, C.c_double]
+        L.ora_new_gravity_source.argtypes = [I3, I3, A4, A4, A4, A4 * 3, C.POINTER(C.c_double * 3), C.c_int, C.c_double,
+                                             C.POINTER(C.c_double * 3)]
         L.ora_level_nsubcycles.argtypes = [C.c_void_p]
         L.ora_level_nretries.argtypes = [C.c_void_p]
         L.ora_level_old_state.restype = C.POINTER(C.c_double)
@@ -245,6 +250,10 @@ class Level:
         p = lib().ora_level_state(self.h)
         nx, ny, nz = self.n
         return np.ctypeslib.as_array(p, shape=(NUM_STATE, nz, ny, nx))
+
+    def set_gravity(self, const_grav, grav_source_type=4):
+        """castro.do_grav = 1, gravity.gravity_type = ConstantGrav, gravity.const_grav (along z)."""
+        lib().ora_level_set_gravity(self.h, 1, float(const_grav), int(grav_source_type))
 
     def old_state(self):
         p = lib().ora_level_old_state(self.h)

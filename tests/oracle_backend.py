@@ -56,11 +56,30 @@ class OracleBackend:
                         arr[self._slices(flux_boxes[d] if flux_boxes is not None else bx, bx[0], hi)] = 0.0
         if update_from_sborder:
             L.ora_fill_interior_copy(sn, sb, O.i3(bx[0]), O.i3(bx[1]))
-        st = L.ora_ctu_hydro_tile(O.i3(bx[0]), O.i3(bx[1]), O.i3(vlo), O.i3(vhi), sb, O.a4(None, bx[0], bx[1]), sn,
+        sa = self._a4(src, src_box) if src is not None else O.a4(None, bx[0], bx[1])
+        st = L.ora_ctu_hydro_tile(O.i3(bx[0]), O.i3(bx[1]), O.i3(vlo), O.i3(vhi), sb, sa, sn,
                                   fa, ma, qa, C.byref(geom), C.byref(params), float(dt))
         assert st == 0
         if clean_ntimes > 0:      # castro_amd_ctu_hydro_clean_fab == the update followed by the separate pass
             self.clean_state_reduce(S_new, snew_box, bx[0], bx[1], geom, params, red, ntimes=clean_ntimes)
+
+    def old_gravity_source(self, state, box, source, src_box, lo, hi, grav, grav_source_type, dt, stream=None):
+        g = (C.c_double * 3)(*[float(x) for x in grav])
+        O.lib().ora_old_gravity_source(O.i3(lo), O.i3(hi), self._a4(state, box), self._a4(source, src_box), C.byref(g),
+                                       int(grav_source_type), float(dt))
+
+    def new_gravity_source(self, state_old, old_box, state_new, new_box, source, src_box, mass_fluxes, flux_boxes, lo, hi,
+                           grav, grav_source_type, dt, geom, stream=None):
+        g = (C.c_double * 3)(*[float(x) for x in grav])
+        dx = (C.c_double * 3)(*[geom.dx[d] for d in range(3)])
+        mf = (O.A4 * 3)()
+        for d in range(3):
+            mf[d] = self._a4(mass_fluxes[d], flux_boxes[d])
+        O.lib().ora_new_gravity_source(O.i3(lo), O.i3(hi), self._a4(state_old, old_box), self._a4(state_new, new_box),
+                                       self._a4(source, src_box), mf, C.byref(g), int(grav_source_type), float(dt), C.byref(dx))
+
+    def saxpy(self, dst, dst_box, a, src, src_box, ncomp, lo, hi, stream=None):
+        O.lib().ora_saxpy(O.i3(lo), O.i3(hi), self._a4(dst, dst_box), float(a), self._a4(src, src_box), int(ncomp))
 
     def derive(self, name, state, box, der, der_box, dcomp, lo, hi, geom, params, center, stream=None):
         from castro_amd._lib import DERIVE_IDS

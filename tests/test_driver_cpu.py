@@ -186,3 +186,85 @@ def test_retry_and_subcycling_match_the_oracle_driver(oracle):
         for _ in range(12):
             c.step(0.05)
     assert "density" in c.last_failure
+
+
+def _hse_atmosphere(n, H=0.25, g=-1.0, gamma=1.4):
+    """isothermal atmosphere in hydrostatic equilibrium along z: rho = exp(-z/H), p = rho * (-g H)"""
+    z = (np.arange(n[2]) + 0.5) / n[2]
+    rho = np.exp(-z / H)[:, None, None] * np.ones((n[2], n[1], n[0]))
+    S = np.zeros((8,) + rho.shape)
+    S[0] = rho
+    S[4] = S[5] = rho * (-g * H) / (gamma - 1.0)
+    S[6] = 1.0
+    S[7] = rho
+    return S
+
+
+@pytest.mark.parametrize("pkw,gtype", [(dict(ppm_type=1), 4), (dict(ppm_type=0), 4), (dict(ppm_type=1), 2), (dict(ppm_type=1), 3)])
+def test_constant_gravity_sources_match_the_oracle_driver(oracle, pkw, gtype):
+    """castro.do_grav with ConstantGrav: old source -> traced in the predictor -> hydro -> new-time corrector
+    (Castro_advance_ctu.cpp:113-143,256-274; Castro_gravity.cpp:234-614): driver == oracle level driver, bitwise;
+    the atmosphere stays close to rest, and PLM with the well-balanced pressure slope does so 50x better."""
+    import castro_amd
+    n = (4, 4, 32)
+    bc = dict(lo_bc=(4, 4, 3), hi_bc=(4, 4, 3))
+    geo = dict(prob_hi=(0.125, 0.125, 1.0))
+    c = castro_amd.Castro(n, params=oracle.default_params(**pkw), hydro=OracleBackend(), do_grav=True, const_grav=-1.0,
+                          grav_source_type=gtype, **bc, **geo)
+    c.set_state(_hse_atmosphere(n))
+    lev = oracle.Level(n, oracle.make_geom(n, probhi=geo["prob_hi"], **bc), oracle.default_params(**pkw), nthreads=4)
+    lev.set_gravity(-1.0, gtype)
+    lev.state()[...] = _hse_atmosphere(n)
+    oracle.lib().ora_level_post_init(lev.h)
+    for _ in range(12):
+        c.step(1.0)
+        lev.step(1.0)
+        assert c.dt == lev.dt
+    assert np.array_equal(c.S_new().numpy(), lev.state())
+    S = lev.state()
+    mach = np.abs(S[3] / S[0]).max() / np.sqrt(1.4 * 0.25)
+    assert mach < (3e-4 if pkw["ppm_type"] == 0 else 3e-2)
+    assert np.abs(S[1]).max() == 0.0 and np.abs(S[2]).max() == 0.0
+    lev.close()
+
+
+def _grav_worker(rank, world, port, n, nsteps, out_path):
+    import torch.distributed as dist
+    import castro_amd
+    from oracle import oracle_lib as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = castro_amd.Castro(n, params=O.default_params(), hydro=OracleBackend(), comm=castro_amd.DistComm(),
+                              do_grav=True, const_grav=-1.0, lo_bc=(0, 4, 3), hi_bc=(0, 4, 3), prob_hi=(0.25, 0.25, 1.0))
+        c.set_state(_hse_atmosphere(n))
+        for _ in range(nsteps):
+            c.step(1.0)
+        mine = c.S_new().contiguous()
+        parts = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        boxes = c.comm.gather_objects((c.lo, c.hi))
+        if rank == 0:
+            full = np.zeros((8, n[2], n[1], n[0]))
+            for p, (lo, hi) in zip(parts, boxes):
+                full[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = p.numpy()
+            np.save(out_path, full)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gravity_run_on_two_ranks_is_bitwise_identical_gloo(tmp_path, oracle):
+    """The Source_Type FillPatch (3 ghost layers, 7 components) goes through the same halo exchange as the state:
+    two ranks split along z (the direction of gravity), periodic in x, give the single-rank bits."""
+    import castro_amd
+    n, nsteps = (8, 8, 32), 5
+    out = str(tmp_path / "grav.npy")
+    mp.spawn(_grav_worker, args=(2, _free_port(), n, nsteps, out), nprocs=2, join=True)
+    c = castro_amd.Castro(n, params=oracle.default_params(), hydro=OracleBackend(), do_grav=True, const_grav=-1.0,
+                          lo_bc=(0, 4, 3), hi_bc=(0, 4, 3), prob_hi=(0.25, 0.25, 1.0))
+    c.set_state(_hse_atmosphere(n))
+    for _ in range(nsteps):
+        c.step(1.0)
+    assert np.array_equal(np.load(out), c.S_new().numpy())
