@@ -115,8 +115,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--periodic", action="store_true", help="periodic instead of outflow boundaries (exercises the halo "
                     "pack/exchange/unpack path even on one GPU)")
-    ap.add_argument("--force-overlap", action="store_true", help="interior + 6 shell tiles with the halo exchange on the "
-                    "communication stream, as every rank of a multi-GPU run does")
+    ap.add_argument("--force-overlap", action="store_true", help="staged overlap (ghost-free part of the update while the halo "
+                    "exchange runs on the communication stream), as every rank of a multi-GPU run does")
+    ap.add_argument("--overlap-tiles", action="store_true", help="the older interior tile + 6 boundary slabs form of the overlap")
     ap.add_argument("--reference-contract", action="store_true",
                     help="zero-fill + accumulate fluxes and run clean_state/estdt as separate passes (600 B/cell form)")
     args = ap.parse_args()
@@ -148,7 +149,8 @@ def main():
     contract = args.reference_contract
     bc = (0, 0, 0) if args.periodic else (2, 2, 2)
     c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc,
-                          overlap=(False if args.no_overlap else (True if args.force_overlap else None)),
+                          overlap=(False if args.no_overlap else ("tiles" if args.overlap_tiles else
+                                                                  (True if args.force_overlap else None))),
                           fuse_clean=not contract, flux_assign=not contract)
     PATH_BYTES_PER_CELL = PATH_BYTES_CONTRACT if contract else PATH_BYTES_ASSIGN
     c.initData("sedov")                      # synthetic input, generated on the device
@@ -209,7 +211,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Sedov 3D %dx%dx%d single level, gamma-law EOS, PPM + CGF Riemann, CTU" % n_cell,
                    "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": c.n[0] * c.n[1] * c.n[2],
-                   "overlap_halo": bool(c.overlap), "sim_time": c.time, "nstep": c.nstep,
+                   "overlap_halo": ("tiles" if c.overlap == "tiles" else bool(c.overlap and c._comm_stream is not None and c.neighbors)), "sim_time": c.time, "nstep": c.nstep,
                    "flux_mode": "accumulate (600 B/cell contract)" if contract else "assign (344 B/cell, declared)",
                    "fused_clean_state": not contract},
         "roofline": roof,

@@ -14,7 +14,7 @@ NUM_STATE, NGDNV, NUM_GROW = 8, 4, 4
 URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
-UPDATE_ADD, UPDATE_FROM_SBORDER, FLUX_ASSIGN = 0, 1, 2
+UPDATE_ADD, UPDATE_FROM_SBORDER, FLUX_ASSIGN, STAGE_A, STAGE_B = 0, 1, 2, 4, 8
 # CASTRO_AMD_DER_* ids, in the order the reference registers the fields (Castro_setup.cpp:756-960)
 DERIVE_IDS = {"pressure": 0, "kineng": 1, "soundspeed": 2, "Gamma_1": 3, "MachNumber": 4, "magvort": 5, "divu": 6,
               "eint_E": 7, "eint_e": 8, "logden": 9, "X(X)": 10, "abar": 11, "x_velocity": 12, "y_velocity": 13,

@@ -148,10 +148,16 @@ class Castro:
         self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)   # [min dt, min rho]
 
         self.neighbors = self._build_neighbors()
-        # Overlapping the halo exchange with an interior tile costs more than it hides on MI355X: the six
-        # 4-zone boundary slabs re-do ctoprim/trace on 3x their volume (+18 % at 256^3, +44 % at 128^3 per
-        # rank, tools/overlap_cost.sh) while the exchange itself is ~1-3 % of a step.  Off by default.
-        self.overlap = False if overlap is None else bool(overlap)
+        # Overlap of the halo exchange with compute: "staged" (True) runs ctoprim on the valid zones and the PPM
+        # tracing of the zones >= 3 from the box faces while the exchange is in flight, then the rest -- no
+        # redundant work.  The older interior-tile + six-slab split ("tiles") re-does ctoprim/trace on 3x the
+        # slab volume (+18 % at 256^3, +44 % at 128^3 per rank, tools/overlap_cost.sh).
+        # Measured on one GPU with periodic self-neighbours (tools/overlap_cost.sh): the staged form costs +4 % at
+        # 256^3 per rank and +16 % at 128^3 (about twenty extra small launches), the exchange itself 1-5 % of a
+        # step; so by default it is used only for boxes of at least 192 zones a side.
+        if overlap is None:
+            overlap = self.comm.size > 1 and min(self.n) >= 192
+        self.overlap = overlap                                                   # True | "tiles" | False
         self.fuse_clean = bool(fuse_clean)
         # one hydro call per step: "zero fluxes, then +=" (Castro_advance.cpp:391-394) is an assignment
         self.flux_assign = bool(flux_assign)
@@ -309,7 +315,7 @@ class Castro:
         return dt_0
 
     # ---- Castro::construct_ctu_hydro_source over this rank's box ------------------------------
-    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None):
+    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None, stage=None):
         """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
         and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
         self.red, which the caller has initialised."""
@@ -320,7 +326,7 @@ class Castro:
                                          mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=src is None,
                                          src=src, src_box=self.sbox if src is not None else None,
                                          clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None,
-                                         flux_assign=self.flux_assign and self._flux_clear)
+                                         flux_assign=self.flux_assign and self._flux_clear, stage=stage)
 
     def _shell_tiles(self):
         """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
@@ -361,7 +367,8 @@ class Castro:
             return self._do_advance_with_sources(time, dt, S)
 
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
-        if use_overlap:
+        if use_overlap and self.overlap == "tiles":
+            # interior tile + six boundary slabs (measured slower than the staged form, kept for comparison)
             interior, shells = self._shell_tiles()
             cur = torch.cuda.current_stream()
             self._comm_stream.wait_stream(cur)
@@ -371,6 +378,16 @@ class Castro:
                 self.construct_ctu_hydro_source(time, dt, tiles=[interior], fuse_clean=fuse)   # overlapped: needs no ghost data
             cur.wait_stream(self._comm_stream)
             self.construct_ctu_hydro_source(time, dt, tiles=shells, fuse_clean=fuse)
+        elif use_overlap:
+            # halo exchange + BC fill on the communication stream while the compute stream runs the part of the
+            # update that reads no ghost zone (ctoprim on the valid zones, PPM tracing 3 zones inside the box)
+            cur = torch.cuda.current_stream()
+            self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                self.expand_state(S)
+            self.construct_ctu_hydro_source(time, dt, stage="A")
+            cur.wait_stream(self._comm_stream)
+            self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, stage="B")
         else:
             self.expand_state(S)
             self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse)

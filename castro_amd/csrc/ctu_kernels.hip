@@ -119,10 +119,19 @@ __device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int&
 // ---------------------------------------------------------------------------------------
 // Castro::ctoprim (Source/hydro/advection_util.cpp:26-200) with the gamma-law EOS inlined
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status)
+// zones inside [lo,hi] are left to another launch (staged execution, see launch_ctu_hydro); empty = none
+struct SkipBox { int lo[3], hi[3]; };
+__device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
+{
+    return i >= s.lo[0] && i <= s.hi[0] && j >= s.lo[1] && j <= s.hi[1] && k >= s.lo[2] && k <= s.hi[2];
+}
+
+__global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
+                                                 SkipBox skip)
 {
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
+    if (in_skip(skip, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const unsigned cu = foff(U, i, j, k);
     const long NC = t.NC;
@@ -1214,13 +1223,21 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 //   F2 slot (N|T): flux in direction N from states corrected with the T-direction flux.
 // (Castro_ctu_hydro.cpp:724-945 for the corrections, :949-1135 for the six solves)
 // ---------------------------------------------------------------------------------------
+template <bool XRIEM>
 __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                    double dt, DevParams P)
+                                                    double dt, DevParams P, SkipBox skip)
 {
     int i, j, k;
-    const bool valid = box_thread(b, i, j, k);     // no early exit: the block synchronises below
+    bool valid = box_thread(b, i, j, k);           // no early exit when XRIEM: the block synchronises below
     if (!valid) { i = b.lo[0]; j = b.lo[1]; k = b.lo[2]; }
-    const bool v1 = valid && i + 1 <= b.hi0;
+    bool v1 = valid && i + 1 <= b.hi0;
+    if (!XRIEM) {
+        // staged execution: zones of the skip box belong to the other launch
+        const bool s0 = in_skip(skip, i, j, k), s1 = in_skip(skip, i + 1, j, k);
+        if ((!valid || s0) && (!v1 || s1)) return;
+        if (s1) v1 = false;
+        if (s0) valid = false;
+    }
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const long NC = t.NC;
@@ -1264,6 +1281,7 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
     dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
     trace_pair_dir<0>(t, Q, c, s.x, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm);
 
+    if (XRIEM)
     // ---- first Riemann solve in x (Castro_ctu_hydro.cpp:719) on the two faces of this thread:
     //      face i+1 lies between its two zones; face i needs the minus state of the zone to the left, which
     //      the neighbouring lane (or, across a wavefront boundary, LDS) hands over.  The first thread of a
@@ -1283,7 +1301,8 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
 #pragma unroll
             for (int n = 0; n < NEDGE; ++n) qmL[n] = xch[wave - 1][n];
         }
-        const bool mA = valid && i >= t.lo[0] && threadIdx.x > 0;     // face i   (plus state: zone i)
+        // face i (plus state: zone i): the left neighbour must be a thread of this row and of this workgroup
+        const bool mA = valid && i >= t.lo[0] && i > b.lo[0] && threadIdx.x > 0;
         const bool mB = v1;                                            // face i+1 (needed: i+1 >= lo always)
         if (mA || mB) {
             const double* Cp = Q + PC * NC;
@@ -1302,11 +1321,9 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
         }
     }
 
-    dp[0] = valid && j >= t.lo[1]; dp[1] = v1 && dp[0];
-    dm[0] = valid && j <= t.hi[1]; dm[1] = v1 && dm[0];
+    { const bool a = j >= t.lo[1], z = j <= t.hi[1]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z; }
     trace_pair_dir<1>(t, Q, c, s.y, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm);
-    dp[0] = valid && k >= t.lo[2]; dp[1] = v1 && dp[0];
-    dm[0] = valid && k <= t.hi[2]; dm[1] = v1 && dm[0];
+    { const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z; }
     trace_pair_dir<2>(t, Q, c, s.z, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm);
 }
 
@@ -1318,7 +1335,7 @@ __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, c
     if (blk >= b.nb) return;
     int i, j, k;
     if (!box_thread_at(b, blk, 0u, i, j, k)) return;
-    if (i < t.lo[0]) return;
+    if (i < t.lo[0] || i == b.lo[0]) return;      // row starts are the caller's business (launch-box faces)
     const unsigned c = goff(t, i, j, k);
     RState ql, qr;
     double Xl, Xr;
@@ -1637,19 +1654,78 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         }                                                                                    \
     } while (0)
 
+// outer box minus inner box as up to six slabs: z slabs over the full x,y extent, y slabs over the inner z range,
+// x slabs over the inner y,z range (thin in x: a wavefront then covers many rows, no idle lanes)
+static int shell_boxes(const int olo[3], const int ohi[3], const int ilo[3], const int ihi[3], int lo[6][3], int hi[6][3])
+{
+    int n = 0;
+    auto add = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
+        if (x0 > x1 || y0 > y1 || z0 > z1) return;
+        lo[n][0] = x0; hi[n][0] = x1; lo[n][1] = y0; hi[n][1] = y1; lo[n][2] = z0; hi[n][2] = z1; ++n;
+    };
+    add(olo[0], ohi[0], olo[1], ohi[1], olo[2], ilo[2] - 1);
+    add(olo[0], ohi[0], olo[1], ohi[1], ihi[2] + 1, ohi[2]);
+    add(olo[0], ohi[0], olo[1], ilo[1] - 1, ilo[2], ihi[2]);
+    add(olo[0], ohi[0], ihi[1] + 1, ohi[1], ilo[2], ihi[2]);
+    add(olo[0], ilo[0] - 1, ilo[1], ihi[1], ilo[2], ihi[2]);
+    add(ihi[0] + 1, ohi[0], ilo[1], ihi[1], ilo[2], ihi[2]);
+    return n;
+}
+
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
                      int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red)
 {
-    {
-        const int qhi[3] = { t.glo[0] + t.NX - 1, t.glo[1] + t.NY - 1, t.glo[2] + t.NZ - 1 };
-        KL("k_ctoprim", k_ctoprim, t.glo, qhi, Sborder, S.Q, P, d_status);
+    // Staged execution (CASTRO_AMD_STAGE_A / _B): A = what needs no ghost zone of Sborder -- ctoprim on the valid
+    // zones, PPM tracing on grow(bx, -3) -- so that a caller can run it while the halo exchange is in flight;
+    // B = the rest (ctoprim on the ghost shell, tracing on the remaining zones, everything downstream).
+    // Only the no-source PPM path is split; otherwise A is empty and B is the whole update.
+    const bool splittable = !Src.p && P.ppm_type == 1;
+    const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
+    const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
+    SkipBox valid_box, inner_box;
+    for (int d = 0; d < 3; ++d) {
+        valid_box.lo[d] = t.lo[d]; valid_box.hi[d] = t.hi[d];
+        inner_box.lo[d] = t.lo[d] + 3; inner_box.hi[d] = t.hi[d] - 3;
     }
+    const bool inner_ok = inner_box.lo[0] <= inner_box.hi[0] && inner_box.lo[1] <= inner_box.hi[1] && inner_box.lo[2] <= inner_box.hi[2];
 
     // boxes
     const int olo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
     const int ohi[3] = { t.hi[0] + 1, t.hi[1] + 1, t.hi[2] + 1 };
+    const int qhi[3] = { t.glo[0] + t.NX - 1, t.glo[1] + t.NY - 1, t.glo[2] + t.NZ - 1 };
+
+    // PPM tracing of the zones of [lo,hi] with the first x Riemann solve fused in, for the faces whose two zones the
+    // launch covers; the faces at the workgroup starts follow in a one-thread-per-workgroup launch, those on the
+    // x faces of the launch box (lo[0] and hi[0] + 1) are left to the caller.
+    auto trace_with_xriemann = [&](const int lo[3], const int hi[3]) {
+        KL2("k_trace", k_trace_pair<true>, lo, hi, S.Q, S, g, dt, P, none);
+        long n_;
+        LinBox b_ = linbox2(lo, hi, n_);
+        if (n_ > 0) {
+            prof_begin(prof, "k_riemann1", stream);
+            hipLaunchKernelGGL(k_riemann1_blockstart, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
+            prof_end(prof, stream);
+        }
+    };
+
+    if (stage_a) {
+        if (splittable) {
+            KL("k_ctoprim", k_ctoprim, t.lo, t.hi, Sborder, S.Q, P, d_status, none);
+            if (inner_ok) trace_with_xriemann(inner_box.lo, inner_box.hi);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    const bool second_half = stage_b && splittable;     // stage A has run on this tile
+    int slo[6][3], shi[6][3];
+    if (second_half) {
+        const int ns = shell_boxes(t.glo, qhi, t.lo, t.hi, slo, shi);
+        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim, slo[m], shi[m], Sborder, S.Q, P, d_status, none);
+    } else {
+        KL("k_ctoprim", k_ctoprim, t.glo, qhi, Sborder, S.Q, P, d_status, none);
+    }
+
     int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
     for (int d = 0; d < 3; ++d)
         for (int e = 0; e < 3; ++e) {
@@ -1669,17 +1745,25 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
-        else {
-            KL2("k_trace", k_trace_pair, olo, ohi, S.Q, S, g, dt, P);
-            // x-faces at the workgroup starts of that launch (one thread per workgroup)
-            long n_;
-            LinBox b_ = linbox2(olo, ohi, n_);
-            prof_begin(prof, "k_riemann1", stream);
-            hipLaunchKernelGGL(k_riemann1_blockstart, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
-            prof_end(prof, stream);
-            x_done = true;
+        else if (second_half) {
+            if (inner_ok) {
+                const int ns = shell_boxes(olo, ohi, inner_box.lo, inner_box.hi, slo, shi);
+                for (int m = 0; m < ns; ++m) trace_with_xriemann(slo[m], shi[m]);
+                // the x faces between the inner launch of stage A and the two x slabs
+                for (int side = 0; side < 2; ++side) {
+                    const int xf = side ? inner_box.hi[0] + 1 : inner_box.lo[0];
+                    const int plo[3] = { xf, inner_box.lo[1], inner_box.lo[2] }, phi[3] = { xf, inner_box.hi[1], inner_box.hi[2] };
+                    KL2("k_riemann1", k_riemann1<0>, plo, phi, S.Q, S, g, P);
+                }
+            } else {
+                trace_with_xriemann(olo, ohi);
+            }
+        } else {
+            trace_with_xriemann(olo, ohi);
         }
+        x_done = P.ppm_type != 0;
     }
+    (void)staged;
 
     if (!x_done) KL2("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
     KL2("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);

@@ -63,7 +63,7 @@ class HipHydro:
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
                                    update_from_sborder=False, src=None, src_box=None, stream=None,
-                                   clean_ntimes=0, red=None, flux_assign=False):
+                                   clean_ntimes=0, red=None, flux_assign=False, stage=None):
         """clean_ntimes > 0 selects castro_amd_ctu_hydro_clean_fab: the update is followed, in the same
         pass, by S_new.min(URHO), clean_state x clean_ntimes and the CFL estimate, reduced into `red`."""
         bxlo, bxhi = bx
@@ -84,6 +84,8 @@ class HipHydro:
         flags = L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD
         if flux_assign:
             flags |= L.FLUX_ASSIGN
+        if stage is not None:         # "A": the ghost-free part (overlaps the halo exchange); "B": the rest
+            flags |= {"A": L.STAGE_A, "B": L.STAGE_B}[stage]
         if clean_ntimes > 0:
             rc = self.lib.castro_amd_ctu_hydro_clean_fab(
                 self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),

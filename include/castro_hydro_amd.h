@@ -120,6 +120,9 @@ int castro_amd_ctx_status(castro_amd_ctx *ctx, void *stream);
 /* flags for castro_amd_ctu_hydro_fab */
 #define CASTRO_AMD_UPDATE_ADD 0      /* S_new += dt*div(F)...   (reference semantics: S_new holds a copy of Sborder) */
 #define CASTRO_AMD_UPDATE_FROM_SBORDER 1 /* S_new = Sborder + ... (elides MultiFab::Copy, Castro_advance_ctu.cpp:94) */
+#define CASTRO_AMD_STAGE_A 4             /* only the part that reads no ghost zone of Sborder (ctoprim on bx, tracing on
+                                          * grow(bx,-3)): may run while the halo exchange fills the ghost zones */
+#define CASTRO_AMD_STAGE_B 8             /* the rest, after CASTRO_AMD_STAGE_A on the same context, tile and arguments */
 #define CASTRO_AMD_FLUX_ASSIGN 2         /* flux_out[d] = 0 + dt*area*flux instead of +=: for callers that would zero
                                           * fluxes[d] just before this (one) hydro call of the step
                                           * (Castro_advance.cpp:391-394); elides that fill and the read of the RMW */

@@ -36,7 +36,9 @@ class OracleBackend:
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
                                    update_from_sborder=False, src=None, src_box=None, stream=None,
-                                   clean_ntimes=0, red=None, flux_assign=False):
+                                   clean_ntimes=0, red=None, flux_assign=False, stage=None):
+        if stage == "A":
+            return              # the oracle has no staged form: everything happens in stage B
         L = O.lib()
         vlo, vhi = vbx if vbx is not None else bx
         fa, ma, qa = (O.A4 * 3)(), (O.A4 * 3)(), (O.A4 * 3)()

@@ -558,3 +558,60 @@ def test_constant_gravity_on_the_device_matches_oracle(oracle, pkw, gtype):
     _assert_exact({"S_new": (c.S_new().cpu().numpy(), lev.state()),
                    "flux2": (c.fluxes[2].cpu().numpy(), lev.flux(2))}, "gravity %s type %d" % (pkw, gtype))
     lev.close()
+
+
+def test_staged_call_equals_one_call(hip, oracle):
+    """CASTRO_AMD_STAGE_A (ctoprim on the valid zones + tracing 3 zones inside the box, no ghost zone read) followed
+    by CASTRO_AMD_STAGE_B equals the single call -- also when the ghost zones only become valid between A and B."""
+    import torch
+    rng = np.random.default_rng(71)
+    bxlo, bxhi = (0, 0, 0), (17, 12, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (21, 16, 13)
+    U = physical_state(rng, sb_lo, sb_hi)
+    import castro_amd
+    n = [bxhi[d] - bxlo[d] + 1 for d in range(3)]
+    G = castro_amd.make_geom(n, prob_hi=[0.02 * x for x in n], domlo=bxlo)
+    P = castro_amd.default_params()
+    sl = (slice(None),) + tuple(slice(4, 4 + n[2 - a]) for a in range(3))
+    res = []
+    for staged in (False, True):
+        Ud = _to_dev(hip, U)
+        Sn = _to_dev(hip, U[sl])
+        fl = [hip.alloc(8, bxlo, [bxhi[e] + (1 if e == d else 0) for e in range(3)], fill=float("nan")) for d in range(3)]
+        fb = [(bxlo, tuple(bxhi[e] + (1 if e == d else 0) for e in range(3))) for d in range(3)]
+        kw = dict(fluxes=fl, flux_boxes=fb, vbx=(bxlo, bxhi), update_from_sborder=True, flux_assign=True)
+        if staged:
+            ghosts = Ud.clone()
+            Ud[:, :4] = float("nan"); Ud[:, -4:] = float("nan"); Ud[:, :, :4] = float("nan"); Ud[:, :, -4:] = float("nan")
+            Ud[:, :, :, :4] = float("nan"); Ud[:, :, :, -4:] = float("nan")          # ghost zones not there yet
+            hip.construct_ctu_hydro_source((bxlo, bxhi), Ud, (sb_lo, sb_hi), Sn, (bxlo, bxhi), G, P, 0.0, 8e-4, stage="A", **kw)
+            Ud.copy_(ghosts)                                                          # "halo exchange" completes
+            hip.construct_ctu_hydro_source((bxlo, bxhi), Ud, (sb_lo, sb_hi), Sn, (bxlo, bxhi), G, P, 0.0, 8e-4, stage="B", **kw)
+        else:
+            hip.construct_ctu_hydro_source((bxlo, bxhi), Ud, (sb_lo, sb_hi), Sn, (bxlo, bxhi), G, P, 0.0, 8e-4, **kw)
+        torch.cuda.synchronize()
+        assert hip.status() == 0
+        res.append([Sn.cpu().numpy()] + [f.cpu().numpy() for f in fl])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", [True, "tiles"])
+def test_overlapped_driver_equals_plain_driver_periodic(mode):
+    """Periodic box on one GPU: the 26 self-neighbour halo regions go through pack/exchange/unpack on the
+    communication stream while the compute stream runs the ghost-free stage (or the interior tile)."""
+    import torch
+    import castro_amd
+    n = (24, 20, 16)
+    out = []
+    for ov in (False, mode):
+        c = castro_amd.Castro(n, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), overlap=ov)
+        c.initData("sedov", r_init=0.1, nsub=4)
+        for _ in range(6):
+            c.step(0.01)
+        torch.cuda.synchronize()
+        out.append((c.S_new().cpu().numpy(), [f.cpu().numpy() for f in c.fluxes], c.dt))
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)

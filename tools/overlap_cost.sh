@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-rank cost of the tiled/overlapped path, emulated on one GPU with periodic self-neighbours
 for n in 128 256; do
-for mode in "--periodic --no-overlap" "--periodic --force-overlap"; do
+for mode in "--periodic --no-overlap" "--periodic --force-overlap" "--periodic --overlap-tiles"; do
   python bench.py --ncell $n --steps 10 --warmup 3 --no-cpu-baseline $mode > gpurun_out/ov.json 2> gpurun_out/ov.err || tail -3 gpurun_out/ov.err
   python - <<PY
 import json
