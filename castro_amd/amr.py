@@ -1,0 +1,167 @@
+"""Two-level AMR with subcycling: a coarse level covering the domain and one refined patch (ratio 2).
+
+First slice of SURVEY.md 8 f-3.  What the reference does through AMReX's Amr / AmrLevel / FluxRegister /
+Interpolater classes [3P] is orchestrated here on top of two `Castro` level objects:
+
+  Amr::timeStep recursion with subcycling        coarse advance, then two fine advances of dt/2
+  AmrLevel::FillPatch (fine level)               own valid data + cell_cons_interp of the time-interpolated coarse
+                                                 state (Castro_setup.cpp:352-364, Castro.cpp:4201-4209), then
+                                                 clean_state of the ghost zones (Castro_advance.cpp:186)
+  Castro::FluxRegCrseInit / FluxRegFineAdd       Castro.cpp:2487-2545
+  Castro::post_timestep: reflux, avgDown,        Castro.cpp:2549-2700, 3096-3113, post_timestep (:2140-2260)
+      clean_state
+  Castro::computeNewDt / computeInitialDt        Castro.cpp:1629-1866 over both levels (n_cycle = 1, 2)
+
+Not provided: regridding / error tagging (the patch is fixed), more than two levels, more than one patch,
+multi-rank AMR, gravity on AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
+(include/castro_hydro_amd.h): parity with an AMReX build is unpinned.
+"""
+import torch
+
+from . import _lib as L
+from .castro import Castro, NUM_GROW, NUM_STATE
+
+
+def _coarsen(i):
+    return i // 2            # floor division is AMReX's coarsen() for negative indices too
+
+
+class _FineLevel(Castro):
+    """The refined patch: FillPatch takes the ghost zones from the coarse level."""
+
+    def bind(self, crse):
+        self.crse = crse
+        self.alpha = 0.0          # (t_fine - t_crse_old) / dt_crse of the advance being prepared
+        # coarse zones under the grown fine box, grown by one for the slopes
+        self.cbox = (tuple(_coarsen(self.glo[d]) - 1 for d in range(3)), tuple(_coarsen(self.ghi[d]) + 1 for d in range(3)))
+        for d in range(3):
+            assert self.cbox[0][d] >= crse.glo[d] and self.cbox[1][d] <= crse.ghi[d], "patch too close to the domain boundary"
+        self.ctmp = self.hydro.alloc(NUM_STATE, *self.cbox)
+        lo, hi, g = self.lo, self.hi, NUM_GROW
+        glo, ghi = self.glo, self.ghi
+        self.shell = [((glo[0], glo[1], glo[2]), (ghi[0], ghi[1], lo[2] - 1)), ((glo[0], glo[1], hi[2] + 1), (ghi[0], ghi[1], ghi[2])),
+                      ((glo[0], glo[1], lo[2]), (ghi[0], lo[1] - 1, hi[2])), ((glo[0], hi[1] + 1, lo[2]), (ghi[0], ghi[1], hi[2])),
+                      ((glo[0], lo[1], lo[2]), (lo[0] - 1, hi[1], hi[2])), ((hi[0] + 1, lo[1], lo[2]), (ghi[0], hi[1], hi[2]))]
+
+    def expand_state(self, S, box=None, neighbors=None):
+        assert box is None, "the refined patch carries no Source_Type data"
+        h, c = self.hydro, self.crse
+        a = self.alpha
+        # StateData time interpolation of the coarse data: (1 - a) old + a new
+        h.lincomb(self.ctmp, self.cbox, 1.0 - a, c.S_old_b, c.gbox, a, c.S_new_b, c.gbox, NUM_STATE, *self.cbox)
+        for lo, hi in self.shell:
+            h.cc_interp(self.ctmp, self.cbox, S, self.gbox, lo, hi, NUM_STATE)
+        h.bc_fill(S, self.gbox, self.geom)                     # fine zones outside the domain (none for an interior patch)
+        for lo, hi in self.shell:                              # clean_state(Sborder) reaches the ghost zones too
+            h.clean_state(S, self.gbox, lo, hi, self.params, ntimes=1)
+
+
+class CastroAmr:
+    def __init__(self, n_cell, patch_crse, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
+                 params=None, make_hydro=None, make_params=None):
+        """patch_crse = (lo, hi): the coarse zones covered by the refined patch."""
+        mk = (lambda: None) if make_hydro is None else make_hydro
+        self.params = params if params is not None else (make_params() if make_params else L.default_params())
+        kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
+        self.crse = Castro(n_cell, hydro=mk(), **kw)
+        self.plo, self.phi = tuple(patch_crse[0]), tuple(patch_crse[1])
+        flo = tuple(2 * x for x in self.plo)
+        fhi = tuple(2 * x + 1 for x in self.phi)
+        self.fine = _FineLevel(tuple(2 * x for x in n_cell), hydro=mk(), box=(flo, fhi), **kw)
+        self.fine.bind(self.crse)
+        self.levels = [self.crse, self.fine]
+        h = self.crse.hydro
+        # flux register: one coarse-face-thick FAB per side of the patch (Orientation = direction x {low, high})
+        self.reg = {}
+        for d in range(3):
+            for side in (0, 1):
+                lo, hi = list(self.plo), list(self.phi)
+                lo[d] = hi[d] = (self.plo[d] if side == 0 else self.phi[d] + 1)
+                self.reg[(d, side)] = (h.alloc(NUM_STATE, lo, hi), (tuple(lo), tuple(hi)))
+        self.time, self.nstep = 0.0, 0
+        self.dt_level = [0.0, 0.0]
+
+    # ---- Amr::init / Castro::post_init --------------------------------------------------------
+    def initData(self, problem="sedov", **kw):
+        for lev in self.levels:
+            lev.initData(problem, **kw)
+        self.avgDown()
+        self.crse.clean_state(self.crse.S_new_b, 1)
+        self.time, self.nstep = 0.0, 0
+
+    # ---- Castro::avgDown (Castro.cpp:3096-3113) --------------------------------------------------
+    def avgDown(self):
+        c, f = self.crse, self.fine
+        c.hydro.avgdown(f.S_new_b, f.gbox, c.S_new_b, c.gbox, self.plo, self.phi, NUM_STATE)
+
+    # ---- Castro::computeInitialDt / computeNewDt over the hierarchy ----------------------------------
+    def _dt0(self, stop_time, initial):
+        P = self.params
+        n_factor, dt_0 = 1, 1.e100
+        for l, lev in enumerate(self.levels):
+            n_factor *= (1 if l == 0 else 2)
+            dt = lev.estTimeStep()
+            if initial:
+                dt *= P.init_shrink
+            else:
+                dt = min(dt, P.change_max * self.dt_level[l])
+            dt_0 = min(dt_0, n_factor * dt)
+        if initial:
+            eps = 0.001 * dt_0
+            if stop_time >= 0.0 and (self.time + dt_0) > (stop_time - eps):
+                dt_0 = stop_time - self.time
+        else:
+            eps = 2.220446049250313e-16
+            if stop_time >= 0.0 and (self.time + dt_0) >= (stop_time - eps):
+                dt_0 = stop_time - self.time
+        return dt_0
+
+    # ---- Amr::coarseTimeStep / timeStep ------------------------------------------------------------
+    def step(self, stop_time=-1.0):
+        c, f, h = self.crse, self.fine, self.crse.hydro
+        dt0 = self._dt0(stop_time, self.nstep == 0)
+        self.dt_level = [dt0, dt0 / 2]
+        t = self.time
+
+        c.advance(t, dt0)
+        c.expand_state(c.S_new_b)                 # ghost zones of the new coarse data, for the fine FillPatch
+        # FluxRegCrseInit: -1 x the coarse fluxes through the faces of the patch
+        for (d, side), (reg, rbox) in self.reg.items():
+            h.fluxreg_crse_init(reg, rbox, c.fluxes[d], c.flux_boxes[d], rbox[0], rbox[1], NUM_STATE, -1.0)
+
+        dt1 = dt0 / 2
+        for it in range(2):
+            f.alpha = 0.5 * it
+            f.advance(t + it * dt1, dt1)
+            # FluxRegFineAdd: + the fine fluxes (already dt x area) summed over the 4 fine faces
+            for (d, side), (reg, rbox) in self.reg.items():
+                h.fluxreg_fine_add(reg, rbox, f.fluxes[d], f.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
+
+        # post_timestep at the coarse level: reflux, avgDown, clean_state
+        vol = c.geom.dx[0] * c.geom.dx[1] * c.geom.dx[2]
+        for (d, side), (reg, rbox) in self.reg.items():
+            h.reflux(c.S_new_b, c.gbox, reg, rbox, rbox[0], rbox[1], d, side, NUM_STATE, vol)
+        self.avgDown()
+        c.clean_state(c.S_new_b, 1)
+
+        self.time = t + dt0
+        self.nstep += 1
+        for lev in self.levels:
+            lev.time, lev.nstep = self.time, self.nstep
+        return dt0
+
+    def evolve(self, stop_time, max_step=10 ** 9):
+        eps = 2.220446049250313e-16
+        while self.nstep < max_step and self.time < stop_time - eps:
+            self.step(stop_time)
+        return self.nstep
+
+    # ---- diagnostics -------------------------------------------------------------------------
+    def composite_sum(self, comp):
+        """Volume integral of a conserved component over the composite grid (fine data where refined)."""
+        c, f = self.crse, self.fine
+        vc = c.geom.dx[0] * c.geom.dx[1] * c.geom.dx[2]
+        S = c.S_new().clone()
+        p, q = self.plo, self.phi
+        S[:, p[2]:q[2] + 1, p[1]:q[1] + 1, p[0]:q[0] + 1] = 0.0
+        return (S[comp].sum().item() * vc) + f.S_new()[comp].sum().item() * vc / 8.0

@@ -102,7 +102,7 @@ class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
-                 do_grav=False, const_grav=0.0, grav_source_type=4):
+                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -129,6 +129,11 @@ class Castro:
             self.lo.append(self.coords[d] * nloc)
             self.hi.append(self.lo[d] + nloc - 1)
         self.lo, self.hi = tuple(self.lo), tuple(self.hi)
+        if box is not None:
+            # a single box that does not tile the domain (a refined patch, castro_amd/amr.py): one rank, no
+            # same-level neighbours; its ghost zones come from the coarser level
+            assert self.comm.size == 1 and not any(self.periodic)
+            self.lo, self.hi = tuple(int(x) for x in box[0]), tuple(int(x) for x in box[1])
         self.n = tuple(self.hi[d] - self.lo[d] + 1 for d in range(3))
         self.glo = tuple(x - NUM_GROW for x in self.lo)
         self.ghi = tuple(x + NUM_GROW for x in self.hi)
@@ -147,7 +152,7 @@ class Castro:
             self.mass_fluxes.append(hydro.alloc(1, self.lo, fhi))
         self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)   # [min dt, min rho]
 
-        self.neighbors = self._build_neighbors()
+        self.neighbors = self._build_neighbors() if box is None else []
         # Overlap of the halo exchange with compute: "staged" (True) runs ctoprim on the valid zones and the PPM
         # tracing of the zones >= 3 from the box faces while the exchange is in flight, then the rest -- no
         # redundant work.  The older interior-tile + six-slab split ("tiles") re-does ctoprim/trace on 3x the

@@ -327,6 +327,132 @@ int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3],
 }
 
 // ---------------------------------------------------------------------------------------
+// two-level AMR building blocks, refinement ratio 2 (FillPatch with cell_cons_interp, Castro_setup.cpp:352-364;
+// FluxRegCrseInit / FluxRegFineAdd, Castro.cpp:2487-2545; reflux :2549-2700; avgDown :3096-3113).  The arithmetic
+// is AMReX's (CellConservativeLinear, FluxRegister, average_down) [3P], restated; see include/castro_hydro_amd.h.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double mc_slope(double um, double u0, double up)
+{
+    double dl = u0 - um, dr = up - u0;
+    double dc = 0.5 * (up - um);
+    if (dl * dr <= 0.0) return 0.0;
+    double lim = 2.0 * amin(fabs(dl), fabs(dr));
+    return copysign(1.0, dc) * amin(fabs(dc), lim);
+}
+
+__device__ __forceinline__ int coarsen2(int i) { return (i >= 0) ? i / 2 : -((-i + 1) / 2); }
+
+__global__ void __launch_bounds__(256) k_cc_interp(DFab C, DFab F, Box3 b, int ncomp)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const int ic = coarsen2(i), jc = coarsen2(j), kc = coarsen2(k);
+    const double ox = (i - 2 * ic == 0) ? -0.25 : 0.25;
+    const double oy = (j - 2 * jc == 0) ? -0.25 : 0.25;
+    const double oz = (k - 2 * kc == 0) ? -0.25 : 0.25;
+    for (int n = 0; n < ncomp; ++n) {
+#define CC(ii, jj, kk) C.p[fidx(C, ic + (ii), jc + (jj), kc + (kk), n)]
+        const double u0 = CC(0, 0, 0);
+        double sx = mc_slope(CC(-1, 0, 0), u0, CC(1, 0, 0));
+        double sy = mc_slope(CC(0, -1, 0), u0, CC(0, 1, 0));
+        double sz = mc_slope(CC(0, 0, -1), u0, CC(0, 0, 1));
+        double umax = u0, umin = u0;
+        for (int kk = -1; kk <= 1; ++kk)
+        for (int jj = -1; jj <= 1; ++jj)
+        for (int ii = -1; ii <= 1; ++ii) {
+            double v = CC(ii, jj, kk);
+            umax = amax(umax, v);
+            umin = amin(umin, v);
+        }
+#undef CC
+        const double dmax = 0.25 * (fabs(sx) + fabs(sy) + fabs(sz));
+        double alpha = 1.0;
+        if (dmax > umax - u0) alpha = amin(alpha, (umax - u0) / dmax);
+        if (dmax > u0 - umin) alpha = amin(alpha, (u0 - umin) / dmax);
+        F.p[fidx(F, i, j, k, n)] = u0 + alpha * (sx * ox + sy * oy + sz * oz);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_avgdown(DFab F, DFab C, Box3 b, int ncomp)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    for (int n = 0; n < ncomp; ++n) {
+        double s = 0.0;
+        for (int kk = 0; kk < 2; ++kk)
+        for (int jj = 0; jj < 2; ++jj)
+        for (int ii = 0; ii < 2; ++ii) s += F.p[fidx(F, 2 * i + ii, 2 * j + jj, 2 * k + kk, n)];
+        C.p[fidx(C, i, j, k, n)] = 0.125 * s;
+    }
+}
+
+// mode 0: reg = mult * cflux (CrseInit); mode 1: reg += mult * sum of the 4 fine faces (FineAdd)
+__global__ void __launch_bounds__(256) k_fluxreg(DFab R, DFab X, Box3 b, int dir, int ncomp, double mult, int mode)
+{
+    int c[3];
+    if (!box_thread3(b.lo, b.n, c[0], c[1], c[2])) return;
+    const int t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
+    for (int n = 0; n < ncomp; ++n) {
+        const long cr = fidx(R, c[0], c[1], c[2], n);
+        if (mode == 0) {
+            R.p[cr] = mult * X.p[fidx(X, c[0], c[1], c[2], n)];
+        } else {
+            int f[3];
+            double s = 0.0;
+            for (int bb = 0; bb < 2; ++bb)
+            for (int aa = 0; aa < 2; ++aa) {
+                f[dir] = 2 * c[dir];
+                f[t1] = 2 * c[t1] + aa;
+                f[t2] = 2 * c[t2] + bb;
+                s += X.p[fidx(X, f[0], f[1], f[2], n)];
+            }
+            R.p[cr] += mult * s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reflux(DFab U, DFab R, Box3 b, int dir, int side, int ncomp, double vol)
+{
+    int c[3];
+    if (!box_thread3(b.lo, b.n, c[0], c[1], c[2])) return;
+    int z[3] = { c[0], c[1], c[2] };
+    if (side == 0) z[dir] -= 1;
+    const double mult = side == 0 ? -1.0 : 1.0;
+    for (int n = 0; n < ncomp; ++n)
+        U.p[fidx(U, z[0], z[1], z[2], n)] += mult * R.p[fidx(R, c[0], c[1], c[2], n)] / vol;
+}
+
+__global__ void __launch_bounds__(256) k_lincomb(DFab D, DFab X, DFab Y, Box3 b, double a, double bb, int ncomp)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    for (int n = 0; n < ncomp; ++n)
+        D.p[fidx(D, i, j, k, n)] = a * X.p[fidx(X, i, j, k, n)] + bb * Y.p[fidx(Y, i, j, k, n)];
+}
+
+#define AMR_LAUNCH(name, kern, ...)                                                                     \
+    long n; Box3 b = make_box3(lo, hi, n);                                                               \
+    if (n <= 0) return 0;                                                                                \
+    prof_begin(prof, name, stream);                                                                      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, __VA_ARGS__);      \
+    prof_end(prof, stream);                                                                              \
+    return 0
+
+int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof)
+{ AMR_LAUNCH("k_cc_interp", k_cc_interp, C, F, b, ncomp); }
+int launch_avgdown(const DFab& F, const DFab& C, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof)
+{ AMR_LAUNCH("k_avgdown", k_avgdown, F, C, b, ncomp); }
+int launch_fluxreg(const DFab& R, const DFab& X, const int lo[3], const int hi[3], int dir, int ncomp, double mult, int mode,
+                   hipStream_t stream, Profiler* prof)
+{ AMR_LAUNCH("k_fluxreg", k_fluxreg, R, X, b, dir, ncomp, mult, mode); }
+int launch_reflux(const DFab& U, const DFab& R, const int lo[3], const int hi[3], int dir, int side, int ncomp, double vol,
+                  hipStream_t stream, Profiler* prof)
+{ AMR_LAUNCH("k_reflux", k_reflux, U, R, b, dir, side, ncomp, vol); }
+int launch_lincomb(const DFab& D, const DFab& X, const DFab& Y, const int lo[3], const int hi[3], double a, double bb, int ncomp,
+                   hipStream_t stream, Profiler* prof)
+{ AMR_LAUNCH("k_lincomb", k_lincomb, D, X, Y, b, a, bb, ncomp); }
+
+// ---------------------------------------------------------------------------------------
 // derived plotfile fields (Source/driver/Derive.cpp); ids = CASTRO_AMD_DER_*
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_derive(DFab U, DFab D, int dcomp, Box3 b, int which, DevParams P,

@@ -396,6 +396,75 @@ int castro_amd_saxpy_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a,
     return launch_saxpy(to_dfab(dst), to_dfab(src), lo, hi, a, ncomp, (hipStream_t)stream, &c->prof);
 }
 
+static bool fab_ok(const castro_amd_fab* f, int ncomp) { return f && f->p && f->ncomp >= ncomp; }
+
+int castro_amd_cc_interp_fab(castro_amd_ctx* c, const castro_amd_fab* crse, const castro_amd_fab* fine,
+                             const int lo[3], const int hi[3], int ncomp, void* stream)
+{
+    if (!c || ncomp < 1 || !fab_ok(crse, ncomp) || !fab_ok(fine, ncomp) || !fab_contains(fine, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    int clo[3], chi[3];
+    for (int d = 0; d < 3; ++d) {
+        clo[d] = (lo[d] >= 0 ? lo[d] / 2 : -((-lo[d] + 1) / 2)) - 1;
+        chi[d] = (hi[d] >= 0 ? hi[d] / 2 : -((-hi[d] + 1) / 2)) + 1;
+    }
+    if (!fab_contains(crse, clo, chi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_cc_interp(to_dfab(crse), to_dfab(fine), lo, hi, ncomp, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_avgdown_fab(castro_amd_ctx* c, const castro_amd_fab* fine, const castro_amd_fab* crse,
+                           const int lo[3], const int hi[3], int ncomp, void* stream)
+{
+    if (!c || ncomp < 1 || !fab_ok(crse, ncomp) || !fab_ok(fine, ncomp) || !fab_contains(crse, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    int flo[3], fhi[3];
+    for (int d = 0; d < 3; ++d) { flo[d] = 2 * lo[d]; fhi[d] = 2 * hi[d] + 1; }
+    if (!fab_contains(fine, flo, fhi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_avgdown(to_dfab(fine), to_dfab(crse), lo, hi, ncomp, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_fluxreg_crse_init_fab(castro_amd_ctx* c, const castro_amd_fab* reg, const castro_amd_fab* crse_flux,
+                                     const int lo[3], const int hi[3], int ncomp, double mult, void* stream)
+{
+    if (!c || ncomp < 1 || !fab_ok(reg, ncomp) || !fab_ok(crse_flux, ncomp)) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(reg, lo, hi) || !fab_contains(crse_flux, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_fluxreg(to_dfab(reg), to_dfab(crse_flux), lo, hi, 0, ncomp, mult, 0, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_fluxreg_fine_add_fab(castro_amd_ctx* c, const castro_amd_fab* reg, const castro_amd_fab* fine_flux,
+                                    const int lo[3], const int hi[3], int dir, int ncomp, double mult, void* stream)
+{
+    if (!c || ncomp < 1 || dir < 0 || dir > 2 || !fab_ok(reg, ncomp) || !fab_ok(fine_flux, ncomp) || !fab_contains(reg, lo, hi))
+        return CASTRO_AMD_ERR_ARG;
+    int flo[3], fhi[3];
+    for (int d = 0; d < 3; ++d) { flo[d] = 2 * lo[d]; fhi[d] = (d == dir) ? 2 * hi[d] : 2 * hi[d] + 1; }
+    if (!fab_contains(fine_flux, flo, fhi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_fluxreg(to_dfab(reg), to_dfab(fine_flux), lo, hi, dir, ncomp, mult, 1, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_reflux_fab(castro_amd_ctx* c, const castro_amd_fab* state, const castro_amd_fab* reg,
+                          const int lo[3], const int hi[3], int dir, int side, int ncomp, double vol, void* stream)
+{
+    if (!c || ncomp < 1 || dir < 0 || dir > 2 || side < 0 || side > 1 || !fab_ok(reg, ncomp) || !fab_ok(state, ncomp)) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(reg, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    int zlo[3] = { lo[0], lo[1], lo[2] }, zhi[3] = { hi[0], hi[1], hi[2] };
+    if (side == 0) { zlo[dir] -= 1; zhi[dir] -= 1; }
+    if (!fab_contains(state, zlo, zhi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_reflux(to_dfab(state), to_dfab(reg), lo, hi, dir, side, ncomp, vol, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_lincomb_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a, const castro_amd_fab* x, double b,
+                           const castro_amd_fab* y, int ncomp, const int lo[3], const int hi[3], void* stream)
+{
+    if (!c || ncomp < 1 || !fab_ok(dst, ncomp) || !fab_ok(x, ncomp) || !fab_ok(y, ncomp)) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(dst, lo, hi) || !fab_contains(x, lo, hi) || !fab_contains(y, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_lincomb(to_dfab(dst), to_dfab(x), to_dfab(y), lo, hi, a, b, ncomp, (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_derive_fab(castro_amd_ctx* c, int which, const castro_amd_fab* state, const castro_amd_fab* der, int dcomp,
                           const int lo[3], const int hi[3], const castro_amd_geom* geom, const castro_amd_params* params,
                           const double center[3], void* stream)

@@ -75,6 +75,14 @@ int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, cons
                            const double grav[3], int type, double dt, const double dx[3], hipStream_t stream, Profiler* prof);
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
+int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);
+int launch_avgdown(const DFab& F, const DFab& C, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);
+int launch_fluxreg(const DFab& R, const DFab& X, const int lo[3], const int hi[3], int dir, int ncomp, double mult, int mode,
+                   hipStream_t stream, Profiler* prof);
+int launch_reflux(const DFab& U, const DFab& R, const int lo[3], const int hi[3], int dir, int side, int ncomp, double vol,
+                  hipStream_t stream, Profiler* prof);
+int launch_lincomb(const DFab& D, const DFab& X, const DFab& Y, const int lo[3], const int hi[3], double a, double bb, int ncomp,
+                   hipStream_t stream, Profiler* prof);
 int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int lo[3], const int hi[3],
                   const double dx[3], const double problo[3], const DevParams& P, const double center[3],
                   hipStream_t stream, Profiler* prof);

@@ -124,6 +124,35 @@ class HipHydro:
         L.check(self.lib.castro_amd_saxpy_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(src, *src_box)),
                                               int(ncomp), L.i3(lo), L.i3(hi), _stream_ptr(stream)), "saxpy_fab")
 
+    # ---- two-level AMR building blocks (include/castro_hydro_amd.h) ------------------------------
+    def cc_interp(self, crse, crse_box, fine, fine_box, lo, hi, ncomp, stream=None):
+        L.check(self.lib.castro_amd_cc_interp_fab(self.h, C.byref(L.fab_of(crse, *crse_box)), C.byref(L.fab_of(fine, *fine_box)),
+                                                  L.i3(lo), L.i3(hi), int(ncomp), _stream_ptr(stream)), "cc_interp_fab")
+
+    def lincomb(self, dst, dst_box, a, x, x_box, b, y, y_box, ncomp, lo, hi, stream=None):
+        L.check(self.lib.castro_amd_lincomb_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(x, *x_box)),
+                                                float(b), C.byref(L.fab_of(y, *y_box)), int(ncomp), L.i3(lo), L.i3(hi),
+                                                _stream_ptr(stream)), "lincomb_fab")
+
+    def avgdown(self, fine, fine_box, crse, crse_box, lo, hi, ncomp, stream=None):
+        L.check(self.lib.castro_amd_avgdown_fab(self.h, C.byref(L.fab_of(fine, *fine_box)), C.byref(L.fab_of(crse, *crse_box)),
+                                                L.i3(lo), L.i3(hi), int(ncomp), _stream_ptr(stream)), "avgdown_fab")
+
+    def fluxreg_crse_init(self, reg, reg_box, cflux, cflux_box, lo, hi, ncomp, mult, stream=None):
+        L.check(self.lib.castro_amd_fluxreg_crse_init_fab(self.h, C.byref(L.fab_of(reg, *reg_box)), C.byref(L.fab_of(cflux, *cflux_box)),
+                                                          L.i3(lo), L.i3(hi), int(ncomp), float(mult), _stream_ptr(stream)),
+                "fluxreg_crse_init_fab")
+
+    def fluxreg_fine_add(self, reg, reg_box, fflux, fflux_box, lo, hi, dir, ncomp, mult, stream=None):
+        L.check(self.lib.castro_amd_fluxreg_fine_add_fab(self.h, C.byref(L.fab_of(reg, *reg_box)), C.byref(L.fab_of(fflux, *fflux_box)),
+                                                         L.i3(lo), L.i3(hi), int(dir), int(ncomp), float(mult), _stream_ptr(stream)),
+                "fluxreg_fine_add_fab")
+
+    def reflux(self, state, state_box, reg, reg_box, lo, hi, dir, side, ncomp, vol, stream=None):
+        L.check(self.lib.castro_amd_reflux_fab(self.h, C.byref(L.fab_of(state, *state_box)), C.byref(L.fab_of(reg, *reg_box)),
+                                               L.i3(lo), L.i3(hi), int(dir), int(side), int(ncomp), float(vol), _stream_ptr(stream)),
+                "reflux_fab")
+
     # ---- derived plotfile fields (Source/driver/Derive.cpp) ---------------------------------
     def derive(self, name, state, box, der, der_box, dcomp, lo, hi, geom, params, center, stream=None):
         ctr = (C.c_double * 3)(*[float(x) for x in center])

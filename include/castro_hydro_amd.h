@@ -210,6 +210,32 @@ int castro_amd_new_gravity_source_fab(castro_amd_ctx *ctx, const castro_amd_fab 
 int castro_amd_saxpy_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double a, const castro_amd_fab *src, int ncomp,
                          const int lo[3], const int hi[3], void *stream);
 
+/* Two-level AMR building blocks, refinement ratio 2 (first slice).  The reference calls AMReX for
+ * all of these [3P, not in the reference tree]; the arithmetic is restated from the published descriptions and is
+ * NOT pinned against an AMReX build:
+ *   castro_amd_cc_interp_fab          FillPatch coarse->fine with cell_cons_interp (Castro_setup.cpp:352-364): MC-limited
+ *                                     slopes, one scaling factor per coarse zone keeping the children inside the range of
+ *                                     the 27 neighbours; fills the fine zones [lo,hi]; crse must cover them grown by one
+ *   castro_amd_lincomb_fab            dst = a x + b y  (time interpolation of the coarse data in FillPatch)
+ *   castro_amd_avgdown_fab            amrex::average_down of Castro::avgDown (Castro.cpp:3096-3113) on coarse zones [lo,hi]
+ *   castro_amd_fluxreg_crse_init_fab  FluxRegister::CrseInit of FluxRegCrseInit (Castro.cpp:2487-2512): reg = mult * flux
+ *   castro_amd_fluxreg_fine_add_fab   FluxRegister::FineAdd of FluxRegFineAdd (:2516-2545): reg += mult * sum of 4 fine faces
+ *   castro_amd_reflux_fab             FluxRegister::Reflux of Castro::reflux (:2549-2700): zones outside the faces [lo,hi]
+ *                                     get -reg/vol (side 0, low face of the fine region) or +reg/vol (side 1)
+ * Register planes are ordinary FABs, one coarse face thick, in coarse face index space. */
+int castro_amd_cc_interp_fab(castro_amd_ctx *ctx, const castro_amd_fab *crse, const castro_amd_fab *fine,
+                             const int lo[3], const int hi[3], int ncomp, void *stream);
+int castro_amd_lincomb_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double a, const castro_amd_fab *x, double b,
+                           const castro_amd_fab *y, int ncomp, const int lo[3], const int hi[3], void *stream);
+int castro_amd_avgdown_fab(castro_amd_ctx *ctx, const castro_amd_fab *fine, const castro_amd_fab *crse,
+                           const int lo[3], const int hi[3], int ncomp, void *stream);
+int castro_amd_fluxreg_crse_init_fab(castro_amd_ctx *ctx, const castro_amd_fab *reg, const castro_amd_fab *crse_flux,
+                                     const int lo[3], const int hi[3], int ncomp, double mult, void *stream);
+int castro_amd_fluxreg_fine_add_fab(castro_amd_ctx *ctx, const castro_amd_fab *reg, const castro_amd_fab *fine_flux,
+                                    const int lo[3], const int hi[3], int dir, int ncomp, double mult, void *stream);
+int castro_amd_reflux_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, const castro_amd_fab *reg,
+                          const int lo[3], const int hi[3], int dir, int side, int ncomp, double vol, void *stream);
+
 /* Derived plotfile fields (Source/driver/Derive.cpp, registered in Castro_setup.cpp:756-960) for the
  * 3-D Cartesian gamma-law build.  Not provided: entropy (needs the Microphysics entropy formula),
  * StateErr, circvel, angular_momentum_{x,y,z}. */

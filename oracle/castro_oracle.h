@@ -105,6 +105,13 @@ void ora_new_gravity_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a
                             const ora_a4 mflux[3], const double grav[3], int grav_source_type, double dt,
                             const double dx[3]);
 void ora_saxpy(const int lo[3], const int hi[3], ora_a4 dst, double a, ora_a4 src, int ncomp);
+/* two-level AMR building blocks (AMReX arithmetic restated, see ora_amr.c) */
+void ora_cc_interp(const int lo[3], const int hi[3], ora_a4 crse, ora_a4 fine, int ncomp);
+void ora_avgdown(const int lo[3], const int hi[3], ora_a4 fine, ora_a4 crse, int ncomp);
+void ora_reg_crse_init(const int lo[3], const int hi[3], ora_a4 reg, ora_a4 cflux, int ncomp, double mult);
+void ora_reg_fine_add(const int lo[3], const int hi[3], ora_a4 reg, ora_a4 fflux, int dir, int ncomp, double mult);
+void ora_reflux(const int lo[3], const int hi[3], ora_a4 state, ora_a4 reg, int dir, int side, int ncomp, double vol);
+void ora_lincomb(const int lo[3], const int hi[3], ora_a4 dst, double a, ora_a4 x, double b, ora_a4 y, int ncomp);
 /* Source/driver/Derive.cpp; `which` uses the CASTRO_AMD_DER_* numbering */
 int ora_derive(int which, const int lo[3], const int hi[3], ora_a4 dat, ora_a4 der, const ora_geom *G,
                const ora_params *P, const double center[3]);

@@ -112,6 +112,12 @@ def lib():
         L.ora_level_advance.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.ora_level_advance_retry.restype = C.c_int
         L.ora_level_advance_retry.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+        L.ora_cc_interp.argtypes = [I3, I3, A4, A4, C.c_int]
+        L.ora_avgdown.argtypes = [I3, I3, A4, A4, C.c_int]
+        L.ora_reg_crse_init.argtypes = [I3, I3, A4, A4, C.c_int, C.c_double]
+        L.ora_reg_fine_add.argtypes = [I3, I3, A4, A4, C.c_int, C.c_int, C.c_double]
+        L.ora_reflux.argtypes = [I3, I3, A4, A4, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.ora_lincomb.argtypes = [I3, I3, A4, C.c_double, A4, C.c_double, A4, C.c_int]
         L.ora_level_set_gravity.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
         L.ora_saxpy.argtypes = [I3, I3, A4, C.c_double, A4, C.c_int]
         L.ora_old_gravity_source.argtypes = [I3, I3, A4, A4, C.POINTER(C.c_double * 3), C.c_int, C.c_double]

@@ -83,6 +83,27 @@ class OracleBackend:
     def saxpy(self, dst, dst_box, a, src, src_box, ncomp, lo, hi, stream=None):
         O.lib().ora_saxpy(O.i3(lo), O.i3(hi), self._a4(dst, dst_box), float(a), self._a4(src, src_box), int(ncomp))
 
+    def cc_interp(self, crse, crse_box, fine, fine_box, lo, hi, ncomp, stream=None):
+        O.lib().ora_cc_interp(O.i3(lo), O.i3(hi), self._a4(crse, crse_box), self._a4(fine, fine_box), int(ncomp))
+
+    def lincomb(self, dst, dst_box, a, x, x_box, b, y, y_box, ncomp, lo, hi, stream=None):
+        O.lib().ora_lincomb(O.i3(lo), O.i3(hi), self._a4(dst, dst_box), float(a), self._a4(x, x_box), float(b),
+                            self._a4(y, y_box), int(ncomp))
+
+    def avgdown(self, fine, fine_box, crse, crse_box, lo, hi, ncomp, stream=None):
+        O.lib().ora_avgdown(O.i3(lo), O.i3(hi), self._a4(fine, fine_box), self._a4(crse, crse_box), int(ncomp))
+
+    def fluxreg_crse_init(self, reg, reg_box, cflux, cflux_box, lo, hi, ncomp, mult, stream=None):
+        O.lib().ora_reg_crse_init(O.i3(lo), O.i3(hi), self._a4(reg, reg_box), self._a4(cflux, cflux_box), int(ncomp), float(mult))
+
+    def fluxreg_fine_add(self, reg, reg_box, fflux, fflux_box, lo, hi, dir, ncomp, mult, stream=None):
+        O.lib().ora_reg_fine_add(O.i3(lo), O.i3(hi), self._a4(reg, reg_box), self._a4(fflux, fflux_box), int(dir), int(ncomp),
+                                 float(mult))
+
+    def reflux(self, state, state_box, reg, reg_box, lo, hi, dir, side, ncomp, vol, stream=None):
+        O.lib().ora_reflux(O.i3(lo), O.i3(hi), self._a4(state, state_box), self._a4(reg, reg_box), int(dir), int(side),
+                           int(ncomp), float(vol))
+
     def derive(self, name, state, box, der, der_box, dcomp, lo, hi, geom, params, center, stream=None):
         from castro_amd._lib import DERIVE_IDS
         ctr = (C.c_double * 3)(*[float(x) for x in center])

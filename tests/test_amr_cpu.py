@@ -1,0 +1,81 @@
+"""Two-level AMR (first slice) with the oracle as the per-FAB backend: interpolation and
+flux-register building blocks, conservation over the composite grid, consistency of coarse data under the patch,
+preservation of a uniform state, agreement with a uniformly fine run."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_backend import OracleBackend
+
+
+def _amr(oracle, n=(16, 16, 16), patch=((4, 4, 4), (11, 11, 11)), **pkw):
+    import castro_amd
+    return castro_amd.CastroAmr(n, patch, params=oracle.default_params(**pkw), make_hydro=OracleBackend)
+
+
+def test_interpolation_is_conservative_linear_and_bounded(oracle):
+    rng = np.random.default_rng(0)
+    clo, chi = (-1, -1, -1), (6, 6, 6)
+    lin = np.fromfunction(lambda n, k, j, i: 1.0 + 0.5 * i - 0.25 * j + 2.0 * k + n, (2, 8, 8, 8))
+    noisy = rng.uniform(1.0, 2.0, size=(2, 8, 8, 8))
+    for crse, is_linear in ((lin, True), (noisy, False)):
+        fine = np.zeros((2, 12, 12, 12))
+        flo, fhi = (0, 0, 0), (11, 11, 11)
+        oracle.lib().ora_cc_interp(oracle.i3(flo), oracle.i3(fhi), oracle.a4(crse, clo, chi), oracle.a4(fine, flo, fhi), 2)
+        back = np.zeros((2, 6, 6, 6))
+        oracle.lib().ora_avgdown(oracle.i3((0, 0, 0)), oracle.i3((5, 5, 5)), oracle.a4(fine, flo, fhi),
+                                 oracle.a4(back, (0, 0, 0), (5, 5, 5)), 2)
+        assert np.allclose(back, crse[:, 1:7, 1:7, 1:7], rtol=1e-15, atol=1e-15)             # conservative
+        if is_linear:                                                                      # exact for linear data
+            # numpy index = coarse index + 1 (the coarse array starts at -1); fine centre in coarse units = (i + .5)/2 - .5
+            want = np.fromfunction(lambda n, k, j, i: 1.0 + 0.5 * ((i + 0.5) / 2 + 0.5) - 0.25 * ((j + 0.5) / 2 + 0.5)
+                                   + 2.0 * ((k + 0.5) / 2 + 0.5) + n, (2, 12, 12, 12))
+            assert np.allclose(fine, want, rtol=1e-14)
+        else:                                                                              # no new extrema
+            assert fine.min() >= crse.min() - 1e-15 and fine.max() <= crse.max() + 1e-15
+
+
+def test_uniform_state_is_preserved(oracle):
+    a = _amr(oracle)
+    for lev in a.levels:
+        S = lev.S_new_b
+        S.zero_()
+        S[0] = 1.0; S[1] = 0.3; S[2] = -0.2; S[3] = 0.1
+        S[5] = 2.5; S[4] = 2.5 + 0.5 * (0.09 + 0.04 + 0.01); S[6] = 1.0; S[7] = 1.0
+        lev.clean_state(S, 1)
+    ref = a.crse.S_new().clone()
+    for _ in range(3):
+        a.step()
+    for lev in a.levels:
+        for comp in (0, 1, 2, 3, 4, 5, 7):
+            assert torch.allclose(lev.S_new()[comp], ref[comp][0, 0, 0].expand_as(lev.S_new()[comp]), rtol=1e-13, atol=1e-14)
+
+
+def test_sedov_amr_conserves_and_tracks_the_fine_solution(oracle):
+    import castro_amd
+    a = _amr(oracle, init_shrink=0.1)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    assert m0 == pytest.approx(1.0, rel=1e-13)
+    a.evolve(0.025)           # the shock crosses the coarse-fine boundary (r = 0.25) at t ~ 0.022; nothing has left the domain yet
+    # reflux makes the composite update conservative (outflow boundaries are still quiescent)
+    assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0
+    assert abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+    # coarse data under the patch is the average of the fine data (avgDown + clean_state)
+    f, c = a.fine.S_new().numpy(), a.crse.S_new().numpy()
+    avg = f.reshape(8, 8, 2, 8, 2, 8, 2).mean(axis=(2, 4, 6))
+    assert np.allclose(c[0][4:12, 4:12, 4:12], avg[0], rtol=1e-13)
+    # a uniformly fine run to the same time: the patch tracks it
+    u = castro_amd.Castro((32, 32, 32), params=oracle.default_params(init_shrink=0.1), hydro=OracleBackend())
+    u.initData("sedov", r_init=0.1, nsub=4)
+    u.evolve(a.time)
+    assert u.time == pytest.approx(a.time, rel=1e-12)
+    uf = u.S_new().numpy()[0][8:24, 8:24, 8:24]
+    err = np.abs(f[0] - uf).mean() / np.abs(uf).mean()
+    assert err < 0.05, err
+    # the shock has crossed the coarse-fine boundary: coarse zones outside the patch are disturbed
+    outside = c[0].copy()
+    outside[4:12, 4:12, 4:12] = 1.0
+    assert np.abs(outside - 1.0).max() > 0.05 and f[0].min() < 0.3
