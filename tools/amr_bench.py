@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Timing of the two-level AMR driver (first slice): 128^3 base + one 128^3 refined patch
+(the central 64^3 coarse zones), Sedov.  Prints zone updates per second counted like the reference's FOM
+(coarse zones + 2 x fine zones per coarse step)."""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import castro_amd
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+q = n // 4
+a = castro_amd.CastroAmr((n, n, n), ((q, q, q), (3 * q - 1, 3 * q - 1, 3 * q - 1)))
+a.initData("sedov")
+for _ in range(3):
+    a.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    a.step()
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+zones = n ** 3 + 2 * (2 * (2 * q)) ** 3
+print(json.dumps({"workload": "Sedov %d^3 base + one %d^3 refined patch, subcycled" % (n, 4 * q), "steps": steps,
+                  "ms_per_coarse_step": wall / steps * 1e3, "zone_updates_per_s": zones * steps / wall,
+                  "mass_drift": a.composite_sum(0) - 1.0}))
