@@ -57,6 +57,14 @@ class DistComm:
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer_rank, tag, tensor).  Grouped point-to-point."""
         dist = self.dist
+        if dist.get_backend(self.group) == "gloo" and any(b.is_cuda for _, _, b in list(sends) + list(recvs)):
+            # test transport only (two ranks sharing one GPU): gloo moves host memory
+            hs = [(p, t, b.cpu()) for p, t, b in sends]
+            hr = [(p, t, torch.empty_like(b, device="cpu"), b) for p, t, b in recvs]
+            self.exchange(hs, [(p, t, h) for p, t, h, _ in hr])
+            for _, _, h, b in hr:
+                b.copy_(h)
+            return
         ops = []
         # post receives first, ordered by (peer, tag) on both sides so the grouped call matches up
         for peer, tag, buf in sorted(recvs, key=lambda x: (x[0], x[1])):
@@ -68,6 +76,11 @@ class DistComm:
                 req.wait()
 
     def allreduce_min(self, t):
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, group=self.group)
+            t.copy_(h)
+            return t
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return t
 

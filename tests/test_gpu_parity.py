@@ -758,3 +758,50 @@ def test_amr_building_blocks_match_oracle(hip, oracle):
     hip.reflux(st_d, (clo, chi), reg_d, (rlo, rhi), rlo, rhi, 1, 1, 8, 0.37)
     torch.cuda.synchronize()
     assert np.array_equal(reg_d.cpu().numpy(), reg_o) and np.array_equal(st_d.cpu().numpy(), st_o)
+
+
+def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap):
+    import torch.distributed as dist
+    import torch
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = castro_amd.Castro(n, comm=castro_amd.DistComm(), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=overlap)
+        c.initData("sedov", r_init=0.1, nsub=4)
+        dts = [c.step(0.01) for _ in range(nsteps)]
+        torch.cuda.synchronize()
+        mine = c.S_new().contiguous().cpu()
+        parts = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        boxes = c.comm.gather_objects((c.lo, c.hi))
+        if rank == 0:
+            full = np.zeros((8, n[2], n[1], n[0]))
+            for p, (lo, hi) in zip(parts, boxes):
+                full[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = p.numpy()
+            np.savez(out_path, S=full, dts=np.array(dts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, overlap):
+    """The N > 1 device path end to end (device pack -> inter-process exchange -> device unpack -> BC fill -> hydro,
+    2-double allreduce), with two processes on the one GPU of the test box.  The transport is gloo (RCCL needs one
+    device per rank); everything else is the code that runs on a multi-GPU node."""
+    import torch
+    import torch.multiprocessing as mp
+    import castro_amd
+    from tests.test_driver_cpu import _free_port
+    n, nsteps = (24, 16, 32), 4
+    out = str(tmp_path / "two.npz")
+    mp.spawn(_two_rank_gpu_worker, args=(2, _free_port(), n, nsteps, out, overlap), nprocs=2, join=True)
+    got = np.load(out)
+    c = castro_amd.Castro(n, lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    dts = [c.step(0.01) for _ in range(nsteps)]
+    torch.cuda.synchronize()
+    assert np.array_equal(got["dts"], np.array(dts))
+    assert np.array_equal(got["S"], c.S_new().cpu().numpy())

@@ -58,5 +58,8 @@ int main()
     run<64, 16, 1>(in, out, "64 in, 16 out", KP);
     run<32, 16, 2>(in, out, "32 in x2 (z,z+1), 16 out", KP);
     run<16, 16, 4>(in, out, "16 in x4 z-planes, 16 out", KP);
+    run<8, 50, 1>(in, out, "8 in, 50 out (trace-like)", KP);
+    run<1, 32, 1>(in, out, "1 in, 32 out", KP);
+    run<32, 1, 1>(in, out, "32 in, 1 out", KP);
     return 0;
 }
