@@ -79,6 +79,29 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def pmc_traffic_per_step(prof, steps):
+    """Sum over the hot-path kernels of (PMC bytes per launch from the committed profile) x (launches per step
+    counted live): the L2->fabric traffic of one step.  None without a committed profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))["kernels"]
+    alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup"}
+    tot = 0.0
+    for name, (ms, launches) in prof.items():
+        k = d.get(name) or d.get(alias.get(name, ""))
+        if k is None:
+            continue
+        if name == "k_riemann1" and "k_riemann1_blockstart" in d:
+            # two full launches + one block-start launch per step share the label
+            per_step = 2 * k["bytes_per_launch"] + d["k_riemann1_blockstart"]["bytes_per_launch"]
+            tot += per_step
+            continue
+        tot += k["bytes_per_launch"] * launches / max(steps, 1)
+    return tot
+
+
 def cpu_baseline(ncell, steps):
     """The CPU oracle (a port organised like the reference's CPU path: ~75 sweeps per tile,
     tiles 1024x16x16, OpenMP over tiles) timed on this host on a bounded Sedov sample."""
@@ -197,10 +220,16 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes}
     hydro_ms = sum(v[0] for k, v in prof.items() if k in ("k_ctoprim", "k_divu", "k_trace", "k_riemann1", "k_trans1",
                                                           "k_final", "k_consup", "k_consup_clean")) / max(args.steps, 1)
+    traffic_step = pmc_traffic_per_step(prof, args.steps) if prof else None
     path = {"bytes_per_cell_update": PATH_BYTES_PER_CELL,
             "achieved_GBs_per_gpu": value / world * PATH_BYTES_PER_CELL / 1e9,
             "frac_of_hbm_peak": value / world * PATH_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS,
             "hydro_kernels_ms_per_step": hydro_ms,
+            # hardware utilisation: PMC traffic of one step (committed rocprofv3 profile of this command) over the
+            # measured step time, against the 8 TB/s peak
+            "pmc_traffic_bytes_per_step": traffic_step,
+            "pmc_traffic_GBs": (traffic_step / (wall / args.steps) / 1e9) if traffic_step and world == 1 and c.n == (256, 256, 256) else None,
+            "pmc_traffic_frac_of_hbm_peak": (traffic_step / (wall / args.steps) / 1e9 / HBM_PEAK_GBS) if traffic_step and world == 1 and c.n == (256, 256, 256) else None,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())}}
 
     out = {
