@@ -8,7 +8,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_lds_pad; }
+namespace cad { extern int g_tile_rows; }
 
 using namespace cad;
 
@@ -126,8 +126,7 @@ static DevGeom to_devgeom(const castro_amd_geom* g)
 static size_t plane_doubles(int nx, int ny, int nz)
 {
     size_t n = (size_t)(nx + 8) * (ny + 8) * (nz + 8);
-    static const long pad = std::getenv("CASTRO_AMD_PLANE_PAD") ? std::atol(std::getenv("CASTRO_AMD_PLANE_PAD")) : 0;
-    return ((n + 31) & ~(size_t)31) + (size_t)pad;     // keep every component plane 256-byte aligned
+    return (n + 31) & ~(size_t)31;     // keep every component plane 256-byte aligned
 }
 
 // number of component planes in the scratch arena
@@ -185,7 +184,6 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (hipMalloc(&c->d_status, sizeof(int)) != hipSuccess) { delete c; return CASTRO_AMD_ERR_NOMEM; }
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
-    if (const char* e = std::getenv("CASTRO_AMD_LDS_PAD")) g_lds_pad = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
     *out = c;
     return CASTRO_AMD_OK;

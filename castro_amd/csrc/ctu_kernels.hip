@@ -1604,7 +1604,6 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 // ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
-int g_lds_pad = 0;        // experiment knob: dynamic LDS bytes per workgroup (caps occupancy)
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
 
 static LinBox linbox(const int lo[3], const int hi[3], long& n)
@@ -1638,7 +1637,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox2(lo, hi, n_);                                                     \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), g_lds_pad, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)
@@ -1649,7 +1648,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox(lo, hi, n_);                                                      \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), g_lds_pad, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)

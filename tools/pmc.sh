@@ -13,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA TA_BUSY_avr"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_p$i -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_p$i -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_p$i.log 2>&1
 done
 cd $REPO
 python3 - <<PY > $OUT/${TAG}_pmc_summary.txt

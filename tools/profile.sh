@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe used for profiles/ (run on the GPU box through gpurun).
-# usage: tools_profile.sh <tag>   -> writes gpurun_out/<tag>_{stats,fetch,write}/ and summaries
+# usage: tools/profile.sh <tag>   -> writes gpurun_out/<tag>_{stats,fetch,write}/ and summaries
 set -u
 TAG=${1:-r01}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,6 +12,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
 cd $REPO
-python3 tools_profile_summary.py $TAG > $OUT/${TAG}_summary.txt 2>&1
+python3 tools/profile_summary.py $TAG > $OUT/${TAG}_summary.txt 2>&1
 # keep only the small files
 find $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write -type f -size +8M -delete 2>/dev/null

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
 def find(d, pat):
