@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
     "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status",
     "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab",
-    "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
+    "castro_amd_error_tag_fab", "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
     "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
@@ -101,6 +101,7 @@ def load():
     L.castro_amd_new_gravity_source_fab.argtypes = [C.c_void_p, PF, PF, PF, PF, I3, I3, D3, C.c_int, C.c_double,
                                                     C.POINTER(Geom), C.c_void_p]
     L.castro_amd_saxpy_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]
+    L.castro_amd_error_tag_fab.argtypes = [C.c_void_p, PF, C.c_int, PF, I3, I3, C.c_int, C.c_double, C.c_void_p]
     L.castro_amd_cc_interp_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.c_void_p]
     L.castro_amd_lincomb_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]
     L.castro_amd_avgdown_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.c_void_p]

@@ -12,8 +12,13 @@ Interpolater classes [3P] is orchestrated here on top of two `Castro` level obje
       clean_state
   Castro::computeNewDt / computeInitialDt        Castro.cpp:1629-1866 over both levels (n_cycle = 1, 2)
 
-Not provided: regridding / error tagging (the patch is fixed), more than two levels, more than one patch,
-multi-rank AMR, gravity on AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
+  Castro::errorEst + Amr::regrid                 amr.refinement_indicators (AMRErrorTag [3P] restated) on the coarse level
+                                                 every regrid_int steps; the refined region is ONE box, the bounding
+                                                 box of the tags grown by n_error_buf and aligned to blocking_factor
+                                                 (AMReX clusters tags into many boxes with Berger-Rigoutsos [3P])
+
+Not provided: Berger-Rigoutsos clustering, more than two levels, more than one patch, multi-rank AMR, gravity on
+AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
 (include/castro_hydro_amd.h): parity with an AMReX build is unpinned.
 """
 import torch
@@ -56,37 +61,119 @@ class _FineLevel(Castro):
             h.clean_state(S, self.gbox, lo, hi, self.params, ntimes=1)
 
 
+_TAG_KINDS = {"value_greater": 0, "value_less": 1, "gradient": 2, "relative_gradient": 3}
+_FIELDS = {"density": 0, "xmom": 1, "ymom": 2, "zmom": 3, "rho_E": 4, "rho_e": 5, "Temp": 6, "rho_X": 7}
+
+
 class CastroAmr:
-    def __init__(self, n_cell, patch_crse, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
-                 params=None, make_hydro=None, make_params=None):
-        """patch_crse = (lo, hi): the coarse zones covered by the refined patch."""
+    def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
+                 params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
+                 blocking_factor=8):
+        """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined patch; or
+        refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name, kind:
+        value_greater | value_less | gradient | relative_gradient) for a patch that follows the tags."""
+        assert (patch_crse is None) != (refine is None), "give either a fixed patch or refinement indicators"
         mk = (lambda: None) if make_hydro is None else make_hydro
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
-        kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
-        self.crse = Castro(n_cell, hydro=mk(), **kw)
-        self.plo, self.phi = tuple(patch_crse[0]), tuple(patch_crse[1])
-        flo = tuple(2 * x for x in self.plo)
-        fhi = tuple(2 * x + 1 for x in self.phi)
-        self.fine = _FineLevel(tuple(2 * x for x in n_cell), hydro=mk(), box=(flo, fhi), **kw)
-        self.fine.bind(self.crse)
-        self.levels = [self.crse, self.fine]
+        self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
+        self.n_cell = tuple(n_cell)
+        self.crse = Castro(n_cell, hydro=mk(), **self._kw)
+        self._fine_hydro = mk()
+        if self._fine_hydro is None:
+            from .hydro import HipHydro
+            self._fine_hydro = HipHydro(torch.cuda.current_device())
+        self.refine = refine
+        self.regrid_int, self.n_error_buf, self.blocking_factor = int(regrid_int), int(n_error_buf), int(blocking_factor)
+        self.fine, self.plo, self.phi, self.reg = None, None, None, {}
+        self.nregrid = 0
+        if patch_crse is not None:
+            self._set_patch(tuple(patch_crse[0]), tuple(patch_crse[1]))
+        self.time, self.nstep = 0.0, 0
+        self.dt_level = [0.0, 0.0]
+
+    @property
+    def levels(self):
+        return [self.crse] if self.fine is None else [self.crse, self.fine]
+
+    def _set_patch(self, plo, phi):
+        """(Re)create the fine level object and its flux register for the coarse zones [plo, phi]."""
+        self.plo, self.phi = plo, phi
+        flo = tuple(2 * x for x in plo)
+        fhi = tuple(2 * x + 1 for x in phi)
+        fine = _FineLevel(tuple(2 * x for x in self.n_cell), hydro=self._fine_hydro, box=(flo, fhi), **self._kw)
+        fine.bind(self.crse)
         h = self.crse.hydro
         # flux register: one coarse-face-thick FAB per side of the patch (Orientation = direction x {low, high})
         self.reg = {}
         for d in range(3):
             for side in (0, 1):
-                lo, hi = list(self.plo), list(self.phi)
-                lo[d] = hi[d] = (self.plo[d] if side == 0 else self.phi[d] + 1)
+                lo, hi = list(plo), list(phi)
+                lo[d] = hi[d] = (plo[d] if side == 0 else phi[d] + 1)
                 self.reg[(d, side)] = (h.alloc(NUM_STATE, lo, hi), (tuple(lo), tuple(hi)))
-        self.time, self.nstep = 0.0, 0
-        self.dt_level = [0.0, 0.0]
+        return fine
+
+    # ---- Castro::errorEst (Castro.cpp:3131-3164) + the one-box stand-in for the grid generator ------
+    def tag_box(self):
+        """Bounding box (coarse zones) of the tagged zones, buffered and aligned; None if nothing is tagged."""
+        c, h = self.crse, self.crse.hydro
+        c.expand_state(c.S_new_b)
+        tags = h.alloc(1, c.lo, c.hi)
+        for field, kind, value in self.refine:
+            h.error_tag(c.S_new_b, c.gbox, _FIELDS[field], tags, (c.lo, c.hi), c.lo, c.hi, _TAG_KINDS[kind], value)
+        nz = torch.nonzero(tags[0] > 0.5)                       # (k, j, i) triples
+        if nz.numel() == 0:
+            return None
+        mn, mx = nz.min(dim=0).values.tolist(), nz.max(dim=0).values.tolist()
+        a = max(self.blocking_factor // 2, 1)                   # blocking_factor is in fine zones
+        lo, hi = [], []
+        for d in range(3):
+            l = mn[2 - d] - self.n_error_buf
+            u = mx[2 - d] + self.n_error_buf
+            l = (l // a) * a
+            u = -((-(u + 1)) // a) * a - 1
+            lo.append(max(l, 0))
+            hi.append(min(u, self.n_cell[d] - 1))
+        return tuple(lo), tuple(hi)
+
+    # ---- Amr::regrid: new fine grids, data from the old fine level where it exists, else interpolated ---
+    def regrid(self):
+        box = self.tag_box()
+        if box is None:
+            self.fine, self.plo, self.phi, self.reg = None, None, None, {}
+            return False
+        if self.fine is not None and box == (self.plo, self.phi):
+            return False
+        old, old_lo, old_hi = self.fine, (self.fine.lo if self.fine is not None else None), (self.fine.hi if self.fine is not None else None)
+        old_S = old.S_new_b.clone() if old is not None else None
+        old_gbox = old.gbox if old is not None else None
+        c, h = self.crse, self.crse.hydro
+        new = self._set_patch(*box)
+        # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
+        new.alpha = 1.0
+        h.lincomb(new.ctmp, new.cbox, 0.0, c.S_old_b, c.gbox, 1.0, c.S_new_b, c.gbox, NUM_STATE, *new.cbox)
+        h.cc_interp(new.ctmp, new.cbox, new.S_new_b, new.gbox, new.lo, new.hi, NUM_STATE)
+        if old is not None:
+            olo = tuple(max(old_lo[d], new.lo[d]) for d in range(3))
+            ohi = tuple(min(old_hi[d], new.hi[d]) for d in range(3))
+            if all(olo[d] <= ohi[d] for d in range(3)):
+                h.copy(new.S_new_b, new.gbox, old_S, old_gbox, olo, ohi)
+        new.time, new.nstep = self.time, self.nstep
+        self.fine = new
+        self.nregrid += 1
+        return True
 
     # ---- Amr::init / Castro::post_init --------------------------------------------------------
     def initData(self, problem="sedov", **kw):
-        for lev in self.levels:
-            lev.initData(problem, **kw)
-        self.avgDown()
-        self.crse.clean_state(self.crse.S_new_b, 1)
+        self.crse.initData(problem, **kw)
+        if self.refine is not None:
+            box = self.tag_box()
+            self.fine = self._set_patch(*box) if box is not None else None
+        elif self.fine is None:
+            self.fine = self._set_patch(self.plo, self.phi)
+        if self.fine is not None:
+            self.fine.initData(problem, **kw)                   # fine levels start from the problem initialiser
+            self.avgDown()
+            self.crse.clean_state(self.crse.S_new_b, 1)
         self.time, self.nstep = 0.0, 0
 
     # ---- Castro::avgDown (Castro.cpp:3096-3113) --------------------------------------------------
@@ -118,8 +205,17 @@ class CastroAmr:
 
     # ---- Amr::coarseTimeStep / timeStep ------------------------------------------------------------
     def step(self, stop_time=-1.0):
+        if self.refine is not None and self.regrid_int > 0 and self.nstep > 0 and self.nstep % self.regrid_int == 0:
+            self.regrid()
         c, f, h = self.crse, self.fine, self.crse.hydro
         dt0 = self._dt0(stop_time, self.nstep == 0)
+        if f is None:
+            self.dt_level = [dt0, dt0 / 2]
+            c.advance(self.time, dt0)
+            self.time += dt0
+            self.nstep += 1
+            c.time, c.nstep = self.time, self.nstep
+            return dt0
         self.dt_level = [dt0, dt0 / 2]
         t = self.time
 
@@ -161,6 +257,8 @@ class CastroAmr:
         """Volume integral of a conserved component over the composite grid (fine data where refined)."""
         c, f = self.crse, self.fine
         vc = c.geom.dx[0] * c.geom.dx[1] * c.geom.dx[2]
+        if f is None:
+            return c.S_new()[comp].sum().item() * vc
         S = c.S_new().clone()
         p, q = self.plo, self.phi
         S[:, p[2]:q[2] + 1, p[1]:q[1] + 1, p[0]:q[0] + 1] = 0.0

@@ -430,6 +430,26 @@ __global__ void __launch_bounds__(256) k_lincomb(DFab D, DFab X, DFab Y, Box3 b,
         D.p[fidx(D, i, j, k, n)] = a * X.p[fidx(X, i, j, k, n)] + bb * Y.p[fidx(Y, i, j, k, n)];
 }
 
+__global__ void __launch_bounds__(256) k_error_tag(DFab Q, int comp, DFab T, Box3 b, int kind, double value)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+#define QQ(ii, jj, kk) Q.p[fidx(Q, ii, jj, kk, comp)]
+    const double u = QQ(i, j, k);
+    bool tag;
+    if (kind == 0) tag = u >= value;
+    else if (kind == 1) tag = u <= value;
+    else {
+        double ax = fabs(QQ(i + 1, j, k) - u); ax = amax(ax, fabs(u - QQ(i - 1, j, k)));
+        double ay = fabs(QQ(i, j + 1, k) - u); ay = amax(ay, fabs(u - QQ(i, j - 1, k)));
+        double az = fabs(QQ(i, j, k + 1) - u); az = amax(az, fabs(u - QQ(i, j, k - 1)));
+        double g = amax(amax(ax, ay), az);
+        tag = (kind == 2) ? (g >= value) : (g >= value * fabs(u));
+    }
+#undef QQ
+    if (tag) T.p[fidx(T, i, j, k, 0)] = 1.0;
+}
+
 #define AMR_LAUNCH(name, kern, ...)                                                                     \
     long n; Box3 b = make_box3(lo, hi, n);                                                               \
     if (n <= 0) return 0;                                                                                \
@@ -448,6 +468,9 @@ int launch_fluxreg(const DFab& R, const DFab& X, const int lo[3], const int hi[3
 int launch_reflux(const DFab& U, const DFab& R, const int lo[3], const int hi[3], int dir, int side, int ncomp, double vol,
                   hipStream_t stream, Profiler* prof)
 { AMR_LAUNCH("k_reflux", k_reflux, U, R, b, dir, side, ncomp, vol); }
+int launch_error_tag(const DFab& Q, int comp, const DFab& T, const int lo[3], const int hi[3], int kind, double value,
+                     hipStream_t stream, Profiler* prof)
+{ AMR_LAUNCH("k_error_tag", k_error_tag, Q, comp, T, b, kind, value); }
 int launch_lincomb(const DFab& D, const DFab& X, const DFab& Y, const int lo[3], const int hi[3], double a, double bb, int ncomp,
                    hipStream_t stream, Profiler* prof)
 { AMR_LAUNCH("k_lincomb", k_lincomb, D, X, Y, b, a, bb, ncomp); }

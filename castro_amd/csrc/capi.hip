@@ -454,6 +454,18 @@ int castro_amd_reflux_fab(castro_amd_ctx* c, const castro_amd_fab* state, const 
     return launch_reflux(to_dfab(state), to_dfab(reg), lo, hi, dir, side, ncomp, vol, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_error_tag_fab(castro_amd_ctx* c, const castro_amd_fab* field, int comp, const castro_amd_fab* tags,
+                             const int lo[3], const int hi[3], int kind, double value, void* stream)
+{
+    if (!c || !field || !field->p || !tags || !tags->p || comp < 0 || comp >= field->ncomp || kind < 0 || kind > 3) return CASTRO_AMD_ERR_ARG;
+    int glo[3], ghi[3];
+    const int g1 = kind >= 2 ? 1 : 0;
+    for (int d = 0; d < 3; ++d) { glo[d] = lo[d] - g1; ghi[d] = hi[d] + g1; }
+    if (!fab_contains(field, glo, ghi) || !fab_contains(tags, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_error_tag(to_dfab(field), comp, to_dfab(tags), lo, hi, kind, value, (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_lincomb_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a, const castro_amd_fab* x, double b,
                            const castro_amd_fab* y, int ncomp, const int lo[3], const int hi[3], void* stream)
 {

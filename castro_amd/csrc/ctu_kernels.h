@@ -81,6 +81,8 @@ int launch_fluxreg(const DFab& R, const DFab& X, const int lo[3], const int hi[3
                    hipStream_t stream, Profiler* prof);
 int launch_reflux(const DFab& U, const DFab& R, const int lo[3], const int hi[3], int dir, int side, int ncomp, double vol,
                   hipStream_t stream, Profiler* prof);
+int launch_error_tag(const DFab& Q, int comp, const DFab& T, const int lo[3], const int hi[3], int kind, double value,
+                     hipStream_t stream, Profiler* prof);
 int launch_lincomb(const DFab& D, const DFab& X, const DFab& Y, const int lo[3], const int hi[3], double a, double bb, int ncomp,
                    hipStream_t stream, Profiler* prof);
 int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int lo[3], const int hi[3],

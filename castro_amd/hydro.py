@@ -125,6 +125,12 @@ class HipHydro:
                                               int(ncomp), L.i3(lo), L.i3(hi), _stream_ptr(stream)), "saxpy_fab")
 
     # ---- two-level AMR building blocks (include/castro_hydro_amd.h) ------------------------------
+    def error_tag(self, field, field_box, comp, tags, tags_box, lo, hi, kind, value, stream=None):
+        """kind: 0 value_greater, 1 value_less, 2 gradient, 3 relative_gradient (AMRErrorTag)."""
+        L.check(self.lib.castro_amd_error_tag_fab(self.h, C.byref(L.fab_of(field, *field_box)), int(comp),
+                                                  C.byref(L.fab_of(tags, *tags_box)), L.i3(lo), L.i3(hi), int(kind),
+                                                  float(value), _stream_ptr(stream)), "error_tag_fab")
+
     def cc_interp(self, crse, crse_box, fine, fine_box, lo, hi, ncomp, stream=None):
         L.check(self.lib.castro_amd_cc_interp_fab(self.h, C.byref(L.fab_of(crse, *crse_box)), C.byref(L.fab_of(fine, *fine_box)),
                                                   L.i3(lo), L.i3(hi), int(ncomp), _stream_ptr(stream)), "cc_interp_fab")

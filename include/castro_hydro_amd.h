@@ -222,9 +222,14 @@ int castro_amd_saxpy_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double 
  *   castro_amd_fluxreg_fine_add_fab   FluxRegister::FineAdd of FluxRegFineAdd (:2516-2545): reg += mult * sum of 4 fine faces
  *   castro_amd_reflux_fab             FluxRegister::Reflux of Castro::reflux (:2549-2700): zones outside the faces [lo,hi]
  *                                     get -reg/vol (side 0, low face of the fine region) or +reg/vol (side 1)
+ *   castro_amd_error_tag_fab          amrex::AMRErrorTag of Castro::errorEst (Castro.cpp:3131-3164): kind 0 value_greater,
+ *                                     1 value_less, 2 gradient, 3 relative_gradient on component `comp` of `field`
+ *                                     (one ghost zone for the gradient kinds); tags (1 comp, 1.0 = tagged) are OR-ed
  * Register planes are ordinary FABs, one coarse face thick, in coarse face index space. */
 int castro_amd_cc_interp_fab(castro_amd_ctx *ctx, const castro_amd_fab *crse, const castro_amd_fab *fine,
                              const int lo[3], const int hi[3], int ncomp, void *stream);
+int castro_amd_error_tag_fab(castro_amd_ctx *ctx, const castro_amd_fab *field, int comp, const castro_amd_fab *tags,
+                             const int lo[3], const int hi[3], int kind, double value, void *stream);
 int castro_amd_lincomb_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double a, const castro_amd_fab *x, double b,
                            const castro_amd_fab *y, int ncomp, const int lo[3], const int hi[3], void *stream);
 int castro_amd_avgdown_fab(castro_amd_ctx *ctx, const castro_amd_fab *fine, const castro_amd_fab *crse,

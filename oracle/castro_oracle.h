@@ -111,6 +111,7 @@ void ora_avgdown(const int lo[3], const int hi[3], ora_a4 fine, ora_a4 crse, int
 void ora_reg_crse_init(const int lo[3], const int hi[3], ora_a4 reg, ora_a4 cflux, int ncomp, double mult);
 void ora_reg_fine_add(const int lo[3], const int hi[3], ora_a4 reg, ora_a4 fflux, int dir, int ncomp, double mult);
 void ora_reflux(const int lo[3], const int hi[3], ora_a4 state, ora_a4 reg, int dir, int side, int ncomp, double vol);
+void ora_error_tag(const int lo[3], const int hi[3], ora_a4 q, int comp, ora_a4 tags, int kind, double value);
 void ora_lincomb(const int lo[3], const int hi[3], ora_a4 dst, double a, ora_a4 x, double b, ora_a4 y, int ncomp);
 /* Source/driver/Derive.cpp; `which` uses the CASTRO_AMD_DER_* numbering */
 int ora_derive(int which, const int lo[3], const int hi[3], ora_a4 dat, ora_a4 der, const ora_geom *G,

@@ -125,3 +125,26 @@ void ora_lincomb(const int lo[3], const int hi[3], ora_a4 dst, double a, ora_a4 
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) A4(dst,i,j,k,n) = a * A4(x,i,j,k,n) + b * A4(y,i,j,k,n);
 }
+
+/* amrex::AMRErrorTag (the amr.refinement_indicators of Castro::errorEst, Castro.cpp:3131-3164) [3P, restated]:
+ * kind 0 value_greater (q >= v), 1 value_less (q <= v), 2 gradient (largest one-sided difference to the six
+ * neighbours >= v), 3 relative_gradient (... >= v |q|).  Tags are OR-ed into `tags` (1.0 = tagged). */
+void ora_error_tag(const int lo[3], const int hi[3], ora_a4 q, int comp, ora_a4 tags, int kind, double value)
+{
+    for (int k = lo[2]; k <= hi[2]; ++k)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+    for (int i = lo[0]; i <= hi[0]; ++i) {
+        const double u = A4(q,i,j,k,comp);
+        int tag = 0;
+        if (kind == 0) tag = u >= value;
+        else if (kind == 1) tag = u <= value;
+        else {
+            double ax = fabs(A4(q,i+1,j,k,comp) - u); ax = amax(ax, fabs(u - A4(q,i-1,j,k,comp)));
+            double ay = fabs(A4(q,i,j+1,k,comp) - u); ay = amax(ay, fabs(u - A4(q,i,j-1,k,comp)));
+            double az = fabs(A4(q,i,j,k+1,comp) - u); az = amax(az, fabs(u - A4(q,i,j,k-1,comp)));
+            double g = amax(amax(ax, ay), az);
+            tag = (kind == 2) ? (g >= value) : (g >= value * fabs(u));
+        }
+        if (tag) A4(tags,i,j,k,0) = 1.0;
+    }
+}

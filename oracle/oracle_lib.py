@@ -117,6 +117,7 @@ def lib():
         L.ora_reg_crse_init.argtypes = [I3, I3, A4, A4, C.c_int, C.c_double]
         L.ora_reg_fine_add.argtypes = [I3, I3, A4, A4, C.c_int, C.c_int, C.c_double]
         L.ora_reflux.argtypes = [I3, I3, A4, A4, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.ora_error_tag.argtypes = [I3, I3, A4, C.c_int, A4, C.c_int, C.c_double]
         L.ora_lincomb.argtypes = [I3, I3, A4, C.c_double, A4, C.c_double, A4, C.c_int]
         L.ora_level_set_gravity.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
         L.ora_saxpy.argtypes = [I3, I3, A4, C.c_double, A4, C.c_int]

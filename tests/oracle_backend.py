@@ -83,6 +83,10 @@ class OracleBackend:
     def saxpy(self, dst, dst_box, a, src, src_box, ncomp, lo, hi, stream=None):
         O.lib().ora_saxpy(O.i3(lo), O.i3(hi), self._a4(dst, dst_box), float(a), self._a4(src, src_box), int(ncomp))
 
+    def error_tag(self, field, field_box, comp, tags, tags_box, lo, hi, kind, value, stream=None):
+        O.lib().ora_error_tag(O.i3(lo), O.i3(hi), self._a4(field, field_box), int(comp), self._a4(tags, tags_box), int(kind),
+                              float(value))
+
     def cc_interp(self, crse, crse_box, fine, fine_box, lo, hi, ncomp, stream=None):
         O.lib().ora_cc_interp(O.i3(lo), O.i3(hi), self._a4(crse, crse_box), self._a4(fine, fine_box), int(ncomp))
 

@@ -805,3 +805,25 @@ def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, overlap):
     torch.cuda.synchronize()
     assert np.array_equal(got["dts"], np.array(dts))
     assert np.array_equal(got["S"], c.S_new().cpu().numpy())
+
+
+def test_tag_driven_amr_on_the_device_matches_oracle_backend(oracle):
+    """Error tagging + single-box regridding + the AMR step on the device against the oracle-backed orchestration:
+    same patch boxes at every step, same data bit for bit."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2, n_error_buf=1,
+              blocking_factor=4)
+    a = castro_amd.CastroAmr((24, 24, 24), params=castro_amd.default_params(init_shrink=0.1), **kw)
+    b = castro_amd.CastroAmr((24, 24, 24), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend, **kw)
+    for x in (a, b):
+        x.initData("sedov", r_init=0.1, nsub=4)
+    assert (a.plo, a.phi) == (b.plo, b.phi)
+    while a.time < 0.012:
+        assert a.step(0.02) == b.step(0.02)
+        assert (a.plo, a.phi) == (b.plo, b.phi)
+    torch.cuda.synchronize()
+    assert a.nregrid == b.nregrid and a.nregrid >= 1
+    _assert_exact({"coarse": (a.crse.S_new().cpu().numpy(), b.crse.S_new().numpy()),
+                   "fine": (a.fine.S_new().cpu().numpy(), b.fine.S_new().numpy())}, "dynamic AMR")
