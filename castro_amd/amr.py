@@ -1,4 +1,4 @@
-"""Two-level AMR with subcycling: a coarse level covering the domain and one refined patch (ratio 2).
+"""AMR with subcycling: a coarse level covering the domain and one refined patch per finer level (ratio 2).
 
 First slice of SURVEY.md 8 f-3.  What the reference does through AMReX's Amr / AmrLevel / FluxRegister /
 Interpolater classes [3P] is orchestrated here on top of two `Castro` level objects:
@@ -17,8 +17,8 @@ Interpolater classes [3P] is orchestrated here on top of two `Castro` level obje
                                                  box of the tags grown by n_error_buf and aligned to blocking_factor
                                                  (AMReX clusters tags into many boxes with Berger-Rigoutsos [3P])
 
-Not provided: Berger-Rigoutsos clustering, more than two levels, more than one patch, multi-rank AMR, gravity on
-AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
+Any number of levels with fixed, properly nested patches (`patches=[...]`); the tag-driven patch is two-level.
+Not provided: Berger-Rigoutsos clustering, more than one patch per level, multi-rank AMR, gravity on AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
 (include/castro_hydro_amd.h): parity with an AMReX build is unpinned.
 """
 import torch
@@ -40,7 +40,8 @@ class _FineLevel(Castro):
         # coarse zones under the grown fine box, grown by one for the slopes
         self.cbox = (tuple(_coarsen(self.glo[d]) - 1 for d in range(3)), tuple(_coarsen(self.ghi[d]) + 1 for d in range(3)))
         for d in range(3):
-            assert self.cbox[0][d] >= crse.glo[d] and self.cbox[1][d] <= crse.ghi[d], "patch too close to the domain boundary"
+            assert self.cbox[0][d] >= crse.glo[d] and self.cbox[1][d] <= crse.ghi[d], \
+                "patch not properly nested: its ghost zones need parent data beyond the parent's own ghost zones"
         self.ctmp = self.hydro.alloc(NUM_STATE, *self.cbox)
         lo, hi, g = self.lo, self.hi, NUM_GROW
         glo, ghi = self.glo, self.ghi
@@ -68,49 +69,70 @@ _FIELDS = {"density": 0, "xmom": 1, "ymom": 2, "zmom": 3, "rho_E": 4, "rho_e": 5
 class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
-                 blocking_factor=8):
-        """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined patch; or
+                 blocking_factor=8, patches=None):
+        """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined patch;
+        patches = [(lo, hi), ...]: one fixed patch per finer level, each in the index space of the level below it
+        (amr.max_level = len(patches)); or
         refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name, kind:
-        value_greater | value_less | gradient | relative_gradient) for a patch that follows the tags."""
-        assert (patch_crse is None) != (refine is None), "give either a fixed patch or refinement indicators"
-        mk = (lambda: None) if make_hydro is None else make_hydro
+        value_greater | value_less | gradient | relative_gradient) for one patch that follows the tags."""
+        if patch_crse is not None:
+            assert patches is None
+            patches = [patch_crse]
+        assert (patches is None) != (refine is None), "give either fixed patches or refinement indicators"
+        self._mk = (lambda: None) if make_hydro is None else make_hydro
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
         self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
         self.n_cell = tuple(n_cell)
-        self.crse = Castro(n_cell, hydro=mk(), **self._kw)
-        self._fine_hydro = mk()
-        if self._fine_hydro is None:
-            from .hydro import HipHydro
-            self._fine_hydro = HipHydro(torch.cuda.current_device())
+        self.lev = [Castro(n_cell, hydro=self._mk(), **self._kw)]      # lev[0] covers the domain
+        self.pbox = [None]                                            # pbox[l]: patch of level l in level l-1 zones
+        self.regs = [None]                                            # regs[l]: flux register around that patch
+        self._hydros = [self.lev[0].hydro]
         self.refine = refine
         self.regrid_int, self.n_error_buf, self.blocking_factor = int(regrid_int), int(n_error_buf), int(blocking_factor)
-        self.fine, self.plo, self.phi, self.reg = None, None, None, {}
         self.nregrid = 0
-        if patch_crse is not None:
-            self._set_patch(tuple(patch_crse[0]), tuple(patch_crse[1]))
+        for pb in (patches or []):
+            self._push_level(tuple(pb[0]), tuple(pb[1]))
         self.time, self.nstep = 0.0, 0
-        self.dt_level = [0.0, 0.0]
+        self.dt_level = [0.0] * 8
 
-    @property
-    def levels(self):
-        return [self.crse] if self.fine is None else [self.crse, self.fine]
+    # two-level views used by the tag-driven mode and the tests
+    crse = property(lambda self: self.lev[0])
+    fine = property(lambda self: self.lev[1] if len(self.lev) > 1 else None)
+    plo = property(lambda self: self.pbox[1][0] if len(self.lev) > 1 else None)
+    phi = property(lambda self: self.pbox[1][1] if len(self.lev) > 1 else None)
+    levels = property(lambda self: list(self.lev))
 
-    def _set_patch(self, plo, phi):
-        """(Re)create the fine level object and its flux register for the coarse zones [plo, phi]."""
-        self.plo, self.phi = plo, phi
+    def _hydro_for(self, l):
+        while len(self._hydros) <= l:
+            h = self._mk()
+            if h is None:
+                from .hydro import HipHydro
+                h = HipHydro(torch.cuda.current_device())
+            self._hydros.append(h)
+        return self._hydros[l]
+
+    def _make_level(self, l, plo, phi):
+        """Level l >= 1 covering the zones [plo, phi] of level l-1, and the flux register around it."""
+        parent = self.lev[l - 1]
         flo = tuple(2 * x for x in plo)
         fhi = tuple(2 * x + 1 for x in phi)
-        fine = _FineLevel(tuple(2 * x for x in self.n_cell), hydro=self._fine_hydro, box=(flo, fhi), **self._kw)
-        fine.bind(self.crse)
-        h = self.crse.hydro
-        # flux register: one coarse-face-thick FAB per side of the patch (Orientation = direction x {low, high})
-        self.reg = {}
+        fine = _FineLevel(tuple((2 ** l) * x for x in self.n_cell), hydro=self._hydro_for(l), box=(flo, fhi), **self._kw)
+        fine.bind(parent)
+        h = parent.hydro
+        reg = {}
         for d in range(3):
             for side in (0, 1):
                 lo, hi = list(plo), list(phi)
                 lo[d] = hi[d] = (plo[d] if side == 0 else phi[d] + 1)
-                self.reg[(d, side)] = (h.alloc(NUM_STATE, lo, hi), (tuple(lo), tuple(hi)))
-        return fine
+                reg[(d, side)] = (h.alloc(NUM_STATE, lo, hi), (tuple(lo), tuple(hi)))
+        return fine, reg
+
+    def _push_level(self, plo, phi):
+        fine, reg = self._make_level(len(self.lev), plo, phi)
+        self.lev.append(fine); self.pbox.append((plo, phi)); self.regs.append(reg)
+
+    def _drop_fine(self):
+        del self.lev[1:], self.pbox[1:], self.regs[1:]
 
     # ---- Castro::errorEst (Castro.cpp:3131-3164) + the one-box stand-in for the grid generator ------
     def tag_box(self):
@@ -139,26 +161,25 @@ class CastroAmr:
     def regrid(self):
         box = self.tag_box()
         if box is None:
-            self.fine, self.plo, self.phi, self.reg = None, None, None, {}
+            self._drop_fine()
             return False
         if self.fine is not None and box == (self.plo, self.phi):
             return False
-        old, old_lo, old_hi = self.fine, (self.fine.lo if self.fine is not None else None), (self.fine.hi if self.fine is not None else None)
+        old = self.fine
         old_S = old.S_new_b.clone() if old is not None else None
-        old_gbox = old.gbox if old is not None else None
         c, h = self.crse, self.crse.hydro
-        new = self._set_patch(*box)
+        self._drop_fine()
+        self._push_level(*box)
+        new = self.fine
         # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
-        new.alpha = 1.0
         h.lincomb(new.ctmp, new.cbox, 0.0, c.S_old_b, c.gbox, 1.0, c.S_new_b, c.gbox, NUM_STATE, *new.cbox)
         h.cc_interp(new.ctmp, new.cbox, new.S_new_b, new.gbox, new.lo, new.hi, NUM_STATE)
         if old is not None:
-            olo = tuple(max(old_lo[d], new.lo[d]) for d in range(3))
-            ohi = tuple(min(old_hi[d], new.hi[d]) for d in range(3))
+            olo = tuple(max(old.lo[d], new.lo[d]) for d in range(3))
+            ohi = tuple(min(old.hi[d], new.hi[d]) for d in range(3))
             if all(olo[d] <= ohi[d] for d in range(3)):
-                h.copy(new.S_new_b, new.gbox, old_S, old_gbox, olo, ohi)
+                h.copy(new.S_new_b, new.gbox, old_S, old.gbox, olo, ohi)
         new.time, new.nstep = self.time, self.nstep
-        self.fine = new
         self.nregrid += 1
         return True
 
@@ -166,26 +187,27 @@ class CastroAmr:
     def initData(self, problem="sedov", **kw):
         self.crse.initData(problem, **kw)
         if self.refine is not None:
+            self._drop_fine()
             box = self.tag_box()
-            self.fine = self._set_patch(*box) if box is not None else None
-        elif self.fine is None:
-            self.fine = self._set_patch(self.plo, self.phi)
-        if self.fine is not None:
-            self.fine.initData(problem, **kw)                   # fine levels start from the problem initialiser
-            self.avgDown()
-            self.crse.clean_state(self.crse.S_new_b, 1)
+            if box is not None:
+                self._push_level(*box)
+        for lev in self.lev[1:]:
+            lev.initData(problem, **kw)                         # fine levels start from the problem initialiser
+        for l in range(len(self.lev) - 1, 0, -1):
+            self.avgDown(l)
+            self.lev[l - 1].clean_state(self.lev[l - 1].S_new_b, 1)
         self.time, self.nstep = 0.0, 0
 
-    # ---- Castro::avgDown (Castro.cpp:3096-3113) --------------------------------------------------
-    def avgDown(self):
-        c, f = self.crse, self.fine
-        c.hydro.avgdown(f.S_new_b, f.gbox, c.S_new_b, c.gbox, self.plo, self.phi, NUM_STATE)
+    # ---- Castro::avgDown (Castro.cpp:3096-3113): level l onto level l-1 ------------------------------
+    def avgDown(self, l=1):
+        c, f = self.lev[l - 1], self.lev[l]
+        c.hydro.avgdown(f.S_new_b, f.gbox, c.S_new_b, c.gbox, self.pbox[l][0], self.pbox[l][1], NUM_STATE)
 
     # ---- Castro::computeInitialDt / computeNewDt over the hierarchy ----------------------------------
     def _dt0(self, stop_time, initial):
         P = self.params
         n_factor, dt_0 = 1, 1.e100
-        for l, lev in enumerate(self.levels):
+        for l, lev in enumerate(self.lev):
             n_factor *= (1 if l == 0 else 2)
             dt = lev.estTimeStep()
             if initial:
@@ -203,46 +225,48 @@ class CastroAmr:
                 dt_0 = stop_time - self.time
         return dt_0
 
-    # ---- Amr::coarseTimeStep / timeStep ------------------------------------------------------------
+    # ---- Amr::timeStep: advance level l, then recursively twice the next finer level, then post_timestep -----
+    def _time_step(self, l, t, dt, alpha):
+        """alpha: position of this level's old time inside the parent's [old, new] interval (0 or 1/2)."""
+        lev, finest = self.lev[l], len(self.lev) - 1
+        if l > 0:
+            lev.alpha = alpha
+        lev.advance(t, dt)
+        if l > 0:
+            # FluxRegFineAdd: + this level's fluxes (already dt x area) summed over the 4 fine faces
+            h = self.lev[l - 1].hydro
+            for (d, side), (reg, rbox) in self.regs[l].items():
+                h.fluxreg_fine_add(reg, rbox, lev.fluxes[d], lev.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
+        if l < finest:
+            h = lev.hydro
+            # ghost zones of the new data of this level, for the FillPatch of the next finer one
+            if l > 0:
+                lev.alpha = alpha + 0.5
+            lev.expand_state(lev.S_new_b)
+            # FluxRegCrseInit: -1 x this level's fluxes through the faces of the finer patch
+            for (d, side), (reg, rbox) in self.regs[l + 1].items():
+                h.fluxreg_crse_init(reg, rbox, lev.fluxes[d], lev.flux_boxes[d], rbox[0], rbox[1], NUM_STATE, -1.0)
+            for it in range(2):
+                self._time_step(l + 1, t + it * (dt / 2), dt / 2, 0.5 * it)
+            # post_timestep: reflux, avgDown, clean_state
+            vol = lev.geom.dx[0] * lev.geom.dx[1] * lev.geom.dx[2]
+            for (d, side), (reg, rbox) in self.regs[l + 1].items():
+                h.reflux(lev.S_new_b, lev.gbox, reg, rbox, rbox[0], rbox[1], d, side, NUM_STATE, vol)
+            self.avgDown(l + 1)
+            lev.clean_state(lev.S_new_b, 1)
+
+    # ---- Amr::coarseTimeStep ---------------------------------------------------------------------
     def step(self, stop_time=-1.0):
         if self.refine is not None and self.regrid_int > 0 and self.nstep > 0 and self.nstep % self.regrid_int == 0:
             self.regrid()
-        c, f, h = self.crse, self.fine, self.crse.hydro
         dt0 = self._dt0(stop_time, self.nstep == 0)
-        if f is None:
-            self.dt_level = [dt0, dt0 / 2]
-            c.advance(self.time, dt0)
-            self.time += dt0
-            self.nstep += 1
-            c.time, c.nstep = self.time, self.nstep
-            return dt0
-        self.dt_level = [dt0, dt0 / 2]
+        for l in range(len(self.dt_level)):
+            self.dt_level[l] = dt0 / (2 ** l)
         t = self.time
-
-        c.advance(t, dt0)
-        c.expand_state(c.S_new_b)                 # ghost zones of the new coarse data, for the fine FillPatch
-        # FluxRegCrseInit: -1 x the coarse fluxes through the faces of the patch
-        for (d, side), (reg, rbox) in self.reg.items():
-            h.fluxreg_crse_init(reg, rbox, c.fluxes[d], c.flux_boxes[d], rbox[0], rbox[1], NUM_STATE, -1.0)
-
-        dt1 = dt0 / 2
-        for it in range(2):
-            f.alpha = 0.5 * it
-            f.advance(t + it * dt1, dt1)
-            # FluxRegFineAdd: + the fine fluxes (already dt x area) summed over the 4 fine faces
-            for (d, side), (reg, rbox) in self.reg.items():
-                h.fluxreg_fine_add(reg, rbox, f.fluxes[d], f.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
-
-        # post_timestep at the coarse level: reflux, avgDown, clean_state
-        vol = c.geom.dx[0] * c.geom.dx[1] * c.geom.dx[2]
-        for (d, side), (reg, rbox) in self.reg.items():
-            h.reflux(c.S_new_b, c.gbox, reg, rbox, rbox[0], rbox[1], d, side, NUM_STATE, vol)
-        self.avgDown()
-        c.clean_state(c.S_new_b, 1)
-
+        self._time_step(0, t, dt0, 0.0)
         self.time = t + dt0
         self.nstep += 1
-        for lev in self.levels:
+        for lev in self.lev:
             lev.time, lev.nstep = self.time, self.nstep
         return dt0
 
@@ -254,12 +278,15 @@ class CastroAmr:
 
     # ---- diagnostics -------------------------------------------------------------------------
     def composite_sum(self, comp):
-        """Volume integral of a conserved component over the composite grid (fine data where refined)."""
-        c, f = self.crse, self.fine
-        vc = c.geom.dx[0] * c.geom.dx[1] * c.geom.dx[2]
-        if f is None:
-            return c.S_new()[comp].sum().item() * vc
-        S = c.S_new().clone()
-        p, q = self.plo, self.phi
-        S[:, p[2]:q[2] + 1, p[1]:q[1] + 1, p[0]:q[0] + 1] = 0.0
-        return (S[comp].sum().item() * vc) + f.S_new()[comp].sum().item() * vc / 8.0
+        """Volume integral of a conserved component over the composite grid (finest data wherever refined)."""
+        tot = 0.0
+        for l, lev in enumerate(self.lev):
+            v = lev.geom.dx[0] * lev.geom.dx[1] * lev.geom.dx[2]
+            S = lev.S_new()[comp]
+            if l + 1 < len(self.lev):
+                S = S.clone()
+                p, q = self.pbox[l + 1]
+                o = lev.lo
+                S[p[2] - o[2]:q[2] - o[2] + 1, p[1] - o[1]:q[1] - o[1] + 1, p[0] - o[0]:q[0] - o[0] + 1] = 0.0
+            tot += S.sum().item() * v
+        return tot

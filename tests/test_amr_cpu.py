@@ -108,3 +108,29 @@ def test_tag_driven_patch_follows_the_shock_and_conserves(oracle):
         assert a.plo[d] % 2 == 0 and (a.phi[d] + 1) % 2 == 0
     # symmetric problem, symmetric patch
     assert a.plo == tuple(24 - 1 - x for x in a.phi)
+
+
+def test_three_levels_with_subcycling_conserve_and_track_the_fine_solution(oracle):
+    """amr.max_level = 2: the Amr::timeStep recursion (1 coarse step = 2 level-1 steps = 4 level-2 steps), FillPatch of
+    level 2 from the time-interpolated level-1 data (whose own ghost zones come from level 0), two flux registers."""
+    import castro_amd
+    a = castro_amd.CastroAmr((16, 16, 16), patches=[((4, 4, 4), (11, 11, 11)), ((12, 12, 12), (19, 19, 19))],
+                             params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend)
+    a.initData("sedov", r_init=0.08, nsub=4)
+    assert [lev.n for lev in a.levels] == [(16, 16, 16), (16, 16, 16), (16, 16, 16)]
+    assert a.levels[2].geom.dx[0] == pytest.approx(1.0 / 64)
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    a.evolve(0.012)          # the shock (r = 0.2 at this time) has crossed the faces of the level-2 patch (half width 0.125)
+    assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0
+    assert abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+    f2, f1, c = (lev.S_new().numpy() for lev in (a.levels[2], a.levels[1], a.levels[0]))
+    assert np.allclose(f1[0][4:12, 4:12, 4:12], f2[0].reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5)), rtol=1e-13)
+    assert np.allclose(c[0][4:12, 4:12, 4:12], f1[0].reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5)), rtol=1e-13)
+    outside2 = f1[0].copy()
+    outside2[4:12, 4:12, 4:12] = 1.0
+    assert np.abs(outside2 - 1.0).max() > 0.5 and f2[0].min() < 0.2      # shell on level 1, evacuated centre on level 2
+    u = castro_amd.Castro((64, 64, 64), params=oracle.default_params(init_shrink=0.1), hydro=OracleBackend())
+    u.initData("sedov", r_init=0.08, nsub=4)
+    u.evolve(a.time)
+    uf = u.S_new().numpy()[0][24:40, 24:40, 24:40]
+    assert np.abs(f2[0] - uf).mean() / np.abs(uf).mean() < 0.08

@@ -827,3 +827,21 @@ def test_tag_driven_amr_on_the_device_matches_oracle_backend(oracle):
     assert a.nregrid == b.nregrid and a.nregrid >= 1
     _assert_exact({"coarse": (a.crse.S_new().cpu().numpy(), b.crse.S_new().numpy()),
                    "fine": (a.fine.S_new().cpu().numpy(), b.fine.S_new().numpy())}, "dynamic AMR")
+
+
+def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
+    """amr.max_level = 2 (1 + 2 + 4 advances per coarse step) on the device vs the oracle-backed orchestration."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(patches=[((4, 4, 4), (11, 11, 11)), ((12, 12, 12), (19, 19, 19))])
+    a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1), **kw)
+    b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend, **kw)
+    for x in (a, b):
+        x.initData("sedov", r_init=0.08, nsub=4)
+    m0 = a.composite_sum(0)
+    for _ in range(12):
+        assert a.step(0.05) == b.step(0.05)
+    torch.cuda.synchronize()
+    _assert_exact({"L%d" % l: (a.levels[l].S_new().cpu().numpy(), b.levels[l].S_new().numpy()) for l in range(3)}, "3-level AMR")
+    assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0

@@ -13,8 +13,13 @@ import castro_amd
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+nfine = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # number of refined levels (BASELINE config 4: 2)
 q = n // 4
-a = castro_amd.CastroAmr((n, n, n), ((q, q, q), (3 * q - 1, 3 * q - 1, 3 * q - 1)))
+patches = [((q, q, q), (3 * q - 1, 3 * q - 1, 3 * q - 1))]
+if nfine == 2:                                                # level-2 patch: the central n/2 zones of the level-1 box
+    lo1 = 2 * q + q
+    patches.append(((lo1, lo1, lo1), (lo1 + 2 * q - 1, lo1 + 2 * q - 1, lo1 + 2 * q - 1)))
+a = castro_amd.CastroAmr((n, n, n), patches=patches)
 a.initData("sedov")
 for _ in range(3):
     a.step()
@@ -24,7 +29,7 @@ for _ in range(steps):
     a.step()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
-zones = n ** 3 + 2 * (2 * (2 * q)) ** 3
-print(json.dumps({"workload": "Sedov %d^3 base + one %d^3 refined patch, subcycled" % (n, 4 * q), "steps": steps,
+zones = n ** 3 + 2 * (4 * q) ** 3 + (4 * (4 * q) ** 3 if nfine == 2 else 0)
+print(json.dumps({"workload": "Sedov %d^3 base + %d refined level(s), one %d^3 patch each, subcycled" % (n, nfine, 4 * q), "steps": steps,
                   "ms_per_coarse_step": wall / steps * 1e3, "zone_updates_per_s": zones * steps / wall,
                   "mass_drift": a.composite_sum(0) - 1.0}))
