@@ -139,6 +139,81 @@ def write_plotfile(dirname, castro, derive=None, job_info=None):
     return names
 
 
+def write_plotfile_amr(dirname, amr, derive=None):
+    """Multi-level plotfile of a CastroAmr hierarchy (single rank): the same Header layout with finest_level > 0
+    (Castro_io.cpp:953-1076 per level) and one Level_l/{Cell_H, Cell_D_00000} per level."""
+    levels = amr.levels
+    nlev = len(levels)
+    per = []
+    for l, lev in enumerate(levels):
+        if l > 0:
+            lev.alpha = 1.0          # ghost zones for the stencil derives: parent data at the current (new) time
+        names, data = plot_data(lev, derive)
+        per.append(data.cpu().numpy() if hasattr(data, "cpu") else np.asarray(data))
+    ncomp = per[0].shape[0]
+    os.makedirs(dirname, exist_ok=True)
+    g0 = levels[0].geom
+    with open(os.path.join(dirname, "Header"), "w") as f:
+        w = f.write
+        w("HyperCLaw-V1.1\n%d\n" % ncomp)
+        for nm in names:
+            w(nm + "\n")
+        w("3\n" + _g(amr.time) + "\n%d\n" % (nlev - 1))
+        w(" ".join(_g(g0.problo[d]) for d in range(3)) + " \n")
+        w(" ".join(_g(g0.probhi[d]) for d in range(3)) + " \n")
+        w("".join("2 " for _ in range(nlev - 1)) + "\n")
+        w("".join(_box([lev.geom.domlo[d] for d in range(3)], [lev.geom.domhi[d] for d in range(3)]) + " " for lev in levels) + "\n")
+        w("".join("%d " % (amr.nstep * 2 ** l) for l in range(nlev)) + "\n")
+        for lev in levels:
+            w(" ".join(_g(lev.geom.dx[d]) for d in range(3)) + " \n")
+        w("%d\n0\n" % g0.coord)
+        for l, lev in enumerate(levels):
+            w("%d 1 %s\n%d\n" % (l, _g(amr.time), amr.nstep * 2 ** l))
+            for d in range(3):
+                w("%s %s\n" % (_g(lev.geom.problo[d] + lev.lo[d] * lev.geom.dx[d]), _g(lev.geom.problo[d] + (lev.hi[d] + 1) * lev.geom.dx[d])))
+            w("Level_%d/Cell\n" % l)
+    for l, (lev, arr) in enumerate(zip(levels, per)):
+        ld = os.path.join(dirname, "Level_%d" % l)
+        os.makedirs(ld, exist_ok=True)
+        with open(os.path.join(ld, "Cell_D_00000"), "wb") as f:
+            f.write(("FAB %s%s %d\n" % (FAB_REAL_DESCRIPTOR, _box(lev.lo, lev.hi), ncomp)).encode("ascii"))
+            np.ascontiguousarray(arr, dtype="<f8").tofile(f)
+        with open(os.path.join(ld, "Cell_H"), "w") as f:
+            f.write("1\n0\n%d\n0\n(1 0\n%s\n)\n1\nFabOnDisk: Cell_D_00000 0\n\n" % (ncomp, _box(lev.lo, lev.hi)))
+            for fn in (np.min, np.max):
+                f.write("1,%d\n" % ncomp + "".join("%.16e," % fn(arr[n]) for n in range(ncomp)) + "\n\n")
+    return names
+
+
+def read_plotfile_amr(dirname):
+    """Levels of a multi-level plotfile: list of dict(box=(lo,hi), dx, data[(ncomp, nz, ny, nx)]) + names, time."""
+    with open(os.path.join(dirname, "Header")) as f:
+        L = [ln.rstrip("\n") for ln in f]
+    ncomp = int(L[1])
+    names = L[2:2 + ncomp]
+    p = 2 + ncomp
+    time, finest = float(L[p + 1]), int(L[p + 2])
+    q = p + 8                                   # first dx line
+    dxs = [[float(x) for x in L[q + l].split()] for l in range(finest + 1)]
+    q += finest + 1 + 2
+    out = []
+    for l in range(finest + 1):
+        ngrids = int(L[q].split()[1])
+        path = L[q + 2 + 3 * ngrids]
+        q += 3 + 3 * ngrids
+        levdir = os.path.join(dirname, os.path.dirname(path))
+        with open(os.path.join(levdir, "Cell_H")) as f:
+            H = [ln.rstrip("\n") for ln in f]
+        v = [int(x) for x in re.findall(r"-?\d+", H[5])]
+        lo, hi = v[0:3], v[3:6]
+        m = [hi[d] - lo[d] + 1 for d in range(3)]
+        with open(os.path.join(levdir, "Cell_D_00000"), "rb") as f:
+            f.readline()
+            a = np.fromfile(f, dtype="<f8", count=ncomp * m[0] * m[1] * m[2]).reshape(ncomp, m[2], m[1], m[0])
+        out.append(dict(box=(lo, hi), dx=dxs[l], data=a))
+    return dict(names=names, time=time, levels=out)
+
+
 def read_plotfile(dirname):
     """Parse a single-level plotfile written by write_plotfile (or by AMReX with the same layout).
     Returns dict(names, time, nstep, prob_lo, prob_hi, domain=(lo,hi), dx, boxes, data) with

@@ -134,3 +134,24 @@ def test_three_levels_with_subcycling_conserve_and_track_the_fine_solution(oracl
     u.evolve(a.time)
     uf = u.S_new().numpy()[0][24:40, 24:40, 24:40]
     assert np.abs(f2[0] - uf).mean() / np.abs(uf).mean() < 0.08
+
+
+def test_multilevel_plotfile_round_trip(tmp_path, oracle):
+    from castro_amd import plotfile as pf
+    a = _amr(oracle, init_shrink=0.1)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    for _ in range(3):
+        a.step()
+    d = str(tmp_path / "plt_amr")
+    names = pf.write_plotfile_amr(d, a)
+    H = open(d + "/Header").read().split("\n")
+    p = 2 + len(names)
+    assert H[p + 2] == "1" and H[p + 5].strip() == "2"
+    assert H[p + 6].strip() == "((0,0,0) (15,15,15) (0,0,0)) ((0,0,0) (31,31,31) (0,0,0))"
+    assert H[p + 7].split() == ["3", "6"]
+    r = pf.read_plotfile_amr(d)
+    assert r["names"] == names and r["time"] == a.time and len(r["levels"]) == 2
+    assert r["levels"][1]["box"] == ([8, 8, 8], [23, 23, 23]) and r["levels"][1]["dx"][0] == 1.0 / 32
+    for lev, got in zip(a.levels, r["levels"]):
+        assert np.array_equal(got["data"][:8], lev.S_new().numpy())
+        assert np.array_equal(got["data"][names.index("x_velocity")], got["data"][1] / got["data"][0])
