@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcastro_hydro_amd.so")
+LIB_PATH = os.environ.get("CASTRO_AMD_LIB", os.path.join(_HERE, "libcastro_hydro_amd.so"))   # override: A/B builds
 
 NUM_STATE, NGDNV, NUM_GROW = 8, 4, 4
 URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
