@@ -845,3 +845,38 @@ def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
     torch.cuda.synchronize()
     _assert_exact({"L%d" % l: (a.levels[l].S_new().cpu().numpy(), b.levels[l].S_new().numpy()) for l in range(3)}, "3-level AMR")
     assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0
+
+
+def test_new_entry_points_reject_bad_arguments(hip):
+    """Argument validation of the AMR / source / derive entry points: boxes that leave their FABs, wrong component
+    counts and unknown selectors are refused (CASTRO_AMD_ERR_ARG), nothing is launched."""
+    import castro_amd
+    G, P = castro_amd.make_geom((8, 8, 8)), castro_amd.default_params()
+    box = ((0, 0, 0), (7, 7, 7))
+    S = hip.alloc(8, *box, fill=1.0)
+    src6 = hip.alloc(6, *box)
+    src7 = hip.alloc(7, *box)
+    bad = pytest.raises(RuntimeError, match="bad argument")
+    with bad:
+        hip.old_gravity_source(S, box, src6, box, (0, 0, 0), (7, 7, 7), (0, 0, -1.0), 4, 1e-3)       # NSRC = 7 needed
+    with bad:
+        hip.old_gravity_source(S, box, src7, box, (0, 0, 0), (7, 7, 7), (0, 0, -1.0), 5, 1e-3)       # grav_source_type 1..4
+    with bad:
+        hip.saxpy(S, box, 1.0, src7, box, 8, (0, 0, 0), (7, 7, 7))                                   # more comps than src has
+    with bad:
+        hip.cc_interp(S, box, hip.alloc(8, (0, 0, 0), (15, 15, 15)), ((0, 0, 0), (15, 15, 15)), (0, 0, 0), (15, 15, 15), 8)
+    with bad:
+        hip.avgdown(hip.alloc(8, (0, 0, 0), (13, 15, 15)), ((0, 0, 0), (13, 15, 15)), S, box, (0, 0, 0), (7, 7, 7), 8)
+    with bad:
+        hip.error_tag(S, box, 0, hip.alloc(1, *box), box, (0, 0, 0), (7, 7, 7), 2, 0.1)              # gradient needs a ghost zone
+    with bad:
+        hip.error_tag(S, box, 9, hip.alloc(1, *box), box, (1, 1, 1), (6, 6, 6), 0, 0.1)              # component out of range
+    with bad:
+        hip.reflux(S, box, hip.alloc(8, (0, 0, 0), (0, 7, 7)), ((0, 0, 0), (0, 7, 7)), (0, 0, 0), (0, 7, 7), 0, 0, 8, 1.0)  # zone -1
+    with bad:
+        hip.derive("divu", S, box, hip.alloc(1, *box), box, 0, (0, 0, 0), (7, 7, 7), G, P, (0.5, 0.5, 0.5))   # needs a ghost zone
+    with bad:
+        hip.derive("pressure", S, box, hip.alloc(2, *box), box, 2, (0, 0, 0), (7, 7, 7), G, P, (0.5, 0.5, 0.5))
+    # and the valid forms of two of them go through
+    hip.error_tag(S, box, 0, hip.alloc(1, *box), box, (1, 1, 1), (6, 6, 6), 2, 0.1)
+    hip.derive("pressure", S, box, hip.alloc(2, *box), box, 1, (0, 0, 0), (7, 7, 7), G, P, (0.5, 0.5, 0.5))
