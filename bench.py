@@ -233,7 +233,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())}}
 
     out = {
-        "metric": "cell-updates/sec, Sedov 3D 256^3 single-level; % HBM roofline",
+        "metric": "cell-updates/sec, Sedov 3D 256\u00b3 single-level at 1/2/4/8 MI355X; % HBM roofline",
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if args.weak else "strong",
