@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of alternative builds of the kernel library (castro_amd/libvariant_*.so) inside one box, interleaved twice
+for rep in 1 2; do
+for v in default $(ls castro_amd/libvariant_*.so 2>/dev/null); do
+  if [ "$v" = default ]; then unset CASTRO_AMD_LIB; else export CASTRO_AMD_LIB=$PWD/$v; fi
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=d['path_roofline']['kernel_ms_per_step']; print('$v', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items() if a in ('k_trace','k_trans1','k_final','k_riemann1','k_consup_clean')})"
+done; done
