@@ -4,17 +4,24 @@
 // Source/hydro/Castro_ctu_hydro.cpp:130-1480):
 //
 //   k_ctoprim      U(Sborder) -> compact primitives Q = (rho,u,v,w,p,rhoe,X,c)     [ctoprim + EOS]
-//   k_divu         Q -> node-centred div(u)                                        [divu]
-//   k_trace        Q -> flattening coefficient (registers only) -> PPM parabolas ->
-//                  characteristic tracing in x,y,z -> edge states QM/QP            [uflatten + 3x trace_ppm]
-//   k_riemann1<D>  QM/QP[D] -> first transverse fluxes F1[D] (+ Godunov un, p)     [cmpflx_plus_godunov x3]
-//   k_trans1<N>    QM/QP[N] + F1[T1], F1[T2] -> corrected states (registers only)
-//                  -> Riemann -> F2[N|T1], F2[N|T2]                                [6x trans_single (x2) + 6x cmpflx]
+//   k_divu         Q -> node-centred div(u) (+ shock flag for the hybrid solver)   [divu, shock]
+//   k_trace_pair   Q -> flattening coefficient (registers only) -> PPM parabolas ->
+//                  characteristic tracing in x,y,z -> edge states QM/QP, and the first
+//                  x Riemann solve on the faces between lanes -> F1[x]             [uflatten + 3x trace_ppm + cmpflx]
+//                  (k_trace<SRC,PLM>: one zone per thread, with old_source / PLM;
+//                   k_riemann1_blockstart: the x faces at workgroup starts)
+//   k_riemann1<D>  QM/QP[D] -> first transverse fluxes F1[D] (+ Godunov un, p)     [cmpflx_plus_godunov, D = y, z]
+//   k_trans1       QM/QP[N] + F1[T1], F1[T2] -> corrected states (registers only)
+//                  -> Riemann -> F2[N|T1], F2[N|T2], N = x, y, z in one launch     [6x trans_single (x2) + 6x cmpflx]
 //   k_final<N>     QM/QP[N] + F2[T1|T2], F2[T2|T1] -> ql,qr (registers) -> Riemann ->
 //                  artificial viscosity, species normalisation, scaling,
-//                  fluxes += , mass_fluxes = , qe                                  [trans_final, cmpflx, apply_av,
+//                  fluxes += / = , mass_fluxes = , qe                              [trans_final, cmpflx, apply_av,
 //                                                                                   normalize_species_fluxes, scale_flux]
-//   k_consup       S_new (+)= dt*div(F) - dt*p*div(u) term                         [consup_hydro]
+//   k_consup       S_new (+)= dt*div(F) - dt*p*div(u) term, optionally followed in
+//                  registers by S_new.min, clean_state and the CFL estimate          [consup_hydro (+ clean_state, estdt_cfl)]
+//
+// The heavy kernels process two x-adjacent zones (faces) per thread with 16-byte accesses; a caller may split
+// the update into the part that reads no ghost zone and the rest (CASTRO_AMD_STAGE_A / _B, launch_ctu_hydro).
 //
 // Data layout.  All scratch arrays share ONE index space: the tile grown by 4 (same as
 // Sborder), unit stride along x, one plane of NC doubles per component (SoA), so every
