@@ -136,6 +136,7 @@ def _single(n, bcs, nsteps, oracle):
     (2, (16, 16, 16), ((2, 2, 2), (2, 2, 2))),          # outflow, split in z
     (2, (16, 8, 16), ((0, 4, 0), (0, 4, 0))),           # periodic x,z (self-wrap in x, peer-wrap in z) + walls in y
     (4, (8, 16, 16), ((2, 3, 2), (2, 2, 5))),           # 1x2x2 grid: faces + an edge neighbour
+    (8, (16, 16, 16), ((2, 2, 2), (2, 2, 2))),          # 2x2x2 grid (the 8-GPU layout): faces, edges and the corner
 ])
 def test_decomposed_run_is_bitwise_identical_gloo(tmp_path, oracle, world, n, bcs):
     """Decomposition independence: ghost data are exact copies, so N ranks give the
