@@ -9,11 +9,11 @@ Layout:
   plotfile.py      Castro plotfile writer / reader
 """
 from ._lib import (NUM_STATE, NGDNV, NUM_GROW, URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS,
-                   default_params, make_geom, LIB_PATH)
+                   default_params, make_geom, make_rotation, LIB_PATH)
 from .castro import Castro, DistComm, SingleComm, AdvanceFailure, default_grid
 from .amr import CastroAmr
 
-__all__ = ["Castro", "CastroAmr", "DistComm", "SingleComm", "AdvanceFailure", "default_grid", "default_params", "make_geom",
+__all__ = ["Castro", "CastroAmr", "DistComm", "SingleComm", "AdvanceFailure", "default_grid", "default_params", "make_geom", "make_rotation",
            "NUM_STATE", "NGDNV", "NUM_GROW", "LIB_PATH"]
 
 

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab",
     "castro_amd_error_tag_fab", "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
+    "castro_amd_old_rotation_source_fab", "castro_amd_new_rotation_source_fab",
     "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
@@ -40,6 +41,27 @@ EXPORTED_SYMBOLS = (
 class Fab(C.Structure):
     """castro_amd_fab: FArrayBox descriptor (pointer, lo, hi, ncomp)."""
     _fields_ = [("p", C.c_void_p), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("ncomp", C.c_int)]
+
+
+class Rotation(C.Structure):
+    """castro_amd_rotation"""
+    _fields_ = [("omega", C.c_double * 3), ("center", C.c_double * 3), ("include_centrifugal", C.c_int),
+                ("include_coriolis", C.c_int), ("rot_source_type", C.c_int), ("implicit_rotation_update", C.c_int)]
+
+
+def make_rotation(rotational_period, rot_axis=3, center=(0.5, 0.5, 0.5), include_centrifugal=1, include_coriolis=1,
+                  rot_source_type=4, implicit_rotation_update=1):
+    """castro.rotational_period / castro.rot_axis -> omega (Source/rotation/Rotation.H:10-22)"""
+    import math
+    R = Rotation()
+    for d in range(3):
+        R.omega[d] = 0.0
+        R.center[d] = center[d]
+    if rotational_period > 0.0:
+        R.omega[rot_axis - 1] = 2.0 * math.pi / rotational_period
+    R.include_centrifugal, R.include_coriolis = include_centrifugal, include_coriolis
+    R.rot_source_type, R.implicit_rotation_update = rot_source_type, implicit_rotation_update
+    return R
 
 
 class Geom(C.Structure):
@@ -100,6 +122,10 @@ def load():
     L.castro_amd_old_gravity_source_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, D3, C.c_int, C.c_double, C.c_void_p]
     L.castro_amd_new_gravity_source_fab.argtypes = [C.c_void_p, PF, PF, PF, PF, I3, I3, D3, C.c_int, C.c_double,
                                                     C.POINTER(Geom), C.c_void_p]
+    L.castro_amd_old_rotation_source_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.POINTER(Rotation), C.POINTER(Geom),
+                                                     C.c_double, C.c_void_p]
+    L.castro_amd_new_rotation_source_fab.argtypes = [C.c_void_p, PF, PF, PF, PF, I3, I3, C.POINTER(Rotation), C.POINTER(Geom),
+                                                     C.c_double, C.c_void_p]
     L.castro_amd_saxpy_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]
     L.castro_amd_error_tag_fab.argtypes = [C.c_void_p, PF, C.c_int, PF, I3, I3, C.c_int, C.c_double, C.c_void_p]
     L.castro_amd_cc_interp_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.c_void_p]

@@ -115,7 +115,7 @@ class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None):
+                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -186,7 +186,10 @@ class Castro:
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
         # castro.do_grav with gravity.gravity_type = "ConstantGrav": g along the last dimension (Gravity.cpp:860-866)
         self.do_grav, self.grav, self.grav_source_type = bool(do_grav), (0.0, 0.0, float(const_grav)), int(grav_source_type)
-        if self.do_grav:
+        # castro.do_rotation: `rotation` = _lib.make_rotation(rotational_period, rot_axis, ...)
+        self.rotation = rotation
+        self.have_sources = self.do_grav or rotation is not None
+        if self.have_sources:
             NSRC, NGS = 7, 3            # NSRC, NUM_GROW_SRC (Castro_setup.cpp:317-327)
             self.sbox = (tuple(x - NGS for x in self.lo), tuple(x + NGS for x in self.hi))
             self.old_source = hydro.alloc(NSRC, *self.sbox)
@@ -379,9 +382,9 @@ class Castro:
         # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
         # (:221-225) and the estTimeStep validity check (:386-392) are fused into the update pass
         # (no new-time source terms on this path) + one 2-double allreduce
-        fuse = self.fuse_clean and not self.do_grav
+        fuse = self.fuse_clean and not self.have_sources
         self.red.fill_(1.e200)
-        if self.do_grav:
+        if self.have_sources:
             return self._do_advance_with_sources(time, dt, S)
 
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
@@ -424,7 +427,8 @@ class Castro:
         return True, "", new_dt
 
     def _do_advance_with_sources(self, time, dt, S):
-        """do_advance_ctu with old- and new-time gravity sources (Castro_advance_ctu.cpp:94-143, 156-274)."""
+        """do_advance_ctu with old- and new-time gravity / rotation sources (Castro_advance_ctu.cpp:94-143, 156-274;
+        construct_old_source / construct_new_source, Source/sources/Castro_sources.cpp:230-349)."""
         h = self.hydro
         lo, hi = self.lo, self.hi
         self.expand_state(S)
@@ -432,7 +436,10 @@ class Castro:
         h.copy(self.S_new_b, self.gbox, S, self.gbox, lo, hi)
         # do_old_sources (:127-131): construct at t^n, apply with the full dt, clean_state; FillPatch the source
         self.old_source.zero_()
-        h.old_gravity_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.grav, self.grav_source_type, dt)
+        if self.do_grav:
+            h.old_gravity_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.grav, self.grav_source_type, dt)
+        if self.rotation is not None:
+            h.old_rotation_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.rotation, self.geom, dt)
         h.saxpy(self.S_new_b, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi)
         h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
         self.expand_state(self.old_source, self.sbox, self.src_neighbors)
@@ -447,8 +454,12 @@ class Castro:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         # do_new_sources (:262-268): corrector from the new state, apply, clean_state
         self.new_source.zero_()
-        h.new_gravity_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
-                             self.flux_boxes, lo, hi, self.grav, self.grav_source_type, dt, self.geom)
+        if self.do_grav:
+            h.new_gravity_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
+                                 self.flux_boxes, lo, hi, self.grav, self.grav_source_type, dt, self.geom)
+        if self.rotation is not None:
+            h.new_rotation_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
+                                  self.flux_boxes, lo, hi, self.rotation, self.geom, dt)
         h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
         h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
         # timestep validity check (:386-392)

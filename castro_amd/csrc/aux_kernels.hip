@@ -2,6 +2,7 @@
 // clean_state, CFL/min-density reduction, physical-BC ghost fill, FAB copy / halo pack,
 // problem initial data.  Reference locations are cited per kernel.
 #include <hip/hip_runtime.h>
+#include "../../include/castro_hydro_amd.h"
 #include "hydro_device.h"
 #include "ctu_kernels.h"
 
@@ -283,6 +284,184 @@ __global__ void __launch_bounds__(256) k_saxpy(DFab D, DFab S, Box3 b, double a,
     for (int n = 0; n < ncomp; ++n) D.p[cd + D.sn * n] += a * S.p[cs + S.sn * n];
 }
 
+// ---------------------------------------------------------------------------------------
+// rotation source terms, state_in_rotating_frame = 1 (Source/rotation/Rotation.H:10-95,
+// Source/rotation/rotation_sources.cpp:9-500; math.H:9-17; position(): Castro_util.H:87-140)
+// ---------------------------------------------------------------------------------------
+struct RotDev {
+    double omega[3], center[3];
+    int include_centrifugal, include_coriolis, rot_source_type, implicit_update;
+    double dx[3], problo[3], probhi[3];
+    int domlo[3], domhi[3], periodic[3];
+    double M[3][3];
+};
+
+__device__ __forceinline__ void cross_product(const double a[3], const double b[3], double c[3])
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ void rot_position(const RotDev& R, int i, int j, int k, double loc[3])
+{
+    const int idx[3] = { i, j, k };
+    for (int d = 0; d < 3; ++d) {
+        double offset = R.problo[d] + 0.5 * R.dx[d];
+        if (R.periodic[d]) {
+            if (idx[d] < R.domlo[d]) offset += R.probhi[d] - R.problo[d];
+            if (idx[d] > R.domhi[d]) offset += R.problo[d] - R.probhi[d];
+        }
+        loc[d] = offset + (double)idx[d] * R.dx[d];
+    }
+}
+
+__device__ __forceinline__ void rotational_acceleration(const RotDev& R, const double r[3], const double v[3], bool coriolis, double Sr[3])
+{
+    Sr[0] = 0.0; Sr[1] = 0.0; Sr[2] = 0.0;
+    const bool c1 = R.include_centrifugal == 1;
+    const bool c2 = R.include_coriolis == 1 && coriolis;
+    double omega_cross_v[3];
+    cross_product(R.omega, v, omega_cross_v);
+    if (c1) {
+        double omega_cross_r[3], omega_cross_omega_cross_r[3];
+        cross_product(R.omega, r, omega_cross_r);
+        cross_product(R.omega, omega_cross_r, omega_cross_omega_cross_r);
+        for (int d = 0; d < 3; ++d) Sr[d] -= omega_cross_omega_cross_r[d];
+    }
+    if (c2) {
+        for (int d = 0; d < 3; ++d) Sr[d] -= 2.0 * omega_cross_v[d];
+    }
+}
+
+__device__ __forceinline__ double rot_phi_at(const RotDev& R, int i, int j, int k)
+{
+    double loc[3];
+    rot_position(R, i, j, k, loc);
+    for (int d = 0; d < 3; ++d) loc[d] -= R.center[d];
+    double phi = 0.0;
+    if (R.include_centrifugal == 1) {
+        double omega_cross_r[3];
+        cross_product(R.omega, loc, omega_cross_r);
+        for (int d = 0; d < 3; ++d) phi -= 0.5 * omega_cross_r[d] * omega_cross_r[d];
+    }
+    return phi;
+}
+
+__global__ void __launch_bounds__(256) k_old_rot_source(DFab U, DFab SRC, Box3 b, RotDev R, double dt)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    double Sr[3], src[NSRC], snew[NUM_STATE], loc[3], v[3];
+    for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
+    rot_position(R, i, j, k, loc);
+    for (int d = 0; d < 3; ++d) loc[d] -= R.center[d];
+    const long c = fidx(U, i, j, k, 0);
+    double rho = U.p[c + U.sn * URHO];
+    double rhoInv = 1.0 / rho;
+    for (int n = 0; n < NUM_STATE; ++n) snew[n] = U.p[c + U.sn * n];
+    const double umx = snew[UMX], umy = snew[UMY], umz = snew[UMZ];
+    double old_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoInv;
+    v[0] = umx * rhoInv;
+    v[1] = umy * rhoInv;
+    v[2] = umz * rhoInv;
+    rotational_acceleration(R, loc, v, true, Sr);
+    for (int n = 0; n < 3; ++n) Sr[n] = rho * Sr[n];
+    src[UMX] = Sr[0]; src[UMY] = Sr[1]; src[UMZ] = Sr[2];
+    snew[UMX] += dt * src[UMX];
+    snew[UMY] += dt * src[UMY];
+    snew[UMZ] += dt * src[UMZ];
+    double SrE;
+    if (R.rot_source_type == 3) {
+        double new_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoInv;
+        SrE = new_ke - old_ke;
+    } else {
+        SrE = umx * rhoInv * Sr[0] + umy * rhoInv * Sr[1] + umz * rhoInv * Sr[2];
+    }
+    src[UEDEN] += SrE;
+    const long cs = fidx(SRC, i, j, k, 0);
+    for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
+}
+
+__global__ void __launch_bounds__(256) k_new_rot_source(DFab UO, DFab UN, DFab SRC, DFab M0, DFab M1, DFab M2, Box3 b, RotDev R, double dt)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const double vol = R.dx[0] * R.dx[1] * R.dx[2];
+    double Sr_old[3], Sr_new[3], Srcorr[3], src[NSRC], snew[NUM_STATE], loc[3];
+    for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
+    rot_position(R, i, j, k, loc);
+    for (int d = 0; d < 3; ++d) loc[d] -= R.center[d];
+    const long co = fidx(UO, i, j, k, 0), cn = fidx(UN, i, j, k, 0);
+    double rhoo = UO.p[co + UO.sn * URHO];
+    double rhooinv = 1.0 / UO.p[co + UO.sn * URHO];
+    double rhon = UN.p[cn + UN.sn * URHO];
+    double rhoninv = 1.0 / UN.p[cn + UN.sn * URHO];
+    for (int n = 0; n < NUM_STATE; ++n) snew[n] = UN.p[cn + UN.sn * n];
+    const double nm[3] = { snew[UMX], snew[UMY], snew[UMZ] };
+    double old_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoninv;
+    double vold[3], vnew[3];
+    vold[0] = UO.p[co + UO.sn * UMX] * rhooinv;
+    vold[1] = UO.p[co + UO.sn * UMY] * rhooinv;
+    vold[2] = UO.p[co + UO.sn * UMZ] * rhooinv;
+    rotational_acceleration(R, loc, vold, true, Sr_old);
+    for (int n = 0; n < 3; ++n) Sr_old[n] = rhoo * Sr_old[n];
+    double SrE_old = vold[0] * Sr_old[0] + vold[1] * Sr_old[1] + vold[2] * Sr_old[2];
+    vnew[0] = nm[0] * rhoninv;
+    vnew[1] = nm[1] * rhoninv;
+    vnew[2] = nm[2] * rhoninv;
+    rotational_acceleration(R, loc, vnew, true, Sr_new);
+    for (int n = 0; n < 3; ++n) Sr_new[n] = rhon * Sr_new[n];
+    double SrE_new = vnew[0] * Sr_new[0] + vnew[1] * Sr_new[1] + vnew[2] * Sr_new[2];
+    for (int n = 0; n < 3; ++n) Srcorr[n] = 0.5 * (Sr_new[n] - Sr_old[n]);
+    if (R.implicit_update == 1) {
+        double acc[3], new_mom_tmp[3], new_mom[3] = { 0.0, 0.0, 0.0 };
+        rotational_acceleration(R, loc, vnew, false, acc);
+        for (int n = 0; n < 3; ++n) new_mom_tmp[n] = nm[n] - 0.5 * Sr_old[n] * dt + 0.5 * rhon * acc[n] * dt;
+        for (int l = 0; l < 3; ++l)
+            for (int m = 0; m < 3; ++m) new_mom[l] += R.M[l][m] * new_mom_tmp[m];
+        for (int n = 0; n < 3; ++n) Srcorr[n] = (new_mom[n] - nm[n]) / dt;
+    }
+    src[UMX] = Srcorr[0]; src[UMY] = Srcorr[1]; src[UMZ] = Srcorr[2];
+    snew[UMX] += dt * src[UMX];
+    snew[UMY] += dt * src[UMY];
+    snew[UMZ] += dt * src[UMZ];
+    double SrEcorr;
+    if (R.rot_source_type == 1) {
+        SrEcorr = 0.5 * (SrE_new - SrE_old);
+    } else if (R.rot_source_type == 2) {
+        double vn[3], acc[3];
+        vn[0] = snew[UMX] * rhoninv; vn[1] = snew[UMY] * rhoninv; vn[2] = snew[UMZ] * rhoninv;
+        rotational_acceleration(R, loc, vn, true, acc);
+        Sr_new[0] = rhon * acc[0]; Sr_new[1] = rhon * acc[1]; Sr_new[2] = rhon * acc[2];
+        double SrE_new2 = vn[0] * Sr_new[0] + vn[1] * Sr_new[1] + vn[2] * Sr_new[2];
+        SrEcorr = 0.5 * (SrE_new2 - SrE_old);
+    } else if (R.rot_source_type == 3) {
+        double new_ke = 0.5 * (snew[UMX] * snew[UMX] + snew[UMY] * snew[UMY] + snew[UMZ] * snew[UMZ]) * rhoninv;
+        SrEcorr = new_ke - old_ke;
+    } else {
+        SrEcorr = -SrE_old;
+        // phi_old == phi_new: the potential of a steady rotation
+        double p0 = rot_phi_at(R, i, j, k);
+        double phi = 0.5 * (p0 + p0);
+        double pxl = rot_phi_at(R, i - 1, j, k), pxr = rot_phi_at(R, i + 1, j, k);
+        double pyl = rot_phi_at(R, i, j - 1, k), pyr = rot_phi_at(R, i, j + 1, k);
+        double pzl = rot_phi_at(R, i, j, k - 1), pzr = rot_phi_at(R, i, j, k + 1);
+        double phixl = 0.5 * (pxl + pxl), phixr = 0.5 * (pxr + pxr);
+        double phiyl = 0.5 * (pyl + pyl), phiyr = 0.5 * (pyr + pyr);
+        double phizl = 0.5 * (pzl + pzl), phizr = 0.5 * (pzr + pzr);
+        SrEcorr = SrEcorr - (0.5 / dt) * ( M0.p[fidx(M0, i, j, k, 0)] * (phi - phixl) -
+                                           M0.p[fidx(M0, i + 1, j, k, 0)] * (phi - phixr) +
+                                           M1.p[fidx(M1, i, j, k, 0)] * (phi - phiyl) -
+                                           M1.p[fidx(M1, i, j + 1, k, 0)] * (phi - phiyr) +
+                                           M2.p[fidx(M2, i, j, k, 0)] * (phi - phizl) -
+                                           M2.p[fidx(M2, i, j, k + 1, 0)] * (phi - phizr) ) / vol;
+    }
+    src[UEDEN] = SrEcorr;
+    const long cs = fidx(SRC, i, j, k, 0);
+    for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
+}
+
 static Box3 make_box3(const int lo[3], const int hi[3], long& n)
 {
     Box3 b;
@@ -311,6 +490,60 @@ int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, cons
     prof_begin(prof, "k_new_grav_source", stream);
     hipLaunchKernelGGL(k_new_grav_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, UO, UN, SRC, M[0], M[1], M[2], b,
                        grav[0], grav[1], grav[2], type, dt, dx[0], dx[1], dx[2]);
+    prof_end(prof, stream);
+    return 0;
+}
+
+static RotDev make_rotdev(const castro_amd_rotation* r, const castro_amd_geom* g, double dt)
+{
+    RotDev R;
+    for (int d = 0; d < 3; ++d) {
+        R.omega[d] = r->omega[d]; R.center[d] = r->center[d];
+        R.dx[d] = g->dx[d]; R.problo[d] = g->problo[d]; R.probhi[d] = g->probhi[d];
+        R.domlo[d] = g->domlo[d]; R.domhi[d] = g->domhi[d];
+        R.periodic[d] = (g->lo_bc[d] == 0 && g->hi_bc[d] == 0) ? 1 : 0;
+    }
+    R.include_centrifugal = r->include_centrifugal; R.include_coriolis = r->include_coriolis;
+    R.rot_source_type = r->rot_source_type; R.implicit_update = r->implicit_rotation_update;
+    // the matrix of the implicit Coriolis update, rotation_sources.cpp:186-237 (host side, like the reference)
+    double w[3];
+    for (int d = 0; d < 3; ++d) w[d] = (r->include_coriolis == 1) ? dt * r->omega[d] : 0.0;
+    for (int l = 0; l < 3; ++l) for (int m = 0; m < 3; ++m) R.M[l][m] = 0.0;
+    if (r->implicit_rotation_update == 1) {
+        R.M[0][0] = 1.0 + w[0] * w[0];
+        R.M[0][1] = w[0] * w[1] + w[2];
+        R.M[0][2] = w[0] * w[2] - w[1];
+        R.M[1][0] = w[1] * w[0] - w[2];
+        R.M[1][1] = 1.0 + w[1] * w[1];
+        R.M[1][2] = w[1] * w[2] + w[0];
+        R.M[2][0] = w[2] * w[0] + w[1];
+        R.M[2][1] = w[2] * w[1] - w[0];
+        R.M[2][2] = 1.0 + w[2] * w[2];
+        for (int l = 0; l < 3; ++l)
+            for (int m = 0; m < 3; ++m) R.M[l][m] /= (1.0 + w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    }
+    return R;
+}
+
+int launch_old_rot_source(const DFab& U, const DFab& SRC, const int lo[3], const int hi[3], const castro_amd_rotation* r,
+                          const castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof)
+{
+    long n; Box3 b = make_box3(lo, hi, n);
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_old_rot_source", stream);
+    hipLaunchKernelGGL(k_old_rot_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, SRC, b, make_rotdev(r, g, dt), dt);
+    prof_end(prof, stream);
+    return 0;
+}
+
+int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
+                          const castro_amd_rotation* r, const castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof)
+{
+    long n; Box3 b = make_box3(lo, hi, n);
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_new_rot_source", stream);
+    hipLaunchKernelGGL(k_new_rot_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, UO, UN, SRC, M[0], M[1], M[2], b,
+                       make_rotdev(r, g, dt), dt);
     prof_end(prof, stream);
     return 0;
 }

@@ -385,6 +385,40 @@ int castro_amd_new_gravity_source_fab(castro_amd_ctx* c, const castro_amd_fab* s
                                   dt, geom->dx, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_old_rotation_source_fab(castro_amd_ctx* c, const castro_amd_fab* state, const castro_amd_fab* source,
+                                       const int lo[3], const int hi[3], const castro_amd_rotation* rot,
+                                       const castro_amd_geom* geom, double dt, void* stream)
+{
+    if (!c || !state || !state->p || !source || !source->p || !rot || !geom) return CASTRO_AMD_ERR_ARG;
+    if (state->ncomp != NUM_STATE || source->ncomp < 7 || rot->rot_source_type < 1 || rot->rot_source_type > 4 || geom->coord != 0)
+        return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state, lo, hi) || !fab_contains(source, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_old_rot_source(to_dfab(state), to_dfab(source), lo, hi, rot, geom, dt, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_new_rotation_source_fab(castro_amd_ctx* c, const castro_amd_fab* state_old, const castro_amd_fab* state_new,
+                                       const castro_amd_fab* source, const castro_amd_fab mass_fluxes[3],
+                                       const int lo[3], const int hi[3], const castro_amd_rotation* rot,
+                                       const castro_amd_geom* geom, double dt, void* stream)
+{
+    if (!c || !state_old || !state_old->p || !state_new || !state_new->p || !source || !source->p || !mass_fluxes || !rot || !geom)
+        return CASTRO_AMD_ERR_ARG;
+    if (state_old->ncomp != NUM_STATE || state_new->ncomp != NUM_STATE || source->ncomp < 7) return CASTRO_AMD_ERR_ARG;
+    if (rot->rot_source_type < 1 || rot->rot_source_type > 4 || geom->coord != 0 || !(dt > 0.0)) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(state_old, lo, hi) || !fab_contains(state_new, lo, hi) || !fab_contains(source, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    DFab M[3];
+    for (int d = 0; d < 3; ++d) {
+        int fhi[3] = { hi[0], hi[1], hi[2] };
+        fhi[d] += 1;
+        if (!mass_fluxes[d].p || mass_fluxes[d].ncomp != 1 || !fab_contains(&mass_fluxes[d], lo, fhi)) return CASTRO_AMD_ERR_ARG;
+        M[d] = to_dfab(&mass_fluxes[d]);
+    }
+    hipSetDevice(c->device);
+    return launch_new_rot_source(to_dfab(state_old), to_dfab(state_new), to_dfab(source), M, lo, hi, rot, geom, dt,
+                                 (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_saxpy_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a, const castro_amd_fab* src, int ncomp,
                          const int lo[3], const int hi[3], void* stream)
 {

@@ -5,6 +5,9 @@
 #include <vector>
 #include "hydro_device.h"
 
+struct castro_amd_rotation;      // include/castro_hydro_amd.h
+struct castro_amd_geom;
+
 namespace cad {
 
 // one tile of work: bx = [lo,hi]; every scratch array is indexed on grow(bx,4)
@@ -73,6 +76,10 @@ int launch_old_grav_source(const DFab& U, const DFab& SRC, const int lo[3], cons
                            int type, double dt, hipStream_t stream, Profiler* prof);
 int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
                            const double grav[3], int type, double dt, const double dx[3], hipStream_t stream, Profiler* prof);
+int launch_old_rot_source(const DFab& U, const DFab& SRC, const int lo[3], const int hi[3], const ::castro_amd_rotation* r,
+                          const ::castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof);
+int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
+                          const ::castro_amd_rotation* r, const ::castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof);
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
 int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);

@@ -119,6 +119,22 @@ class HipHydro:
                                                            int(grav_source_type), float(dt), C.byref(geom), _stream_ptr(stream)),
                 "new_gravity_source_fab")
 
+    def old_rotation_source(self, state, box, source, src_box, lo, hi, rot, geom, dt, stream=None):
+        L.check(self.lib.castro_amd_old_rotation_source_fab(self.h, C.byref(L.fab_of(state, *box)), C.byref(L.fab_of(source, *src_box)),
+                                                            L.i3(lo), L.i3(hi), C.byref(rot), C.byref(geom), float(dt),
+                                                            _stream_ptr(stream)), "old_rotation_source_fab")
+
+    def new_rotation_source(self, state_old, old_box, state_new, new_box, source, src_box, mass_fluxes, flux_boxes, lo, hi,
+                            rot, geom, dt, stream=None):
+        mb = (L.Fab * 3)()
+        for d in range(3):
+            mb[d] = L.fab_of(mass_fluxes[d], *flux_boxes[d])
+        L.check(self.lib.castro_amd_new_rotation_source_fab(self.h, C.byref(L.fab_of(state_old, *old_box)),
+                                                            C.byref(L.fab_of(state_new, *new_box)),
+                                                            C.byref(L.fab_of(source, *src_box)), mb, L.i3(lo), L.i3(hi),
+                                                            C.byref(rot), C.byref(geom), float(dt), _stream_ptr(stream)),
+                "new_rotation_source_fab")
+
     def saxpy(self, dst, dst_box, a, src, src_box, ncomp, lo, hi, stream=None):
         """dst[:ncomp] += a * src[:ncomp] on [lo,hi] (Castro::apply_source_to_state)."""
         L.check(self.lib.castro_amd_saxpy_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(src, *src_box)),

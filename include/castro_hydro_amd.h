@@ -210,6 +210,28 @@ int castro_amd_new_gravity_source_fab(castro_amd_ctx *ctx, const castro_amd_fab 
 int castro_amd_saxpy_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double a, const castro_amd_fab *src, int ncomp,
                          const int lo[3], const int hi[3], void *stream);
 
+/* Rotation source terms in the rotating frame (castro.do_rotation, state_in_rotating_frame = 1):
+ *   castro_amd_old_rotation_source_fab  Castro::rsrc,     Source/rotation/rotation_sources.cpp:9-137
+ *   castro_amd_new_rotation_source_fab  Castro::corrrsrc, :140-500 (implicit Coriolis update :186-237,318-355;
+ *                                       rot_source_type 4 uses mass_fluxes[d] and the rotational potential,
+ *                                       Source/rotation/Rotation.H:77-95)
+ * omega = 2 pi / castro.rotational_period along castro.rot_axis (Rotation.H:10-22); center = problem::center. */
+typedef struct castro_amd_rotation {
+    double omega[3];
+    double center[3];
+    int include_centrifugal;        /* castro.rotation_include_centrifugal (default 1) */
+    int include_coriolis;           /* castro.rotation_include_coriolis (1) */
+    int rot_source_type;            /* castro.rot_source_type 1..4 (4) */
+    int implicit_rotation_update;   /* castro.implicit_rotation_update (1) */
+} castro_amd_rotation;
+int castro_amd_old_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, const castro_amd_fab *source,
+                                       const int lo[3], const int hi[3], const castro_amd_rotation *rot,
+                                       const castro_amd_geom *geom, double dt, void *stream);
+int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab *state_old, const castro_amd_fab *state_new,
+                                       const castro_amd_fab *source, const castro_amd_fab mass_fluxes[3],
+                                       const int lo[3], const int hi[3], const castro_amd_rotation *rot,
+                                       const castro_amd_geom *geom, double dt, void *stream);
+
 /* Two-level AMR building blocks, refinement ratio 2 (first slice).  The reference calls AMReX for
  * all of these [3P, not in the reference tree]; the arithmetic is restated from the published descriptions and is
  * NOT pinned against an AMReX build:

@@ -105,6 +105,19 @@ void ora_new_gravity_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a
                             const ora_a4 mflux[3], const double grav[3], int grav_source_type, double dt,
                             const double dx[3]);
 void ora_saxpy(const int lo[3], const int hi[3], ora_a4 dst, double a, ora_a4 src, int ncomp);
+/* castro.do_rotation with state_in_rotating_frame = 1 (Source/rotation): omega = 2 pi / rotational_period along rot_axis */
+typedef struct {
+    double omega[3];
+    double center[3];              /* problem::center */
+    int include_centrifugal;       /* castro.rotation_include_centrifugal (1) */
+    int include_coriolis;          /* castro.rotation_include_coriolis (1) */
+    int rot_source_type;           /* castro.rot_source_type 1..4 (4) */
+    int implicit_rotation_update;  /* castro.implicit_rotation_update (1) */
+} ora_rotation;
+void ora_old_rotation_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a4 source, const ora_rotation *R,
+                             const ora_geom *G, double dt);
+void ora_new_rotation_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a4 unew, ora_a4 source,
+                             const ora_a4 mflux[3], const ora_rotation *R, const ora_geom *G, double dt);
 /* two-level AMR building blocks (AMReX arithmetic restated, see ora_amr.c) */
 void ora_cc_interp(const int lo[3], const int hi[3], ora_a4 crse, ora_a4 fine, int ncomp);
 void ora_avgdown(const int lo[3], const int hi[3], ora_a4 fine, ora_a4 crse, int ncomp);
@@ -207,6 +220,7 @@ int  ora_level_nretries(ora_level *L);
 double *ora_level_old_state(ora_level *L);
 /* castro.do_grav with gravity.gravity_type = ConstantGrav: sources in do_advance_ctu (Castro_advance_ctu.cpp:113-143,256-274) */
 void ora_level_set_gravity(ora_level *L, int do_grav, double const_grav, int grav_source_type);
+void ora_level_set_rotation(ora_level *L, int do_rot, const ora_rotation *R);
 double ora_level_last_hydro_seconds(ora_level *L);
 
 #ifdef __cplusplus

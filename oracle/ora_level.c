@@ -30,6 +30,8 @@ struct ora_level {
     int do_grav, grav_source_type;   /* castro.do_grav, castro.grav_source_type; gravity.const_grav along z */
     double grav[3];
     double *old_source, *new_source; /* Source_Type old (NUM_GROW_SRC ghosts) / new data */
+    int do_rot;                      /* castro.do_rotation */
+    ora_rotation rot;
 };
 
 static double now_s(void)
@@ -174,7 +176,8 @@ static int level_do_advance(ora_level *L, double time, double dt)
     ora_a4 src; memset(&src, 0, sizeof(src));
     ora_a4 osrc, nsrc;
     int slo[3], shi[3];
-    if (L->do_grav) {
+    const int have_src = L->do_grav || L->do_rot;
+    if (have_src) {
         size_t ns = 1, nv1 = 1;
         for (int d = 0; d < 3; ++d) {
             slo[d] = L->lo[d] - NUM_GROW_SRC; shi[d] = L->hi[d] + NUM_GROW_SRC;
@@ -185,7 +188,8 @@ static int level_do_advance(ora_level *L, double time, double dt)
         memset(L->old_source, 0, sizeof(double) * ns * NSRC);
         osrc = ora_make_a4(L->old_source, slo, shi, NSRC);
         nsrc = ora_make_a4(L->new_source, L->lo, L->hi, NSRC);
-        ora_old_gravity_source(L->lo, L->hi, Sb, osrc, L->grav, L->grav_source_type, dt);
+        if (L->do_grav) ora_old_gravity_source(L->lo, L->hi, Sb, osrc, L->grav, L->grav_source_type, dt);
+        if (L->do_rot) ora_old_rotation_source(L->lo, L->hi, Sb, osrc, &L->rot, &L->G, dt);
         ora_saxpy(L->lo, L->hi, S_new, dt, osrc, NSRC);
         ora_clean_state(L->lo, L->hi, S_new, P);
         ora_bc_fill(osrc, &L->G);
@@ -206,9 +210,10 @@ static int level_do_advance(ora_level *L, double time, double dt)
     ora_clean_state(L->lo, L->hi, S_new, P);
 
     /* new-time sources (:256-274): do_new_sources = construct the corrector, apply, clean_state */
-    if (L->do_grav) {
+    if (have_src) {
         memset(L->new_source, 0, sizeof(double) * (size_t)nsrc.sn * NSRC);
-        ora_new_gravity_source(L->lo, L->hi, Sb, S_new, nsrc, mf, L->grav, L->grav_source_type, dt, L->G.dx);
+        if (L->do_grav) ora_new_gravity_source(L->lo, L->hi, Sb, S_new, nsrc, mf, L->grav, L->grav_source_type, dt, L->G.dx);
+        if (L->do_rot) ora_new_rotation_source(L->lo, L->hi, Sb, S_new, nsrc, mf, &L->rot, &L->G, dt);
         ora_saxpy(L->lo, L->hi, S_new, dt, nsrc, NSRC);
         ora_clean_state(L->lo, L->hi, S_new, P);
     }
@@ -287,6 +292,12 @@ void ora_level_set_gravity(ora_level *L, int do_grav, double const_grav, int gra
 {
     L->do_grav = do_grav; L->grav_source_type = grav_source_type;
     L->grav[0] = 0.0; L->grav[1] = 0.0; L->grav[2] = const_grav;     /* Gravity.cpp:860-866 */
+}
+
+void ora_level_set_rotation(ora_level *L, int do_rot, const ora_rotation *R)
+{
+    L->do_rot = do_rot;
+    if (R) L->rot = *R;
 }
 
 int ora_level_nsubcycles(ora_level *L) { return L->nsubcycles; }

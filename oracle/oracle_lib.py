@@ -29,6 +29,26 @@ class Params(C.Structure):
             "eos_gamma", "small_x", "T_guess", "abar", "pslope_cutoff_density")]
 
 
+class Rotation(C.Structure):
+    _fields_ = [("omega", C.c_double * 3), ("center", C.c_double * 3), ("include_centrifugal", C.c_int),
+                ("include_coriolis", C.c_int), ("rot_source_type", C.c_int), ("implicit_rotation_update", C.c_int)]
+
+
+def make_rotation(rotational_period, rot_axis=3, center=(0.5, 0.5, 0.5), include_centrifugal=1, include_coriolis=1,
+                  rot_source_type=4, implicit_rotation_update=1):
+    """castro.rotational_period / rot_axis -> omega (Rotation.H:10-22)"""
+    import math
+    R = Rotation()
+    for d in range(3):
+        R.omega[d] = 0.0
+        R.center[d] = center[d]
+    if rotational_period > 0.0:
+        R.omega[rot_axis - 1] = 2.0 * math.pi / rotational_period
+    R.include_centrifugal, R.include_coriolis = include_centrifugal, include_coriolis
+    R.rot_source_type, R.implicit_rotation_update = rot_source_type, implicit_rotation_update
+    return R
+
+
 class Geom(C.Structure):
     _fields_ = [("dx", C.c_double * 3), ("problo", C.c_double * 3), ("probhi", C.c_double * 3),
                 ("domlo", C.c_int * 3), ("domhi", C.c_int * 3),
@@ -119,6 +139,9 @@ def lib():
         L.ora_reflux.argtypes = [I3, I3, A4, A4, C.c_int, C.c_int, C.c_int, C.c_double]
         L.ora_error_tag.argtypes = [I3, I3, A4, C.c_int, A4, C.c_int, C.c_double]
         L.ora_lincomb.argtypes = [I3, I3, A4, C.c_double, A4, C.c_double, A4, C.c_int]
+        L.ora_level_set_rotation.argtypes = [C.c_void_p, C.c_int, C.POINTER(Rotation)]
+        L.ora_old_rotation_source.argtypes = [I3, I3, A4, A4, C.POINTER(Rotation), C.POINTER(Geom), C.c_double]
+        L.ora_new_rotation_source.argtypes = [I3, I3, A4, A4, A4, A4 * 3, C.POINTER(Rotation), C.POINTER(Geom), C.c_double]
         L.ora_level_set_gravity.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
         L.ora_saxpy.argtypes = [I3, I3, A4, C.c_double, A4, C.c_int]
         L.ora_old_gravity_source.argtypes = [I3, I3, A4, A4, C.POINTER(C.c_double * 3), C.c_int, C.c_double]
@@ -261,6 +284,11 @@ class Level:
     def set_gravity(self, const_grav, grav_source_type=4):
         """castro.do_grav = 1, gravity.gravity_type = ConstantGrav, gravity.const_grav (along z)."""
         lib().ora_level_set_gravity(self.h, 1, float(const_grav), int(grav_source_type))
+
+    def set_rotation(self, rot):
+        """castro.do_rotation = 1 with the parameters of make_rotation()."""
+        self._rot = rot
+        lib().ora_level_set_rotation(self.h, 1, C.byref(rot))
 
     def old_state(self):
         p = lib().ora_level_old_state(self.h)

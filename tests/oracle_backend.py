@@ -80,6 +80,25 @@ class OracleBackend:
         O.lib().ora_new_gravity_source(O.i3(lo), O.i3(hi), self._a4(state_old, old_box), self._a4(state_new, new_box),
                                        self._a4(source, src_box), mf, C.byref(g), int(grav_source_type), float(dt), C.byref(dx))
 
+    @staticmethod
+    def _rot(rot):
+        R = O.Rotation()
+        for f, _ in O.Rotation._fields_:
+            setattr(R, f, getattr(rot, f))
+        return R
+
+    def old_rotation_source(self, state, box, source, src_box, lo, hi, rot, geom, dt, stream=None):
+        O.lib().ora_old_rotation_source(O.i3(lo), O.i3(hi), self._a4(state, box), self._a4(source, src_box),
+                                        C.byref(self._rot(rot)), C.byref(geom), float(dt))
+
+    def new_rotation_source(self, state_old, old_box, state_new, new_box, source, src_box, mass_fluxes, flux_boxes, lo, hi,
+                            rot, geom, dt, stream=None):
+        mf = (O.A4 * 3)()
+        for d in range(3):
+            mf[d] = self._a4(mass_fluxes[d], flux_boxes[d])
+        O.lib().ora_new_rotation_source(O.i3(lo), O.i3(hi), self._a4(state_old, old_box), self._a4(state_new, new_box),
+                                        self._a4(source, src_box), mf, C.byref(self._rot(rot)), C.byref(geom), float(dt))
+
     def saxpy(self, dst, dst_box, a, src, src_box, ncomp, lo, hi, stream=None):
         O.lib().ora_saxpy(O.i3(lo), O.i3(hi), self._a4(dst, dst_box), float(a), self._a4(src, src_box), int(ncomp))
 
