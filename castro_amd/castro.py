@@ -16,7 +16,6 @@ xGMI link) on a communication stream, overlapped with the hydro update of the in
 sub-box, which needs no remote data, on the compute stream.
 """
 import itertools
-import time as _time
 
 import torch
 
