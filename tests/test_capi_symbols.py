@@ -36,6 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Fab) == 40
     assert C.sizeof(_lib.Geom) == 3 * 24 + 4 * 12 + 4 + 4
     assert C.sizeof(_lib.Params) == 14 * 4 + 16 * 8
+    assert C.sizeof(_lib.Rotation) == 6 * 8 + 4 * 4           # castro_amd_rotation
 
 
 def test_default_params_agree_with_oracle(lib, oracle):
