@@ -674,37 +674,39 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     const double cc[2] = { ccv.a, ccv.b };
 
     TraceW w[2];
-    double sA[5], sB[5];
     double un[2];
+    // software pipeline: the stencil of the next variable is requested before the parabola of the current one
+    // is evaluated (two register buffers): 3.30 -> 3.16 ms at 256^3
+    double aA[5], aB[5], bA[5], bB[5];
 
-    load_stencil_2<D>(Q + (long)QUN * NC, c, sd, sA, sB);
-    un[0] = sA[2]; un[1] = sB[2];
-    ppm_waves<2>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_un, w[0].Im_un);
-    ppm_waves<2>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
+    load_stencil_2<D>(Q + (long)QUN * NC, c, sd, aA, aB);
+    load_stencil_2<D>(Q + (long)PRHO * NC, c, sd, bA, bB);
+    un[0] = aA[2]; un[1] = aB[2];
+    ppm_waves<2>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_un, w[0].Im_un);
+    ppm_waves<2>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
 
-    load_stencil_2<D>(Q + (long)PRHO * NC, c, sd, sA, sB);
-    ppm_waves<3>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
-    ppm_waves<3>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
+    load_stencil_2<D>(Q + (long)PP * NC, c, sd, aA, aB);
+    ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
+    ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
 
-    load_stencil_2<D>(Q + (long)PP * NC, c, sd, sA, sB);
-    ppm_waves<3>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
-    ppm_waves<3>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
+    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB);
+    ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
+    ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
 
-    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, sA, sB);
-    ppm_waves<3>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_re, w[0].Im_re);
-    ppm_waves<3>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_re, w[1].Im_re);
+    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, aA, aB);
+    ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_re, w[0].Im_re);
+    ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_re, w[1].Im_re);
 
-    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, sA, sB);
-    ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
-    ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
+    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, bA, bB);
+    ppm_waves<1>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
+    ppm_waves<1>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
 
-    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, sA, sB);
-    ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
-    ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
+    load_stencil_2<D>(Q + (long)PX * NC, c, sd, aA, aB);
+    ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
+    ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
 
-    load_stencil_2<D>(Q + (long)PX * NC, c, sd, sA, sB);
-    ppm_waves<1>(sA, flat[0], un[0], cc[0], dtdx, w[0].Ip_X, w[0].Im_X);
-    ppm_waves<1>(sB, flat[1], un[1], cc[1], dtdx, w[1].Ip_X, w[1].Im_X);
+    ppm_waves<1>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_X, w[0].Im_X);
+    ppm_waves<1>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_X, w[1].Im_X);
 
     trace_finish<D>(w[0], un[0], cc[0], P, qp[0], qm[0]);
     trace_finish<D>(w[1], un[1], cc[1], P, qp[1], qm[1]);
