@@ -17,7 +17,10 @@ Interpolater classes [3P] is orchestrated here on top of two `Castro` level obje
                                                  box of the tags grown by n_error_buf and aligned to blocking_factor
                                                  (AMReX clusters tags into many boxes with Berger-Rigoutsos [3P])
 
-Any number of levels with fixed, properly nested patches (`patches=[...]`); the tag-driven patch is two-level.
+Any number of levels, either fixed, properly nested patches (`patches=[...]`) or tag-driven (`refine=[...]`,
+`max_level`): Amr::grid_places restated for one box per level -- tags are evaluated from the finest level down,
+each new box is the aligned, buffered bounding box of the tags of the level below united with the (coarsened,
+buffered) new box of the level above, so the hierarchy stays properly nested; a regrid adds at most one level.
 Not provided: Berger-Rigoutsos clustering, more than one patch per level, multi-rank AMR, gravity on AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
 (include/castro_hydro_amd.h): parity with an AMReX build is unpinned.
 """
@@ -69,12 +72,13 @@ _FIELDS = {"density": 0, "xmom": 1, "ymom": 2, "zmom": 3, "rho_E": 4, "rho_e": 5
 class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
-                 blocking_factor=8, patches=None):
+                 blocking_factor=8, patches=None, max_level=1):
         """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined patch;
         patches = [(lo, hi), ...]: one fixed patch per finer level, each in the index space of the level below it
         (amr.max_level = len(patches)); or
         refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name, kind:
-        value_greater | value_less | gradient | relative_gradient) for one patch that follows the tags."""
+        value_greater | value_less | gradient | relative_gradient) for patches that follow the tags, one per level up
+        to amr.max_level = max_level."""
         if patch_crse is not None:
             assert patches is None
             patches = [patch_crse]
@@ -90,6 +94,7 @@ class CastroAmr:
         self.refine = refine
         self.regrid_int, self.n_error_buf, self.blocking_factor = int(regrid_int), int(n_error_buf), int(blocking_factor)
         self.nregrid = 0
+        self.max_level = int(max_level) if refine is not None else len(patches or [])
         for pb in (patches or []):
             self._push_level(tuple(pb[0]), tuple(pb[1]))
         self.time, self.nstep = 0.0, 0
@@ -135,64 +140,121 @@ class CastroAmr:
         del self.lev[1:], self.pbox[1:], self.regs[1:]
 
     # ---- Castro::errorEst (Castro.cpp:3131-3164) + the one-box stand-in for the grid generator ------
-    def tag_box(self):
-        """Bounding box (coarse zones) of the tagged zones, buffered and aligned; None if nothing is tagged."""
-        c, h = self.crse, self.crse.hydro
-        c.expand_state(c.S_new_b)
+    def _fill_ghosts_new(self, upto):
+        """Ghost zones of the new-time data of levels 0..upto (each FillPatch reads the level below it)."""
+        for l in range(upto + 1):
+            lev = self.lev[l]
+            if l > 0:
+                lev.alpha = 1.0
+            lev.expand_state(lev.S_new_b)
+
+    def _align(self, lo, hi, l):
+        """Grow [lo, hi] (level-l zones) to multiples of blocking_factor/2 and clip it to the level-l domain."""
+        a = max(self.blocking_factor // 2, 1)                   # blocking_factor is in zones of level l+1
+        olo, ohi = [], []
+        for d in range(3):
+            olo.append(max((lo[d] // a) * a, 0))
+            ohi.append(min(-((-(hi[d] + 1)) // a) * a - 1, (2 ** l) * self.n_cell[d] - 1))
+        return tuple(olo), tuple(ohi)
+
+    def tag_box(self, l=0, ghosts_filled=False):
+        """Bounding box (level-l zones) of the tagged zones of level l, buffered and aligned; None if nothing is
+        tagged.  The box stays inside level l's own box."""
+        c = self.lev[l]
+        h = c.hydro
+        if not ghosts_filled:
+            self._fill_ghosts_new(l)
         tags = h.alloc(1, c.lo, c.hi)
         for field, kind, value in self.refine:
             h.error_tag(c.S_new_b, c.gbox, _FIELDS[field], tags, (c.lo, c.hi), c.lo, c.hi, _TAG_KINDS[kind], value)
-        nz = torch.nonzero(tags[0] > 0.5)                       # (k, j, i) triples
+        nz = torch.nonzero(tags[0] > 0.5)                       # (k, j, i) triples relative to c.lo
         if nz.numel() == 0:
             return None
         mn, mx = nz.min(dim=0).values.tolist(), nz.max(dim=0).values.tolist()
-        a = max(self.blocking_factor // 2, 1)                   # blocking_factor is in fine zones
-        lo, hi = [], []
-        for d in range(3):
-            l = mn[2 - d] - self.n_error_buf
-            u = mx[2 - d] + self.n_error_buf
-            l = (l // a) * a
-            u = -((-(u + 1)) // a) * a - 1
-            lo.append(max(l, 0))
-            hi.append(min(u, self.n_cell[d] - 1))
-        return tuple(lo), tuple(hi)
+        lo = tuple(max(c.lo[d] + mn[2 - d] - self.n_error_buf, c.lo[d]) for d in range(3))
+        hi = tuple(min(c.lo[d] + mx[2 - d] + self.n_error_buf, c.hi[d]) for d in range(3))
+        return self._align(lo, hi, l)
+
+    def _grid_places(self):
+        """boxes[l] (l >= 1, level l-1 zones) of the new hierarchy, or None from the first level that disappears."""
+        finest = len(self.lev) - 1
+        top = min(finest, self.max_level - 1)                   # the finest level that may carry tags
+        self._fill_ghosts_new(top)
+        boxes = {}
+        for l in range(top, -1, -1):
+            b = self.tag_box(l, ghosts_filled=True)
+            up = boxes.get(l + 2)
+            if up is not None:                                  # proper nesting: cover the level above + a buffer
+                ulo = tuple(_coarsen(up[0][d]) - self.n_error_buf for d in range(3))
+                uhi = tuple(_coarsen(up[1][d]) + self.n_error_buf for d in range(3))
+                c = self.lev[l]
+                ulo = tuple(max(ulo[d], c.lo[d]) for d in range(3))
+                uhi = tuple(min(uhi[d], c.hi[d]) for d in range(3))
+                if b is not None:
+                    ulo = tuple(min(ulo[d], b[0][d]) for d in range(3))
+                    uhi = tuple(max(uhi[d], b[1][d]) for d in range(3))
+                b = self._align(ulo, uhi, l)
+            boxes[l + 1] = b
+        out = []
+        for l in range(1, top + 2):
+            if boxes.get(l) is None:
+                break
+            out.append(boxes[l])
+        # a box of level l+1 must lie inside the NEW box of level l (tags were taken on the old one)
+        for i in range(1, len(out)):
+            plo, phi = out[i - 1]
+            lo = tuple(max(out[i][0][d], 2 * plo[d]) for d in range(3))
+            hi = tuple(min(out[i][1][d], 2 * phi[d] + 1) for d in range(3))
+            if any(lo[d] > hi[d] for d in range(3)):
+                del out[i:]
+                break
+            out[i] = (lo, hi)
+        return out
 
     # ---- Amr::regrid: new fine grids, data from the old fine level where it exists, else interpolated ---
     def regrid(self):
-        box = self.tag_box()
-        if box is None:
-            self._drop_fine()
+        boxes = self._grid_places()
+        if boxes == self.pbox[1:]:
             return False
-        if self.fine is not None and box == (self.plo, self.phi):
-            return False
-        old = self.fine
-        old_S = old.S_new_b.clone() if old is not None else None
-        c, h = self.crse, self.crse.hydro
-        self._drop_fine()
-        self._push_level(*box)
-        new = self.fine
-        # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
-        h.lincomb(new.ctmp, new.cbox, 0.0, c.S_old_b, c.gbox, 1.0, c.S_new_b, c.gbox, NUM_STATE, *new.cbox)
-        h.cc_interp(new.ctmp, new.cbox, new.S_new_b, new.gbox, new.lo, new.hi, NUM_STATE)
-        if old is not None:
-            olo = tuple(max(old.lo[d], new.lo[d]) for d in range(3))
-            ohi = tuple(min(old.hi[d], new.hi[d]) for d in range(3))
-            if all(olo[d] <= ohi[d] for d in range(3)):
-                h.copy(new.S_new_b, new.gbox, old_S, old.gbox, olo, ohi)
-        new.time, new.nstep = self.time, self.nstep
+        old_lev, old_S = list(self.lev), [lev.S_new_b for lev in self.lev]
+        keep = 1                                                # levels below the first changed box are kept as they are
+        while keep <= min(len(boxes), len(self.lev) - 1) and boxes[keep - 1] == self.pbox[keep]:
+            keep += 1
+        del self.lev[keep:], self.pbox[keep:], self.regs[keep:]
+        for l in range(keep, len(boxes) + 1):
+            self._push_level(*boxes[l - 1])
+            new, c = self.lev[l], self.lev[l - 1]
+            h = c.hydro
+            # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
+            if l - 1 >= keep:                                   # a level made in this regrid: its ghost zones are not filled yet
+                c.alpha = 1.0
+                c.expand_state(c.S_new_b)
+            h.lincomb(new.ctmp, new.cbox, 0.0, c.S_new_b, c.gbox, 1.0, c.S_new_b, c.gbox, NUM_STATE, *new.cbox)
+            h.cc_interp(new.ctmp, new.cbox, new.S_new_b, new.gbox, new.lo, new.hi, NUM_STATE)
+            if l < len(old_lev):
+                old = old_lev[l]
+                olo = tuple(max(old.lo[d], new.lo[d]) for d in range(3))
+                ohi = tuple(min(old.hi[d], new.hi[d]) for d in range(3))
+                if all(olo[d] <= ohi[d] for d in range(3)):
+                    h.copy(new.S_new_b, new.gbox, old_S[l], old.gbox, olo, ohi)
+            new.time, new.nstep = self.time, self.nstep
         self.nregrid += 1
         return True
 
-    # ---- Amr::init / Castro::post_init --------------------------------------------------------
+    # ---- Amr::init (bldFineLevels: one new level per pass) / Castro::post_init ---------------------------
     def initData(self, problem="sedov", **kw):
         self.crse.initData(problem, **kw)
         if self.refine is not None:
             self._drop_fine()
-            box = self.tag_box()
-            if box is not None:
+            while len(self.lev) - 1 < self.max_level:
+                box = self.tag_box(len(self.lev) - 1)
+                if box is None:
+                    break
                 self._push_level(*box)
-        for lev in self.lev[1:]:
-            lev.initData(problem, **kw)                         # fine levels start from the problem initialiser
+                self.lev[-1].initData(problem, **kw)            # fine levels start from the problem initialiser
+        else:
+            for lev in self.lev[1:]:
+                lev.initData(problem, **kw)
         for l in range(len(self.lev) - 1, 0, -1):
             self.avgDown(l)
             self.lev[l - 1].clean_state(self.lev[l - 1].S_new_b, 1)

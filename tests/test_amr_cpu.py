@@ -136,6 +136,40 @@ def test_three_levels_with_subcycling_conserve_and_track_the_fine_solution(oracl
     assert np.abs(f2[0] - uf).mean() / np.abs(uf).mean() < 0.08
 
 
+def test_tag_driven_three_levels_stay_nested_and_conserve(oracle):
+    """Amr::grid_places restated for one box per level: tags from the finest level down, every new box covers the
+    (coarsened, buffered) box of the level above it; a regrid moves both refined levels with the blast."""
+    import castro_amd
+    a = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+                             refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2,
+                             n_error_buf=1, blocking_factor=4, max_level=2)
+    a.initData("sedov", r_init=0.08, nsub=4)
+    assert len(a.levels) == 3                                   # bldFineLevels: one level per pass
+    first = list(a.pbox)
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    while a.time < 0.004:
+        a.step(0.02)
+        assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+        for l in range(2, len(a.levels)):                       # level l inside level l-1, aligned to blocking_factor
+            (plo, phi), (qlo, qhi) = a.pbox[l - 1], a.pbox[l]
+            for d in range(3):
+                assert 2 * plo[d] <= qlo[d] and qhi[d] <= 2 * phi[d] + 1
+                assert qlo[d] % 2 == 0 and (qhi[d] + 1) % 2 == 0
+    assert a.nregrid >= 1 and a.pbox != first and len(a.levels) == 3
+    # coarse data under each patch is the average of the finer data
+    for l in (2, 1):
+        f, c = a.levels[l].S_new().numpy()[0], a.levels[l - 1]
+        (plo, phi) = a.pbox[l]
+        nz, ny, nx = f.shape
+        avg = f.reshape(nz // 2, 2, ny // 2, 2, nx // 2, 2).mean(axis=(1, 3, 5))
+        o = c.lo
+        got = c.S_new().numpy()[0][plo[2] - o[2]:phi[2] - o[2] + 1, plo[1] - o[1]:phi[1] - o[1] + 1, plo[0] - o[0]:phi[0] - o[0] + 1]
+        assert np.allclose(got, avg, rtol=1e-13)
+    # a level disappears when nothing is tagged any more
+    a.refine = [("density", "value_greater", 1e9)]
+    assert a.regrid() and len(a.levels) == 1
+
+
 def test_multilevel_plotfile_round_trip(tmp_path, oracle):
     from castro_amd import plotfile as pf
     a = _amr(oracle, init_shrink=0.1)

@@ -829,6 +829,31 @@ def test_tag_driven_amr_on_the_device_matches_oracle_backend(oracle):
                    "fine": (a.fine.S_new().cpu().numpy(), b.fine.S_new().numpy())}, "dynamic AMR")
 
 
+def test_tag_driven_three_level_amr_on_the_device_matches_oracle_backend(oracle):
+    """amr.max_level = 2 with both refined levels following the tags (grid_places for one box per level, regrid
+    every 2 coarse steps): same boxes at every step and the same data bit for bit on all three levels."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2, n_error_buf=1,
+              blocking_factor=4, max_level=2)
+    a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1), **kw)
+    b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend, **kw)
+    for x in (a, b):
+        x.initData("sedov", r_init=0.08, nsub=4)
+    assert len(a.levels) == 3 and a.pbox == b.pbox
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    first = list(a.pbox)
+    while a.time < 0.01:
+        assert a.step(0.02) == b.step(0.02)
+        assert a.pbox == b.pbox
+    torch.cuda.synchronize()
+    assert a.nregrid == b.nregrid and a.nregrid >= 2 and a.pbox != first
+    _assert_exact({"L%d" % l: (a.levels[l].S_new().cpu().numpy(), b.levels[l].S_new().numpy()) for l in range(3)},
+                  "dynamic 3-level AMR")
+    assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+
+
 def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
     """amr.max_level = 2 (1 + 2 + 4 advances per coarse step) on the device vs the oracle-backed orchestration."""
     import torch
