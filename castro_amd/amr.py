@@ -1,32 +1,40 @@
-"""AMR with subcycling: a coarse level covering the domain and one refined patch per finer level (ratio 2).
+"""AMR with subcycling: a coarse level covering the domain and any number of refined levels (ratio 2), each a list of
+boxes.
 
-First slice of SURVEY.md 8 f-3.  What the reference does through AMReX's Amr / AmrLevel / FluxRegister /
-Interpolater classes [3P] is orchestrated here on top of two `Castro` level objects:
+SURVEY.md 8 f-3.  What the reference does through AMReX's Amr / AmrLevel / FluxRegister / Interpolater / grid
+generation classes [3P] is orchestrated here on top of `Castro` objects, one per box:
 
-  Amr::timeStep recursion with subcycling        coarse advance, then two fine advances of dt/2
-  AmrLevel::FillPatch (fine level)               own valid data + cell_cons_interp of the time-interpolated coarse
-                                                 state (Castro_setup.cpp:352-364, Castro.cpp:4201-4209), then
-                                                 clean_state of the ghost zones (Castro_advance.cpp:186)
-  Castro::FluxRegCrseInit / FluxRegFineAdd       Castro.cpp:2487-2545
-  Castro::post_timestep: reflux, avgDown,        Castro.cpp:2549-2700, 3096-3113, post_timestep (:2140-2260)
-      clean_state
-  Castro::computeNewDt / computeInitialDt        Castro.cpp:1629-1866 over both levels (n_cycle = 1, 2)
+  Amr::timeStep recursion with subcycling        coarse advance, then two fine advances of dt/2, down the hierarchy
+  AmrLevel::FillPatch (fine level)               cell_cons_interp of the time-interpolated coarse state
+                                                 (Castro_setup.cpp:352-364, Castro.cpp:4201-4209), clean_state of those
+                                                 ghost zones (Castro_advance.cpp:186), then valid data of the other
+                                                 boxes of the level, then the physical boundary fill
+  Castro::FluxRegCrseInit / FluxRegFineAdd       Castro.cpp:2487-2545 -- one register per face of every fine box
+  Castro::post_timestep: reflux, avgDown,        Castro.cpp:2549-2700, 3096-3113, post_timestep (:2140-2260); a coarse
+      clean_state                                zone under another fine box is refluxed too and then overwritten by
+                                                 avgDown, like in AMReX
+  Castro::computeNewDt / computeInitialDt        Castro.cpp:1629-1866 over all levels (n_cycle = 1, 2, 2, ...)
+  Castro::errorEst + Amr::regrid / grid_places   amr.refinement_indicators (AMRErrorTag [3P] restated) on every level
+                                                 below max_level, every regrid_int coarse steps: tags from the finest
+                                                 level down, buffered by n_error_buf, united with the (coarsened,
+                                                 buffered) new boxes of the level above (proper nesting), clustered
+                                                 into boxes (castro_amd/cluster.py: Berger-Rigoutsos with grid_eff,
+                                                 blocking_factor, max_grid_size; `cluster=False`: one bounding box per
+                                                 level).  New boxes take the data of the old boxes of their level
+                                                 where they overlap and interpolated coarse data elsewhere; a regrid
+                                                 adds at most one level; Amr::bldFineLevels at start-up.
 
-  Castro::errorEst + Amr::regrid                 amr.refinement_indicators (AMRErrorTag [3P] restated) on the coarse level
-                                                 every regrid_int steps; the refined region is ONE box, the bounding
-                                                 box of the tags grown by n_error_buf and aligned to blocking_factor
-                                                 (AMReX clusters tags into many boxes with Berger-Rigoutsos [3P])
-
-Any number of levels, either fixed, properly nested patches (`patches=[...]`) or tag-driven (`refine=[...]`,
-`max_level`): Amr::grid_places restated for one box per level -- tags are evaluated from the finest level down,
-each new box is the aligned, buffered bounding box of the tags of the level below united with the (coarsened,
-buffered) new box of the level above, so the hierarchy stays properly nested; a regrid adds at most one level.
-Not provided: Berger-Rigoutsos clustering, more than one patch per level, multi-rank AMR, gravity on AMR levels.  The interpolation and flux-register arithmetic is AMReX's, restated
-(include/castro_hydro_amd.h): parity with an AMReX build is unpinned.
+Fixed hierarchies: `patches=[...]`, one entry per refined level: a box (lo, hi) or a list of boxes, in the zones of
+the level below.  Level 0 is one box (per rank; this driver is single-rank).
+Not provided: multi-rank AMR, gravity / rotation on AMR levels, regridding inside a coarse step.  The interpolation,
+flux-register and clustering arithmetic is AMReX's, restated from its published description
+(include/castro_hydro_amd.h, castro_amd/cluster.py): parity with an AMReX build is unpinned.
 """
+import numpy as np
 import torch
 
 from . import _lib as L
+from . import cluster as CL
 from .castro import Castro, NUM_GROW, NUM_STATE
 
 
@@ -34,35 +42,182 @@ def _coarsen(i):
     return i // 2            # floor division is AMReX's coarsen() for negative indices too
 
 
-class _FineLevel(Castro):
-    """The refined patch: FillPatch takes the ghost zones from the coarse level."""
+def _is_box(x):
+    return len(x) == 2 and len(x[0]) == 3 and not hasattr(x[0][0], "__len__")
 
-    def bind(self, crse):
-        self.crse = crse
-        self.alpha = 0.0          # (t_fine - t_crse_old) / dt_crse of the advance being prepared
+
+class _Patch(Castro):
+    """One box of a refined level: FillPatch takes ghost zones from the coarser level and from its siblings."""
+
+    def bind(self, level, pbox):
+        self.level, self.pbox = level, pbox
         # coarse zones under the grown fine box, grown by one for the slopes
         self.cbox = (tuple(_coarsen(self.glo[d]) - 1 for d in range(3)), tuple(_coarsen(self.ghi[d]) + 1 for d in range(3)))
-        for d in range(3):
-            assert self.cbox[0][d] >= crse.glo[d] and self.cbox[1][d] <= crse.ghi[d], \
-                "patch not properly nested: its ghost zones need parent data beyond the parent's own ghost zones"
         self.ctmp = self.hydro.alloc(NUM_STATE, *self.cbox)
-        lo, hi, g = self.lo, self.hi, NUM_GROW
+        lo, hi = self.lo, self.hi
         glo, ghi = self.glo, self.ghi
         self.shell = [((glo[0], glo[1], glo[2]), (ghi[0], ghi[1], lo[2] - 1)), ((glo[0], glo[1], hi[2] + 1), (ghi[0], ghi[1], ghi[2])),
                       ((glo[0], glo[1], lo[2]), (ghi[0], lo[1] - 1, hi[2])), ((glo[0], hi[1] + 1, lo[2]), (ghi[0], ghi[1], hi[2])),
                       ((glo[0], lo[1], lo[2]), (lo[0] - 1, hi[1], hi[2])), ((hi[0] + 1, lo[1], lo[2]), (ghi[0], hi[1], hi[2]))]
+        # flux registers: the coarse faces on the six sides of this box
+        plo, phi = pbox
+        self.regs = {}
+        for d in range(3):
+            for side in (0, 1):
+                rlo, rhi = list(plo), list(phi)
+                rlo[d] = rhi[d] = (plo[d] if side == 0 else phi[d] + 1)
+                self.regs[(d, side)] = (self.hydro.alloc(NUM_STATE, rlo, rhi), (tuple(rlo), tuple(rhi)))
 
     def expand_state(self, S, box=None, neighbors=None):
-        assert box is None, "the refined patch carries no Source_Type data"
-        h, c = self.hydro, self.crse
-        a = self.alpha
+        assert box is None, "refined boxes carry no Source_Type data"
+        self.level.fill_box(self, S)
+
+
+class _Level:
+    """The boxes of one level and the level-wide parts of Castro::advance."""
+
+    def __init__(self, amr, l, boxes):
+        self.amr, self.l, self.boxes = amr, l, list(boxes)
+        self.alpha = 0.0          # (t_level - t_parent_old) / dt_parent of the FillPatch being prepared
+        b0 = self.boxes[0]
+        self.hydro, self.params, self.geom = b0.hydro, b0.params, b0.geom
+        self.red = b0.red
+        for b in self.boxes:
+            b.red = self.red      # one [min dt, min rho] pair for the level: every box reduces into it
+        for k in ("use_retry", "retry_subcycle_factor", "max_subcycles", "dt_cutoff"):
+            setattr(self, k, getattr(b0, k))
+        self.fuse_clean = b0.fuse_clean
+        self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
+        self.time, self.nstep = 0.0, 0
+
+    def __getattr__(self, name):
+        # a level of one box answers for its box (S_new(), lo, hi, n, gbox, S_new_b, ...)
+        boxes = self.__dict__.get("boxes", ())
+        if len(boxes) == 1:
+            return getattr(boxes[0], name)
+        raise AttributeError("%s (level %d has %d boxes)" % (name, self.__dict__.get("l", -1), len(boxes)))
+
+    def box_list(self):
+        return [b.bx for b in self.boxes]
+
+    # ---- static overlap tables (rebuilt at every regrid) -----------------------------------------
+    def bind(self):
+        if self.l == 0:
+            return
+        parents = self.amr.lev[self.l - 1].boxes
+        for b in self.boxes:
+            b.sib = [(s, it) for s in self.boxes if s is not b for it in [CL.intersect(b.gbox, s.bx)] if it]
+            b.csrc = [(p, it) for p in parents for it in [CL.intersect(b.cbox, p.gbox)] if it]
+            if len(b.csrc) == 1:
+                assert b.csrc[0][1] == b.cbox, "box not properly nested: its ghost zones need parent data beyond the parent's own ghost zones"
+                b.csrc_valid = []
+            else:
+                # several parents: ghost zones first, valid zones last, so that valid data wins
+                b.csrc_valid = [(p, it) for p in parents for it in [CL.intersect(b.cbox, p.bx)] if it]
+                cov = np.zeros(tuple(b.cbox[1][d] - b.cbox[0][d] + 1 for d in (2, 1, 0)), dtype=bool)
+                for _, (lo, hi) in b.csrc:
+                    o = b.cbox[0]
+                    cov[lo[2] - o[2]:hi[2] - o[2] + 1, lo[1] - o[1]:hi[1] - o[1] + 1, lo[0] - o[0]:hi[0] - o[0] + 1] = True
+                assert cov.all(), "box not properly nested in the union of its parents"
+            # FluxRegCrseInit sources and reflux targets per register
+            b.crse_init, b.reflux_to = {}, {}
+            for (d, side), (reg, rbox) in b.regs.items():
+                b.crse_init[(d, side)] = [(p, it) for p in parents for it in [CL.intersect(rbox, p.flux_boxes[d])] if it]
+                sh = -1 if side == 0 else 0           # the coarse zone outside the fine box: face - 1 (low side) or face
+                zlo, zhi = list(rbox[0]), list(rbox[1])
+                zlo[d] += sh; zhi[d] += sh
+                tg = []
+                for p in parents:
+                    it = CL.intersect((tuple(zlo), tuple(zhi)), p.bx)
+                    if it:
+                        flo, fhi = list(it[0]), list(it[1])
+                        flo[d] -= sh; fhi[d] -= sh
+                        tg.append((p, (tuple(flo), tuple(fhi))))
+                b.reflux_to[(d, side)] = tg
+            b.avg_to = [(p, it) for p in parents for it in [CL.intersect(b.pbox, p.bx)] if it]
+
+    # ---- AmrLevel::FillPatch ---------------------------------------------------------------------
+    def _interp_ghosts(self, b, S):
+        h, a = self.hydro, self.alpha
         # StateData time interpolation of the coarse data: (1 - a) old + a new
-        h.lincomb(self.ctmp, self.cbox, 1.0 - a, c.S_old_b, c.gbox, a, c.S_new_b, c.gbox, NUM_STATE, *self.cbox)
-        for lo, hi in self.shell:
-            h.cc_interp(self.ctmp, self.cbox, S, self.gbox, lo, hi, NUM_STATE)
-        h.bc_fill(S, self.gbox, self.geom)                     # fine zones outside the domain (none for an interior patch)
-        for lo, hi in self.shell:                              # clean_state(Sborder) reaches the ghost zones too
-            h.clean_state(S, self.gbox, lo, hi, self.params, ntimes=1)
+        for p, (lo, hi) in b.csrc + b.csrc_valid:
+            h.lincomb(b.ctmp, b.cbox, 1.0 - a, p.S_old_b, p.gbox, a, p.S_new_b, p.gbox, NUM_STATE, lo, hi)
+        for lo, hi in b.shell:
+            h.cc_interp(b.ctmp, b.cbox, S, b.gbox, lo, hi, NUM_STATE)
+        for lo, hi in b.shell:                                 # clean_state(Sborder) reaches the ghost zones too
+            h.clean_state(S, b.gbox, lo, hi, b.params, ntimes=1)
+
+    def _copy_siblings(self, b, S, which):
+        h = self.hydro
+        for s, (lo, hi) in b.sib:
+            h.copy(S, b.gbox, getattr(s, which), s.gbox, lo, hi)
+        h.bc_fill(S, b.gbox, b.geom)                           # fine zones outside the domain
+
+    def fill(self, which):
+        """Ghost zones of S_old_b / S_new_b (`which`) of every box of the level."""
+        if self.l == 0:
+            for b in self.boxes:
+                b.expand_state(getattr(b, which))
+            return
+        for b in self.boxes:
+            self._interp_ghosts(b, getattr(b, which))
+        for b in self.boxes:                                   # valid zones are final only after every box's clean pass
+            self._copy_siblings(b, getattr(b, which), which)
+
+    def fill_box(self, b, S):
+        which = "S_new_b" if S is b.S_new_b else "S_old_b"
+        assert S is getattr(b, which)
+        self._interp_ghosts(b, S)
+        self._copy_siblings(b, S, which)
+
+    # ---- Castro::advance over the boxes of the level (Castro_advance.cpp:19-121) ----------------------
+    def _swap_state_time_levels(self):
+        for b in self.boxes:
+            b._swap_state_time_levels()
+
+    def _zero_fluxes(self):
+        for b in self.boxes:
+            b._zero_fluxes()
+
+    def _save_old_state(self):
+        return [b.S_old_b.clone() for b in self.boxes]
+
+    def _restore_old_state(self, prev):
+        for b, p in zip(self.boxes, prev):
+            b.S_old_b.copy_(p)
+
+    advance = Castro.advance
+    subcycle_advance_ctu = Castro.subcycle_advance_ctu
+
+    def do_advance_ctu(self, time, dt):
+        """Castro::do_advance_ctu (Castro_advance_ctu.cpp:15-397) with every stage done for all boxes before the next."""
+        for b in self.boxes:
+            b.clean_state(b.S_old_b, 2)
+        self.red.fill_(1.e200)
+        self.fill("S_old_b")
+        for b in self.boxes:
+            b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
+            b._flux_clear = False
+        if not self.fuse_clean:
+            for b in self.boxes:
+                self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
+        est, rho_min = self.red.tolist()
+        if rho_min < self.params.small_dens:
+            return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
+        new_dt = min(1.e200, est * self.params.cfl)
+        if self.params.change_max * new_dt < dt:
+            return False, "timestep validity check failed", None
+        return True, "", new_dt
+
+    def estTimeStep(self):
+        self.red.fill_(1.e200)
+        for b in self.boxes:
+            self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
+        return min(1.e200, self.red.tolist()[0] * self.params.cfl)
+
+    def clean_new(self):
+        for b in self.boxes:
+            b.clean_state(b.S_new_b, 1)
 
 
 _TAG_KINDS = {"value_greater": 0, "value_less": 1, "gradient": 2, "relative_gradient": 3}
@@ -72,13 +227,14 @@ _FIELDS = {"density": 0, "xmom": 1, "ymom": 2, "zmom": 3, "rho_E": 4, "rho_e": 5
 class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
-                 blocking_factor=8, patches=None, max_level=1):
-        """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined patch;
-        patches = [(lo, hi), ...]: one fixed patch per finer level, each in the index space of the level below it
-        (amr.max_level = len(patches)); or
+                 blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128):
+        """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined box;
+        patches = [entry, ...]: one entry per refined level, a box (lo, hi) or a list of boxes in the zones of the
+        level below it (amr.max_level = len(patches)); or
         refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name, kind:
-        value_greater | value_less | gradient | relative_gradient) for patches that follow the tags, one per level up
-        to amr.max_level = max_level."""
+        value_greater | value_less | gradient | relative_gradient) for boxes that follow the tags up to
+        amr.max_level = max_level: one bounding box per level, or with cluster=True the Berger-Rigoutsos boxes
+        (amr.grid_eff, amr.blocking_factor and amr.max_grid_size in zones of the new level)."""
         if patch_crse is not None:
             assert patches is None
             patches = [patch_crse]
@@ -87,25 +243,30 @@ class CastroAmr:
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
         self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
         self.n_cell = tuple(n_cell)
-        self.lev = [Castro(n_cell, hydro=self._mk(), **self._kw)]      # lev[0] covers the domain
-        self.pbox = [None]                                            # pbox[l]: patch of level l in level l-1 zones
-        self.regs = [None]                                            # regs[l]: flux register around that patch
-        self._hydros = [self.lev[0].hydro]
+        self._hydros = []
+        base = Castro(n_cell, hydro=self._hydro_for(0), **self._kw)
+        self.lev = [_Level(self, 0, [base])]                          # lev[0] covers the domain
         self.refine = refine
         self.regrid_int, self.n_error_buf, self.blocking_factor = int(regrid_int), int(n_error_buf), int(blocking_factor)
+        self.cluster = bool(cluster)
+        self.grid_eff = float(grid_eff) if cluster else 0.0           # 0: the bounding box of the tags is accepted as it is
+        self.max_grid_size = int(max_grid_size) if cluster else None
         self.nregrid = 0
         self.max_level = int(max_level) if refine is not None else len(patches or [])
         for pb in (patches or []):
-            self._push_level(tuple(pb[0]), tuple(pb[1]))
+            self._push_level([tuple(map(tuple, pb))] if _is_box(pb) else [tuple(map(tuple, b)) for b in pb])
         self.time, self.nstep = 0.0, 0
-        self.dt_level = [0.0] * 8
+        self.dt_level = [0.0] * 16
 
-    # two-level views used by the tag-driven mode and the tests
+    # views used by the tests and the plotfile writer
     crse = property(lambda self: self.lev[0])
     fine = property(lambda self: self.lev[1] if len(self.lev) > 1 else None)
+    levels = property(lambda self: list(self.lev))
+    boxes = property(lambda self: [None] + [[b.pbox for b in lev.boxes] for lev in self.lev[1:]])
+    # pbox[l]: the box of level l in level l-1 zones when the level has one box, else the list of its boxes
+    pbox = property(lambda self: [None] + [bl[0] if len(bl) == 1 else bl for bl in self.boxes[1:]])
     plo = property(lambda self: self.pbox[1][0] if len(self.lev) > 1 else None)
     phi = property(lambda self: self.pbox[1][1] if len(self.lev) > 1 else None)
-    levels = property(lambda self: list(self.lev))
 
     def _hydro_for(self, l):
         while len(self._hydros) <= l:
@@ -116,154 +277,167 @@ class CastroAmr:
             self._hydros.append(h)
         return self._hydros[l]
 
-    def _make_level(self, l, plo, phi):
-        """Level l >= 1 covering the zones [plo, phi] of level l-1, and the flux register around it."""
-        parent = self.lev[l - 1]
-        flo = tuple(2 * x for x in plo)
-        fhi = tuple(2 * x + 1 for x in phi)
-        fine = _FineLevel(tuple((2 ** l) * x for x in self.n_cell), hydro=self._hydro_for(l), box=(flo, fhi), **self._kw)
-        fine.bind(parent)
-        h = parent.hydro
-        reg = {}
-        for d in range(3):
-            for side in (0, 1):
-                lo, hi = list(plo), list(phi)
-                lo[d] = hi[d] = (plo[d] if side == 0 else phi[d] + 1)
-                reg[(d, side)] = (h.alloc(NUM_STATE, lo, hi), (tuple(lo), tuple(hi)))
-        return fine, reg
+    def _make_level(self, l, pboxes):
+        """Level l >= 1 covering the boxes `pboxes` (zones of level l-1), with its flux registers."""
+        boxes = []
+        for plo, phi in pboxes:
+            flo = tuple(2 * x for x in plo)
+            fhi = tuple(2 * x + 1 for x in phi)
+            b = _Patch(tuple((2 ** l) * x for x in self.n_cell), hydro=self._hydro_for(l), box=(flo, fhi), **self._kw)
+            boxes.append(b)
+        lev = _Level(self, l, boxes)
+        for b, pb in zip(boxes, pboxes):
+            b.bind(lev, pb)
+        return lev
 
-    def _push_level(self, plo, phi):
-        fine, reg = self._make_level(len(self.lev), plo, phi)
-        self.lev.append(fine); self.pbox.append((plo, phi)); self.regs.append(reg)
+    def _push_level(self, pboxes):
+        lev = self._make_level(len(self.lev), pboxes)
+        self.lev.append(lev)
+        lev.bind()
 
     def _drop_fine(self):
-        del self.lev[1:], self.pbox[1:], self.regs[1:]
+        del self.lev[1:]
 
-    # ---- Castro::errorEst (Castro.cpp:3131-3164) + the one-box stand-in for the grid generator ------
+    # ---- Castro::errorEst (Castro.cpp:3131-3164) ---------------------------------------------------
     def _fill_ghosts_new(self, upto):
         """Ghost zones of the new-time data of levels 0..upto (each FillPatch reads the level below it)."""
         for l in range(upto + 1):
-            lev = self.lev[l]
-            if l > 0:
-                lev.alpha = 1.0
-            lev.expand_state(lev.S_new_b)
+            self.lev[l].alpha = 1.0
+            self.lev[l].fill("S_new_b")
 
-    def _align(self, lo, hi, l):
-        """Grow [lo, hi] (level-l zones) to multiples of blocking_factor/2 and clip it to the level-l domain."""
-        a = max(self.blocking_factor // 2, 1)                   # blocking_factor is in zones of level l+1
-        olo, ohi = [], []
-        for d in range(3):
-            olo.append(max((lo[d] // a) * a, 0))
-            ohi.append(min(-((-(hi[d] + 1)) // a) * a - 1, (2 ** l) * self.n_cell[d] - 1))
-        return tuple(olo), tuple(ohi)
+    def _tags(self, l):
+        """(tags, mask, origin): tagged zones and valid zones of level l as host arrays over the bounding region."""
+        lev = self.lev[l]
+        bl = lev.box_list()
+        olo = tuple(min(b[0][d] for b in bl) for d in range(3))
+        ohi = tuple(max(b[1][d] for b in bl) for d in range(3))
+        shape = tuple(ohi[d] - olo[d] + 1 for d in (2, 1, 0))
+        tags, mask = np.zeros(shape, dtype=bool), np.zeros(shape, dtype=bool)
+        h = lev.hydro
+        for b in lev.boxes:
+            t = h.alloc(1, b.lo, b.hi)
+            for field, kind, value in self.refine:
+                h.error_tag(b.S_new_b, b.gbox, _FIELDS[field], t, (b.lo, b.hi), b.lo, b.hi, _TAG_KINDS[kind], value)
+            sl = tuple(slice(b.lo[d] - olo[d], b.hi[d] - olo[d] + 1) for d in (2, 1, 0))
+            tags[sl] = (t[0] > 0.5).cpu().numpy()
+            mask[sl] = True
+        return tags, mask, olo
 
-    def tag_box(self, l=0, ghosts_filled=False):
-        """Bounding box (level-l zones) of the tagged zones of level l, buffered and aligned; None if nothing is
-        tagged.  The box stays inside level l's own box."""
-        c = self.lev[l]
-        h = c.hydro
+    def tag_boxes(self, l=0, ghosts_filled=False, cover=()):
+        """New boxes of level l+1 in level-l zones: clustered, buffered tags of level l, also covering `cover`
+        (boxes in level-l zones that the new boxes must contain: the footprint of the level above)."""
         if not ghosts_filled:
             self._fill_ghosts_new(l)
-        tags = h.alloc(1, c.lo, c.hi)
-        for field, kind, value in self.refine:
-            h.error_tag(c.S_new_b, c.gbox, _FIELDS[field], tags, (c.lo, c.hi), c.lo, c.hi, _TAG_KINDS[kind], value)
-        nz = torch.nonzero(tags[0] > 0.5)                       # (k, j, i) triples relative to c.lo
-        if nz.numel() == 0:
-            return None
-        mn, mx = nz.min(dim=0).values.tolist(), nz.max(dim=0).values.tolist()
-        lo = tuple(max(c.lo[d] + mn[2 - d] - self.n_error_buf, c.lo[d]) for d in range(3))
-        hi = tuple(min(c.lo[d] + mx[2 - d] + self.n_error_buf, c.hi[d]) for d in range(3))
-        return self._align(lo, hi, l)
+        tags, mask, o = self._tags(l)
+        if self.n_error_buf > 0:
+            tags = CL.dilate(tags, self.n_error_buf)
+        for lo, hi in cover:
+            it = CL.intersect((lo, hi), (o, tuple(o[d] + tags.shape[2 - d] - 1 for d in range(3))))
+            if it:
+                tags[it[0][2] - o[2]:it[1][2] - o[2] + 1, it[0][1] - o[1]:it[1][1] - o[1] + 1, it[0][0] - o[0]:it[1][0] - o[0] + 1] = True
+        tags &= mask
+        if not tags.any():
+            return []
+        a = max(self.blocking_factor // 2, 1)                   # blocking_factor is in zones of level l+1
+        assert all(x % a == 0 for x in o) and all(s % a == 0 for s in tags.shape), "level boxes must be multiples of blocking_factor/2"
+        return CL.make_boxes(tags, o, mask, n_error_buf=0, blocking=a, grid_eff=self.grid_eff,
+                             max_size=None if self.max_grid_size is None else max(self.max_grid_size // 2, a))
 
+    def tag_box(self, l=0):
+        """The one-box form: (lo, hi) in level-l zones or None."""
+        bl = self.tag_boxes(l)
+        return bl[0] if bl else None
+
+    # ---- Amr::grid_places: new box lists for levels 1.. (at most one level more than now) ----------
     def _grid_places(self):
-        """boxes[l] (l >= 1, level l-1 zones) of the new hierarchy, or None from the first level that disappears."""
         finest = len(self.lev) - 1
         top = min(finest, self.max_level - 1)                   # the finest level that may carry tags
         self._fill_ghosts_new(top)
-        boxes = {}
+        new = {}
         for l in range(top, -1, -1):
-            b = self.tag_box(l, ghosts_filled=True)
-            up = boxes.get(l + 2)
-            if up is not None:                                  # proper nesting: cover the level above + a buffer
-                ulo = tuple(_coarsen(up[0][d]) - self.n_error_buf for d in range(3))
-                uhi = tuple(_coarsen(up[1][d]) + self.n_error_buf for d in range(3))
-                c = self.lev[l]
-                ulo = tuple(max(ulo[d], c.lo[d]) for d in range(3))
-                uhi = tuple(min(uhi[d], c.hi[d]) for d in range(3))
-                if b is not None:
-                    ulo = tuple(min(ulo[d], b[0][d]) for d in range(3))
-                    uhi = tuple(max(uhi[d], b[1][d]) for d in range(3))
-                b = self._align(ulo, uhi, l)
-            boxes[l + 1] = b
+            cover = []
+            for lo, hi in new.get(l + 2, []):                   # proper nesting: contain the level above + a buffer
+                cover.append((tuple(_coarsen(lo[d]) - self.n_error_buf for d in range(3)),
+                              tuple(_coarsen(hi[d]) + self.n_error_buf for d in range(3))))
+            new[l + 1] = self.tag_boxes(l, ghosts_filled=True, cover=cover)
         out = []
         for l in range(1, top + 2):
-            if boxes.get(l) is None:
+            if not new.get(l):
                 break
-            out.append(boxes[l])
-        # a box of level l+1 must lie inside the NEW box of level l (tags were taken on the old one)
+            out.append(new[l])
+        # boxes of level l+1 were placed on the OLD level-l boxes: keep what lies inside the NEW ones
         for i in range(1, len(out)):
-            plo, phi = out[i - 1]
-            lo = tuple(max(out[i][0][d], 2 * plo[d]) for d in range(3))
-            hi = tuple(min(out[i][1][d], 2 * phi[d] + 1) for d in range(3))
-            if any(lo[d] > hi[d] for d in range(3)):
+            kept = []
+            for b in out[i]:
+                for plo, phi in out[i - 1]:
+                    it = CL.intersect(b, (tuple(2 * x for x in plo), tuple(2 * x + 1 for x in phi)))
+                    if it:
+                        kept.append(it)
+            if not kept:
                 del out[i:]
                 break
-            out[i] = (lo, hi)
+            out[i] = sorted(kept, key=lambda b: (b[0][2], b[0][1], b[0][0]))
         return out
 
     # ---- Amr::regrid: new fine grids, data from the old fine level where it exists, else interpolated ---
     def regrid(self):
-        boxes = self._grid_places()
-        if boxes == self.pbox[1:]:
+        new = self._grid_places()
+        if new == self.boxes[1:]:
             return False
-        old_lev, old_S = list(self.lev), [lev.S_new_b for lev in self.lev]
-        keep = 1                                                # levels below the first changed box are kept as they are
-        while keep <= min(len(boxes), len(self.lev) - 1) and boxes[keep - 1] == self.pbox[keep]:
+        old_lev = list(self.lev)
+        keep = 1                                                # levels below the first changed box list stay as they are
+        while keep <= min(len(new), len(self.lev) - 1) and new[keep - 1] == self.boxes[keep]:
             keep += 1
-        del self.lev[keep:], self.pbox[keep:], self.regs[keep:]
-        for l in range(keep, len(boxes) + 1):
-            self._push_level(*boxes[l - 1])
-            new, c = self.lev[l], self.lev[l - 1]
-            h = c.hydro
-            # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
+        del self.lev[keep:]
+        for l in range(keep, len(new) + 1):
+            parent = self.lev[l - 1]
             if l - 1 >= keep:                                   # a level made in this regrid: its ghost zones are not filled yet
-                c.alpha = 1.0
-                c.expand_state(c.S_new_b)
-            h.lincomb(new.ctmp, new.cbox, 0.0, c.S_new_b, c.gbox, 1.0, c.S_new_b, c.gbox, NUM_STATE, *new.cbox)
-            h.cc_interp(new.ctmp, new.cbox, new.S_new_b, new.gbox, new.lo, new.hi, NUM_STATE)
-            if l < len(old_lev):
-                old = old_lev[l]
-                olo = tuple(max(old.lo[d], new.lo[d]) for d in range(3))
-                ohi = tuple(min(old.hi[d], new.hi[d]) for d in range(3))
-                if all(olo[d] <= ohi[d] for d in range(3)):
-                    h.copy(new.S_new_b, new.gbox, old_S[l], old.gbox, olo, ohi)
-            new.time, new.nstep = self.time, self.nstep
+                parent.alpha = 1.0
+                parent.fill("S_new_b")
+            self._push_level(new[l - 1])
+            lev = self.lev[l]
+            h = lev.hydro
+            for b in lev.boxes:
+                # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
+                for p, (lo, hi) in b.csrc + b.csrc_valid:
+                    h.lincomb(b.ctmp, b.cbox, 0.0, p.S_new_b, p.gbox, 1.0, p.S_new_b, p.gbox, NUM_STATE, lo, hi)
+                h.cc_interp(b.ctmp, b.cbox, b.S_new_b, b.gbox, b.lo, b.hi, NUM_STATE)
+                if l < len(old_lev):
+                    for ob in old_lev[l].boxes:
+                        it = CL.intersect(ob.bx, b.bx)
+                        if it:
+                            h.copy(b.S_new_b, b.gbox, ob.S_new_b, ob.gbox, it[0], it[1])
+            lev.time, lev.nstep = self.time, self.nstep
         self.nregrid += 1
         return True
 
     # ---- Amr::init (bldFineLevels: one new level per pass) / Castro::post_init ---------------------------
     def initData(self, problem="sedov", **kw):
-        self.crse.initData(problem, **kw)
+        self.crse.boxes[0].initData(problem, **kw)
         if self.refine is not None:
             self._drop_fine()
             while len(self.lev) - 1 < self.max_level:
-                box = self.tag_box(len(self.lev) - 1)
-                if box is None:
+                bl = self.tag_boxes(len(self.lev) - 1)
+                if not bl:
                     break
-                self._push_level(*box)
-                self.lev[-1].initData(problem, **kw)            # fine levels start from the problem initialiser
+                self._push_level(bl)
+                for b in self.lev[-1].boxes:
+                    b.initData(problem, **kw)                   # fine levels start from the problem initialiser
         else:
             for lev in self.lev[1:]:
-                lev.initData(problem, **kw)
+                for b in lev.boxes:
+                    b.initData(problem, **kw)
         for l in range(len(self.lev) - 1, 0, -1):
             self.avgDown(l)
-            self.lev[l - 1].clean_state(self.lev[l - 1].S_new_b, 1)
+            self.lev[l - 1].clean_new()
         self.time, self.nstep = 0.0, 0
 
     # ---- Castro::avgDown (Castro.cpp:3096-3113): level l onto level l-1 ------------------------------
     def avgDown(self, l=1):
-        c, f = self.lev[l - 1], self.lev[l]
-        c.hydro.avgdown(f.S_new_b, f.gbox, c.S_new_b, c.gbox, self.pbox[l][0], self.pbox[l][1], NUM_STATE)
+        h = self.lev[l].hydro
+        for b in self.lev[l].boxes:
+            for p, (lo, hi) in b.avg_to:
+                h.avgdown(b.S_new_b, b.gbox, p.S_new_b, p.gbox, lo, hi, NUM_STATE)
 
     # ---- Castro::computeInitialDt / computeNewDt over the hierarchy ----------------------------------
     def _dt0(self, stop_time, initial):
@@ -291,31 +465,34 @@ class CastroAmr:
     def _time_step(self, l, t, dt, alpha):
         """alpha: position of this level's old time inside the parent's [old, new] interval (0 or 1/2)."""
         lev, finest = self.lev[l], len(self.lev) - 1
-        if l > 0:
-            lev.alpha = alpha
+        h = lev.hydro
+        lev.alpha = alpha
         lev.advance(t, dt)
         if l > 0:
             # FluxRegFineAdd: + this level's fluxes (already dt x area) summed over the 4 fine faces
-            h = self.lev[l - 1].hydro
-            for (d, side), (reg, rbox) in self.regs[l].items():
-                h.fluxreg_fine_add(reg, rbox, lev.fluxes[d], lev.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
+            for b in lev.boxes:
+                for (d, side), (reg, rbox) in b.regs.items():
+                    h.fluxreg_fine_add(reg, rbox, b.fluxes[d], b.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
         if l < finest:
-            h = lev.hydro
+            fine = self.lev[l + 1]
             # ghost zones of the new data of this level, for the FillPatch of the next finer one
-            if l > 0:
-                lev.alpha = alpha + 0.5
-            lev.expand_state(lev.S_new_b)
-            # FluxRegCrseInit: -1 x this level's fluxes through the faces of the finer patch
-            for (d, side), (reg, rbox) in self.regs[l + 1].items():
-                h.fluxreg_crse_init(reg, rbox, lev.fluxes[d], lev.flux_boxes[d], rbox[0], rbox[1], NUM_STATE, -1.0)
+            lev.alpha = alpha + 0.5
+            lev.fill("S_new_b")
+            # FluxRegCrseInit: -1 x this level's fluxes through the faces of the finer boxes
+            for b in fine.boxes:
+                for (d, side), (reg, rbox) in b.regs.items():
+                    for p, (lo, hi) in b.crse_init[(d, side)]:
+                        h.fluxreg_crse_init(reg, rbox, p.fluxes[d], p.flux_boxes[d], lo, hi, NUM_STATE, -1.0)
             for it in range(2):
                 self._time_step(l + 1, t + it * (dt / 2), dt / 2, 0.5 * it)
             # post_timestep: reflux, avgDown, clean_state
             vol = lev.geom.dx[0] * lev.geom.dx[1] * lev.geom.dx[2]
-            for (d, side), (reg, rbox) in self.regs[l + 1].items():
-                h.reflux(lev.S_new_b, lev.gbox, reg, rbox, rbox[0], rbox[1], d, side, NUM_STATE, vol)
+            for b in fine.boxes:
+                for (d, side), (reg, rbox) in b.regs.items():
+                    for p, (lo, hi) in b.reflux_to[(d, side)]:
+                        h.reflux(p.S_new_b, p.gbox, reg, rbox, lo, hi, d, side, NUM_STATE, vol)
             self.avgDown(l + 1)
-            lev.clean_state(lev.S_new_b, 1)
+            lev.clean_new()
 
     # ---- Amr::coarseTimeStep ---------------------------------------------------------------------
     def step(self, stop_time=-1.0):
@@ -344,11 +521,19 @@ class CastroAmr:
         tot = 0.0
         for l, lev in enumerate(self.lev):
             v = lev.geom.dx[0] * lev.geom.dx[1] * lev.geom.dx[2]
-            S = lev.S_new()[comp]
-            if l + 1 < len(self.lev):
-                S = S.clone()
-                p, q = self.pbox[l + 1]
-                o = lev.lo
-                S[p[2] - o[2]:q[2] - o[2] + 1, p[1] - o[1]:q[1] - o[1] + 1, p[0] - o[0]:q[0] - o[0] + 1] = 0.0
-            tot += S.sum().item() * v
+            for b in lev.boxes:
+                S = b.S_new()[comp]
+                if l + 1 < len(self.lev):
+                    S = S.clone()
+                    o = b.lo
+                    for f in self.lev[l + 1].boxes:
+                        it = CL.intersect(f.pbox, b.bx)
+                        if it:
+                            (p, q) = it
+                            S[p[2] - o[2]:q[2] - o[2] + 1, p[1] - o[1]:q[1] - o[1] + 1, p[0] - o[0]:q[0] - o[0] + 1] = 0.0
+                tot += S.sum().item() * v
         return tot
+
+    def zones_advanced_per_coarse_step(self):
+        """Zone updates of one coarse step (level l advances 2^l times): the reference's FOM numerator."""
+        return sum((2 ** l) * sum(b.n[0] * b.n[1] * b.n[2] for b in lev.boxes) for l, lev in enumerate(self.lev))

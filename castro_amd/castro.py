@@ -471,6 +471,12 @@ class Castro:
     def _swap_state_time_levels(self):
         self.S_old_b, self.S_new_b = self.S_new_b, self.S_old_b
 
+    def _save_old_state(self):
+        return self.S_old_b.clone()
+
+    def _restore_old_state(self, prev):
+        self.S_old_b.copy_(prev)
+
     def _zero_fluxes(self):
         """fluxes[d].setVal(0) (Castro_advance.cpp:391-394, Castro_advance_ctu.cpp:455-461).  In flux-assign mode
         the fill is not executed: the next hydro call overwrites every face instead of accumulating."""
@@ -523,7 +529,7 @@ class Castro:
                 # retry_advance_ctu: halve the subcycle, keep the original old data, clear the fluxes
                 dt_subcycle = min(dt_subcycle, dt_subcycle) * self.retry_subcycle_factor
                 if prev_old is None:
-                    prev_old = self.S_old_b.clone()
+                    prev_old = self._save_old_state()
                 self._zero_fluxes()
                 do_swap = False
                 self.nretries += 1
@@ -532,7 +538,7 @@ class Castro:
             subcycle_time += dt_subcycle
             sub_iteration += 1
         if sub_iteration > 1 and prev_old is not None:
-            self.S_old_b.copy_(prev_old)          # state[k].replaceOldData(*prev_state[k])
+            self._restore_old_state(prev_old)     # state[k].replaceOldData(*prev_state[k])
         self.nsubcycles = sub_iteration
         return new_dt
 

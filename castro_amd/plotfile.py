@@ -141,16 +141,19 @@ def write_plotfile(dirname, castro, derive=None, job_info=None):
 
 def write_plotfile_amr(dirname, amr, derive=None):
     """Multi-level plotfile of a CastroAmr hierarchy (single rank): the same Header layout with finest_level > 0
-    (Castro_io.cpp:953-1076 per level) and one Level_l/{Cell_H, Cell_D_00000} per level."""
+    (Castro_io.cpp:953-1076 per level) and one Level_l/{Cell_H, Cell_D_00000} per level holding the FABs of all boxes
+    of the level one after the other (VisMF [3P]: Cell_H lists the boxes, each FAB's byte offset and its min/max)."""
     levels = amr.levels
     nlev = len(levels)
     per = []
     for l, lev in enumerate(levels):
-        if l > 0:
-            lev.alpha = 1.0          # ghost zones for the stencil derives: parent data at the current (new) time
-        names, data = plot_data(lev, derive)
-        per.append(data.cpu().numpy() if hasattr(data, "cpu") else np.asarray(data))
-    ncomp = per[0].shape[0]
+        lev.alpha = 1.0              # ghost zones for the stencil derives: parent data at the current (new) time
+        fabs = []
+        for b in lev.boxes:
+            names, data = plot_data(b, derive)
+            fabs.append(data.cpu().numpy() if hasattr(data, "cpu") else np.asarray(data))
+        per.append(fabs)
+    ncomp = per[0][0].shape[0]
     os.makedirs(dirname, exist_ok=True)
     g0 = levels[0].geom
     with open(os.path.join(dirname, "Header"), "w") as f:
@@ -168,25 +171,37 @@ def write_plotfile_amr(dirname, amr, derive=None):
             w(" ".join(_g(lev.geom.dx[d]) for d in range(3)) + " \n")
         w("%d\n0\n" % g0.coord)
         for l, lev in enumerate(levels):
-            w("%d 1 %s\n%d\n" % (l, _g(amr.time), amr.nstep * 2 ** l))
-            for d in range(3):
-                w("%s %s\n" % (_g(lev.geom.problo[d] + lev.lo[d] * lev.geom.dx[d]), _g(lev.geom.problo[d] + (lev.hi[d] + 1) * lev.geom.dx[d])))
+            w("%d %d %s\n%d\n" % (l, len(lev.boxes), _g(amr.time), amr.nstep * 2 ** l))
+            for b in lev.boxes:
+                for d in range(3):
+                    w("%s %s\n" % (_g(lev.geom.problo[d] + b.lo[d] * lev.geom.dx[d]), _g(lev.geom.problo[d] + (b.hi[d] + 1) * lev.geom.dx[d])))
             w("Level_%d/Cell\n" % l)
-    for l, (lev, arr) in enumerate(zip(levels, per)):
+    for l, (lev, fabs) in enumerate(zip(levels, per)):
         ld = os.path.join(dirname, "Level_%d" % l)
         os.makedirs(ld, exist_ok=True)
+        offsets = []
         with open(os.path.join(ld, "Cell_D_00000"), "wb") as f:
-            f.write(("FAB %s%s %d\n" % (FAB_REAL_DESCRIPTOR, _box(lev.lo, lev.hi), ncomp)).encode("ascii"))
-            np.ascontiguousarray(arr, dtype="<f8").tofile(f)
+            for b, arr in zip(lev.boxes, fabs):
+                offsets.append(f.tell())
+                f.write(("FAB %s%s %d\n" % (FAB_REAL_DESCRIPTOR, _box(b.lo, b.hi), ncomp)).encode("ascii"))
+                np.ascontiguousarray(arr, dtype="<f8").tofile(f)
+        ng = len(fabs)
         with open(os.path.join(ld, "Cell_H"), "w") as f:
-            f.write("1\n0\n%d\n0\n(1 0\n%s\n)\n1\nFabOnDisk: Cell_D_00000 0\n\n" % (ncomp, _box(lev.lo, lev.hi)))
+            f.write("1\n0\n%d\n0\n(%d 0\n" % (ncomp, ng) + "".join(_box(b.lo, b.hi) + "\n" for b in lev.boxes) + ")\n%d\n" % ng)
+            for off in offsets:
+                f.write("FabOnDisk: Cell_D_00000 %d\n" % off)
+            f.write("\n")
             for fn in (np.min, np.max):
-                f.write("1,%d\n" % ncomp + "".join("%.16e," % fn(arr[n]) for n in range(ncomp)) + "\n\n")
+                f.write("%d,%d\n" % (ng, ncomp))
+                for arr in fabs:
+                    f.write("".join("%.16e," % fn(arr[n]) for n in range(ncomp)) + "\n")
+                f.write("\n")
     return names
 
 
 def read_plotfile_amr(dirname):
-    """Levels of a multi-level plotfile: list of dict(box=(lo,hi), dx, data[(ncomp, nz, ny, nx)]) + names, time."""
+    """Levels of a multi-level plotfile: names, time and per level dict(dx, boxes=[(lo, hi)], fabs=[(ncomp, nz, ny, nx)]);
+    a level of one box also carries box= and data= for that box."""
     with open(os.path.join(dirname, "Header")) as f:
         L = [ln.rstrip("\n") for ln in f]
     ncomp = int(L[1])
@@ -204,13 +219,24 @@ def read_plotfile_amr(dirname):
         levdir = os.path.join(dirname, os.path.dirname(path))
         with open(os.path.join(levdir, "Cell_H")) as f:
             H = [ln.rstrip("\n") for ln in f]
-        v = [int(x) for x in re.findall(r"-?\d+", H[5])]
-        lo, hi = v[0:3], v[3:6]
-        m = [hi[d] - lo[d] + 1 for d in range(3)]
-        with open(os.path.join(levdir, "Cell_D_00000"), "rb") as f:
-            f.readline()
-            a = np.fromfile(f, dtype="<f8", count=ncomp * m[0] * m[1] * m[2]).reshape(ncomp, m[2], m[1], m[0])
-        out.append(dict(box=(lo, hi), dx=dxs[l], data=a))
+        assert int(H[4].strip("(").split()[0]) == ngrids
+        boxes, fabs = [], []
+        for g in range(ngrids):
+            v = [int(x) for x in re.findall(r"-?\d+", H[5 + g])]
+            boxes.append((v[0:3], v[3:6]))
+        r = 5 + ngrids + 2                      # first FabOnDisk line
+        for g in range(ngrids):
+            _, fname, off = H[r + g].split()
+            lo, hi = boxes[g]
+            m = [hi[d] - lo[d] + 1 for d in range(3)]
+            with open(os.path.join(levdir, fname), "rb") as f:
+                f.seek(int(off))
+                f.readline()
+                fabs.append(np.fromfile(f, dtype="<f8", count=ncomp * m[0] * m[1] * m[2]).reshape(ncomp, m[2], m[1], m[0]))
+        lev = dict(dx=dxs[l], boxes=boxes, fabs=fabs)
+        if ngrids == 1:
+            lev.update(box=boxes[0], data=fabs[0])
+        out.append(lev)
     return dict(names=names, time=time, levels=out)
 
 

@@ -170,6 +170,90 @@ def test_tag_driven_three_levels_stay_nested_and_conserve(oracle):
     assert a.regrid() and len(a.levels) == 1
 
 
+def _assemble(level, lo, n):
+    """Valid data of all boxes of a level pasted into one array covering [lo, lo + n)."""
+    out = np.full((8, n[2], n[1], n[0]), np.nan)
+    for b in level.boxes:
+        o = [b.lo[d] - lo[d] for d in range(3)]
+        out[:, o[2]:o[2] + b.n[2], o[1]:o[1] + b.n[1], o[0]:o[0] + b.n[0]] = b.S_new().numpy()
+    return out
+
+
+def test_splitting_a_refined_level_into_boxes_changes_nothing(oracle):
+    """The same refined region as one box, as two boxes and as eight boxes: same-level ghost copies, one flux register
+    per box face (fine-fine faces are refluxed into covered coarse zones and overwritten by avgDown), level-wide dt and
+    retry -- bit for bit the same coarse and fine data after the shock has crossed the coarse-fine boundary."""
+    import castro_amd
+    kw = dict(params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend)
+    one = castro_amd.CastroAmr((16, 16, 16), patches=[((4, 4, 4), (11, 11, 11))], **kw)
+    two = castro_amd.CastroAmr((16, 16, 16), patches=[[((4, 4, 4), (7, 11, 11)), ((8, 4, 4), (11, 11, 11))]], **kw)
+    eight = castro_amd.CastroAmr((16, 16, 16), patches=[[((4 + 4 * i, 4 + 4 * j, 4 + 4 * k), (7 + 4 * i, 7 + 4 * j, 7 + 4 * k))
+                                                         for k in range(2) for j in range(2) for i in range(2)]], **kw)
+    for a in (one, two, eight):
+        a.initData("sedov", r_init=0.1, nsub=4)
+    assert len(eight.fine.boxes) == 8 and eight.pbox[1] == eight.boxes[1]
+    while one.time < 0.025 - 1e-15:
+        d = one.step(0.025)
+        assert two.step(0.025) == d and eight.step(0.025) == d
+    ref_c, ref_f = one.crse.S_new().numpy(), one.fine.S_new().numpy()
+    assert np.abs(ref_c[0] - 1.0).max() > 0.05                      # the shock is outside the refined region
+    for a in (two, eight):
+        assert np.array_equal(a.crse.S_new().numpy(), ref_c)
+        assert np.array_equal(_assemble(a.fine, (8, 8, 8), (16, 16, 16)), ref_f)
+        assert abs(a.composite_sum(0) - 1.0) <= 1e-12
+
+
+def test_a_box_over_two_parent_boxes(oracle):
+    """Level 2 sits across the two boxes of level 1: its coarse data, flux-register sources, reflux targets and avgDown
+    targets come from both parents.  Same result as with level 1 in one piece."""
+    import castro_amd
+    kw = dict(params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend)
+    l2 = ((12, 12, 12), (19, 19, 19))
+    one = castro_amd.CastroAmr((16, 16, 16), patches=[((4, 4, 4), (11, 11, 11)), l2], **kw)
+    two = castro_amd.CastroAmr((16, 16, 16), patches=[[((4, 4, 4), (11, 7, 11)), ((4, 8, 4), (11, 11, 11))], l2], **kw)
+    for a in (one, two):
+        a.initData("sedov", r_init=0.08, nsub=4)
+    assert len(two.levels[2].boxes[0].csrc) == 2 and len(two.levels[2].boxes[0].avg_to) == 2
+    for _ in range(10):
+        assert one.step(0.05) == two.step(0.05)
+    assert np.abs(one.levels[1].S_new().numpy()[0] - 1.0).max() > 0.5   # the shock has left level 2
+    assert np.array_equal(two.crse.S_new().numpy(), one.crse.S_new().numpy())
+    assert np.array_equal(_assemble(two.levels[1], (8, 8, 8), (16, 16, 16)), one.levels[1].S_new().numpy())
+    assert np.array_equal(two.levels[2].S_new().numpy(), one.levels[2].S_new().numpy())
+
+
+def test_clustered_boxes_follow_the_shock_and_conserve(oracle):
+    """cluster=True: Berger-Rigoutsos boxes around the tagged shell instead of its bounding box, regridded every two
+    coarse steps; composite mass and energy survive every regrid, the boxes are disjoint, nested and aligned."""
+    import castro_amd
+    from castro_amd import cluster as CL
+    a = castro_amd.CastroAmr((32, 32, 32), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+                             refine=[("density", "gradient", 0.1), ("rho_E", "relative_gradient", 0.5)], regrid_int=2,
+                             n_error_buf=1, blocking_factor=4, cluster=True, grid_eff=0.7, max_grid_size=16)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    assert a.fine is not None
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    nbox = []
+    while a.time < 0.012:
+        a.step(0.02)
+        assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+        bl = a.boxes[1]
+        nbox.append(len(bl))
+        cov = np.zeros((32, 32, 32), dtype=np.int32)
+        for lo, hi in bl:
+            assert all(l % 2 == 0 and (h + 1) % 2 == 0 and h - l + 1 <= 8 for l, h in zip(lo, hi))
+            cov[lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] += 1
+        assert cov.max() == 1
+    assert a.nregrid >= 2 and max(nbox) > 8
+    # the evacuated centre is no longer refined once the shell has moved out: fewer zones than the bounding box
+    lo = [min(b[0][d] for b in bl) for d in range(3)]
+    hi = [max(b[1][d] for b in bl) for d in range(3)]
+    assert cov.sum() < 0.9 * np.prod([hi[d] - lo[d] + 1 for d in range(3)])
+    # every currently tagged coarse zone is refined
+    tags, mask, o = a._tags(0)
+    assert tags.any() and not (tags & (cov == 0)).any()
+
+
 def test_multilevel_plotfile_round_trip(tmp_path, oracle):
     from castro_amd import plotfile as pf
     a = _amr(oracle, init_shrink=0.1)
@@ -189,3 +273,28 @@ def test_multilevel_plotfile_round_trip(tmp_path, oracle):
     for lev, got in zip(a.levels, r["levels"]):
         assert np.array_equal(got["data"][:8], lev.S_new().numpy())
         assert np.array_equal(got["data"][names.index("x_velocity")], got["data"][1] / got["data"][0])
+
+
+def test_plotfile_of_a_level_with_several_boxes(tmp_path, oracle):
+    import castro_amd
+    from castro_amd import plotfile as pf
+    a = castro_amd.CastroAmr((16, 16, 16), patches=[[((4, 4, 4), (7, 11, 11)), ((8, 4, 4), (11, 11, 11))]],
+                             params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    for _ in range(2):
+        a.step()
+    d = str(tmp_path / "plt_mb")
+    names = pf.write_plotfile_amr(d, a)
+    H = open(d + "/Header").read().split("\n")
+    p = 2 + len(names)
+    q = p + 8 + 2 + 2
+    assert H[q].split()[:2] == ["0", "1"] and H[q + 6].split()[:2] == ["1", "2"]      # level 1 lists two grids
+    assert H[q + 8].split() == ["0.25", "0.5"] and H[q + 11].split() == ["0.5", "0.75"]
+    cell_h = open(d + "/Level_1/Cell_H").read().split("\n")
+    assert cell_h[4] == "(2 0" and cell_h[5] == "((8,8,8) (15,23,23) (0,0,0))" and cell_h[6] == "((16,8,8) (23,23,23) (0,0,0))"
+    r = pf.read_plotfile_amr(d)
+    assert [len(lv["fabs"]) for lv in r["levels"]] == [1, 2]
+    for b, got, box in zip(a.fine.boxes, r["levels"][1]["fabs"], r["levels"][1]["boxes"]):
+        assert (tuple(box[0]), tuple(box[1])) == b.bx
+        assert np.array_equal(got[:8], b.S_new().numpy())
+        assert np.array_equal(got[names.index("x_velocity")], got[1] / got[0])

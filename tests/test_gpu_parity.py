@@ -854,6 +854,58 @@ def test_tag_driven_three_level_amr_on_the_device_matches_oracle_backend(oracle)
     assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
 
 
+def test_clustered_amr_on_the_device_matches_oracle_backend(oracle):
+    """Berger-Rigoutsos boxes (several per level, two refined levels) on the device against the oracle-backed
+    orchestration: same box lists at every step, same data bit for bit in every box."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(refine=[("density", "gradient", 0.1), ("rho_E", "relative_gradient", 0.5)], regrid_int=2, n_error_buf=1,
+              blocking_factor=4, max_level=2, cluster=True, grid_eff=0.7, max_grid_size=16)
+    a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1), **kw)
+    b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend, **kw)
+    for x in (a, b):
+        x.initData("sedov", r_init=0.08, nsub=4)
+    assert len(a.levels) == 3 and a.boxes == b.boxes
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    most = 0
+    while a.time < 0.01:
+        assert a.step(0.02) == b.step(0.02)
+        assert a.boxes == b.boxes
+        most = max(most, max(len(bl) for bl in a.boxes[1:]))
+    torch.cuda.synchronize()
+    assert a.nregrid == b.nregrid and a.nregrid >= 2 and most > 1
+    pairs = {}
+    for l in range(len(a.levels)):
+        for i, (x, y) in enumerate(zip(a.levels[l].boxes, b.levels[l].boxes)):
+            pairs["L%d box %d" % (l, i)] = (x.S_new().cpu().numpy(), y.S_new().numpy())
+    _assert_exact(pairs, "clustered AMR")
+    assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+
+
+def test_split_refined_level_on_the_device_equals_one_box():
+    """The refined region as eight boxes == as one box, bit for bit, on the device (same-level ghost copies, per-box
+    flux registers, level-wide reductions)."""
+    import torch
+    import castro_amd
+    P = castro_amd.default_params(init_shrink=0.1)
+    one = castro_amd.CastroAmr((16, 16, 16), patches=[((4, 4, 4), (11, 11, 11))], params=P)
+    eight = castro_amd.CastroAmr((16, 16, 16), params=P,
+                                 patches=[[((4 + 4 * i, 4 + 4 * j, 4 + 4 * k), (7 + 4 * i, 7 + 4 * j, 7 + 4 * k))
+                                           for k in range(2) for j in range(2) for i in range(2)]])
+    for x in (one, eight):
+        x.initData("sedov", r_init=0.1, nsub=4)
+    while one.time < 0.025 - 1e-15:
+        assert one.step(0.025) == eight.step(0.025)
+    torch.cuda.synchronize()
+    f = np.full((8, 16, 16, 16), np.nan)
+    for b in eight.fine.boxes:
+        o = [b.lo[d] - 8 for d in range(3)]
+        f[:, o[2]:o[2] + 8, o[1]:o[1] + 8, o[0]:o[0] + 8] = b.S_new().cpu().numpy()
+    _assert_exact({"coarse": (eight.crse.S_new().cpu().numpy(), one.crse.S_new().cpu().numpy()),
+                   "fine": (f, one.fine.S_new().cpu().numpy())}, "split level")
+
+
 def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
     """amr.max_level = 2 (1 + 2 + 4 advances per coarse step) on the device vs the oracle-backed orchestration."""
     import torch

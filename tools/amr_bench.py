@@ -19,13 +19,18 @@ patches = [((q, q, q), (3 * q - 1, 3 * q - 1, 3 * q - 1))]
 if nfine == 2:                                                # level-2 patch: the central n/2 zones of the level-1 box
     lo1 = 2 * q + q
     patches.append(((lo1, lo1, lo1), (lo1 + 2 * q - 1, lo1 + 2 * q - 1, lo1 + 2 * q - 1)))
-dynamic = len(sys.argv) > 4 and sys.argv[4] == "tags"          # both refined levels follow the tags (regrid every 2 steps)
+mode = sys.argv[4] if len(sys.argv) > 4 else ""                # "tags": one bounding box per level; "cluster": Berger-Rigoutsos boxes
+dynamic = mode in ("tags", "cluster")                          # the refined levels follow the tags (regrid every 2 steps)
+t_start = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0     # evolve to this time first (a developed blast wave)
 if dynamic:
     a = castro_amd.CastroAmr((n, n, n), refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)],
-                             regrid_int=2, n_error_buf=2, blocking_factor=8, max_level=nfine)
+                             regrid_int=2, n_error_buf=2, blocking_factor=16 if mode == "cluster" else 8, max_level=nfine,
+                             cluster=mode == "cluster", grid_eff=0.7, max_grid_size=128)
 else:
     a = castro_amd.CastroAmr((n, n, n), patches=patches)
 a.initData("sedov")
+if t_start > 0.0:
+    a.evolve(t_start)
 for _ in range(3):
     a.step()
 torch.cuda.synchronize()
@@ -33,13 +38,16 @@ t0 = time.perf_counter()
 zones = 0
 for _ in range(steps):
     a.step()
-    zones += sum((2 ** l) * lev.n[0] * lev.n[1] * lev.n[2] for l, lev in enumerate(a.levels))
+    zones += a.zones_advanced_per_coarse_step()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 if dynamic:
-    print(json.dumps({"workload": "Sedov %d^3 base + up to %d tag-driven refined levels (one box each), subcycled, regrid_int 2" % (n, nfine),
+    print(json.dumps({"workload": "Sedov %d^3 base + up to %d tag-driven refined levels (%s), subcycled, regrid_int 2, from t = %g"
+                      % (n, nfine, "Berger-Rigoutsos boxes" if mode == "cluster" else "one box each", t_start),
                       "steps": steps, "ms_per_coarse_step": wall / steps * 1e3, "zone_updates_per_s": zones / wall,
-                      "levels": [lev.n for lev in a.levels], "regrids": a.nregrid, "mass_drift": a.composite_sum(0) - 1.0}))
+                      "boxes_per_level": [len(lev.boxes) for lev in a.levels],
+                      "zones_per_level": [sum(b.n[0] * b.n[1] * b.n[2] for b in lev.boxes) for lev in a.levels],
+                      "regrids": a.nregrid, "mass_drift": a.composite_sum(0) - 1.0}))
     sys.exit(0)
 zones = (n ** 3 + 2 * (4 * q) ** 3 + (4 * (4 * q) ** 3 if nfine == 2 else 0)) * steps
 print(json.dumps({"workload": "Sedov %d^3 base + %d refined level(s), one %d^3 patch each, subcycled" % (n, nfine, 4 * q), "steps": steps,
