@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
+    "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
@@ -138,6 +139,8 @@ def load():
     L.castro_amd_copy_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_void_p]
     L.castro_amd_pack_fab.argtypes = [C.c_void_p, PF, I3, I3, C.c_void_p, C.c_void_p]
     L.castro_amd_unpack_fab.argtypes = [C.c_void_p, PF, I3, I3, C.c_void_p, C.c_void_p]
+    for f in (L.castro_amd_pack_regions_fab, L.castro_amd_unpack_regions_fab):
+        f.argtypes = [C.c_void_p, PF, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_void_p, C.c_void_p]
     L.castro_amd_sedov_init_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params),
                                             C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
     L.castro_amd_sod_init_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params)] + \

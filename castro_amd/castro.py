@@ -164,6 +164,7 @@ class Castro:
             self.mass_fluxes.append(hydro.alloc(1, self.lo, fhi))
         self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)   # [min dt, min rho]
 
+        self._plans = {}
         self.neighbors = self._build_neighbors() if box is None else []
         # Overlap of the halo exchange with compute: "staged" (True) runs ctoprim on the valid zones and the PPM
         # tracing of the zones >= 3 from the box faces while the exchange is in flight, then the rest -- no
@@ -249,12 +250,32 @@ class Castro:
             # what I send towards `off` is what the peer receives from direction -off
             out.append(dict(peer=peer, send_tag=code, recv_tag=rcode, sbox=(tuple(slo), tuple(shi)),
                             rbox=(tuple(rlo), tuple(rhi)), off=off))
+        # one contiguous send and one receive buffer, a slice per neighbour: all regions are packed / unpacked by one
+        # launch each (castro_amd_pack_regions_fab); a periodic wrap onto this rank unpacks straight from the send buffer
+        sizes = []
         for nbr in out:
             n = 1
             for d in range(3):
                 n *= nbr["sbox"][1][d] - nbr["sbox"][0][d] + 1
-            nbr["sbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * ncomp - 1, 0, 0)).reshape(-1)
-            nbr["rbuf"] = self.hydro.alloc(1, (0, 0, 0), (n * ncomp - 1, 0, 0)).reshape(-1)
+            sizes.append(n * ncomp)
+        total = max(sum(sizes), 1)
+        sall = self.hydro.alloc(1, (0, 0, 0), (total - 1, 0, 0)).reshape(-1)
+        rall = self.hydro.alloc(1, (0, 0, 0), (total - 1, 0, 0)).reshape(-1)
+        off = 0
+        for nbr, n in zip(out, sizes):
+            nbr["off"] = off
+            nbr["sbuf"], nbr["rbuf"] = sall[off:off + n], rall[off:off + n]
+            off += n
+        if out and hasattr(self.hydro, "region_table"):
+            h = self.hydro
+            local = [nb for nb in out if nb["peer"] == self.comm.rank]
+            remote = [nb for nb in out if nb["peer"] != self.comm.rank]
+            plan = dict(sall=sall, rall=rall, pack=h.region_table([nb["sbox"] for nb in out], [nb["off"] for nb in out]))
+            # what I send towards `off` is what I receive from `-off`
+            src = {nb["send_tag"]: nb for nb in local}
+            plan["unpack_local"] = h.region_table([nb["rbox"] for nb in local], [src[nb["recv_tag"]]["off"] for nb in local]) if local else None
+            plan["unpack_remote"] = h.region_table([nb["rbox"] for nb in remote], [nb["off"] for nb in remote]) if remote else None
+            self._plans[id(out)] = plan
         return out
 
     # ---- AmrLevel::FillPatch at a single level: same-level copy + physical BCs ----
@@ -263,6 +284,18 @@ class Castro:
         h = self.hydro
         box = self.gbox if box is None else box
         neighbors = self.neighbors if neighbors is None else neighbors
+        plan = self._plans.get(id(neighbors))
+        if plan is not None:
+            h.pack_regions(S, box, plan["pack"], plan["sall"])
+            sends = [(nb["peer"], nb["send_tag"], nb["sbuf"]) for nb in neighbors if nb["peer"] != self.comm.rank]
+            recvs = [(nb["peer"], nb["recv_tag"], nb["rbuf"]) for nb in neighbors if nb["peer"] != self.comm.rank]
+            self.comm.exchange(sends, recvs)
+            if plan["unpack_local"] is not None:
+                h.unpack_regions(S, box, plan["unpack_local"], plan["sall"])
+            if plan["unpack_remote"] is not None:
+                h.unpack_regions(S, box, plan["unpack_remote"], plan["rall"])
+            h.bc_fill(S, box, self.geom)
+            return
         sends, recvs, local = [], [], []
         for nb in neighbors:
             h.pack(S, box, nb["sbox"][0], nb["sbox"][1], nb["sbuf"])

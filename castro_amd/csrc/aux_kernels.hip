@@ -907,6 +907,59 @@ int launch_pack(const DFab& f, const int lo[3], const int hi[3], int ncomp, doub
     return 0;
 }
 
+// All halo regions of one FillBoundary in one launch: region r owns threads [start[r], start[r+1]) and the
+// doubles buf[off[r] ...] (same ordering as k_pack, restricted to the region).
+struct PackRegions {
+    int n;
+    int lo[CASTRO_AMD_MAX_REGIONS][3], nn[CASTRO_AMD_MAX_REGIONS][3];
+    long off[CASTRO_AMD_MAX_REGIONS];
+    long start[CASTRO_AMD_MAX_REGIONS + 1];
+};
+
+__global__ void __launch_bounds__(256) k_pack_regions(DFab f, PackRegions R, int ncomp, double* buf, int unpack)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= R.start[R.n]) return;
+    int r = 0;
+    while (tid >= R.start[r + 1]) ++r;
+    const long t = tid - R.start[r];
+    const int n0 = R.nn[r][0], n1 = R.nn[r][1];
+    const int ii = (int)(t % n0);
+    const long q = t / n0;
+    const int jj = (int)(q % n1), kk = (int)(q / n1);
+    const long cf = fidx(f, R.lo[r][0] + ii, R.lo[r][1] + jj, R.lo[r][2] + kk, 0);
+    const long nb = (long)n0 * n1 * R.nn[r][2];
+    double* b = buf + R.off[r] + t;
+    if (unpack) {
+        for (int n = 0; n < ncomp; ++n) f.p[cf + f.sn * n] = b[nb * n];
+    } else {
+        for (int n = 0; n < ncomp; ++n) b[nb * n] = f.p[cf + f.sn * n];
+    }
+}
+
+int launch_pack_regions(const DFab& f, int nreg, const int* lo, const int* hi, const long long* off, int ncomp, double* buf,
+                        int unpack, hipStream_t stream, Profiler* prof)
+{
+    PackRegions R;
+    R.n = 0;
+    R.start[0] = 0;
+    for (int r = 0; r < nreg; ++r) {
+        long n = 1;
+        int nn[3];
+        for (int d = 0; d < 3; ++d) { nn[d] = hi[3 * r + d] - lo[3 * r + d] + 1; n *= nn[d] > 0 ? nn[d] : 0; }
+        if (n <= 0) continue;
+        const int m = R.n++;
+        for (int d = 0; d < 3; ++d) { R.lo[m][d] = lo[3 * r + d]; R.nn[m][d] = nn[d]; }
+        R.off[m] = (long)off[r];
+        R.start[m + 1] = R.start[m] + n;
+    }
+    if (R.n == 0) return 0;
+    prof_begin(prof, unpack ? "k_unpack" : "k_pack", stream);
+    hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((R.start[R.n] + 255) / 256)), dim3(256), 0, stream, f, R, ncomp, buf, unpack);
+    prof_end(prof, stream);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // Sedov initial data (Exec/hydro_tests/Sedov/problem_initialize_state_data.H:8-148, Cartesian)
 // ---------------------------------------------------------------------------------------

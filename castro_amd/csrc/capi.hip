@@ -559,6 +559,25 @@ int castro_amd_unpack_fab(castro_amd_ctx* c, const castro_amd_fab* fab, const in
     return launch_pack(to_dfab(fab), lo, hi, fab->ncomp, const_cast<double*>(buf), 1, (hipStream_t)stream, &c->prof);
 }
 
+static int pack_regions(castro_amd_ctx* c, const castro_amd_fab* fab, int nregions, const int* lo, const int* hi,
+                        const long long* offsets, double* buf, int unpack, void* stream)
+{
+    if (!c || !fab || !fab->p || !buf || !lo || !hi || !offsets || nregions < 0 || nregions > CASTRO_AMD_MAX_REGIONS)
+        return CASTRO_AMD_ERR_ARG;
+    for (int r = 0; r < nregions; ++r)
+        if (!fab_contains(fab, lo + 3 * r, hi + 3 * r) || offsets[r] < 0) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_pack_regions(to_dfab(fab), nregions, lo, hi, offsets, fab->ncomp, buf, unpack, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_pack_regions_fab(castro_amd_ctx* c, const castro_amd_fab* fab, int nregions, const int* lo, const int* hi,
+                                const long long* offsets, double* buf, void* stream)
+{ return pack_regions(c, fab, nregions, lo, hi, offsets, buf, 0, stream); }
+
+int castro_amd_unpack_regions_fab(castro_amd_ctx* c, const castro_amd_fab* fab, int nregions, const int* lo, const int* hi,
+                                  const long long* offsets, const double* buf, void* stream)
+{ return pack_regions(c, fab, nregions, lo, hi, offsets, const_cast<double*>(buf), 1, stream); }
+
 // Exec/hydro_tests/Sedov/problem_initialize.H:8-113 (host part) + the per-zone kernel
 int castro_amd_sedov_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
                               const castro_amd_geom* geom, const castro_amd_params* params,

@@ -101,6 +101,8 @@ int launch_copy(const DFab& dst, const DFab& src, const int lo[3], const int hi[
                 hipStream_t stream, Profiler* prof);
 int launch_pack(const DFab& f, const int lo[3], const int hi[3], int ncomp, double* buf, int unpack,
                 hipStream_t stream, Profiler* prof);
+int launch_pack_regions(const DFab& f, int nreg, const int* lo, const int* hi, const long long* off, int ncomp, double* buf,
+                        int unpack, hipStream_t stream, Profiler* prof);
 int launch_sedov_init(const DFab& U, const int lo[3], const int hi[3], const DevParams& P,
                       const double dx[3], const double problo[3], const double center[3],
                       double r_init, double e_exp, double e_ambient, double temp_ambient,

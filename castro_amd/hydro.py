@@ -221,6 +221,26 @@ class HipHydro:
                                                C.c_void_p(buf.data_ptr()), _stream_ptr(stream)), "unpack_fab")
 
     # ---- problem setups ----------------------------------------------------------------------
+    @staticmethod
+    def region_table(boxes, offsets):
+        """ctypes arrays for pack_regions / unpack_regions: boxes [(lo, hi)], offsets in doubles."""
+        n = len(boxes)
+        lo = (C.c_int * (3 * n))(*[x for b in boxes for x in b[0]])
+        hi = (C.c_int * (3 * n))(*[x for b in boxes for x in b[1]])
+        off = (C.c_longlong * n)(*offsets)
+        return n, lo, hi, off
+
+    def pack_regions(self, state, box, table, buf, stream=None):
+        """Every region of `table` (region_table) of the FAB into its slice of `buf`, one launch."""
+        n, lo, hi, off = table
+        L.check(self.lib.castro_amd_pack_regions_fab(self.h, C.byref(L.fab_of(state, *box)), n, lo, hi, off,
+                                                     C.c_void_p(buf.data_ptr()), _stream_ptr(stream)), "pack_regions_fab")
+
+    def unpack_regions(self, state, box, table, buf, stream=None):
+        n, lo, hi, off = table
+        L.check(self.lib.castro_amd_unpack_regions_fab(self.h, C.byref(L.fab_of(state, *box)), n, lo, hi, off,
+                                                       C.c_void_p(buf.data_ptr()), _stream_ptr(stream)), "unpack_regions_fab")
+
     def sedov_init(self, state, box, lo, hi, geom, params, r_init=0.01, p_ambient=1.e-5, exp_energy=1.0,
                    dens_ambient=1.0, nsub=10, stream=None):
         L.check(self.lib.castro_amd_sedov_init_fab(self.h, C.byref(L.fab_of(state, *box)), L.i3(lo), L.i3(hi),

@@ -322,6 +322,14 @@ int castro_amd_pack_fab(castro_amd_ctx *ctx, const castro_amd_fab *fab, const in
 int castro_amd_unpack_fab(castro_amd_ctx *ctx, const castro_amd_fab *fab, const int lo[3], const int hi[3],
                           const double *buf, void *stream);
 
+/* The same for all regions of one FillBoundary in ONE launch (a rank has up to 26 neighbours): region r is the box
+ * lo[3r..3r+2] : hi[3r..3r+2] and lives at buf + offsets[r] (in doubles), r < nregions <= CASTRO_AMD_MAX_REGIONS. */
+#define CASTRO_AMD_MAX_REGIONS 32
+int castro_amd_pack_regions_fab(castro_amd_ctx *ctx, const castro_amd_fab *fab, int nregions, const int *lo, const int *hi,
+                                const long long *offsets, double *buf, void *stream);
+int castro_amd_unpack_regions_fab(castro_amd_ctx *ctx, const castro_amd_fab *fab, int nregions, const int *lo, const int *hi,
+                                  const long long *offsets, const double *buf, void *stream);
+
 /* Problem initial data on [lo,hi] of `state` (ncomp 8):
  * Exec/hydro_tests/Sedov/problem_initialize.H:8-113 + problem_initialize_state_data.H:8-148 */
 int castro_amd_sedov_init_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, const int lo[3], const int hi[3],
