@@ -114,7 +114,7 @@ class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None):
+                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -184,6 +184,8 @@ class Castro:
         self.use_retry, self.retry_subcycle_factor = bool(use_retry), float(retry_subcycle_factor)
         self.max_subcycles, self.dt_cutoff = int(max_subcycles), float(dt_cutoff)
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
+        # castro.fixed_dt / castro.initial_dt (_cpp_parameters; Castro.cpp:1490-1513, 1655)
+        self.fixed_dt, self.initial_dt = float(fixed_dt), float(initial_dt)
         # castro.do_grav with gravity.gravity_type = "ConstantGrav": g along the last dimension (Gravity.cpp:860-866)
         self.do_grav, self.grav, self.grav_source_type = bool(do_grav), (0.0, 0.0, float(const_grav)), int(grav_source_type)
         # castro.do_rotation: `rotation` = _lib.make_rotation(rotational_period, rot_axis, ...)
@@ -349,19 +351,23 @@ class Castro:
         return v[0], v[1]
 
     def estTimeStep(self):
+        if self.fixed_dt > 0.0:                                 # Castro.cpp:1511-1513
+            return self.fixed_dt
         est, _ = self._reduce()
         return min(1.e200, est * self.params.cfl)
 
     def computeInitialDt(self, stop_time=-1.0):
-        dt_0 = self.params.init_shrink * self.estTimeStep()
+        # Castro::initialTimeStep (Castro.cpp:1490-1504)
+        dt_0 = self.initial_dt if self.initial_dt > 0.0 else self.params.init_shrink * self.estTimeStep()
         eps = 0.001 * dt_0
         if stop_time >= 0.0 and (self.time + dt_0) > (stop_time - eps):
             dt_0 = stop_time - self.time
         return dt_0
 
     def computeNewDt(self, dt_old, stop_time=-1.0, est=None):
-        dt_0 = self.estTimeStep() if est is None else est
-        dt_0 = min(dt_0, self.params.change_max * dt_old)
+        dt_0 = self.estTimeStep() if (est is None or self.fixed_dt > 0.0) else est
+        if self.fixed_dt <= 0.0:                                # Castro.cpp:1655
+            dt_0 = min(dt_0, self.params.change_max * dt_old)
         eps = 2.220446049250313e-16
         if stop_time >= 0.0 and (self.time + dt_0) >= (stop_time - eps):
             dt_0 = stop_time - self.time
@@ -453,7 +459,7 @@ class Castro:
         if rho_min < self.params.small_dens:
             # retry_small_density_cutoff keeps its default (-1e200): every such step is rejected
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        new_dt = min(1.e200, est * self.params.cfl)
+        new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(1.e200, est * self.params.cfl)
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None
         return True, "", new_dt
@@ -495,8 +501,7 @@ class Castro:
         h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
         h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
         # timestep validity check (:386-392)
-        est, _ = self._reduce()
-        new_dt = min(1.e200, est * self.params.cfl)
+        new_dt = self.estTimeStep()
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None
         return True, "", new_dt

@@ -298,3 +298,20 @@ def test_plotfile_of_a_level_with_several_boxes(tmp_path, oracle):
         assert (tuple(box[0]), tuple(box[1])) == b.bx
         assert np.array_equal(got[:8], b.S_new().numpy())
         assert np.array_equal(got[names.index("x_velocity")], got[1] / got[0])
+
+
+def test_level_wide_retry_on_a_refined_level_stays_conservative(oracle):
+    """init_shrink = 1 makes the first step fail its validity check: every level goes through retry_advance_ctu as a
+    whole (all boxes of the level back to the old state, fluxes cleared, two subcycles); the fluxes that reach the
+    flux registers are the sums over the subcycles, so the composite update stays conservative."""
+    import castro_amd
+    a = castro_amd.CastroAmr((16, 16, 16), patches=[[((4, 4, 4), (7, 11, 11)), ((8, 4, 4), (11, 11, 11))]],
+                             params=oracle.default_params(init_shrink=1.0, cfl=0.9), make_hydro=OracleBackend)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    a.step()
+    assert [(lev.nsubcycles, lev.nretries) for lev in a.levels] == [(2, 1), (2, 1)]
+    assert "validity" in a.levels[1].last_failure
+    for _ in range(3):
+        a.step()
+    assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0

@@ -322,3 +322,33 @@ def test_rotation_sources_inertial_oscillation_and_oracle_driver(oracle, rst, im
         lev.step(2.0)
     assert np.array_equal(c.S_new().numpy(), lev.state())
     lev.close()
+
+
+def _acoustic_pulse(n, gamma=1.4, rho0=1.4, drho0=0.14):
+    """Exec/hydro_tests/acoustic_pulse/problem_initialize_state_data.H:29-75 (McCorquodale & Colella 2011)."""
+    x = (np.arange(n) + 0.5) / n
+    zz, yy, xx = np.meshgrid(x, x, x, indexing="ij")
+    dist = np.sqrt((0.5 - xx) ** 2 + (0.5 - yy) ** 2 + (0.5 - zz) ** 2)
+    rho = np.where(dist <= 0.5, rho0 + drho0 * np.exp(-16.0 * dist * dist) * np.cos(np.pi * dist) ** 6, rho0)
+    p = (rho / rho0) ** gamma
+    S = np.zeros((8, n, n, n))
+    S[0] = rho; S[4] = p / (gamma - 1.0); S[5] = S[4]; S[7] = rho
+    return S
+
+
+@pytest.mark.parametrize("fixed_dt,steps", [(3.0e-3, 81), (1.5e-3, 161)])
+def test_fixed_dt_step_counts_of_the_acoustic_pulse_scripts(oracle, fixed_dt, steps):
+    """Exec/hydro_tests/acoustic_pulse/convergence_ppm.sh compares plt00081 (inputs.64, fixed_dt = 3e-3), plt00161
+    (inputs.128, 1.5e-3) and plt00321 (inputs.256, 7.5e-4) at stop_time = 0.24: the first step is init_shrink x fixed_dt
+    (Castro::initialTimeStep), every later one fixed_dt without the change_max limit (Castro.cpp:1655), the last one
+    is clipped to stop_time.  The counts do not depend on the resolution, so they are checked on 8^3 zones."""
+    import castro_amd
+    c = castro_amd.Castro((8, 8, 8), lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), params=oracle.default_params(init_shrink=0.01),
+                          hydro=OracleBackend(), fixed_dt=fixed_dt)
+    c.set_state(_acoustic_pulse(8))
+    dts = []
+    while c.time < 0.24 - 2.220446049250313e-16:
+        dts.append(c.step(0.24))
+    assert c.nstep == steps and c.time == 0.24
+    assert dts[0] == 0.01 * fixed_dt and all(d == fixed_dt for d in dts[1:-1]) and 0.0 < dts[-1] <= fixed_dt
+    assert c.nretries == 0

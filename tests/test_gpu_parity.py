@@ -906,6 +906,28 @@ def test_split_refined_level_on_the_device_equals_one_box():
                    "fine": (f, one.fine.S_new().cpu().numpy())}, "split level")
 
 
+def test_amr_retry_on_the_device_matches_oracle_backend(oracle):
+    """A rejected first step (init_shrink = 1) on a two-box refined level: level-wide retry with two subcycles, on the
+    device and with the oracle backend -- same retry counts, same data."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(patches=[[((4, 4, 4), (7, 11, 11)), ((8, 4, 4), (11, 11, 11))]])
+    a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=1.0, cfl=0.9), **kw)
+    b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=1.0, cfl=0.9), make_hydro=OracleBackend, **kw)
+    for x in (a, b):
+        x.initData("sedov", r_init=0.1, nsub=4)
+    for _ in range(4):
+        assert a.step() == b.step()
+        assert [(l.nsubcycles, l.nretries) for l in a.levels] == [(l.nsubcycles, l.nretries) for l in b.levels]
+    torch.cuda.synchronize()
+    assert a.levels[1].nretries == 0 and a.nstep == 4
+    pairs = {"coarse": (a.crse.S_new().cpu().numpy(), b.crse.S_new().numpy())}
+    for i, (x, y) in enumerate(zip(a.fine.boxes, b.fine.boxes)):
+        pairs["fine box %d" % i] = (x.S_new().cpu().numpy(), y.S_new().numpy())
+    _assert_exact(pairs, "AMR retry")
+
+
 def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
     """amr.max_level = 2 (1 + 2 + 4 advances per coarse step) on the device vs the oracle-backed orchestration."""
     import torch
@@ -1034,3 +1056,35 @@ def test_rotation_on_the_device_matches_oracle(oracle, rst, implicit):
     torch.cuda.synchronize()
     _assert_exact({"S_new": (c.S_new().cpu().numpy(), lev.state())}, "rotation type %d implicit %d" % (rst, implicit))
     lev.close()
+
+
+def test_acoustic_pulse_convergence_like_the_reference_scripts():
+    """Exec/hydro_tests/acoustic_pulse (McCorquodale & Colella 2011) with inputs.64 / .128 / .256 (periodic, fixed_dt =
+    3e-3 / 1.5e-3 / 7.5e-4, init_shrink 0.01, stop_time 0.24, PPM + CTU) on the device: the runs end at the step
+    numbers of the plotfiles the reference's convergence_ppm.sh compares (plt00081, plt00161, plt00321), and the
+    Richardson estimate between them shows the second-order convergence of the unsplit PPM scheme on smooth flow."""
+    import torch
+    import castro_amd
+    from tests.test_driver_cpu import _acoustic_pulse
+    sol = {}
+    for n, fixed_dt, steps in ((64, 3.0e-3, 81), (128, 1.5e-3, 161), (256, 7.5e-4, 321)):
+        c = castro_amd.Castro((n, n, n), lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), params=castro_amd.default_params(init_shrink=0.01),
+                              fixed_dt=fixed_dt)
+        c.set_state(_acoustic_pulse(n))
+        c.evolve(0.24)
+        torch.cuda.synchronize()
+        assert c.nstep == steps and c.time == 0.24 and c.nretries == 0
+        sol[n] = c.S_new().cpu().numpy()
+        del c
+
+    def coarsen(a):
+        m = a.shape[-1] // 2
+        return a.reshape(a.shape[0], m, 2, m, 2, m, 2).mean(axis=(2, 4, 6))
+
+    for comp, name in ((0, "density"), (1, "xmom"), (4, "rho_E")):
+        e_lo = np.abs(coarsen(sol[128])[comp] - sol[64][comp]).mean()
+        e_hi = np.abs(coarsen(sol[256])[comp] - sol[128][comp]).mean()
+        rate = np.log2(e_lo / e_hi)
+        assert 1.8 < rate < 3.2, (name, e_lo, e_hi, rate)
+    # the pulse has spread symmetrically: mass is conserved to round-off on the periodic domain
+    assert abs(sol[256][0].mean() - _acoustic_pulse(256)[0].mean()) < 1e-13
