@@ -786,18 +786,20 @@ def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, overlap):
+@pytest.mark.parametrize("world,overlap", [(2, False), (2, True), (8, False)])
+def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, world, overlap):
     """The N > 1 device path end to end (device pack -> inter-process exchange -> device unpack -> BC fill -> hydro,
-    2-double allreduce), with two processes on the one GPU of the test box.  The transport is gloo (RCCL needs one
-    device per rank); everything else is the code that runs on a multi-GPU node."""
+    2-double allreduce), with two processes (z split) or eight (the 2x2x2 layout of an 8-GPU node: faces, edges and
+    corners to 7 peers, and two messages per peer pair across the periodic x direction) on the one GPU of the test
+    box.  The transport is gloo (RCCL needs one device per rank); everything else is the code that runs on a
+    multi-GPU node."""
     import torch
     import torch.multiprocessing as mp
     import castro_amd
     from tests.test_driver_cpu import _free_port
     n, nsteps = (24, 16, 32), 4
     out = str(tmp_path / "two.npz")
-    mp.spawn(_two_rank_gpu_worker, args=(2, _free_port(), n, nsteps, out, overlap), nprocs=2, join=True)
+    mp.spawn(_two_rank_gpu_worker, args=(world, _free_port(), n, nsteps, out, overlap), nprocs=world, join=True)
     got = np.load(out)
     c = castro_amd.Castro(n, lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
     c.initData("sedov", r_init=0.1, nsub=4)
