@@ -659,12 +659,16 @@ __device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, uns
     }
 }
 
-template <int D>
-__device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd,
+// aA/aB enter holding the stencils of the normal velocity, bA/bB those of the density; with NEXT >= 0 they leave
+// holding the density (a) and normal-velocity (b) stencils of direction NEXT (stride sdn), requested before the
+// characteristic projection and the stores of this direction.
+template <int D, int NEXT>
+__device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd, unsigned sdn,
                                                const double flat[2], double dtdx, const DevParams& P,
                                                const bool do_plus[2], const bool do_minus[2],
                                                double* __restrict__ QMd, double* __restrict__ QPd,
-                                               double qp[2][NEDGE], double qm[2][NEDGE])
+                                               double qp[2][NEDGE], double qm[2][NEDGE],
+                                               double aA[5], double aB[5], double bA[5], double bB[5])
 {
     constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
     constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
@@ -677,10 +681,6 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     double un[2];
     // software pipeline: the stencil of the next variable is requested before the parabola of the current one
     // is evaluated (two register buffers): 3.30 -> 3.16 ms at 256^3
-    double aA[5], aB[5], bA[5], bB[5];
-
-    load_stencil_2<D>(Q + (long)QUN * NC, c, sd, aA, aB);
-    load_stencil_2<D>(Q + (long)PRHO * NC, c, sd, bA, bB);
     un[0] = aA[2]; un[1] = aB[2];
     ppm_waves<2>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_un, w[0].Im_un);
     ppm_waves<2>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
@@ -705,8 +705,10 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
     ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
 
+    if (NEXT >= 0) load_stencil_2<(NEXT >= 0 ? NEXT : 0)>(Q + (long)(NEXT == 1 ? PV : PW) * NC, c, sdn, bA, bB);
     ppm_waves<1>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_X, w[0].Im_X);
     ppm_waves<1>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_X, w[1].Im_X);
+    if (NEXT >= 0) load_stencil_2<(NEXT >= 0 ? NEXT : 0)>(Q + (long)PRHO * NC, c, sdn, aA, aB);
 
     trace_finish<D>(w[0], un[0], cc[0], P, qp[0], qm[0]);
     trace_finish<D>(w[1], un[1], cc[1], P, qp[1], qm[1]);
@@ -1256,30 +1258,27 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
     if (P.first_order_hydro == 1) {
         flat[0] = flat[1] = 0.0;
     } else if (P.use_flattening == 1) {
+        // all three directions' stencils are requested before the first coefficient is evaluated
         const double* Pp = Q + PP * NC;
-        double pA[7], pB[7], uA[5], uB[5];
+        double pxA[7], pxB[7], uxA[5], uxB[5], pyA[7], pyB[7], uyA[5], uyB[5], pzA[7], pzB[7], uzA[5], uzB[5];
         {
             const D2 p0 = ldg2(Pp, c - 24u), p1 = ldg2(Pp, c - 8u), p2 = ldg2(Pp, c + 8u), p3 = ldg2(Pp, c + 24u);
-            pA[0] = p0.a; pA[1] = p0.b; pA[2] = p1.a; pA[3] = p1.b; pA[4] = p2.a; pA[5] = p2.b; pA[6] = p3.a;
-            pB[0] = p0.b; pB[1] = p1.a; pB[2] = p1.b; pB[3] = p2.a; pB[4] = p2.b; pB[5] = p3.a; pB[6] = p3.b;
-            load_stencil_2<0>(Q + PU * NC, c, s.x, uA, uB);
-            flat[0] = flatten_1d(pA, uA);
-            flat[1] = flatten_1d(pB, uB);
+            pxA[0] = p0.a; pxA[1] = p0.b; pxA[2] = p1.a; pxA[3] = p1.b; pxA[4] = p2.a; pxA[5] = p2.b; pxA[6] = p3.a;
+            pxB[0] = p0.b; pxB[1] = p1.a; pxB[2] = p1.b; pxB[3] = p2.a; pxB[4] = p2.b; pxB[5] = p3.a; pxB[6] = p3.b;
+            load_stencil_2<0>(Q + PU * NC, c, s.x, uxA, uxB);
         }
-        {
 #pragma unroll
-            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.y); pA[m + 3] = v.a; pB[m + 3] = v.b; }
-            load_stencil_2<1>(Q + PV * NC, c, s.y, uA, uB);
-            flat[0] = amin(flat[0], flatten_1d(pA, uA));
-            flat[1] = amin(flat[1], flatten_1d(pB, uB));
-        }
-        {
+        for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.y); pyA[m + 3] = v.a; pyB[m + 3] = v.b; }
+        load_stencil_2<1>(Q + PV * NC, c, s.y, uyA, uyB);
 #pragma unroll
-            for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.z); pA[m + 3] = v.a; pB[m + 3] = v.b; }
-            load_stencil_2<2>(Q + PW * NC, c, s.z, uA, uB);
-            flat[0] = amin(flat[0], flatten_1d(pA, uA));
-            flat[1] = amin(flat[1], flatten_1d(pB, uB));
-        }
+        for (int m = -3; m <= 3; ++m) { const D2 v = ldg2(Pp, c + m * s.z); pzA[m + 3] = v.a; pzB[m + 3] = v.b; }
+        load_stencil_2<2>(Q + PW * NC, c, s.z, uzA, uzB);
+        flat[0] = flatten_1d(pxA, uxA);
+        flat[1] = flatten_1d(pxB, uxB);
+        flat[0] = amin(flat[0], flatten_1d(pyA, uyA));
+        flat[1] = amin(flat[1], flatten_1d(pyB, uyB));
+        flat[0] = amin(flat[0], flatten_1d(pzA, uzA));
+        flat[1] = amin(flat[1], flatten_1d(pzB, uzB));
     } else {
         flat[0] = flat[1] = 1.0;
     }
@@ -1288,7 +1287,10 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
     double qp[2][NEDGE], qm[2][NEDGE];
     dp[0] = valid && i >= t.lo[0]; dp[1] = v1 && i + 1 >= t.lo[0];
     dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
-    trace_pair_dir<0>(t, Q, c, s.x, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm);
+    double sa[2][5], sb[2][5];
+    load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1]);
+    load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1]);
+    trace_pair_dir<0, 1>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1]);
 
     if (XRIEM)
     // ---- first Riemann solve in x (Castro_ctu_hydro.cpp:719) on the two faces of this thread:
@@ -1331,9 +1333,9 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
     }
 
     { const bool a = j >= t.lo[1], z = j <= t.hi[1]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z; }
-    trace_pair_dir<1>(t, Q, c, s.y, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm);
+    trace_pair_dir<1, 2>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sb[0], sb[1], sa[0], sa[1]);
     { const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z; }
-    trace_pair_dir<2>(t, Q, c, s.z, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm);
+    trace_pair_dir<2, -1>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
 }
 
 // the x-faces k_trace_pair leaves out: face i of the first thread of every workgroup of that launch
