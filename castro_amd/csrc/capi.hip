@@ -131,6 +131,7 @@ static size_t plane_doubles(int nx, int ny, int nz)
 
 // number of component planes in the scratch arena
 static constexpr int kPlanes = NPRIM + 2 + 6 + 6 * NEDGE + 3 * NF1 + 6 * NF1 + 3 * NFIN;
+static constexpr int kPlanesResetRhoe = 9;     // F1E[3] + F2E[6], only with transverse_reset_rhoe = 1
 
 extern "C" {
 
@@ -201,16 +202,21 @@ void castro_amd_ctx_destroy(castro_amd_ctx* c)
     delete c;
 }
 
-int castro_amd_ctx_reserve(castro_amd_ctx* c, int nx, int ny, int nz)
+static int reserve_planes(castro_amd_ctx* c, int nx, int ny, int nz, int planes)
 {
     if (!c || nx <= 0 || ny <= 0 || nz <= 0) return CASTRO_AMD_ERR_ARG;
-    size_t need = plane_doubles(nx, ny, nz) * (size_t)kPlanes;
+    size_t need = plane_doubles(nx, ny, nz) * (size_t)planes;
     if (need <= c->arena_doubles) return CASTRO_AMD_OK;
     hipSetDevice(c->device);
     if (c->arena) { hipDeviceSynchronize(); hipFree(c->arena); c->arena = nullptr; c->arena_doubles = 0; }
     if (hipMalloc(&c->arena, need * sizeof(double)) != hipSuccess) return CASTRO_AMD_ERR_NOMEM;
     c->arena_doubles = need;
     return CASTRO_AMD_OK;
+}
+
+int castro_amd_ctx_reserve(castro_amd_ctx* c, int nx, int ny, int nz)
+{
+    return reserve_planes(c, nx, ny, nz, kPlanes);
 }
 
 long long castro_amd_ctx_scratch_bytes(const castro_amd_ctx* c)
@@ -257,8 +263,6 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     if (params->ppm_type != 0 && params->ppm_type != 1) return CASTRO_AMD_ERR_ARG;
     if (params->riemann_solver < 0 || params->riemann_solver > 2) return CASTRO_AMD_ERR_ARG;
     if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
-    // transverse_reset_rhoe needs the eint flux of the transverse solves, which the flux record does not carry
-    if (params->transverse_reset_rhoe != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
     if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
 
     Tile t;
@@ -283,7 +287,8 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     }
 
     hipSetDevice(c->device);
-    int rc = castro_amd_ctx_reserve(c, nx, ny, nz);
+    const bool reset_rhoe = params->transverse_reset_rhoe == 1;
+    int rc = reserve_planes(c, nx, ny, nz, kPlanes + (reset_rhoe ? kPlanesResetRhoe : 0));
     if (rc != CASTRO_AMD_OK) return rc;
 
     DevScratch S;
@@ -297,6 +302,8 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     for (int d = 0; d < 3; ++d) { S.F1[d] = p; p += NC * NF1; }
     for (int d = 0; d < 6; ++d) { S.F2[d] = p; p += NC * NF1; }
     for (int d = 0; d < 3; ++d) { S.FL[d] = p; p += NC * NFIN; }
+    for (int d = 0; d < 3; ++d) { S.F1E[d] = reset_rhoe ? p : nullptr; if (reset_rhoe) p += NC; }
+    for (int d = 0; d < 6; ++d) { S.F2E[d] = reset_rhoe ? p : nullptr; if (reset_rhoe) p += NC; }
 
     DFab dS = to_dfab(Sborder), dN = to_dfab(S_new);
     DFab dF[3], dM[3], dQ[3];

@@ -42,6 +42,8 @@ struct DevScratch {
     double* F1[3];    // NF1 planes each
     double* F2[6];    // NF1 planes each, slot f2_slot(N,T)
     double* FL[3];    // NFIN planes each
+    double* F1E[3];   // (rho e) flux of the first solves, 1 plane each -- written and read only with transverse_reset_rhoe = 1
+    double* F2E[6];   // the same for the transverse-stage solves
 };
 
 // hipEvent-based per-kernel timing (enabled on request only: it serialises nothing, the

@@ -1023,9 +1023,11 @@ __device__ __forceinline__ bool face_shock(const DevScratch& S, const DevParams&
 }
 
 // write a transverse-stage flux record at face offset c (global component order)
+// FEI: plane of the (rho e) flux, nullptr unless transverse_reset_rhoe = 1
 template <int D>
-__device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsigned c, const IFlux& f)
+__device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsigned c, const IFlux& f, double* __restrict__ FEI = nullptr)
 {
+    if (FEI) stg(FEI, c, f.eint);
     stg(F + FRHO * NC, c, f.rho);
     stg(F + (FMX + RDir<D>::n) * NC, c, f.mn);
     stg(F + (FMX + RDir<D>::t) * NC, c, f.mt);
@@ -1064,8 +1066,14 @@ __device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long N
 }
 
 template <int D>
-__device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1)
+__device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1,
+                                           double* __restrict__ FEI = nullptr)
 {
+    if (FEI) {
+        if (m0 && m1) stg2(FEI, c, f[0].eint, f[1].eint);
+        else if (m0) stg(FEI, c, f[0].eint);
+        else if (m1) stg(FEI, c + 8u, f[1].eint);
+    }
     if (m0 && m1) {
         stg2(F + FRHO * NC, c, f[0].rho, f[1].rho);
         stg2(F + (FMX + RDir<D>::n) * NC, c, f[0].mn, f[1].mn);
@@ -1113,7 +1121,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
         interface_flux<D>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<D>(g, idx),
                           face_shock(S, P, c + 8u * w, sd), P, f[w]);
     }
-    store_f1_2<D>(S.F1[D], t.NC, c, f, true, v1);
+    store_f1_2<D>(S.F1[D], t.NC, c, f, true, v1, S.F1E[D]);
 }
 
 // shared tail of the final stage for a pair of x-adjacent faces: flux in conserved order, artificial
@@ -1328,7 +1336,7 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
             rstate_from_edge<0>(qm[0], P.gamma, ql, Xl);
             rstate_from_edge<0>(qp[1], P.gamma, qr, Xr);
             interface_flux<0>(ql, qr, Xl, Xr, cc01.a, cc01.b, wall_fac<0>(g, i + 1), face_shock(S, P, c + 8u, 8u), P, f[1]);
-            store_f1_2<0>(S.F1[0], NC, c, f, mA, mB);
+            store_f1_2<0>(S.F1[0], NC, c, f, mA, mB, S.F1E[0]);
         }
     }
 
@@ -1356,12 +1364,12 @@ __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, c
     const double cr = ldg(Q + PC * t.NC, c);
     IFlux f;
     interface_flux<0>(ql, qr, Xl, Xr, cl, cr, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f);
-    store_f1<0>(S.F1[0], t.NC, c, f);
+    store_f1<0>(S.F1[0], t.NC, c, f, S.F1E[0]);
 }
 
 
 
-template <int N, int T>
+template <int N, int T, bool RE>
 __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, unsigned c, unsigned sn, unsigned st,
                                             const double qm[2][NEDGE], const double qp[2][NEDGE],
                                             const D2& cl, const D2& cr, const double bnd_fac[2], double cdtdx,
@@ -1372,14 +1380,26 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     // minus states live in zones c - sn; their T-faces are (c - sn) and (c - sn + st)
     load_f1_2(S.F1[T], t.NC, c - sn + st, fr);
     load_f1_2(S.F1[T], t.NC, c - sn, fl);
+    if (RE) {                                      // transverse_reset_rhoe = 1: the (rho e) flux differences as well
+        const D2 er = ldg2(S.F1E[T], c - sn + st), el = ldg2(S.F1E[T], c - sn);
+        trans_single<T>(qm[0], fr[0], fl[0], P.gamma, cdtdx, P, qmo[0], er.a, el.a);
+        trans_single<T>(qm[1], fr[1], fl[1], P.gamma, cdtdx, P, qmo[1], er.b, el.b);
+    } else {
 #pragma unroll
-    for (int w = 0; w < 2; ++w) trans_single<T>(qm[w], fr[w], fl[w], P.gamma, cdtdx, P, qmo[w]);
+        for (int w = 0; w < 2; ++w) trans_single<T>(qm[w], fr[w], fl[w], P.gamma, cdtdx, P, qmo[w]);
+    }
 
     // plus states live in zones c
     load_f1_2(S.F1[T], t.NC, c + st, fr);
     load_f1_2(S.F1[T], t.NC, c, fl);
+    if (RE) {
+        const D2 er = ldg2(S.F1E[T], c + st), el = ldg2(S.F1E[T], c);
+        trans_single<T>(qp[0], fr[0], fl[0], P.gamma, cdtdx, P, qpo[0], er.a, el.a);
+        trans_single<T>(qp[1], fr[1], fl[1], P.gamma, cdtdx, P, qpo[1], er.b, el.b);
+    } else {
 #pragma unroll
-    for (int w = 0; w < 2; ++w) trans_single<T>(qp[w], fr[w], fl[w], P.gamma, cdtdx, P, qpo[w]);
+        for (int w = 0; w < 2; ++w) trans_single<T>(qp[w], fr[w], fl[w], P.gamma, cdtdx, P, qpo[w]);
+    }
 
     IFlux f[2];
 #pragma unroll
@@ -1391,11 +1411,11 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
         interface_flux<N>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
     }
-    store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1);
+    store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, RE ? S.F2E[f2_slot(N, T)] : nullptr);
 }
 
 // one normal direction of the transverse stage for the faces (ijk) and (ijk + x) -- `v1`: the second face exists
-template <int N>
+template <int N, bool RE>
 __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], bool v1, unsigned c,
                                             const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                             double cdtdx_t1, double cdtdx_t2, const DevParams& P)
@@ -1428,12 +1448,13 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
     bnd_fac[0] = wall_fac<N>(g, ijk[N]);
     bnd_fac[1] = wall_fac<N>(g, ijk[N] + (N == 0 ? 1 : 0));
 
-    if (any1) trans1_pair<N, T1>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, in_t1[0], in_t1[1], P);
-    if (any2) trans1_pair<N, T2>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
+    if (any1) trans1_pair<N, T1, RE>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, in_t1[0], in_t1[1], P);
+    if (any2) trans1_pair<N, T2, RE>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
 }
 
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one
 // kernel instead of two (F1[T] serves the two N != T), the other reads hit in L2.
+template <bool RE>
 __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                 double cdtdx, double cdtdy, double cdtdz, DevParams P)
 {
@@ -1441,14 +1462,14 @@ __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* 
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second zone of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    trans1_body<0>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
-    trans1_body<1>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdz, P);
-    trans1_body<2>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdy, P);
+    trans1_body<0, RE>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
+    trans1_body<1, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdz, P);
+    trans1_body<2, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdy, P);
 }
 
 // one normal direction of the final stage for the faces (ijk) and (ijk + x); v0 / v1: the faces belong to
 // nodal(bx, N)
-template <int N>
+template <int N, bool RE>
 __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool v0, bool v1, unsigned c,
                                            const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                            const DFab& U, const DFab& fluxes, const DFab& mass, const DFab& qe,
@@ -1473,8 +1494,16 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     load_f1_2(F12, NC, c - sn, f1l);
     load_f1_2(F21, NC, c - sn + s2, f2r);
     load_f1_2(F21, NC, c - sn, f2l);
+    if (RE) {                                      // transverse_reset_rhoe = 1: the (rho e) flux differences as well
+        const double* E12 = S.F2E[f2_slot(T1, T2)];
+        const double* E21 = S.F2E[f2_slot(T2, T1)];
+        const D2 e1r = ldg2(E12, c - sn + s1), e1l = ldg2(E12, c - sn), e2r = ldg2(E21, c - sn + s2), e2l = ldg2(E21, c - sn);
+        trans_final(q[0], f1r[0], f1l[0], f2r[0], f2l[0], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[0], e1r.a, e1l.a, e2r.a, e2l.a);
+        trans_final(q[1], f1r[1], f1l[1], f2r[1], f2l[1], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[1], e1r.b, e1l.b, e2r.b, e2l.b);
+    } else {
 #pragma unroll
-    for (int w = 0; w < 2; ++w) trans_final(q[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[w]);
+        for (int w = 0; w < 2; ++w) trans_final(q[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[w]);
+    }
 
     // plus states (zones c)
     load_edge_2(S.QP[N], NC, c, q);
@@ -1482,8 +1511,16 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     load_f1_2(F12, NC, c, f1l);
     load_f1_2(F21, NC, c + s2, f2r);
     load_f1_2(F21, NC, c, f2l);
+    if (RE) {
+        const double* E12 = S.F2E[f2_slot(T1, T2)];
+        const double* E21 = S.F2E[f2_slot(T2, T1)];
+        const D2 e1r = ldg2(E12, c + s1), e1l = ldg2(E12, c), e2r = ldg2(E21, c + s2), e2l = ldg2(E21, c);
+        trans_final(q[0], f1r[0], f1l[0], f2r[0], f2l[0], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[0], e1r.a, e1l.a, e2r.a, e2l.a);
+        trans_final(q[1], f1r[1], f1l[1], f2r[1], f2l[1], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[1], e1r.b, e1l.b, e2r.b, e2l.b);
+    } else {
 #pragma unroll
-    for (int w = 0; w < 2; ++w) trans_final(q[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[w]);
+        for (int w = 0; w < 2; ++w) trans_final(q[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[w]);
+    }
 
     const D2 cl = ldg2(Q + PC * NC, c - sn);
     const D2 cr = ldg2(Q + PC * NC, c);
@@ -1518,7 +1555,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 
 // One launch per normal direction.  (All three in one launch, which fetches Sborder and div(u) once instead of
 // three times, measured slower: 5.0 vs 4.6 ms at 256^3 -- ~150 concurrent streams per workgroup.)
-template <int N>
+template <int N, bool RE>
 __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
@@ -1528,7 +1565,7 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    final_body<N>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P);
+    final_body<N, RE>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1784,13 +1821,20 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
     const double area0 = g.dx[1] * g.dx[2], area1 = g.dx[0] * g.dx[2], area2 = g.dx[0] * g.dx[1];
 
-    KL2("k_trans1", k_trans1, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-    KL2("k_final", k_final<0>, nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],
-       hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P);
-    KL2("k_final", k_final<1>, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],
-       hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
-    KL2("k_final", k_final<2>, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],
-       hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+    // transverse_reset_rhoe = 1 (non-default) runs its own instantiations: the extra (rho e) flux loads cost the
+    // default path 2 % when they sit behind a run-time branch
+#define TRANSVERSE_STAGES(RE)                                                                                     \
+    do {                                                                                                          \
+        KL2("k_trans1", k_trans1<RE>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);                              \
+        KL2("k_final", (k_final<0, RE>), nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],           \
+            hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P);                                 \
+        KL2("k_final", (k_final<1, RE>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],           \
+            hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);                                 \
+        KL2("k_final", (k_final<2, RE>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],           \
+            hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);                                 \
+    } while (0)
+    if (P.reset_rhoe == 1) TRANSVERSE_STAGES(true); else TRANSVERSE_STAGES(false);
+#undef TRANSVERSE_STAGES
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];
     if (clean_ntimes > 0) {

@@ -1008,10 +1008,19 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
 //   fr/fl = flux record (FRHO..FPG) at the high/low transverse face
 // ---------------------------------------------------------------------------------------
 // Castro::reset_edge_state_thermo (Source/hydro/edge_util.cpp:6-76) with transverse_use_eos = 1:
-// make (rho e, p) of a corrected edge state EOS-consistent.  (transverse_reset_rhoe is rejected
-// on the host; with both flags 0 -- the default -- the reference's 18 launches are no-ops.)
+// make (rho e, p) of a corrected edge state EOS-consistent; with transverse_reset_rhoe = 1: a still negative
+// (rho e) is replaced by the EOS value at small_temp.  (With both flags 0 -- the default -- the reference's 18
+// launches are no-ops.)
 __device__ __forceinline__ void reset_edge_state_thermo(double q[NEDGE], const DevParams& P)
 {
+    if (P.reset_rhoe == 1) {
+        if (q[PRE] < 0.0) {
+            const double e = eos_e_of_T(P, P.small_temp);            // eos(eos_input_rt)
+            const double p = (P.gamma - 1.0) * q[PRHO] * e;
+            q[PRE] = q[PRHO] * e;
+            q[PP] = p;
+        }
+    }
     if (P.use_eos == 1) {
         double e = q[PRE] / q[PRHO];
         double p = (P.gamma - 1.0) * q[PRHO] * e;
@@ -1021,9 +1030,11 @@ __device__ __forceinline__ void reset_edge_state_thermo(double q[NEDGE], const D
 }
 
 // actual_trans_single, trans.cpp:66-437 (3-D branch). TD = transverse direction.
+// fer / fel: (rho e) flux at the high / low transverse face, read only when transverse_reset_rhoe = 1.
 template <int TD>
 __device__ __forceinline__ void trans_single(const double q[NEDGE], const double fr[NF1], const double fl[NF1],
-                                             double gamc, double cdtdx, const DevParams& P, double qo[NEDGE])
+                                             double gamc, double cdtdx, const DevParams& P, double qo[NEDGE],
+                                             double fer = 0.0, double fel = 0.0)
 {
     // passive :171-189
     {
@@ -1074,8 +1085,10 @@ __device__ __forceinline__ void trans_single(const double q[NEDGE], const double
     qo[PRE] = renewn - rhoekenn;
 
     if (!reset_state) {
-        // transverse_reset_rhoe == 1 needs the eint flux, which the transverse flux record
-        // does not carry: rejected on the host (CASTRO_AMD_ERR_UNSUPPORTED)
+        if (P.reset_rhoe == 1 && qo[PRE] <= 0.0) {
+            // the discretised (rho e) equation instead (trans.cpp:377-388)
+            qo[PRE] = q[PRE] - cdtdx * (fer - fel + pav * du);
+        }
         if (qo[PRE] <= 0.0) {
             qo[PRE] = q[PRE];
         }
@@ -1093,7 +1106,8 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
                                             const double f1r[NF1], const double f1l[NF1],
                                             const double f2r[NF1], const double f2l[NF1],
                                             double gamc, double cdtdx_t1, double cdtdx_t2,
-                                            const DevParams& P, double qo[NEDGE])
+                                            const DevParams& P, double qo[NEDGE],
+                                            double fe1r = 0.0, double fe1l = 0.0, double fe2r = 0.0, double fe2l = 0.0)
 {
     {
         double rrn = q[PRHO];
@@ -1148,6 +1162,12 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
     qo[PRE] = renewn - rhoekenn;
 
     if (!reset_state) {
+        if (P.reset_rhoe == 1 && qo[PRE] <= 0.0) {
+            // trans.cpp:797-806
+            qo[PRE] = q[PRE]
+                - cdtdx_t1 * (fe1r - fe1l + pt1av * dut1)
+                - cdtdx_t2 * (fe2r - fe2l + pt2av * dut2);
+        }
         if (qo[PRE] <= 0.0) {
             qo[PRE] = q[PRE];
         }

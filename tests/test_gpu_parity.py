@@ -204,6 +204,27 @@ def test_ctu_hydro_solver_options(hip, oracle, pkw):
     _assert_exact(out, "options %s" % (pkw,))
 
 
+@pytest.mark.parametrize("pkw", [dict(transverse_reset_rhoe=1), dict(transverse_reset_rhoe=1, transverse_use_eos=1)])
+def test_transverse_reset_rhoe_in_a_cold_flow(hip, oracle, pkw):
+    """castro.transverse_reset_rhoe = 1 (trans.cpp:377-388, 797-806; edge_util.cpp:20-40): where the transverse
+    correction leaves (rho e) <= 0 the discretised (rho e) equation is used, which needs the (rho e) flux of the first
+    and of the transverse-stage solves.  A cold, kinetic-energy dominated state makes the branch fire (the oracle's
+    result changes with the flag); HIP == oracle bit for bit."""
+    rng = np.random.default_rng(77)
+    bxlo, bxhi = (0, 0, 0), (13, 11, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (17, 15, 13)
+    U = physical_state(rng, sb_lo, sb_hi, smooth=False, vel=3.0)
+    ke = 0.5 * (U[1] ** 2 + U[2] ** 2 + U[3] ** 2) / U[0]
+    U[5] *= 2e-3
+    U[4] = U[5] + ke
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), pkw=pkw)
+    _assert_exact(out, "reset_rhoe %s" % (pkw,))
+    off = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02),
+                    pkw=dict(pkw, transverse_reset_rhoe=0))
+    _assert_exact(off, "reset_rhoe off")
+    assert not np.array_equal(out["S_new"][1], off["S_new"][1]), "the reset branch did not fire"
+
+
 @pytest.mark.parametrize("sparse", [False, True])
 def test_ctu_hydro_with_old_sources(hip, oracle, sparse):
     """Non-zero old_source (gravity-like momentum/energy sources): src_to_prim + source tracing in
@@ -317,7 +338,7 @@ def test_unsupported_options_fail_loudly(hip):
     G = castro_amd.make_geom(n)
     S = hip.alloc(8, (-4, -4, -4), (11, 11, 11), fill=1.0)
     N = hip.alloc(8, (0, 0, 0), (7, 7, 7), fill=1.0)
-    for kw in (dict(transverse_reset_rhoe=1), dict(ppm_temp_fix=2)):
+    for kw in (dict(ppm_temp_fix=2),):
         P = castro_amd.default_params(**kw)
         with pytest.raises(RuntimeError, match="unsupported"):
             hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
