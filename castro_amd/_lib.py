@@ -18,7 +18,8 @@ UPDATE_ADD, UPDATE_FROM_SBORDER, FLUX_ASSIGN, STAGE_A, STAGE_B = 0, 1, 2, 4, 8
 # CASTRO_AMD_DER_* ids, in the order the reference registers the fields (Castro_setup.cpp:756-960)
 DERIVE_IDS = {"pressure": 0, "kineng": 1, "soundspeed": 2, "Gamma_1": 3, "MachNumber": 4, "magvort": 5, "divu": 6,
               "eint_E": 7, "eint_e": 8, "logden": 9, "X(X)": 10, "abar": 11, "x_velocity": 12, "y_velocity": 13,
-              "z_velocity": 14, "magvel": 15, "radvel": 16, "magmom": 17}
+              "z_velocity": 14, "magvel": 15, "radvel": 16, "magmom": 17, "StateErr_0": 18, "StateErr_1": 19, "StateErr_2": 20,
+              "circvel": 21, "angular_momentum_x": 22, "angular_momentum_y": 23, "angular_momentum_z": 24}
 
 # every symbol include/castro_hydro_amd.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = (

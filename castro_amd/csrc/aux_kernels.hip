@@ -778,6 +778,27 @@ __global__ void __launch_bounds__(256) k_derive(DFab U, DFab D, int dcomp, Box3 
         v = (mx * x + my * y + mz * z) / (rho * r);
         break; }
     case 17: v = sqrt(mx * mx + my * my + mz * mz); break;
+    case 18: v = rho; break;
+    case 19: v = UU(i, j, k, UTEMP); break;
+    case 20: v = UU(i, j, k, UFS) / rho; break;
+    case 21: {
+        double x = plo0 + ((double)i + 0.5) * dx0 - c0;
+        double y = plo1 + ((double)j + 0.5) * dx1 - c1;
+        double z = plo2 + ((double)k + 0.5) * dx2 - c2;
+        double r = sqrt(x * x + y * y + z * z);
+        double vtot2 = (mx * mx + my * my + mz * mz) / (rho * rho);
+        double vr = (mx * x + my * y + mz * z) / (rho * r);
+        v = sqrt(amax(vtot2 - vr * vr, 0.0));
+        break; }
+    case 22: case 23: case 24: {
+        double loc0 = plo0 + (0.5 + (double)i) * dx0;
+        double loc1 = plo1 + (0.5 + (double)j) * dx1;
+        double loc2 = plo2 + (0.5 + (double)k) * dx2;
+        loc0 -= c0; loc1 -= c1; loc2 -= c2;
+        if (which == 22) v = loc1 * mz - loc2 * my;
+        else if (which == 23) v = loc2 * mx - loc0 * mz;
+        else v = loc0 * my - loc1 * mx;
+        break; }
     }
 #undef UU
     D.p[fidx(D, i, j, k, dcomp)] = v;

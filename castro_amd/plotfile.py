@@ -19,10 +19,11 @@ import numpy as np
 
 # Source/driver/Castro_setup.cpp:493-556 (one species named X: networks/general_null/gammalaw.net [3P])
 STATE_NAMES = ["density", "xmom", "ymom", "zmom", "rho_E", "rho_e", "Temp", "rho_X"]
-# registration order of Castro_setup.cpp:756-960 for a 3-D pure-hydro build; not provided: entropy, StateErr,
-# circvel, angular_momentum_{x,y,z} (include/castro_hydro_amd.h)
+# registration order of Castro_setup.cpp:756-960 for a 3-D pure-hydro build (a derive with several components is
+# written as name_0, name_1, ...: Castro_io.cpp:954-965); not provided: entropy (the EOS's entropy is Microphysics's)
 DERIVE_NAMES = ["pressure", "kineng", "soundspeed", "Gamma_1", "MachNumber", "magvort", "divu", "eint_E", "eint_e",
-                "logden", "X(X)", "abar", "x_velocity", "y_velocity", "z_velocity", "magvel", "radvel", "magmom"]
+                "logden", "StateErr_0", "StateErr_1", "StateErr_2", "X(X)", "abar", "x_velocity", "y_velocity", "z_velocity",
+                "magvel", "radvel", "circvel", "magmom", "angular_momentum_x", "angular_momentum_y", "angular_momentum_z"]
 _STENCIL = ("magvort", "divu")
 
 FAB_REAL_DESCRIPTOR = "((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))"   # IEEE-754 binary64, little endian

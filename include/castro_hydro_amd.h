@@ -285,6 +285,13 @@ enum {
     CASTRO_AMD_DER_MAGVEL,         /* ca_dermagvel       :532 */
     CASTRO_AMD_DER_RADVEL,         /* ca_derradialvel    :572 (about `center`) */
     CASTRO_AMD_DER_MAGMOM,         /* ca_dermagmom       :692 */
+    CASTRO_AMD_DER_STATEERR_0,     /* ca_derstate        :1087 (three components: density, Temp, X) */
+    CASTRO_AMD_DER_STATEERR_1,
+    CASTRO_AMD_DER_STATEERR_2,
+    CASTRO_AMD_DER_CIRCVEL,        /* ca_dercircvel      :627 (about `center`, domain_is_plane_parallel = 0) */
+    CASTRO_AMD_DER_ANGMOM_X,       /* ca_derangmomx/y/z  :711-870 (about `center`) */
+    CASTRO_AMD_DER_ANGMOM_Y,
+    CASTRO_AMD_DER_ANGMOM_Z,
     CASTRO_AMD_DER_COUNT
 };
 /* der(:,:,:,dcomp) = derived field `which` of `state` on [lo,hi]; `center` = problem::center (radvel only). */

@@ -7,7 +7,8 @@
 /* ids shared with include/castro_hydro_amd.h (CASTRO_AMD_DER_*) */
 enum { DER_PRESSURE = 0, DER_KINENG, DER_SOUNDSPEED, DER_GAMMA_1, DER_MACHNUMBER, DER_MAGVORT, DER_DIVU,
        DER_EINT_E1, DER_EINT_E2, DER_LOGDEN, DER_SPEC, DER_ABAR, DER_X_VELOCITY, DER_Y_VELOCITY, DER_Z_VELOCITY,
-       DER_MAGVEL, DER_RADVEL, DER_MAGMOM, DER_COUNT };
+       DER_MAGVEL, DER_RADVEL, DER_MAGMOM, DER_STATEERR_0, DER_STATEERR_1, DER_STATEERR_2, DER_CIRCVEL,
+       DER_ANGMOM_X, DER_ANGMOM_Y, DER_ANGMOM_Z, DER_COUNT };
 
 static void zone_eos(ora_a4 dat, int i, int j, int k, const ora_params *P, ora_eos_t *es)
 {
@@ -106,6 +107,29 @@ int ora_derive(int which, const int lo[3], const int hi[3], ora_a4 dat, ora_a4 d
             v = sqrt(A4(dat,i,j,k,UMX) * A4(dat,i,j,k,UMX) + A4(dat,i,j,k,UMY) * A4(dat,i,j,k,UMY) +
                      A4(dat,i,j,k,UMZ) * A4(dat,i,j,k,UMZ));
             break;
+        case DER_STATEERR_0: v = A4(dat,i,j,k,URHO); break;                        /* ca_derstate :1087-1110 */
+        case DER_STATEERR_1: v = A4(dat,i,j,k,UTEMP); break;
+        case DER_STATEERR_2: v = A4(dat,i,j,k,UFS) / A4(dat,i,j,k,URHO); break;
+        case DER_CIRCVEL: {     /* ca_dercircvel :627-689, not plane-parallel */
+            double x = G->problo[0] + ((double)i + 0.5) * dx[0] - center[0];
+            double y = G->problo[1] + ((double)j + 0.5) * dx[1] - center[1];
+            double z = G->problo[2] + ((double)k + 0.5) * dx[2] - center[2];
+            double r = sqrt(x * x + y * y + z * z);
+            double vtot2 = (A4(dat,i,j,k,UMX) * A4(dat,i,j,k,UMX) + A4(dat,i,j,k,UMY) * A4(dat,i,j,k,UMY) +
+                            A4(dat,i,j,k,UMZ) * A4(dat,i,j,k,UMZ)) / (A4(dat,i,j,k,URHO) * A4(dat,i,j,k,URHO));
+            double vr = (A4(dat,i,j,k,UMX) * x + A4(dat,i,j,k,UMY) * y + A4(dat,i,j,k,UMZ) * z) / (A4(dat,i,j,k,URHO) * r);
+            v = sqrt(amax(vtot2 - vr * vr, 0.0));
+            break; }
+        case DER_ANGMOM_X: case DER_ANGMOM_Y: case DER_ANGMOM_Z: {   /* ca_derangmomx/y/z :711-870 */
+            double loc[3];
+            loc[0] = G->problo[0] + (0.5 + i) * dx[0];
+            loc[1] = G->problo[1] + (0.5 + j) * dx[1];
+            loc[2] = G->problo[2] + (0.5 + k) * dx[2];
+            for (int dir = 0; dir < 3; ++dir) loc[dir] -= center[dir];
+            if (which == DER_ANGMOM_X) v = loc[1] * A4(dat,i,j,k,UMZ) - loc[2] * A4(dat,i,j,k,UMY);
+            else if (which == DER_ANGMOM_Y) v = loc[2] * A4(dat,i,j,k,UMX) - loc[0] * A4(dat,i,j,k,UMZ);
+            else v = loc[0] * A4(dat,i,j,k,UMY) - loc[1] * A4(dat,i,j,k,UMX);
+            break; }
         }
         A4(der,i,j,k,0) = v;
     }
