@@ -1111,3 +1111,37 @@ def test_acoustic_pulse_convergence_like_the_reference_scripts():
         assert 1.8 < rate < 3.2, (name, e_lo, e_hi, rate)
     # the pulse has spread symmetrically: mass is conserved to round-off on the periodic domain
     assert abs(sol[256][0].mean() - _acoustic_pulse(256)[0].mean()) < 1e-13
+
+
+def test_hydro_call_is_hipgraph_capturable(hip):
+    """The boundary's contract: once the scratch is reserved a call allocates nothing and never
+    synchronises, so it can be captured into a hipGraph on the caller's stream; the replay gives the same bits
+    as the direct call, including the fused clean_state + reduction."""
+    import torch
+    import castro_amd
+    rng = np.random.default_rng(5)
+    bxlo, bxhi = (0, 0, 0), (31, 23, 15)
+    sb = ((-4, -4, -4), (35, 27, 19))
+    U = _to_dev(hip, physical_state(rng, *sb))
+    n = [32, 24, 16]
+    G = castro_amd.make_geom(n, prob_hi=[0.02 * x for x in n])
+    P = castro_amd.default_params()
+
+    def call(Sn, red):
+        hip.construct_ctu_hydro_source((bxlo, bxhi), U, sb, Sn, (bxlo, bxhi), G, P, 0.0, 8e-4, update_from_sborder=True,
+                                       clean_ntimes=1, red=red)
+
+    ref, red_ref = hip.alloc(8, bxlo, bxhi), torch.full((2,), 1e200, dtype=torch.float64, device="cuda")
+    call(ref, red_ref)                                   # also reserves the scratch
+    torch.cuda.synchronize()
+    Sn, red = hip.alloc(8, bxlo, bxhi), torch.full((2,), 1e200, dtype=torch.float64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        call(Sn, red)
+    torch.cuda.synchronize()
+    assert float(Sn.abs().sum()) == 0.0                 # captured, not executed
+    for _ in range(2):
+        Sn.zero_(); red.fill_(1e200)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(Sn, ref) and torch.equal(red, red_ref)
