@@ -279,6 +279,20 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
 
     if (!fab_contains(Sborder, glo, ghi)) return CASTRO_AMD_ERR_ARG;
     if (!fab_contains(S_new, bxlo, bxhi)) return CASTRO_AMD_ERR_ARG;
+    // the kernels address a component plane with a 32-bit byte offset: scratch planes and the caller's component
+    // planes must stay below 4 GiB (a box of more than ~800^3 zones has to be tiled by the caller)
+    {
+        const double lim = 4294967296.0;
+        auto plane_bytes = [](const castro_amd_fab* f) {
+            return 8.0 * (double)(f->hi[0] - f->lo[0] + 1) * (double)(f->hi[1] - f->lo[1] + 1) * (double)(f->hi[2] - f->lo[2] + 1);
+        };
+        if (8.0 * (double)t.NC >= lim || plane_bytes(Sborder) >= lim || plane_bytes(S_new) >= lim) return CASTRO_AMD_ERR_UNSUPPORTED;
+        for (int d = 0; d < 3; ++d) {
+            if (flux_out && flux_out[d].p && plane_bytes(&flux_out[d]) >= lim) return CASTRO_AMD_ERR_UNSUPPORTED;
+            if (mass_flux_out && mass_flux_out[d].p && plane_bytes(&mass_flux_out[d]) >= lim) return CASTRO_AMD_ERR_UNSUPPORTED;
+            if (qe_out && qe_out[d].p && plane_bytes(&qe_out[d]) >= lim) return CASTRO_AMD_ERR_UNSUPPORTED;
+        }
+    }
     if (src && src->p) {
         // old_source: NSRC = 7 components, NUM_GROW_SRC = 3 ghost zones (Castro_setup.cpp:317-327)
         int s3lo[3], s3hi[3];

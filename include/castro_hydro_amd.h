@@ -138,6 +138,9 @@ int castro_amd_ctx_status(castro_amd_ctx *ctx, void *stream);
  *   flux_out[d] : in/out, += dt*area*flux on nodaltilebox(d), ncomp 8 (Castro::fluxes[d]); p NULL to skip
  *   mass_flux_out[d] : out, = scaled density flux, ncomp 1            (Castro::mass_fluxes[d]); p NULL to skip
  *   qe_out[d]   : out (optional, p NULL to skip), Godunov state u,v,w,p on the same faces, ncomp 4 (qe[d])
+ * Returns CASTRO_AMD_ERR_ARG for boxes / component counts that do not fit, CASTRO_AMD_ERR_UNSUPPORTED for
+ * ppm_temp_fix > 0, non-Cartesian coordinates, and for a tile or FAB whose component plane reaches 4 GiB (the
+ * kernels address a plane with 32-bit byte offsets: tile boxes beyond ~800^3 zones).
  */
 int castro_amd_ctu_hydro_fab(castro_amd_ctx *ctx,
                              const int bxlo[3], const int bxhi[3],

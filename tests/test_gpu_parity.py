@@ -343,8 +343,21 @@ def test_unsupported_options_fail_loudly(hip):
         with pytest.raises(RuntimeError, match="unsupported"):
             hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
                                            ((0, 0, 0), (7, 7, 7)), G, P, 0.0, 1e-3)
-    # Sborder too small -> bad argument
+    # a box whose component planes exceed the 32-bit byte offsets of the kernels (here 1100^3 zones, described
+    # by descriptors over a small buffer: validation precedes every memory access) -> unsupported, tile it
+    import ctypes as C
     P = castro_amd.default_params()
+    big = 1099
+    Gb = castro_amd.make_geom((big + 1,) * 3)
+    nofab = (L.Fab * 3)()
+    for d in range(3):
+        nofab[d] = L.fab_desc(None, (0, 0, 0), (big, big, big), 0)
+    rc = hip.lib.castro_amd_ctu_hydro_fab(
+        hip.h, L.i3((0, 0, 0)), L.i3((big,) * 3), L.i3((0, 0, 0)), L.i3((big,) * 3),
+        C.byref(L.fab_desc(S.data_ptr(), (-4, -4, -4), (big + 4,) * 3, 8)), C.byref(L.fab_desc(None, (0, 0, 0), (big,) * 3, 0)),
+        C.byref(L.fab_desc(N.data_ptr(), (0, 0, 0), (big,) * 3, 8)), nofab, nofab, nofab, C.byref(Gb), C.byref(P), 0.0, 1e-3, 0, None)
+    assert rc == L.ERR_UNSUPPORTED
+    # Sborder too small -> bad argument
     with pytest.raises(RuntimeError, match="bad argument"):
         hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), N, ((0, 0, 0), (7, 7, 7)), N,
                                        ((0, 0, 0), (7, 7, 7)), G, P, 0.0, 1e-3)
