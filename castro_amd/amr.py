@@ -15,7 +15,8 @@ generation classes [3P] is orchestrated here on top of `Castro` objects, one per
                                                  avgDown, like in AMReX
   Castro::computeNewDt / computeInitialDt        Castro.cpp:1629-1866 over all levels (n_cycle = 1, 2, 2, ...)
   Castro::errorEst + Amr::regrid / grid_places   amr.refinement_indicators (AMRErrorTag [3P] restated) on every level
-                                                 below max_level, every regrid_int coarse steps: tags from the finest
+                                                 below max_level, whenever a level has taken regrid_int steps since
+                                                 its last regrid (Amr::level_count; grids above it): tags from the finest
                                                  level down, buffered by n_error_buf, united with the (coarsened,
                                                  buffered) new boxes of the level above (proper nesting), clustered
                                                  into boxes (castro_amd/cluster.py: Berger-Rigoutsos with grid_eff,
@@ -26,7 +27,7 @@ generation classes [3P] is orchestrated here on top of `Castro` objects, one per
 
 Fixed hierarchies: `patches=[...]`, one entry per refined level: a box (lo, hi) or a list of boxes, in the zones of
 the level below.  Level 0 is one box (per rank; this driver is single-rank).
-Not provided: multi-rank AMR, gravity / rotation on AMR levels, regridding inside a coarse step.  The interpolation,
+Not provided: multi-rank AMR, gravity / rotation on AMR levels.  The interpolation,
 flux-register and clustering arithmetic is AMReX's, restated from its published description
 (include/castro_hydro_amd.h, castro_amd/cluster.py): parity with an AMReX build is unpinned.
 """
@@ -257,6 +258,7 @@ class CastroAmr:
             self._push_level([tuple(map(tuple, pb))] if _is_box(pb) else [tuple(map(tuple, b)) for b in pb])
         self.time, self.nstep = 0.0, 0
         self.dt_level = [0.0] * 16
+        self.level_count = [0] * 16                                   # Amr::level_count: steps of a level since its last regrid
 
     # views used by the tests and the plotfile writer
     crse = property(lambda self: self.lev[0])
@@ -299,10 +301,11 @@ class CastroAmr:
         del self.lev[1:]
 
     # ---- Castro::errorEst (Castro.cpp:3131-3164) ---------------------------------------------------
-    def _fill_ghosts_new(self, upto):
-        """Ghost zones of the new-time data of levels 0..upto (each FillPatch reads the level below it)."""
-        for l in range(upto + 1):
-            self.lev[l].alpha = 1.0
+    def _fill_ghosts_new(self, upto, lbase=0, alpha=1.0):
+        """Ghost zones of the new-time data of levels lbase..upto (each FillPatch reads the level below it).  Level
+        lbase sits at `alpha` inside its parent's [old, new] interval, the finer ones are synchronised with it."""
+        for l in range(lbase, upto + 1):
+            self.lev[l].alpha = alpha if l == lbase else 1.0
             self.lev[l].fill("S_new_b")
 
     def _tags(self, l):
@@ -348,13 +351,13 @@ class CastroAmr:
         bl = self.tag_boxes(l)
         return bl[0] if bl else None
 
-    # ---- Amr::grid_places: new box lists for levels 1.. (at most one level more than now) ----------
-    def _grid_places(self):
+    # ---- Amr::grid_places: new box lists for levels lbase+1.. (at most one level more than now) ------
+    def _grid_places(self, lbase=0, alpha=1.0):
         finest = len(self.lev) - 1
         top = min(finest, self.max_level - 1)                   # the finest level that may carry tags
-        self._fill_ghosts_new(top)
-        new = {}
-        for l in range(top, -1, -1):
+        self._fill_ghosts_new(top, lbase, alpha)
+        new = {l: self.boxes[l] for l in range(1, lbase + 1)}   # levels up to lbase keep their boxes
+        for l in range(top, lbase - 1, -1):
             cover = []
             for lo, hi in new.get(l + 2, []):                   # proper nesting: contain the level above + a buffer
                 cover.append((tuple(_coarsen(lo[d]) - self.n_error_buf for d in range(3)),
@@ -366,7 +369,7 @@ class CastroAmr:
                 break
             out.append(new[l])
         # boxes of level l+1 were placed on the OLD level-l boxes: keep what lies inside the NEW ones
-        for i in range(1, len(out)):
+        for i in range(max(lbase, 1), len(out)):
             kept = []
             for b in out[i]:
                 for plo, phi in out[i - 1]:
@@ -379,9 +382,10 @@ class CastroAmr:
             out[i] = sorted(kept, key=lambda b: (b[0][2], b[0][1], b[0][0]))
         return out
 
-    # ---- Amr::regrid: new fine grids, data from the old fine level where it exists, else interpolated ---
-    def regrid(self):
-        new = self._grid_places()
+    # ---- Amr::regrid(lbase): new grids above level lbase, data from the old boxes of a level where they exist,
+    #      else interpolated ---------------------------------------------------------------------------------
+    def regrid(self, lbase=0, alpha=1.0):
+        new = self._grid_places(lbase, alpha)
         if new == self.boxes[1:]:
             return False
         old_lev = list(self.lev)
@@ -431,6 +435,7 @@ class CastroAmr:
             self.avgDown(l)
             self.lev[l - 1].clean_new()
         self.time, self.nstep = 0.0, 0
+        self.level_count = [0] * 16
 
     # ---- Castro::avgDown (Castro.cpp:3096-3113): level l onto level l-1 ------------------------------
     def avgDown(self, l=1):
@@ -464,10 +469,21 @@ class CastroAmr:
     # ---- Amr::timeStep: advance level l, then recursively twice the next finer level, then post_timestep -----
     def _time_step(self, l, t, dt, alpha):
         """alpha: position of this level's old time inside the parent's [old, new] interval (0 or 1/2)."""
+        # Amr::timeStep: every level i >= l that has taken regrid_int steps since its last regrid gets new grids above
+        # it (all those levels are synchronised at time t here)
+        if self.refine is not None and self.regrid_int > 0:
+            i = l
+            while i <= min(len(self.lev) - 1, self.max_level - 1):
+                if self.level_count[i] >= self.regrid_int:
+                    self.regrid(i, alpha if i == l else 1.0)
+                    for k in range(i, len(self.level_count)):
+                        self.level_count[k] = 0
+                i += 1
         lev, finest = self.lev[l], len(self.lev) - 1
         h = lev.hydro
         lev.alpha = alpha
         lev.advance(t, dt)
+        self.level_count[l] += 1
         if l > 0:
             # FluxRegFineAdd: + this level's fluxes (already dt x area) summed over the 4 fine faces
             for b in lev.boxes:
@@ -496,8 +512,6 @@ class CastroAmr:
 
     # ---- Amr::coarseTimeStep ---------------------------------------------------------------------
     def step(self, stop_time=-1.0):
-        if self.refine is not None and self.regrid_int > 0 and self.nstep > 0 and self.nstep % self.regrid_int == 0:
-            self.regrid()
         dt0 = self._dt0(stop_time, self.nstep == 0)
         for l in range(len(self.dt_level)):
             self.dt_level[l] = dt0 / (2 ** l)

@@ -315,3 +315,50 @@ def test_level_wide_retry_on_a_refined_level_stays_conservative(oracle):
     for _ in range(3):
         a.step()
     assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+
+
+def _spy_regrids(a):
+    calls = []
+    orig = a.regrid
+
+    def spy(lbase=0, alpha=1.0):
+        r = orig(lbase, alpha)
+        calls.append((a.nstep, lbase, alpha, r))
+        return r
+    a.regrid = spy
+    return calls
+
+
+def test_levels_regrid_on_their_own_step_counts(oracle):
+    """Amr::level_count: with regrid_int = 1 level 1 regrids the level above it at the start of each of its own
+    steps, i.e. also in the middle of a coarse step (its ghost zones are then filled at alpha = 1/2 of the coarse
+    interval); with four levels and regrid_int = 2, level 2 regrids level 3 at a level-1 boundary inside the coarse
+    step.  Composite mass and energy survive all of them."""
+    import castro_amd
+    kw = dict(params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+              refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], n_error_buf=1, blocking_factor=4)
+    a = castro_amd.CastroAmr((16, 16, 16), regrid_int=1, max_level=2, **kw)
+    a.initData("sedov", r_init=0.08, nsub=4)
+    calls = _spy_regrids(a)
+    m0, e0 = a.composite_sum(0), a.composite_sum(4)
+    for _ in range(8):
+        a.step()
+        assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0 and abs(a.composite_sum(4) - e0) <= 1e-12 * e0
+    assert [(c[1], c[2]) for c in calls[:3]] == [(1, 0.5), (0, 0.0), (1, 0.5)]          # step 0: only the mid-step one
+    assert any(c[1] == 1 and c[2] == 0.5 and c[3] for c in calls), "no mid-step regrid changed the grids"
+    assert any(c[1] == 0 and c[3] for c in calls)
+
+    b = castro_amd.CastroAmr((16, 16, 16), regrid_int=2, max_level=3, **kw)
+    b.initData("sedov", r_init=0.08, nsub=4)
+    assert len(b.levels) == 4
+    calls = _spy_regrids(b)
+    m0, e0 = b.composite_sum(0), b.composite_sum(4)
+    for _ in range(3):
+        b.step()
+    assert abs(b.composite_sum(0) - m0) <= 1e-12 * m0 and abs(b.composite_sum(4) - e0) <= 1e-12 * e0
+    # coarse step 0: level 2 has taken two steps when level 1 starts its second one; coarse step 1 starts with level 1's
+    # turn (two steps taken), coarse step 2 with level 0's
+    assert [(c[0], c[1]) for c in calls] == [(0, 2), (1, 1), (1, 2), (2, 0), (2, 2)]
+    for l in range(2, 4):
+        (plo, phi), (qlo, qhi) = b.pbox[l - 1], b.pbox[l]
+        assert all(2 * plo[d] <= qlo[d] and qhi[d] <= 2 * phi[d] + 1 for d in range(3))

@@ -964,6 +964,28 @@ def test_amr_retry_on_the_device_matches_oracle_backend(oracle):
     _assert_exact(pairs, "AMR retry")
 
 
+def test_mid_step_regrids_on_the_device_match_oracle_backend(oracle):
+    """regrid_int = 1: level 1 regrids level 2 in the middle of every coarse step (Amr::level_count); device vs
+    oracle-backed orchestration, same boxes and the same bits."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=1, n_error_buf=1,
+              blocking_factor=4, max_level=2)
+    a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1), **kw)
+    b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend, **kw)
+    for x in (a, b):
+        x.initData("sedov", r_init=0.08, nsub=4)
+    first = list(a.pbox)
+    for _ in range(10):
+        assert a.step() == b.step()
+        assert a.pbox == b.pbox
+    torch.cuda.synchronize()
+    assert a.nregrid == b.nregrid and a.nregrid >= 2 and a.pbox != first
+    _assert_exact({"L%d" % l: (a.levels[l].S_new().cpu().numpy(), b.levels[l].S_new().numpy()) for l in range(3)},
+                  "mid-step regrid")
+
+
 def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
     """amr.max_level = 2 (1 + 2 + 4 advances per coarse step) on the device vs the oracle-backed orchestration."""
     import torch
