@@ -309,42 +309,54 @@ class CastroAmr:
             self.lev[l].fill("S_new_b")
 
     def _tags(self, l):
-        """(tags, mask, origin): tagged zones and valid zones of level l as host arrays over the bounding region."""
+        """(tags, mask, origin): tagged zones and valid zones of level l as 0/1 tensors (on the level's device) over the
+        bounding region of its boxes."""
         lev = self.lev[l]
         bl = lev.box_list()
         olo = tuple(min(b[0][d] for b in bl) for d in range(3))
         ohi = tuple(max(b[1][d] for b in bl) for d in range(3))
-        shape = tuple(ohi[d] - olo[d] + 1 for d in (2, 1, 0))
-        tags, mask = np.zeros(shape, dtype=bool), np.zeros(shape, dtype=bool)
         h = lev.hydro
+        tags, mask = h.alloc(1, olo, ohi)[0], h.alloc(1, olo, ohi)[0]
         for b in lev.boxes:
             t = h.alloc(1, b.lo, b.hi)
             for field, kind, value in self.refine:
                 h.error_tag(b.S_new_b, b.gbox, _FIELDS[field], t, (b.lo, b.hi), b.lo, b.hi, _TAG_KINDS[kind], value)
             sl = tuple(slice(b.lo[d] - olo[d], b.hi[d] - olo[d] + 1) for d in (2, 1, 0))
-            tags[sl] = (t[0] > 0.5).cpu().numpy()
-            mask[sl] = True
+            tags[sl] = (t[0] > 0.5).to(tags.dtype)
+            mask[sl] = 1.0
         return tags, mask, olo
 
     def tag_boxes(self, l=0, ghosts_filled=False, cover=()):
         """New boxes of level l+1 in level-l zones: clustered, buffered tags of level l, also covering `cover`
-        (boxes in level-l zones that the new boxes must contain: the footprint of the level above)."""
+        (boxes in level-l zones that the new boxes must contain: the footprint of the level above).  Buffering and
+        the reduction to blocking_factor/2-sized cells run where the tags are (max-pooling); only the reduced arrays
+        go to the host for the clustering."""
+        import torch.nn.functional as F
         if not ghosts_filled:
             self._fill_ghosts_new(l)
         tags, mask, o = self._tags(l)
-        if self.n_error_buf > 0:
-            tags = CL.dilate(tags, self.n_error_buf)
+        n = self.n_error_buf
+        if n > 0:                                               # amr.n_error_buf: a (2n+1)^3 maximum
+            tags = F.max_pool3d(tags[None, None], kernel_size=2 * n + 1, stride=1, padding=n)[0, 0]
+        shape = tags.shape
         for lo, hi in cover:
-            it = CL.intersect((lo, hi), (o, tuple(o[d] + tags.shape[2 - d] - 1 for d in range(3))))
+            it = CL.intersect((lo, hi), (o, tuple(o[d] + shape[2 - d] - 1 for d in range(3))))
             if it:
-                tags[it[0][2] - o[2]:it[1][2] - o[2] + 1, it[0][1] - o[1]:it[1][1] - o[1] + 1, it[0][0] - o[0]:it[1][0] - o[0] + 1] = True
-        tags &= mask
-        if not tags.any():
-            return []
+                tags[it[0][2] - o[2]:it[1][2] - o[2] + 1, it[0][1] - o[1]:it[1][1] - o[1] + 1, it[0][0] - o[0]:it[1][0] - o[0] + 1] = 1.0
+        tags = tags * mask
         a = max(self.blocking_factor // 2, 1)                   # blocking_factor is in zones of level l+1
-        assert all(x % a == 0 for x in o) and all(s % a == 0 for s in tags.shape), "level boxes must be multiples of blocking_factor/2"
-        return CL.make_boxes(tags, o, mask, n_error_buf=0, blocking=a, grid_eff=self.grid_eff,
-                             max_size=None if self.max_grid_size is None else max(self.max_grid_size // 2, a))
+        assert all(x % a == 0 for x in o) and all(s % a == 0 for s in shape), "level boxes must be multiples of blocking_factor/2"
+        if a > 1:                                               # any zone tagged / all zones valid per a^3 cell
+            ct = F.max_pool3d(tags[None, None], kernel_size=a, stride=a)[0, 0]
+            cm = -F.max_pool3d(-mask[None, None], kernel_size=a, stride=a)[0, 0]
+        else:
+            ct, cm = tags, mask
+        ct = (ct > 0.5).cpu().numpy()
+        if not ct.any():
+            return []
+        cm = (cm > 0.5).cpu().numpy()
+        return CL.boxes_from_coarse(ct, cm, o, a, grid_eff=self.grid_eff,
+                                    max_size=None if self.max_grid_size is None else max(self.max_grid_size // 2, a))
 
     def tag_box(self, l=0):
         """The one-box form: (lo, hi) in level-l zones or None."""

@@ -153,6 +153,18 @@ def chop_max_size(boxes, max_size):
     return out
 
 
+def boxes_from_coarse(ct, cm, origin, blocking, grid_eff=0.7, max_size=None):
+    """Clustering of already buffered tags given per blocking^3 cell (ct: any zone tagged, cm: all zones allowed):
+    sorted boxes in level-l zones, aligned to `blocking`."""
+    a = int(blocking)
+    boxes = berger_rigoutsos(ct, cm, grid_eff)
+    if max_size is not None:
+        boxes = chop_max_size(boxes, max(int(max_size) // a, 1))
+    out = [(tuple(origin[d] + a * lo[d] for d in range(3)), tuple(origin[d] + a * (hi[d] + 1) - 1 for d in range(3)))
+           for lo, hi in boxes]
+    return sorted(out, key=lambda b: (b[0][2], b[0][1], b[0][0]))
+
+
 def make_boxes(tags, origin, mask=None, n_error_buf=1, blocking=1, grid_eff=0.7, max_size=None):
     """Level-l tags (array over the region starting at `origin`, shape a multiple of `blocking`) -> sorted list of
     boxes in level-l zones, aligned to `blocking` zones, covering the buffered tags inside `mask`."""
@@ -160,10 +172,4 @@ def make_boxes(tags, origin, mask=None, n_error_buf=1, blocking=1, grid_eff=0.7,
     mask = np.ones_like(tags) if mask is None else np.asarray(mask, dtype=bool)
     t = dilate(tags, n_error_buf) & mask if n_error_buf > 0 else tags & mask
     a = int(blocking)
-    ct, cm = coarsen_any(t, a), coarsen_all(mask, a)
-    boxes = berger_rigoutsos(ct, cm, grid_eff)
-    if max_size is not None:
-        boxes = chop_max_size(boxes, max(int(max_size) // a, 1))
-    out = [(tuple(origin[d] + a * lo[d] for d in range(3)), tuple(origin[d] + a * (hi[d] + 1) - 1 for d in range(3)))
-           for lo, hi in boxes]
-    return sorted(out, key=lambda b: (b[0][2], b[0][1], b[0][0]))
+    return boxes_from_coarse(coarsen_any(t, a), coarsen_all(mask, a), origin, a, grid_eff, max_size)
