@@ -143,6 +143,9 @@ class _Level:
         # StateData time interpolation of the coarse data: (1 - a) old + a new
         for p, (lo, hi) in b.csrc + b.csrc_valid:
             h.lincomb(b.ctmp, b.cbox, 1.0 - a, p.S_old_b, p.gbox, a, p.S_new_b, p.gbox, NUM_STATE, lo, hi)
+        if hasattr(h, "fillpatch_shell"):                       # both passes over the six slabs in one launch
+            h.fillpatch_shell(b.ctmp, b.cbox, S, b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1)
+            return
         for lo, hi in b.shell:
             h.cc_interp(b.ctmp, b.cbox, S, b.gbox, lo, hi, NUM_STATE)
         for lo, hi in b.shell:                                 # clean_state(Sborder) reaches the ghost zones too

@@ -575,35 +575,84 @@ __device__ __forceinline__ double mc_slope(double um, double u0, double up)
 
 __device__ __forceinline__ int coarsen2(int i) { return (i >= 0) ? i / 2 : -((-i + 1) / 2); }
 
-__global__ void __launch_bounds__(256) k_cc_interp(DFab C, DFab F, Box3 b, int ncomp)
+// cell_cons_interp of component n of the coarse FAB at fine zone (i, j, k)
+__device__ __forceinline__ double cc_interp_value(const DFab& C, int i, int j, int k, int n)
 {
-    int i, j, k;
-    if (!box_thread3(b.lo, b.n, i, j, k)) return;
     const int ic = coarsen2(i), jc = coarsen2(j), kc = coarsen2(k);
     const double ox = (i - 2 * ic == 0) ? -0.25 : 0.25;
     const double oy = (j - 2 * jc == 0) ? -0.25 : 0.25;
     const double oz = (k - 2 * kc == 0) ? -0.25 : 0.25;
-    for (int n = 0; n < ncomp; ++n) {
 #define CC(ii, jj, kk) C.p[fidx(C, ic + (ii), jc + (jj), kc + (kk), n)]
-        const double u0 = CC(0, 0, 0);
-        double sx = mc_slope(CC(-1, 0, 0), u0, CC(1, 0, 0));
-        double sy = mc_slope(CC(0, -1, 0), u0, CC(0, 1, 0));
-        double sz = mc_slope(CC(0, 0, -1), u0, CC(0, 0, 1));
-        double umax = u0, umin = u0;
-        for (int kk = -1; kk <= 1; ++kk)
-        for (int jj = -1; jj <= 1; ++jj)
-        for (int ii = -1; ii <= 1; ++ii) {
-            double v = CC(ii, jj, kk);
-            umax = amax(umax, v);
-            umin = amin(umin, v);
-        }
-#undef CC
-        const double dmax = 0.25 * (fabs(sx) + fabs(sy) + fabs(sz));
-        double alpha = 1.0;
-        if (dmax > umax - u0) alpha = amin(alpha, (umax - u0) / dmax);
-        if (dmax > u0 - umin) alpha = amin(alpha, (u0 - umin) / dmax);
-        F.p[fidx(F, i, j, k, n)] = u0 + alpha * (sx * ox + sy * oy + sz * oz);
+    const double u0 = CC(0, 0, 0);
+    double sx = mc_slope(CC(-1, 0, 0), u0, CC(1, 0, 0));
+    double sy = mc_slope(CC(0, -1, 0), u0, CC(0, 1, 0));
+    double sz = mc_slope(CC(0, 0, -1), u0, CC(0, 0, 1));
+    double umax = u0, umin = u0;
+    for (int kk = -1; kk <= 1; ++kk)
+    for (int jj = -1; jj <= 1; ++jj)
+    for (int ii = -1; ii <= 1; ++ii) {
+        double v = CC(ii, jj, kk);
+        umax = amax(umax, v);
+        umin = amin(umin, v);
     }
+#undef CC
+    const double dmax = 0.25 * (fabs(sx) + fabs(sy) + fabs(sz));
+    double alpha = 1.0;
+    if (dmax > umax - u0) alpha = amin(alpha, (umax - u0) / dmax);
+    if (dmax > u0 - umin) alpha = amin(alpha, (u0 - umin) / dmax);
+    return u0 + alpha * (sx * ox + sy * oy + sz * oz);
+}
+
+__global__ void __launch_bounds__(256) k_cc_interp(DFab C, DFab F, Box3 b, int ncomp)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    for (int n = 0; n < ncomp; ++n) F.p[fidx(F, i, j, k, n)] = cc_interp_value(C, i, j, k, n);
+}
+
+// The coarse-level part of a fine box's FillPatch in one launch: every zone of grow(valid, ng) \ valid gets the
+// cell-conservative interpolation of the coarse state and then clean_state x ntimes (Castro_advance.cpp:186 cleans
+// the ghost zones of Sborder too).  The shell is six slabs (z slabs over the full x-y extent, then y, then x).
+struct Slabs { int lo[6][3], nn[6][3]; long start[7]; };
+
+__global__ void __launch_bounds__(256) k_fillpatch_shell(DFab C, DFab F, Slabs S, DevParams P, int ntimes)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= S.start[6]) return;
+    int r = 0;
+    while (tid >= S.start[r + 1]) ++r;
+    const long t = tid - S.start[r];
+    const int n0 = S.nn[r][0], n1 = S.nn[r][1];
+    const int i = S.lo[r][0] + (int)(t % n0);
+    const long q = t / n0;
+    const int j = S.lo[r][1] + (int)(q % n1), k = S.lo[r][2] + (int)(q / n1);
+    double u[NUM_STATE];
+    for (int n = 0; n < NUM_STATE; ++n) u[n] = cc_interp_value(C, i, j, k, n);
+    if (ntimes > 0) clean_zone(P, ntimes, u[URHO], u[UMX], u[UMY], u[UMZ], u[UEDEN], u[UEINT], u[UTEMP], u[UFS]);
+    for (int n = 0; n < NUM_STATE; ++n) F.p[fidx(F, i, j, k, n)] = u[n];
+}
+
+int launch_fillpatch_shell(const DFab& C, const DFab& F, const int vlo[3], const int vhi[3], int ng, const DevParams& P, int ntimes,
+                           hipStream_t stream, Profiler* prof)
+{
+    Slabs S;
+    int glo[3], ghi[3];
+    for (int d = 0; d < 3; ++d) { glo[d] = vlo[d] - ng; ghi[d] = vhi[d] + ng; }
+    const int lo[6][3] = { { glo[0], glo[1], glo[2] }, { glo[0], glo[1], vhi[2] + 1 }, { glo[0], glo[1], vlo[2] },
+                           { glo[0], vhi[1] + 1, vlo[2] }, { glo[0], vlo[1], vlo[2] }, { vhi[0] + 1, vlo[1], vlo[2] } };
+    const int hi[6][3] = { { ghi[0], ghi[1], vlo[2] - 1 }, { ghi[0], ghi[1], ghi[2] }, { ghi[0], vlo[1] - 1, vhi[2] },
+                           { ghi[0], ghi[1], vhi[2] }, { vlo[0] - 1, vhi[1], vhi[2] }, { ghi[0], vhi[1], vhi[2] } };
+    S.start[0] = 0;
+    for (int r = 0; r < 6; ++r) {
+        long n = 1;
+        for (int d = 0; d < 3; ++d) { S.lo[r][d] = lo[r][d]; S.nn[r][d] = hi[r][d] - lo[r][d] + 1; n *= S.nn[r][d] > 0 ? S.nn[r][d] : 0; }
+        S.start[r + 1] = S.start[r] + n;
+    }
+    if (S.start[6] <= 0) return 0;
+    prof_begin(prof, "k_fillpatch_shell", stream);
+    hipLaunchKernelGGL(k_fillpatch_shell, dim3((unsigned)((S.start[6] + 255) / 256)), dim3(256), 0, stream, C, F, S, P, ntimes);
+    prof_end(prof, stream);
+    return 0;
 }
 
 __global__ void __launch_bounds__(256) k_avgdown(DFab F, DFab C, Box3 b, int ncomp)

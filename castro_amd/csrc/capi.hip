@@ -465,6 +465,25 @@ int castro_amd_cc_interp_fab(castro_amd_ctx* c, const castro_amd_fab* crse, cons
     return launch_cc_interp(to_dfab(crse), to_dfab(fine), lo, hi, ncomp, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_fillpatch_shell_fab(castro_amd_ctx* c, const castro_amd_fab* crse, const castro_amd_fab* fine,
+                                   const int vlo[3], const int vhi[3], int ngrow, const castro_amd_params* params,
+                                   int clean_ntimes, void* stream)
+{
+    if (!c || !params || !fab_ok(crse, NUM_STATE) || !fab_ok(fine, NUM_STATE) || ngrow < 1 || clean_ntimes < 0) return CASTRO_AMD_ERR_ARG;
+    if (crse->ncomp != NUM_STATE || fine->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
+    int glo[3], ghi[3], clo[3], chi[3];
+    for (int d = 0; d < 3; ++d) {
+        if (vhi[d] < vlo[d]) return CASTRO_AMD_ERR_ARG;
+        glo[d] = vlo[d] - ngrow; ghi[d] = vhi[d] + ngrow;
+        clo[d] = (glo[d] >= 0 ? glo[d] / 2 : -((-glo[d] + 1) / 2)) - 1;
+        chi[d] = (ghi[d] >= 0 ? ghi[d] / 2 : -((-ghi[d] + 1) / 2)) + 1;
+    }
+    if (!fab_contains(fine, glo, ghi) || !fab_contains(crse, clo, chi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_fillpatch_shell(to_dfab(crse), to_dfab(fine), vlo, vhi, ngrow, to_devparams(params), clean_ntimes,
+                                  (hipStream_t)stream, &c->prof);
+}
+
 int castro_amd_avgdown_fab(castro_amd_ctx* c, const castro_amd_fab* fine, const castro_amd_fab* crse,
                            const int lo[3], const int hi[3], int ncomp, void* stream)
 {

@@ -85,6 +85,8 @@ int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
 int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);
+int launch_fillpatch_shell(const DFab& C, const DFab& F, const int vlo[3], const int vhi[3], int ng, const DevParams& P, int ntimes,
+                           hipStream_t stream, Profiler* prof);
 int launch_avgdown(const DFab& F, const DFab& C, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);
 int launch_fluxreg(const DFab& R, const DFab& X, const int lo[3], const int hi[3], int dir, int ncomp, double mult, int mode,
                    hipStream_t stream, Profiler* prof);

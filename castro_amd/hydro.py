@@ -151,6 +151,12 @@ class HipHydro:
         L.check(self.lib.castro_amd_cc_interp_fab(self.h, C.byref(L.fab_of(crse, *crse_box)), C.byref(L.fab_of(fine, *fine_box)),
                                                   L.i3(lo), L.i3(hi), int(ncomp), _stream_ptr(stream)), "cc_interp_fab")
 
+    def fillpatch_shell(self, crse, crse_box, fine, fine_box, vlo, vhi, ngrow, params, ntimes=1, stream=None):
+        """cc_interp + clean_state x ntimes on grow([vlo, vhi], ngrow) minus [vlo, vhi], one launch."""
+        L.check(self.lib.castro_amd_fillpatch_shell_fab(self.h, C.byref(L.fab_of(crse, *crse_box)), C.byref(L.fab_of(fine, *fine_box)),
+                                                        L.i3(vlo), L.i3(vhi), int(ngrow), C.byref(params), int(ntimes),
+                                                        _stream_ptr(stream)), "fillpatch_shell_fab")
+
     def lincomb(self, dst, dst_box, a, x, x_box, b, y, y_box, ncomp, lo, hi, stream=None):
         L.check(self.lib.castro_amd_lincomb_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(x, *x_box)),
                                                 float(b), C.byref(L.fab_of(y, *y_box)), int(ncomp), L.i3(lo), L.i3(hi),

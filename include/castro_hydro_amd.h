@@ -250,7 +250,13 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
  *   castro_amd_error_tag_fab          amrex::AMRErrorTag of Castro::errorEst (Castro.cpp:3131-3164): kind 0 value_greater,
  *                                     1 value_less, 2 gradient, 3 relative_gradient on component `comp` of `field`
  *                                     (one ghost zone for the gradient kinds); tags (1 comp, 1.0 = tagged) are OR-ed
+ *   castro_amd_fillpatch_shell_fab    the coarse-level part of a fine box's FillPatch in one launch: cc_interp into every
+ *                                     zone of grow([vlo,vhi], ngrow) outside [vlo,vhi], followed by clean_state x
+ *                                     clean_ntimes there (Castro_advance.cpp:186); ncomp 8
  * Register planes are ordinary FABs, one coarse face thick, in coarse face index space. */
+int castro_amd_fillpatch_shell_fab(castro_amd_ctx *ctx, const castro_amd_fab *crse, const castro_amd_fab *fine,
+                                   const int vlo[3], const int vhi[3], int ngrow, const castro_amd_params *params,
+                                   int clean_ntimes, void *stream);
 int castro_amd_cc_interp_fab(castro_amd_ctx *ctx, const castro_amd_fab *crse, const castro_amd_fab *fine,
                              const int lo[3], const int hi[3], int ncomp, void *stream);
 int castro_amd_error_tag_fab(castro_amd_ctx *ctx, const castro_amd_fab *field, int comp, const castro_amd_fab *tags,

@@ -794,6 +794,45 @@ def test_amr_building_blocks_match_oracle(hip, oracle):
     assert np.array_equal(reg_d.cpu().numpy(), reg_o) and np.array_equal(st_d.cpu().numpy(), st_o)
 
 
+def test_fillpatch_shell_equals_interp_then_clean(hip, oracle):
+    """castro_amd_fillpatch_shell_fab (one launch) == cc_interp on the six ghost slabs followed by clean_state there,
+    on the device and in the oracle; the valid zones are not touched."""
+    import torch
+    import castro_amd
+    rng = np.random.default_rng(23)
+    vlo, vhi, g = (2, 4, 6), (13, 11, 17), 4
+    flo, fhi = tuple(x - g for x in vlo), tuple(x + g for x in vhi)
+    clo, chi = tuple(x // 2 - 1 for x in flo), tuple(x // 2 + 1 for x in fhi)
+    crse = physical_state(rng, clo, chi, smooth=False)
+    crse[0] *= rng.uniform(0.2, 1.0, size=crse[0].shape)                # rho X != rho, some low densities
+    fine0 = rng.uniform(1.0, 2.0, size=(8,) + tuple(fhi[d] - flo[d] + 1 for d in (2, 1, 0)))
+    P = castro_amd.default_params(small_dens=0.3)
+    cd = _to_dev(hip, crse)
+    one, six = _to_dev(hip, fine0), _to_dev(hip, fine0)
+    hip.fillpatch_shell(cd, (clo, chi), one, (flo, fhi), vlo, vhi, g, P, ntimes=1)
+    shell = [((flo[0], flo[1], flo[2]), (fhi[0], fhi[1], vlo[2] - 1)), ((flo[0], flo[1], vhi[2] + 1), (fhi[0], fhi[1], fhi[2])),
+             ((flo[0], flo[1], vlo[2]), (fhi[0], vlo[1] - 1, vhi[2])), ((flo[0], vhi[1] + 1, vlo[2]), (fhi[0], fhi[1], vhi[2])),
+             ((flo[0], vlo[1], vlo[2]), (vlo[0] - 1, vhi[1], vhi[2])), ((vhi[0] + 1, vlo[1], vlo[2]), (fhi[0], vhi[1], vhi[2]))]
+    for lo, hi in shell:
+        hip.cc_interp(cd, (clo, chi), six, (flo, fhi), lo, hi, 8)
+    for lo, hi in shell:
+        hip.clean_state(six, (flo, fhi), lo, hi, P, ntimes=1)
+    torch.cuda.synchronize()
+    a, b = one.cpu().numpy(), six.cpu().numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, g:-g, g:-g, g:-g], fine0[:, g:-g, g:-g, g:-g])          # valid zones untouched
+    assert not np.array_equal(a, fine0)
+    # and the oracle's two passes
+    want = fine0.copy()
+    Po = oracle.default_params(small_dens=0.3)
+    for lo, hi in shell:
+        oracle.lib().ora_cc_interp(oracle.i3(lo), oracle.i3(hi), oracle.a4(crse, clo, chi), oracle.a4(want, flo, fhi), 8)
+    import ctypes as C
+    for lo, hi in shell:
+        oracle.lib().ora_clean_state(oracle.i3(lo), oracle.i3(hi), oracle.a4(want, flo, fhi), C.byref(Po))
+    assert np.array_equal(a, want)
+
+
 def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap):
     import torch.distributed as dist
     import torch

@@ -42,3 +42,24 @@ wall = time.perf_counter() - t0
 print("ms per coarse step: total %.2f, regrid %.2f (grid_places %.2f of which tags %.2f)" %
       tuple(1e3 * x / steps for x in (wall, acc["regrid"], acc["places"], acc["tags"])))
 print("boxes per level", [len(lev.boxes) for lev in a.levels], "zones per level", [sum(b.n[0] * b.n[1] * b.n[2] for b in lev.boxes) for lev in a.levels])
+
+# per-kernel device time of one coarse step (hipEvent-timed inside the library), all levels together
+for h in a._hydros:
+    h.profile(True)
+    h.profile_reset()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    a.step()
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+tot = {}
+for h in a._hydros:
+    for k, (ms, n_) in h.profile_report().items():
+        e = tot.setdefault(k, [0.0, 0])
+        e[0] += ms; e[1] += n_
+    h.profile(False)
+ksum = sum(v[0] for v in tot.values())
+print("with kernel timing on: %.2f ms per coarse step, kernels %.2f ms" % (1e3 * wall / steps, ksum / steps))
+for k, (ms, n_) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
+    print("  %-22s %8.3f ms  %6.1f launches per coarse step" % (k, ms / steps, n_ / steps))
