@@ -794,6 +794,50 @@ def test_amr_building_blocks_match_oracle(hip, oracle):
     assert np.array_equal(reg_d.cpu().numpy(), reg_o) and np.array_equal(st_d.cpu().numpy(), st_o)
 
 
+def _rccl_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        c = castro_amd.Castro((24, 16, 32), comm=castro_amd.DistComm(), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
+        c.initData("sedov", r_init=0.1, nsub=4)
+        dts = [c.step(0.01) for _ in range(3)]
+        c.comm.barrier()
+        # the grouped point-to-point call of the halo exchange (batch_isend_irecv => ncclGroupStart / ncclSend / ncclRecv),
+        # two messages to the only peer there is -- this rank -- posted in different orders on the two sides
+        a = torch.arange(10, dtype=torch.float64, device="cuda")
+        b = torch.arange(10, 20, dtype=torch.float64, device="cuda")
+        ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+        c.comm.exchange([(0, 5, b), (0, 3, a)], [(0, 3, ra), (0, 5, rb)])
+        torch.cuda.synchronize()
+        assert torch.equal(ra, a) and torch.equal(rb, b)
+        np.savez(out_path, S=c.S_new().cpu().numpy(), dts=np.array(dts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_process_group_of_one_rank(tmp_path):
+    """The collective calls of the N > 1 path on the real backend (backend "nccl" is RCCL here): process-group
+    creation bound to the device, the 2-double all_reduce(MIN) of [dt, min rho] in FP64, barrier, and the grouped
+    send/recv of the halo exchange (to itself) -- with a group of one rank, which is all a one-GPU box allows.  Same steps and state as a run without a communicator."""
+    import torch
+    import torch.multiprocessing as mp
+    import castro_amd
+    from tests.test_driver_cpu import _free_port
+    out = str(tmp_path / "rccl.npz")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = np.load(out)
+    c = castro_amd.Castro((24, 16, 32), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    dts = [c.step(0.01) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert np.array_equal(got["dts"], np.array(dts)) and np.array_equal(got["S"], c.S_new().cpu().numpy())
+
+
 def test_fillpatch_shell_equals_interp_then_clean(hip, oracle):
     """castro_amd_fillpatch_shell_fab (one launch) == cc_interp on the six ghost slabs followed by clean_state there,
     on the device and in the oracle; the valid zones are not touched."""
