@@ -146,6 +146,7 @@ void castro_amd_default_params(castro_amd_params* p)
     p->transverse_use_eos = 0; p->transverse_reset_density = 1; p->transverse_reset_rhoe = 0;
     p->ppm_temp_fix = 0;
     p->plm_iorder = 2; p->plm_limiter = 2; p->use_pslope = 1; p->pslope_cutoff_density = -1.e20;
+    p->limit_fluxes_on_small_dens = 0; p->limit_fluxes_on_large_vel = 0; p->speed_limit = 0.0;
     p->difmag = 0.1;
     p->small_dens = -1.e200; p->small_temp = -1.e200; p->small_pres = -1.e200; p->small_ener = -1.e200;
     p->cg_tol = 1.0e-5;
@@ -264,6 +265,8 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     if (params->riemann_solver < 0 || params->riemann_solver > 2) return CASTRO_AMD_ERR_ARG;
     if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
     if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (params->limit_fluxes_on_small_dens != 0 || params->limit_fluxes_on_large_vel != 0 || params->speed_limit > 0.0)
+        return CASTRO_AMD_ERR_UNSUPPORTED;
 
     Tile t;
     int glo[3], ghi[3];
@@ -348,6 +351,7 @@ int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, c
 {
     if (!c || !state || !state->p || !params || state->ncomp != NUM_STATE || ntimes < 1) return CASTRO_AMD_ERR_ARG;
     if (!fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    if (params->speed_limit > 0.0) return CASTRO_AMD_ERR_UNSUPPORTED;      // enforce_speed_limit is not implemented
     hipSetDevice(c->device);
     return launch_clean_state(to_dfab(state), lo, hi, to_devparams(params), ntimes, (hipStream_t)stream, &c->prof);
 }

@@ -338,7 +338,7 @@ def test_unsupported_options_fail_loudly(hip):
     G = castro_amd.make_geom(n)
     S = hip.alloc(8, (-4, -4, -4), (11, 11, 11), fill=1.0)
     N = hip.alloc(8, (0, 0, 0), (7, 7, 7), fill=1.0)
-    for kw in (dict(ppm_temp_fix=2),):
+    for kw in (dict(ppm_temp_fix=2), dict(limit_fluxes_on_small_dens=1), dict(limit_fluxes_on_large_vel=1), dict(speed_limit=1.e9)):
         P = castro_amd.default_params(**kw)
         with pytest.raises(RuntimeError, match="unsupported"):
             hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
