@@ -1132,11 +1132,18 @@ def test_sedov_256_cubed_to_t_001_against_the_reference_analytic_table():
     n = 256
     c = castro_amd.Castro((n, n, n))
     c.initData("sedov")
+    m0, e0 = c.S_new()[0].sum().item(), c.S_new()[4].sum().item()
     c.evolve(0.01)
     torch.cuda.synchronize()
     assert c.time == 0.01 and 200 < c.nstep < 2000 and c.nretries == 0
+    # nothing has reached the outflow boundaries: mass and total energy are conserved to round-off over ~700 steps
+    assert abs(c.S_new()[0].sum().item() - m0) <= 1e-12 * m0 and abs(c.S_new()[4].sum().item() - e0) <= 1e-11 * e0
     gold = os.path.join(os.path.dirname(__file__), "golden", "reference_verification", "spherical_sedov.dat")
     ex = np.loadtxt(gold)
+    # the other panels of the reference's testsuite_analysis/sedov_3d_sph.py: radial velocity and pressure
+    from tests.util import sedov_l1_errors
+    l1, _, _ = sedov_l1_errors(c, ex)
+    assert l1["density"] < 0.04 and l1["velocity"] < 0.12 and l1["pressure"] < 0.15, l1   # measured 0.032 / 0.104 / 0.132
     r_ex, den_ex = ex[:, 1], ex[:, 2]
     r_shock_exact = r_ex[np.argmax(den_ex)]
     rho = c.S_new()[0]

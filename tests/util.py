@@ -1,5 +1,6 @@
 """Shared helpers for the parity tests (tests only)."""
 import numpy as np
+import torch
 
 
 def physical_state(rng, lo, hi, smooth=True, vel=1.0, jump=True):
@@ -45,3 +46,50 @@ def ulp_report(a, b):
     """(#different entries, max abs diff, max rel diff)"""
     ne = int((a != b).sum())
     return ne, float(np.abs(a - b).max()), float(max_rel(a, b))
+
+
+# ---- radial profiles of a Sedov run against the reference's analytic table (the four panels of
+# Exec/hydro_tests/Sedov/testsuite_analysis/sedov_3d_sph.py) ----
+def sedov_profiles(c, gamma=1.4, rmax=0.36):
+    n = c.n_cell[0]
+    S = c.S_new()
+    rho = S[0]
+    x = (torch.arange(n, device=rho.device, dtype=torch.float64) + 0.5) / n - 0.5
+    X, Y, Z = x[None, None, :], x[None, :, None], x[:, None, None]
+    r = torch.sqrt(X ** 2 + Y ** 2 + Z ** 2)
+    vr = (S[1] * X + S[2] * Y + S[3] * Z) / (rho * r)
+    p = (gamma - 1.0) * S[5]
+    e = S[5] / rho
+    dx = 1.0 / n
+    nb = int(rmax / dx)
+    idx = torch.clamp((r / dx).long(), max=nb).ravel()
+    cnt = torch.zeros(nb + 1, device=rho.device, dtype=torch.float64).index_add_(0, idx, torch.ones_like(rho).ravel())
+    out = {}
+    for name, f in (("density", rho), ("velocity", vr), ("pressure", p), ("eint", e)):
+        tot = torch.zeros(nb + 1, device=rho.device, dtype=torch.float64).index_add_(0, idx, f.ravel())
+        out[name] = (tot / cnt)[:nb].cpu().numpy()
+    edges = np.arange(nb + 1) * dx
+    return edges, out
+
+
+def analytic_bins(edges, table, col, fill):
+    """Volume average of column `col` of the analytic table over the radial bins."""
+    r_ex, f_ex = table[:, 1], table[:, col]
+    rf = np.linspace(0.0, edges[-1], 200001)
+    ff = np.interp(rf, r_ex, f_ex, right=fill)
+    cum = np.concatenate([[0.0], np.cumsum(0.5 * (ff[1:] * rf[1:] ** 2 + ff[:-1] * rf[:-1] ** 2) * np.diff(rf))])
+    vol = rf ** 3 / 3.0
+    return np.diff(np.interp(edges, rf, cum)) / np.diff(np.interp(edges, rf, vol))
+
+
+def sedov_l1_errors(c, table):
+    edges, prof = sedov_profiles(c)
+    rc = 0.5 * (edges[1:] + edges[:-1])
+    w = rc ** 2
+    res = {}
+    for name, col, fill in (("density", 2, 1.0), ("velocity", 5, 0.0), ("pressure", 4, 1.e-5)):
+        ref = analytic_bins(edges, table, col, fill)
+        res[name] = float((np.abs(prof[name] - ref) * w).sum() / (np.abs(ref) * w).sum())
+    return res, rc, prof
+
+
