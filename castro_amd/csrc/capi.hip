@@ -106,6 +106,8 @@ static DevParams to_devparams(const castro_amd_params* p)
     P.ppm_temp_fix = p->ppm_temp_fix;
     P.ppm_type = p->ppm_type; P.plm_iorder = p->plm_iorder; P.plm_limiter = p->plm_limiter; P.use_pslope = p->use_pslope;
     P.pslope_cutoff_density = p->pslope_cutoff_density;
+    P.cfl = p->cfl; P.speed_limit = p->speed_limit;
+    P.limit_small_dens = p->limit_fluxes_on_small_dens; P.limit_large_vel = p->limit_fluxes_on_large_vel;
     return P;
 }
 
@@ -265,8 +267,6 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     if (params->riemann_solver < 0 || params->riemann_solver > 2) return CASTRO_AMD_ERR_ARG;
     if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
     if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
-    if (params->limit_fluxes_on_small_dens != 0 || params->limit_fluxes_on_large_vel != 0 || params->speed_limit > 0.0)
-        return CASTRO_AMD_ERR_UNSUPPORTED;
 
     Tile t;
     int glo[3], ghi[3];
@@ -351,7 +351,6 @@ int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, c
 {
     if (!c || !state || !state->p || !params || state->ncomp != NUM_STATE || ntimes < 1) return CASTRO_AMD_ERR_ARG;
     if (!fab_contains(state, lo, hi)) return CASTRO_AMD_ERR_ARG;
-    if (params->speed_limit > 0.0) return CASTRO_AMD_ERR_UNSUPPORTED;      // enforce_speed_limit is not implemented
     hipSetDevice(c->device);
     return launch_clean_state(to_dfab(state), lo, hi, to_devparams(params), ntimes, (hipStream_t)stream, &c->prof);
 }

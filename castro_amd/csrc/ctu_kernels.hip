@@ -1128,11 +1128,11 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
 // viscosity, species normalisation, record for consup, scaling and accumulation
 //   (Castro_ctu_hydro.cpp:1192-1243, 1322-1433; apply_av advection_util.cpp:482-528;
 //    normalize_species_fluxes :577-613; scale_flux :616-641)
-template <int N>
+template <int N, bool LIM>
 __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch& S, const IFlux f[2], unsigned c,
                                                 unsigned s1, unsigned s2, const DFab& U, unsigned cu, unsigned un_,
                                                 const DFab& fluxes, const DFab& mass, const DFab& qe,
-                                                int i, int j, int k, double dt, double area, double dxn,
+                                                int i, int j, int k, double dt, double area, double dxn, double vol,
                                                 int acc_hi, bool assign, bool v0, bool v1, const DevParams& P, double R[2][NFIN])
 {
     double F[2][NUM_STATE];
@@ -1156,14 +1156,32 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
         div1[1] = 0.25 * (d00.b + d10.b + d01.b + d11.b);
         div1[0] = P.difmag * amin(0.0, div1[0]);
         div1[1] = P.difmag * amin(0.0, div1[1]);
+        double uR[2][NUM_STATE], uL[2][NUM_STATE];            // kept only by the flux limiters
 #pragma unroll
         for (int m = 0; m < NUM_STATE; ++m) {
-            if (m == UTEMP) continue;
+            if (m == UTEMP) { if (LIM) { uR[0][m] = uR[1][m] = uL[0][m] = uL[1][m] = 0.0; } continue; }
             const D2 uc = ldg2(U.p + m * U.sn, cu), ul = ldg2(U.p + m * U.sn, cu - un_);
             double d1 = div1[0] * (uc.a - ul.a);
             F[0][m] += dxn * d1;
             d1 = div1[1] * (uc.b - ul.b);
             F[1][m] += dxn * d1;
+            if (LIM) { uR[0][m] = uc.a; uR[1][m] = uc.b; uL[0][m] = ul.a; uL[1][m] = ul.b; }
+        }
+        if (LIM) {
+            // limit_fluxes_on_small_dens / _large_vel (Castro_ctu_hydro.cpp:1219-1239), between apply_av and the
+            // species normalisation; normal velocity and pressure of the zones either side of the face
+            const unsigned sn = dstr(gstr(t), N);
+            const D2 vr = ldg2(S.Q + (long)(PU + N) * t.NC, c), vl = ldg2(S.Q + (long)(PU + N) * t.NC, c - sn);
+            const D2 pr = ldg2(S.Q + (long)PP * t.NC, c), pl = ldg2(S.Q + (long)PP * t.NC, c - sn);
+            const double dtdx = dt / dxn;
+            if (P.limit_small_dens == 1) {
+                limit_flux_small_dens<N>(uL[0], uR[0], vl.a, pl.a, vr.a, pr.a, dt, dtdx, area, vol, P, F[0]);
+                limit_flux_small_dens<N>(uL[1], uR[1], vl.b, pl.b, vr.b, pr.b, dt, dtdx, area, vol, P, F[1]);
+            }
+            if (P.limit_large_vel == 1) {
+                limit_flux_large_vel<N>(uL[0], uR[0], vl.a, pl.a, vr.a, pr.a, dt, dtdx, area, vol, P, F[0]);
+                limit_flux_large_vel<N>(uL[1], uR[1], vl.b, pl.b, vr.b, pr.b, dt, dtdx, area, vol, P, F[1]);
+            }
         }
     }
 
@@ -1469,7 +1487,7 @@ __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* 
 
 // one normal direction of the final stage for the faces (ijk) and (ijk + x); v0 / v1: the faces belong to
 // nodal(bx, N)
-template <int N, bool RE>
+template <int N, bool RE, bool LIM>
 __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool v0, bool v1, unsigned c,
                                            const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                            const DFab& U, const DFab& fluxes, const DFab& mass, const DFab& qe,
@@ -1538,8 +1556,8 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
         interface_flux<N>(rl, rr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
     }
-    final_flux_tail<N>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
-                       ijk[0], ijk[1], ijk[2], dt, area, dxn, acc_hi, assign != 0, v0, v1, P, R);
+    final_flux_tail<N, LIM>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
+                            ijk[0], ijk[1], ijk[2], dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
     double* FL = S.FL[N];
     if (v0 && v1) {
 #pragma unroll
@@ -1555,7 +1573,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 
 // One launch per normal direction.  (All three in one launch, which fetches Sborder and div(u) once instead of
 // three times, measured slower: 5.0 vs 4.6 ms at 256^3 -- ~150 concurrent streams per workgroup.)
-template <int N, bool RE>
+template <int N, bool RE, bool LIM>
 __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
@@ -1565,7 +1583,7 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    final_body<N, RE>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P);
+    final_body<N, RE, LIM>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1823,17 +1841,20 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 
     // transverse_reset_rhoe = 1 (non-default) runs its own instantiations: the extra (rho e) flux loads cost the
     // default path 2 % when they sit behind a run-time branch
-#define TRANSVERSE_STAGES(RE)                                                                                     \
+#define TRANSVERSE_STAGES(RE, LIM)                                                                                \
     do {                                                                                                          \
         KL2("k_trans1", k_trans1<RE>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);                              \
-        KL2("k_final", (k_final<0, RE>), nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],           \
+        KL2("k_final", (k_final<0, RE, LIM>), nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],      \
             hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P);                                 \
-        KL2("k_final", (k_final<1, RE>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],           \
+        KL2("k_final", (k_final<1, RE, LIM>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],      \
             hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);                                 \
-        KL2("k_final", (k_final<2, RE>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],           \
+        KL2("k_final", (k_final<2, RE, LIM>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],      \
             hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);                                 \
     } while (0)
-    if (P.reset_rhoe == 1) TRANSVERSE_STAGES(true); else TRANSVERSE_STAGES(false);
+    // the flux limiters (non-default too) share one extra pair of instantiations: both flags are tested inside
+    const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
+    if (P.reset_rhoe == 1) { if (lim) TRANSVERSE_STAGES(true, true); else TRANSVERSE_STAGES(true, false); }
+    else { if (lim) TRANSVERSE_STAGES(false, true); else TRANSVERSE_STAGES(false, false); }
 #undef TRANSVERSE_STAGES
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];

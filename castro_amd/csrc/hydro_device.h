@@ -42,6 +42,8 @@ struct DevParams {
     int ppm_temp_fix;
     int ppm_type, plm_iorder, plm_limiter, use_pslope;
     double pslope_cutoff_density;
+    double cfl, speed_limit;
+    int limit_small_dens, limit_large_vel;
 };
 
 // amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument
@@ -206,6 +208,24 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
             mx = 0.0; my = 0.0; mz = 0.0;
             eint = rho * e;
             eden = eint;
+        }
+
+        // enforce_speed_limit (Castro.cpp:3049-3092), off by default
+        if (P.speed_limit > 0.0) {
+            double rhoInv = 1.0 / rho;
+            double vx = mx * rhoInv;
+            double vy = my * rhoInv;
+            double vz = mz * rhoInv;
+            double v = sqrt(vx * vx + vy * vy + vz * vz);
+            if (v > P.speed_limit) {
+                double reduce_factor = P.speed_limit / v;
+                mx *= reduce_factor;
+                my *= reduce_factor;
+                mz *= reduce_factor;
+                eden -= 0.5 * rhoInv * (rho * vx * rho * vx - mx * mx +
+                                        rho * vy * rho * vy - my * my +
+                                        rho * vz * rho * vz - mz * mz);
+            }
         }
 
         // normalize_species (NumSpec = 1)
@@ -1180,6 +1200,139 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
 
     qo[PP] = amax(qo[PP], P.small_pres);
     reset_edge_state_thermo(qo, P);
+}
+
+// ---------------------------------------------------------------------------------------
+// flux limiters of Castro_ctu_hydro.cpp:1219-1239 (both off by default), applied to one face between apply_av and
+// normalize_species_fluxes.  uL / uR: conserved states of the zones left / right of the face (UTEMP not needed: its
+// flux is zeroed), vL / vR and pL / pR: their normal velocity and pressure, F: the face flux in conserved order.
+// ---------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void dflux_zone(const double u[NUM_STATE], double v_adv, double p, double f[NUM_STATE])
+{
+    // advection_util.H:10-79, 3-D Cartesian (mom_flux_has_p is always true), no hybrid momentum
+    f[URHO] = u[URHO] * v_adv;
+    f[UMX] = u[UMX] * v_adv;
+    f[UMY] = u[UMY] * v_adv;
+    f[UMZ] = u[UMZ] * v_adv;
+    f[UEDEN] = (u[UEDEN] + p) * v_adv;
+    f[UEINT] = u[UEINT] * v_adv;
+    f[UTEMP] = 0.0;
+    f[UMX + N] = f[UMX + N] + p;
+    f[UFS] = u[UFS] * v_adv;
+}
+
+// limit_hydro_fluxes_on_small_dens, advection_util.cpp:657-903 (Hu, Adams & Shu 2013)
+template <int N>
+__device__ __forceinline__ void limit_flux_small_dens(const double uL[NUM_STATE], const double uR[NUM_STATE],
+                                                      double vL, double pL, double vR, double pR,
+                                                      double dt, double dtdx, double area, double vol,
+                                                      const DevParams& P, double F[NUM_STATE])
+{
+    const double density_floor_tolerance = 1.1;
+    double density_floor = P.small_dens * density_floor_tolerance;
+    density_floor *= 3 * 2;
+    const double lcfl = P.cfl;
+    const double alpha = 1.0 / 3;
+
+    if (uR[URHO] < density_floor || uL[URHO] < density_floor) {
+#pragma unroll
+        for (int n = 0; n < NUM_STATE; ++n) F[n] = 0.0;
+        return;
+    }
+    double fluxL[NUM_STATE], fluxR[NUM_STATE], fluxLF[NUM_STATE];
+    dflux_zone<N>(uL, vL, pL, fluxL);
+    dflux_zone<N>(uR, vR, pR, fluxR);
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) {
+        if (n == UTEMP) { fluxLF[n] = 0.0; continue; }        // discarded below
+        fluxLF[n] = 0.5 * (fluxL[n] + fluxR[n] + (lcfl / dtdx / alpha) * (uL[n] - uR[n]));
+    }
+    double flux_coefR = 2.0 * (dt / alpha) * area / vol;
+    double flux_coefL = 2.0 * (dt / alpha) * area / vol;
+
+    double drhoL = flux_coefL * F[URHO];
+    double rhoL = uL[URHO] - drhoL;
+    double drhoR = flux_coefR * F[URHO];
+    double rhoR = uR[URHO] + drhoR;
+
+    double theta = 1.0;
+    if (rhoL < density_floor) {
+        double drhoLF = flux_coefL * fluxLF[URHO];
+        double rhoLF = uL[URHO] - drhoLF;
+        theta = amin(theta, (density_floor - rhoLF) / (rhoL - rhoLF));
+    } else if (rhoR < density_floor) {
+        double drhoLF = flux_coefR * fluxLF[URHO];
+        double rhoLF = uR[URHO] + drhoLF;
+        theta = amin(theta, (density_floor - rhoLF) / (rhoR - rhoLF));
+    }
+    theta = amin(1.0, amax(theta, 0.0));
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) F[n] = (1.0 - theta) * fluxLF[n] + theta * F[n];
+    F[UTEMP] = 0.0;
+
+    drhoR = flux_coefR * F[URHO];
+    drhoL = flux_coefL * F[URHO];
+    if (uR[URHO] + drhoR < density_floor) {
+        const double fac = fabs((density_floor - uR[URHO]) / drhoR);
+#pragma unroll
+        for (int n = 0; n < NUM_STATE; ++n) F[n] = F[n] * fac;
+    } else if (uL[URHO] - drhoL < density_floor) {
+        const double fac = fabs((density_floor - uL[URHO]) / drhoL);
+#pragma unroll
+        for (int n = 0; n < NUM_STATE; ++n) F[n] = F[n] * fac;
+    }
+}
+
+// limit_hydro_fluxes_on_large_vel, advection_util.cpp:907-1075
+template <int N>
+__device__ __forceinline__ void limit_flux_large_vel(const double uL[NUM_STATE], const double uR[NUM_STATE],
+                                                     double vL, double pL, double vR, double pR,
+                                                     double dt, double dtdx, double area, double vol,
+                                                     const DevParams& P, double F[NUM_STATE])
+{
+    if (P.speed_limit <= 0.0) return;
+    const double lcfl = P.cfl;
+    const double alpha = 1.0 / 3;
+    const double lspeed_limit = P.speed_limit / (2 * 3);
+
+    double fluxL[NUM_STATE], fluxR[NUM_STATE], fluxLF[NUM_STATE];
+    dflux_zone<N>(uL, vL, pL, fluxL);
+    dflux_zone<N>(uR, vR, pR, fluxR);
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) {
+        if (n == UTEMP) { fluxLF[n] = 0.0; continue; }
+        fluxLF[n] = 0.5 * (fluxL[n] + fluxR[n] + (lcfl / dtdx / alpha) * (uL[n] - uR[n]));
+    }
+    double flux_coefR = 2.0 * (dt / alpha) * area / vol;
+    double flux_coefL = 2.0 * (dt / alpha) * area / vol;
+
+    double theta = 1.0;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int UMOM = UMX + n;
+        double drhouL = flux_coefL * F[UMOM];
+        double rhouL = fabs(uL[UMOM] - drhouL);
+        double drhoL = flux_coefL * F[URHO];
+        double rhoL = uL[URHO] - drhoL;
+        double drhouR = flux_coefR * F[UMOM];
+        double rhouR = fabs(uR[UMOM] + drhouR);
+        double drhoR = flux_coefR * F[URHO];
+        double rhoR = uR[URHO] + drhoR;
+        if (fabs(rhouL) > rhoL * lspeed_limit) {
+            double drhouLF = flux_coefL * fluxLF[UMOM];
+            double rhouLF = fabs(uL[UMOM] - drhouLF);
+            theta = amin(theta, fabs(rhoL * lspeed_limit - rhouLF) / fabs(rhouL - rhouLF));
+        } else if (fabs(rhouR) > rhoR * lspeed_limit) {
+            double drhouLF = flux_coefR * fluxLF[UMOM];
+            double rhouLF = fabs(uR[UMOM] + drhouLF);
+            theta = amin(theta, fabs(rhoR * lspeed_limit - rhouLF) / fabs(rhouR - rhouLF));
+        }
+    }
+    theta = amin(1.0, amax(theta, 0.0));
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) F[n] = (1.0 - theta) * fluxLF[n] + theta * F[n];
+    F[UTEMP] = 0.0;
 }
 
 } // namespace cad

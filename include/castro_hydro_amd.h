@@ -95,11 +95,9 @@ typedef struct castro_amd_params {
     double T_guess;
     double abar;                  /* mean molecular weight with eos_assume_neutral = 1 */
     double pslope_cutoff_density;
-    /* options of the path that are NOT implemented: a non-default value makes the entry points return
-     * CASTRO_AMD_ERR_UNSUPPORTED instead of being ignored */
-    int limit_fluxes_on_small_dens;   /* 0 (default); limit_hydro_fluxes_on_small_dens, advection_util.cpp:680-903 */
-    int limit_fluxes_on_large_vel;    /* 0 (default); limit_hydro_fluxes_on_large_vel, :907-1075 */
-    double speed_limit;               /* 0 (default: off); enforce_speed_limit in clean_state, Castro.cpp:3050 */
+    int limit_fluxes_on_small_dens;   /* 0 (default); limit_hydro_fluxes_on_small_dens, advection_util.cpp:657-903 */
+    int limit_fluxes_on_large_vel;    /* 0 (default); limit_hydro_fluxes_on_large_vel, :907-1075 (needs speed_limit > 0) */
+    double speed_limit;               /* 0 (default: off); also enforce_speed_limit in clean_state, Castro.cpp:3049-3092 */
 } castro_amd_params;
 
 typedef struct castro_amd_ctx castro_amd_ctx;

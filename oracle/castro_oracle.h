@@ -79,6 +79,9 @@ typedef struct {
     double T_guess;
     double abar;                  /* species A (eos_assume_neutral=1 => mu = abar) */
     double pslope_cutoff_density; /* :165 */
+    int limit_fluxes_on_small_dens;   /* :168 */
+    int limit_fluxes_on_large_vel;    /* :171 */
+    double speed_limit;               /* :175 */
 } ora_params;
 
 typedef struct {
@@ -159,6 +162,10 @@ void ora_reset_edge_state_thermo(const int lo[3], const int hi[3], ora_a4 qedge,
 void ora_apply_av(const int lo[3], const int hi[3], int idir, ora_a4 div, ora_a4 uin, ora_a4 flux,
                   const ora_geom *G, const ora_params *P);
 void ora_normalize_species_fluxes(const int lo[3], const int hi[3], ora_a4 flux);
+void ora_limit_hydro_fluxes_on_small_dens(const int lo[3], const int hi[3], int idir, ora_a4 u, ora_a4 q, ora_a4 flux,
+                                          const ora_geom *G, const ora_params *P, double dt);
+void ora_limit_hydro_fluxes_on_large_vel(const int lo[3], const int hi[3], int idir, ora_a4 u, ora_a4 q, ora_a4 flux,
+                                         const ora_geom *G, const ora_params *P, double dt);
 void ora_scale_flux(const int lo[3], const int hi[3], ora_a4 flux, double area, double dt);
 void ora_consup_hydro(const int lo[3], const int hi[3], ora_a4 U_new, ora_a4 flux0, ora_a4 qx,
                       ora_a4 flux1, ora_a4 qy, ora_a4 flux2, ora_a4 qz, double dt, const ora_geom *G);

@@ -239,7 +239,10 @@ static int ctu_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], cons
         for (int i = nlo[0]; i <= nhi[0]; ++i) A4(f,i,j,k,UTEMP) = 0.e0;
 
         ora_apply_av(nlo, nhi, idir, S->div.a, Sborder, f, G, P);
-        /* limit_fluxes_on_small_dens / _large_vel: default off (not restated) */
+        if (P->limit_fluxes_on_small_dens == 1)                      /* :1219-1228 */
+            ora_limit_hydro_fluxes_on_small_dens(nlo, nhi, idir, Sborder, S->q.a, f, G, P, dt);
+        if (P->limit_fluxes_on_large_vel == 1)                       /* :1230-1239 */
+            ora_limit_hydro_fluxes_on_large_vel(nlo, nhi, idir, Sborder, S->q.a, f, G, P, dt);
         ora_normalize_species_fluxes(nlo, nhi, f);
     }
 

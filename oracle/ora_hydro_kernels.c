@@ -28,6 +28,9 @@ void ora_default_params(ora_params *p)
     p->transverse_use_eos = 0;
     p->transverse_reset_density = 1;
     p->transverse_reset_rhoe = 0;
+    p->limit_fluxes_on_small_dens = 0;
+    p->limit_fluxes_on_large_vel = 0;
+    p->speed_limit = 0.0;
     p->ppm_temp_fix = 0;
     p->plm_iorder = 2;
     p->plm_limiter = 2;
@@ -388,6 +391,164 @@ void ora_apply_av(const int lo[3], const int hi[3], int idir, ora_a4 div, ora_a4
             }
             A4(flux,i,j,k,n) += G->dx[idir] * div1;
         }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* dflux (Source/hydro/advection_util.H:10-79): the flux of a cell-centred state, 3-D Cartesian
+ * (mom_flux_has_p is always true there), no hybrid momentum                                    */
+/* ------------------------------------------------------------------ */
+static void dflux(const double u[NUM_STATE], const double q[NQ], int dir, double flux[NUM_STATE])
+{
+    for (int n = 0; n < NUM_STATE; ++n) flux[n] = 0.0;
+    double v_adv = q[QU + dir];
+    flux[URHO] = u[URHO] * v_adv;
+    flux[UMX] = u[UMX] * v_adv;
+    flux[UMY] = u[UMY] * v_adv;
+    flux[UMZ] = u[UMZ] * v_adv;
+    flux[UEDEN] = (u[UEDEN] + q[QPRES]) * v_adv;
+    flux[UEINT] = u[UEINT] * v_adv;
+    flux[UMX + dir] = flux[UMX + dir] + q[QPRES];
+    for (int ip = 0; ip < NPASSIVE; ++ip) {
+        int n = upassmap(ip);
+        flux[n] = u[n] * v_adv;
+    }
+}
+
+static void limiter_states(ora_a4 u, ora_a4 q, int idir, int i, int j, int k,
+                           double uL[NUM_STATE], double qL[NQ], double uR[NUM_STATE], double qR[NQ])
+{
+    const int il = i - (idir == 0), jl = j - (idir == 1), kl = k - (idir == 2);
+    for (int n = 0; n < NUM_STATE; ++n) { uR[n] = A4(u,i,j,k,n); uL[n] = A4(u,il,jl,kl,n); }
+    for (int n = 0; n < NQ; ++n) { qR[n] = A4(q,i,j,k,n); qL[n] = A4(q,il,jl,kl,n); }
+}
+
+/* ------------------------------------------------------------------ */
+/* Castro::limit_hydro_fluxes_on_small_dens (advection_util.cpp:657-903), Hu, Adams & Shu (2013)  */
+/* ------------------------------------------------------------------ */
+void ora_limit_hydro_fluxes_on_small_dens(const int lo[3], const int hi[3], int idir, ora_a4 u, ora_a4 q, ora_a4 flux,
+                                          const ora_geom *G, const ora_params *P, double dt)
+{
+    const double density_floor_tolerance = 1.1;
+    double density_floor = P->small_dens * density_floor_tolerance;
+    density_floor *= 3 * 2;
+    const double dtdx = dt / G->dx[idir];
+    const double lcfl = P->cfl;
+    const double alpha = 1.0 / 3;
+    const double vol = G->dx[0] * G->dx[1] * G->dx[2];
+    const double area = (idir == 0) ? G->dx[1] * G->dx[2] : (idir == 1) ? G->dx[0] * G->dx[2] : G->dx[0] * G->dx[1];
+
+    for (int k = lo[2]; k <= hi[2]; ++k)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+    for (int i = lo[0]; i <= hi[0]; ++i) {
+        double uL[NUM_STATE], uR[NUM_STATE], qL[NQ], qR[NQ];
+        limiter_states(u, q, idir, i, j, k, uL, qL, uR, qR);
+        const double volR = vol, volL = vol;
+
+        if (uR[URHO] < density_floor || uL[URHO] < density_floor) {
+            for (int n = 0; n < NUM_STATE; ++n) A4(flux,i,j,k,n) = 0.0;
+            continue;
+        }
+
+        double fluxL[NUM_STATE], fluxR[NUM_STATE], fluxLF[NUM_STATE];
+        dflux(uL, qL, idir, fluxL);
+        dflux(uR, qR, idir, fluxR);
+        for (int n = 0; n < NUM_STATE; ++n)
+            fluxLF[n] = 0.5 * (fluxL[n] + fluxR[n] + (lcfl / dtdx / alpha) * (uL[n] - uR[n]));
+
+        double flux_coefR = 2.0 * (dt / alpha) * area / volR;
+        double flux_coefL = 2.0 * (dt / alpha) * area / volL;
+
+        double drhoL = flux_coefL * A4(flux,i,j,k,URHO);
+        double rhoL = uL[URHO] - drhoL;
+        double drhoR = flux_coefR * A4(flux,i,j,k,URHO);
+        double rhoR = uR[URHO] + drhoR;
+
+        double theta = 1.0;
+        if (rhoL < density_floor) {
+            double drhoLF = flux_coefL * fluxLF[URHO];
+            double rhoLF = uL[URHO] - drhoLF;
+            theta = amin(theta, (density_floor - rhoLF) / (rhoL - rhoLF));
+        } else if (rhoR < density_floor) {
+            double drhoLF = flux_coefR * fluxLF[URHO];
+            double rhoLF = uR[URHO] + drhoLF;
+            theta = amin(theta, (density_floor - rhoLF) / (rhoR - rhoLF));
+        }
+        theta = amin(1.0, amax(theta, 0.0));
+
+        for (int n = 0; n < NUM_STATE; ++n)
+            A4(flux,i,j,k,n) = (1.0 - theta) * fluxLF[n] + theta * A4(flux,i,j,k,n);
+        A4(flux,i,j,k,UTEMP) = 0.0;
+
+        drhoR = flux_coefR * A4(flux,i,j,k,URHO);
+        drhoL = flux_coefL * A4(flux,i,j,k,URHO);
+        if (uR[URHO] + drhoR < density_floor) {
+            for (int n = 0; n < NUM_STATE; ++n)
+                A4(flux,i,j,k,n) = A4(flux,i,j,k,n) * fabs((density_floor - uR[URHO]) / drhoR);
+        } else if (uL[URHO] - drhoL < density_floor) {
+            for (int n = 0; n < NUM_STATE; ++n)
+                A4(flux,i,j,k,n) = A4(flux,i,j,k,n) * fabs((density_floor - uL[URHO]) / drhoL);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Castro::limit_hydro_fluxes_on_large_vel (advection_util.cpp:907-1075)                          */
+/* ------------------------------------------------------------------ */
+void ora_limit_hydro_fluxes_on_large_vel(const int lo[3], const int hi[3], int idir, ora_a4 u, ora_a4 q, ora_a4 flux,
+                                         const ora_geom *G, const ora_params *P, double dt)
+{
+    if (P->speed_limit <= 0.0) return;
+    const double dtdx = dt / G->dx[idir];
+    const double lcfl = P->cfl;
+    const double alpha = 1.0 / 3;
+    const double vol = G->dx[0] * G->dx[1] * G->dx[2];
+    const double area = (idir == 0) ? G->dx[1] * G->dx[2] : (idir == 1) ? G->dx[0] * G->dx[2] : G->dx[0] * G->dx[1];
+    const double lspeed_limit = P->speed_limit / (2 * 3);
+
+    for (int k = lo[2]; k <= hi[2]; ++k)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+    for (int i = lo[0]; i <= hi[0]; ++i) {
+        double uL[NUM_STATE], uR[NUM_STATE], qL[NQ], qR[NQ];
+        limiter_states(u, q, idir, i, j, k, uL, qL, uR, qR);
+        const double volR = vol, volL = vol;
+
+        double fluxL[NUM_STATE], fluxR[NUM_STATE], fluxLF[NUM_STATE];
+        dflux(uL, qL, idir, fluxL);
+        dflux(uR, qR, idir, fluxR);
+        for (int n = 0; n < NUM_STATE; ++n)
+            fluxLF[n] = 0.5 * (fluxL[n] + fluxR[n] + (lcfl / dtdx / alpha) * (uL[n] - uR[n]));
+
+        double flux_coefR = 2.0 * (dt / alpha) * area / volR;
+        double flux_coefL = 2.0 * (dt / alpha) * area / volL;
+
+        double theta = 1.0;
+        for (int n = 0; n < 3; ++n) {
+            int UMOM = UMX + n;
+            double drhouL = flux_coefL * A4(flux,i,j,k,UMOM);
+            double rhouL = fabs(uL[UMOM] - drhouL);
+            double drhoL = flux_coefL * A4(flux,i,j,k,URHO);
+            double rhoL = uL[URHO] - drhoL;
+            double drhouR = flux_coefR * A4(flux,i,j,k,UMOM);
+            double rhouR = fabs(uR[UMOM] + drhouR);
+            double drhoR = flux_coefR * A4(flux,i,j,k,URHO);
+            double rhoR = uR[URHO] + drhoR;
+
+            if (fabs(rhouL) > rhoL * lspeed_limit) {
+                double drhouLF = flux_coefL * fluxLF[UMOM];
+                double rhouLF = fabs(uL[UMOM] - drhouLF);
+                theta = amin(theta, fabs(rhoL * lspeed_limit - rhouLF) / fabs(rhouL - rhouLF));
+            } else if (fabs(rhouR) > rhoR * lspeed_limit) {
+                double drhouLF = flux_coefR * fluxLF[UMOM];
+                double rhouLF = fabs(uR[UMOM] + drhouLF);
+                theta = amin(theta, fabs(rhoR * lspeed_limit - rhouLF) / fabs(rhouR - rhouLF));
+            }
+        }
+        theta = amin(1.0, amax(theta, 0.0));
+
+        for (int n = 0; n < NUM_STATE; ++n)
+            A4(flux,i,j,k,n) = (1.0 - theta) * fluxLF[n] + theta * A4(flux,i,j,k,n);
+        A4(flux,i,j,k,UTEMP) = 0.0;
     }
 }
 

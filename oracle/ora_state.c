@@ -44,7 +44,28 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
         }
     }
 
-    /* enforce_speed_limit: speed_limit = 0 by default => no-op (Castro.cpp:3050) */
+    /* enforce_speed_limit (Castro.cpp:3049-3092) */
+    if (P->speed_limit > 0.0) {
+        for (int k = lo[2]; k <= hi[2]; ++k)
+        for (int j = lo[1]; j <= hi[1]; ++j)
+        for (int i = lo[0]; i <= hi[0]; ++i) {
+            double rho = A4(u,i,j,k,URHO);
+            double rhoInv = 1.0 / rho;
+            double vx = A4(u,i,j,k,UMX) * rhoInv;
+            double vy = A4(u,i,j,k,UMY) * rhoInv;
+            double vz = A4(u,i,j,k,UMZ) * rhoInv;
+            double v = sqrt(vx * vx + vy * vy + vz * vz);
+            if (v > P->speed_limit) {
+                double reduce_factor = P->speed_limit / v;
+                A4(u,i,j,k,UMX) *= reduce_factor;
+                A4(u,i,j,k,UMY) *= reduce_factor;
+                A4(u,i,j,k,UMZ) *= reduce_factor;
+                A4(u,i,j,k,UEDEN) -= 0.5 * rhoInv * (rho * vx * rho * vx - A4(u,i,j,k,UMX) * A4(u,i,j,k,UMX) +
+                                                     rho * vy * rho * vy - A4(u,i,j,k,UMY) * A4(u,i,j,k,UMY) +
+                                                     rho * vz * rho * vz - A4(u,i,j,k,UMZ) * A4(u,i,j,k,UMZ));
+            }
+        }
+    }
 
     /* normalize_species */
     for (int k = lo[2]; k <= hi[2]; ++k)

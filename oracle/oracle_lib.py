@@ -26,7 +26,8 @@ class Params(C.Structure):
         [(n, C.c_double) for n in (
             "difmag", "small_dens", "small_temp", "small_pres", "small_ener", "cg_tol",
             "dual_energy_eta1", "dual_energy_eta2", "cfl", "init_shrink", "change_max",
-            "eos_gamma", "small_x", "T_guess", "abar", "pslope_cutoff_density")]
+            "eos_gamma", "small_x", "T_guess", "abar", "pslope_cutoff_density")] + \
+        [("limit_fluxes_on_small_dens", C.c_int), ("limit_fluxes_on_large_vel", C.c_int), ("speed_limit", C.c_double)]
 
 
 class Rotation(C.Structure):
