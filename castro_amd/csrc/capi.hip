@@ -266,7 +266,7 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     if (params->ppm_type != 0 && params->ppm_type != 1) return CASTRO_AMD_ERR_ARG;
     if (params->riemann_solver < 0 || params->riemann_solver > 2) return CASTRO_AMD_ERR_ARG;
     if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
-    if (params->ppm_temp_fix != 0) return CASTRO_AMD_ERR_UNSUPPORTED;
+    if (params->ppm_temp_fix < 0 || params->ppm_temp_fix > 2) return CASTRO_AMD_ERR_ARG;    // 1 is a no-op in the CTU path
 
     Tile t;
     int glo[3], ghi[3];

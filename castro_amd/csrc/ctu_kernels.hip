@@ -1094,7 +1094,10 @@ __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsi
 // first Riemann solves: F^x, F^y, F^z on grow(nodal(bx,D), 1 in both transverse directions)
 // (Castro_ctu_hydro.cpp:719, :796, :875)
 // ---------------------------------------------------------------------------------------
-template <int D>
+// TFIX: castro.ppm_temp_fix = 2 -- the EOS fix of riemann_state on the two input states (the reference changes them
+// in place; here the stored states stay as traced and every later reader applies the fix where the reference's
+// order of operations has it: see trans1_body / final_body)
+template <int D, bool TFIX = false>
 __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
                                                   DevGeom g, DevParams P)
 {
@@ -1107,6 +1110,10 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
     double qm[2][NEDGE], qp[2][NEDGE];
     load_edge_2(S.QM[D], t.NC, c, qm);
     load_edge_2(S.QP[D], t.NC, c, qp);
+    if (TFIX) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) { temp_fix_edge(qm[w], P); temp_fix_edge(qp[w], P); }
+    }
     const D2 cl = ldg2(Q + PC * t.NC, c - sd);
     const D2 cr = ldg2(Q + PC * t.NC, c);
 
@@ -1398,7 +1405,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     // minus states live in zones c - sn; their T-faces are (c - sn) and (c - sn + st)
     load_f1_2(S.F1[T], t.NC, c - sn + st, fr);
     load_f1_2(S.F1[T], t.NC, c - sn, fl);
-    if (RE) {                                      // transverse_reset_rhoe = 1: the (rho e) flux differences as well
+    if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
         const D2 er = ldg2(S.F1E[T], c - sn + st), el = ldg2(S.F1E[T], c - sn);
         trans_single<T>(qm[0], fr[0], fl[0], P.gamma, cdtdx, P, qmo[0], er.a, el.a);
         trans_single<T>(qm[1], fr[1], fl[1], P.gamma, cdtdx, P, qmo[1], er.b, el.b);
@@ -1410,7 +1417,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     // plus states live in zones c
     load_f1_2(S.F1[T], t.NC, c + st, fr);
     load_f1_2(S.F1[T], t.NC, c, fl);
-    if (RE) {
+    if (RE && P.reset_rhoe == 1) {
         const D2 er = ldg2(S.F1E[T], c + st), el = ldg2(S.F1E[T], c);
         trans_single<T>(qp[0], fr[0], fl[0], P.gamma, cdtdx, P, qpo[0], er.a, el.a);
         trans_single<T>(qp[1], fr[1], fl[1], P.gamma, cdtdx, P, qpo[1], er.b, el.b);
@@ -1419,6 +1426,10 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
         for (int w = 0; w < 2; ++w) trans_single<T>(qp[w], fr[w], fl[w], P.gamma, cdtdx, P, qpo[w]);
     }
 
+    if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) { temp_fix_edge(qmo[w], P); temp_fix_edge(qpo[w], P); }
+    }
     IFlux f[2];
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
@@ -1466,6 +1477,23 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
     bnd_fac[0] = wall_fac<N>(g, ijk[N]);
     bnd_fac[1] = wall_fac<N>(g, ijk[N] + (N == 0 ? 1 : 0));
 
+    if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) {
+        // The reference's first solves change their input states in place, in the order x, y, z, each followed by the
+        // transverse corrections that use its flux (Castro_ctu_hydro.cpp:719-945): the N states corrected with the T
+        // flux have been through their own first solve by then iff N comes before T.
+        double qmf[2][NEDGE], qpf[2][NEDGE];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+#pragma unroll
+            for (int n = 0; n < NEDGE; ++n) { qmf[w][n] = qm[w][n]; qpf[w][n] = qp[w][n]; }
+            temp_fix_edge(qmf[w], P); temp_fix_edge(qpf[w], P);
+        }
+        if (any1) trans1_pair<N, T1, RE>(t, S, c, sn, dstr(s, T1), (N < T1) ? qmf : qm, (N < T1) ? qpf : qp, cl, cr, bnd_fac,
+                                         cdtdx_t1, in_t1[0], in_t1[1], P);
+        if (any2) trans1_pair<N, T2, RE>(t, S, c, sn, dstr(s, T2), (N < T2) ? qmf : qm, (N < T2) ? qpf : qp, cl, cr, bnd_fac,
+                                         cdtdx_t2, in_t2[0], in_t2[1], P);
+        return;
+    }
     if (any1) trans1_pair<N, T1, RE>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, in_t1[0], in_t1[1], P);
     if (any2) trans1_pair<N, T2, RE>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
 }
@@ -1508,11 +1536,12 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 
     // minus states (zones c - sn)
     load_edge_2(S.QM[N], NC, c, q);
+    if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }   // changed by its first solve
     load_f1_2(F12, NC, c - sn + s1, f1r);
     load_f1_2(F12, NC, c - sn, f1l);
     load_f1_2(F21, NC, c - sn + s2, f2r);
     load_f1_2(F21, NC, c - sn, f2l);
-    if (RE) {                                      // transverse_reset_rhoe = 1: the (rho e) flux differences as well
+    if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
         const double* E12 = S.F2E[f2_slot(T1, T2)];
         const double* E21 = S.F2E[f2_slot(T2, T1)];
         const D2 e1r = ldg2(E12, c - sn + s1), e1l = ldg2(E12, c - sn), e2r = ldg2(E21, c - sn + s2), e2l = ldg2(E21, c - sn);
@@ -1525,11 +1554,12 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 
     // plus states (zones c)
     load_edge_2(S.QP[N], NC, c, q);
+    if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }
     load_f1_2(F12, NC, c + s1, f1r);
     load_f1_2(F12, NC, c, f1l);
     load_f1_2(F21, NC, c + s2, f2r);
     load_f1_2(F21, NC, c, f2l);
-    if (RE) {
+    if (RE && P.reset_rhoe == 1) {
         const double* E12 = S.F2E[f2_slot(T1, T2)];
         const double* E21 = S.F2E[f2_slot(T2, T1)];
         const D2 e1r = ldg2(E12, c + s1), e1l = ldg2(E12, c), e2r = ldg2(E21, c + s2), e2l = ldg2(E21, c);
@@ -1544,6 +1574,10 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     const D2 cr = ldg2(Q + PC * NC, c);
     const unsigned usn = 8u * (N == 0 ? 1u : N == 1 ? (unsigned)U.sy : (unsigned)U.sz);
 
+    if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) { temp_fix_edge(ql[w], P); temp_fix_edge(qr[w], P); }
+    }
     double R[2][NFIN];
     IFlux f[2];
 #pragma unroll
@@ -1746,7 +1780,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // zones, PPM tracing on grow(bx, -3) -- so that a caller can run it while the halo exchange is in flight;
     // B = the rest (ctoprim on the ghost shell, tracing on the remaining zones, everything downstream).
     // Only the no-source PPM path is split; otherwise A is empty and B is the whole update.
-    const bool splittable = !Src.p && P.ppm_type == 1;
+    // ppm_temp_fix = 2: the first solves go through k_riemann1<D, TFIX>: no fused x solve, no staging
+    const bool tfix = P.ppm_temp_fix == 2 && P.riemann_solver != 2;
+    const bool splittable = !Src.p && P.ppm_type == 1 && !tfix;
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
     const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
     SkipBox valid_box, inner_box;
@@ -1810,6 +1846,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
+        else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none); }
         else if (second_half) {
             if (inner_ok) {
                 const int ns = shell_boxes(olo, ohi, inner_box.lo, inner_box.hi, slo, shi);
@@ -1826,13 +1863,19 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         } else {
             trace_with_xriemann(olo, ohi);
         }
-        x_done = P.ppm_type != 0;
+        x_done = P.ppm_type != 0 && !tfix;
     }
     (void)staged;
 
-    if (!x_done) KL2("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
-    KL2("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
-    KL2("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
+    if (tfix) {
+        KL2("k_riemann1", (k_riemann1<0, true>), flo[0], fhi[0], S.Q, S, g, P);
+        KL2("k_riemann1", (k_riemann1<1, true>), flo[1], fhi[1], S.Q, S, g, P);
+        KL2("k_riemann1", (k_riemann1<2, true>), flo[2], fhi[2], S.Q, S, g, P);
+    } else {
+        if (!x_done) KL2("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
+        KL2("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
+        KL2("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
+    }
 
     // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690); hdtdx = 0.5*dt/dx (:684-686)
     const double cdtdx = dt / g.dx[0] / 3.0, cdtdy = dt / g.dx[1] / 3.0, cdtdz = dt / g.dx[2] / 3.0;
@@ -1853,7 +1896,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     } while (0)
     // the flux limiters (non-default too) share one extra pair of instantiations: both flags are tested inside
     const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
-    if (P.reset_rhoe == 1) { if (lim) TRANSVERSE_STAGES(true, true); else TRANSVERSE_STAGES(true, false); }
+    if (P.reset_rhoe == 1 || tfix) { if (lim) TRANSVERSE_STAGES(true, true); else TRANSVERSE_STAGES(true, false); }
     else { if (lim) TRANSVERSE_STAGES(false, true); else TRANSVERSE_STAGES(false, false); }
 #undef TRANSVERSE_STAGES
 

@@ -1027,6 +1027,19 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
 // state q[NEDGE] = (rho,u,v,w,p,rhoe,X); flux differences are passed pre-loaded:
 //   fr/fl = flux record (FRHO..FPG) at the high/low transverse face
 // ---------------------------------------------------------------------------------------
+// castro.ppm_temp_fix = 2 (riemann_solvers.H:1281-1330): before a CGF / CG Riemann solve the edge states get (rho e)
+// and p recomputed by the EOS from (rho, e, X) -- in place in the reference, so the states of the first solves keep the
+// change for whatever reads them AFTERWARDS; here the stored states are never changed and each reader applies the fix
+// when the reference's order of operations has already passed that state's first solve.  (ppm_temp_fix = 1 only exists in the method-of-lines integrator.)
+__device__ __forceinline__ void temp_fix_edge(double q[NEDGE], const DevParams& P)
+{
+    const double rho = q[PRHO];
+    const double e = q[PRE] / q[PRHO];
+    const double p = (P.gamma - 1.0) * rho * e;          // eos(eos_input_re)
+    q[PRE] = e * rho;
+    q[PP] = p;
+}
+
 // Castro::reset_edge_state_thermo (Source/hydro/edge_util.cpp:6-76) with transverse_use_eos = 1:
 // make (rho e, p) of a corrected edge state EOS-consistent; with transverse_reset_rhoe = 1: a still negative
 // (rho e) is replaced by the EOS value at small_temp.  (With both flags 0 -- the default -- the reference's 18

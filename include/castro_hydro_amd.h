@@ -81,7 +81,7 @@ typedef struct castro_amd_params {
     int transverse_use_eos;
     int transverse_reset_density;
     int transverse_reset_rhoe;
-    int ppm_temp_fix;
+    int ppm_temp_fix;             /* 0 (default); 2 = EOS fix of the Riemann input states; 1 is a no-op in the CTU path */
     int plm_iorder;               /* 2 (default) or 1 */
     int plm_limiter;              /* 2 = 4th-order MC (default), 1 = 2nd-order MC */
     int use_pslope;               /* 1 (default): well-balanced pressure slope in PLM */
@@ -142,7 +142,7 @@ int castro_amd_ctx_status(castro_amd_ctx *ctx, void *stream);
  *   mass_flux_out[d] : out, = scaled density flux, ncomp 1            (Castro::mass_fluxes[d]); p NULL to skip
  *   qe_out[d]   : out (optional, p NULL to skip), Godunov state u,v,w,p on the same faces, ncomp 4 (qe[d])
  * Returns CASTRO_AMD_ERR_ARG for boxes / component counts that do not fit, CASTRO_AMD_ERR_UNSUPPORTED for
- * ppm_temp_fix > 0, non-Cartesian coordinates, and for a tile or FAB whose component plane reaches 4 GiB (the
+ * non-Cartesian coordinates and for a tile or FAB whose component plane reaches 4 GiB (the
  * kernels address a plane with 32-bit byte offsets: tile boxes beyond ~800^3 zones).
  */
 int castro_amd_ctu_hydro_fab(castro_amd_ctx *ctx,

@@ -272,6 +272,24 @@ def test_speed_limit_in_clean_state(hip, oracle):
     assert before.max() > 1.0 and speed.max() <= 0.8 * (1 + 1e-14) and (speed < before - 1e-3).any()
 
 
+@pytest.mark.parametrize("pkw", [dict(ppm_temp_fix=2), dict(ppm_temp_fix=2, riemann_solver=1), dict(ppm_temp_fix=2, ppm_type=0),
+                                 dict(ppm_temp_fix=2, riemann_solver=2), dict(ppm_temp_fix=1)])
+def test_ppm_temp_fix(hip, oracle, pkw):
+    """castro.ppm_temp_fix = 2 (riemann_solvers.H:1281-1330): (rho e) and p of the edge states recomputed by the EOS
+    before every CGF / CG Riemann solve, in place for the first solves so that the transverse corrections see the
+    changed states.  It is not applied by the HLLC solver, and ppm_temp_fix = 1 does nothing in the CTU path (it only
+    exists in Castro_mol_hydro.cpp): those two cases must equal ppm_temp_fix = 0."""
+    rng = np.random.default_rng(51)
+    bxlo, bxhi = (0, 0, 0), (13, 11, 9)
+    sb_lo, sb_hi = (-4, -4, -4), (17, 15, 13)
+    U = physical_state(rng, sb_lo, sb_hi, vel=1.5)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), pkw=pkw)
+    _assert_exact(out, "ppm_temp_fix %s" % (pkw,))
+    ref = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, dx=(0.02, 0.02, 0.02), pkw=dict(pkw, ppm_temp_fix=0))
+    same = np.array_equal(out["S_new"][1], ref["S_new"][1])
+    assert same == (pkw.get("riemann_solver") == 2 or pkw["ppm_temp_fix"] == 1)
+
+
 @pytest.mark.parametrize("sparse", [False, True])
 def test_ctu_hydro_with_old_sources(hip, oracle, sparse):
     """Non-zero old_source (gravity-like momentum/energy sources): src_to_prim + source tracing in
@@ -385,11 +403,15 @@ def test_unsupported_options_fail_loudly(hip):
     G = castro_amd.make_geom(n)
     S = hip.alloc(8, (-4, -4, -4), (11, 11, 11), fill=1.0)
     N = hip.alloc(8, (0, 0, 0), (7, 7, 7), fill=1.0)
-    for kw in (dict(ppm_temp_fix=2),):
-        P = castro_amd.default_params(**kw)
-        with pytest.raises(RuntimeError, match="unsupported"):
-            hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
-                                           ((0, 0, 0), (7, 7, 7)), G, P, 0.0, 1e-3)
+    P = castro_amd.default_params(ppm_temp_fix=3)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
+                                       ((0, 0, 0), (7, 7, 7)), G, P, 0.0, 1e-3)
+    Gs = castro_amd.make_geom(n)
+    Gs.coord = 2
+    with pytest.raises(RuntimeError, match="unsupported"):
+        hip.construct_ctu_hydro_source(((0, 0, 0), (7, 7, 7)), S, ((-4, -4, -4), (11, 11, 11)), N,
+                                       ((0, 0, 0), (7, 7, 7)), Gs, castro_amd.default_params(), 0.0, 1e-3)
     # a box whose component planes exceed the 32-bit byte offsets of the kernels (here 1100^3 zones, described
     # by descriptors over a small buffer: validation precedes every memory access) -> unsupported, tile it
     import ctypes as C
