@@ -85,7 +85,7 @@ class _Level:
         self.red = b0.red
         for b in self.boxes:
             b.red = self.red      # one [min dt, min rho] pair for the level: every box reduces into it
-        for k in ("use_retry", "retry_subcycle_factor", "max_subcycles", "dt_cutoff"):
+        for k in ("use_retry", "retry_subcycle_factor", "max_subcycles", "dt_cutoff", "max_dt", "fixed_dt"):
             setattr(self, k, getattr(b0, k))
         self.fuse_clean = b0.fuse_clean
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
@@ -208,7 +208,7 @@ class _Level:
         est, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        new_dt = min(1.e200, est * self.params.cfl)
+        new_dt = min(self.max_dt, est * self.params.cfl)
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None
         return True, "", new_dt
@@ -217,7 +217,7 @@ class _Level:
         self.red.fill_(1.e200)
         for b in self.boxes:
             self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
-        return min(1.e200, self.red.tolist()[0] * self.params.cfl)
+        return min(self.max_dt, self.red.tolist()[0] * self.params.cfl)
 
     def clean_new(self):
         for b in self.boxes:

@@ -114,7 +114,7 @@ class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0):
+                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0, max_dt=1.e200):
         self.n_cell = tuple(int(x) for x in n_cell)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
@@ -186,6 +186,7 @@ class Castro:
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
         # castro.fixed_dt / castro.initial_dt (_cpp_parameters; Castro.cpp:1490-1513, 1655)
         self.fixed_dt, self.initial_dt = float(fixed_dt), float(initial_dt)
+        self.max_dt = float(max_dt)                             # castro.max_dt (Castro.cpp:1515-1530)
         # castro.do_grav with gravity.gravity_type = "ConstantGrav": g along the last dimension (Gravity.cpp:860-866)
         self.do_grav, self.grav, self.grav_source_type = bool(do_grav), (0.0, 0.0, float(const_grav)), int(grav_source_type)
         # castro.do_rotation: `rotation` = _lib.make_rotation(rotational_period, rot_axis, ...)
@@ -354,7 +355,7 @@ class Castro:
         if self.fixed_dt > 0.0:                                 # Castro.cpp:1511-1513
             return self.fixed_dt
         est, _ = self._reduce()
-        return min(1.e200, est * self.params.cfl)
+        return min(self.max_dt, est * self.params.cfl)
 
     def computeInitialDt(self, stop_time=-1.0):
         # Castro::initialTimeStep (Castro.cpp:1490-1504)
@@ -459,7 +460,7 @@ class Castro:
         if rho_min < self.params.small_dens:
             # retry_small_density_cutoff keeps its default (-1e200): every such step is rejected
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(1.e200, est * self.params.cfl)
+        new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None
         return True, "", new_dt

@@ -352,3 +352,17 @@ def test_fixed_dt_step_counts_of_the_acoustic_pulse_scripts(oracle, fixed_dt, st
     assert c.nstep == steps and c.time == 0.24
     assert dts[0] == 0.01 * fixed_dt and all(d == fixed_dt for d in dts[1:-1]) and 0.0 < dts[-1] <= fixed_dt
     assert c.nretries == 0
+
+
+def test_max_dt_caps_the_step(oracle):
+    """castro.max_dt (Castro.cpp:1515-1530): the hydro estimate is capped, also inside the validity check."""
+    import castro_amd
+    c = castro_amd.Castro((8, 8, 8), lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), params=oracle.default_params(init_shrink=1.0),
+                          hydro=OracleBackend(), max_dt=1.0e-3)
+    c.set_state(_acoustic_pulse(8))
+    dts = [c.step() for _ in range(3)]
+    assert dts == [1.0e-3] * 3 and c.nretries == 0
+    free = castro_amd.Castro((8, 8, 8), lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), params=oracle.default_params(init_shrink=1.0),
+                             hydro=OracleBackend())
+    free.set_state(_acoustic_pulse(8))
+    assert free.step() > 1.0e-2
