@@ -282,6 +282,47 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
     }
 }
 
+// the same for two x-adjacent nodes per thread (no shock flag): per velocity plane and row one 16-byte load of the
+// zones (i, i+1) and one 8-byte load of zone i-1 instead of four 8-byte loads
+__global__ void __launch_bounds__(256) k_divu_pair(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
+                                                   double dxinv, double dyinv, double dzinv)
+{
+    int i, j, k;
+    if (!box_thread(b, i, j, k)) return;
+    const bool v1 = i + 1 <= b.hi0;
+    const unsigned c = goff(t, i, j, k);
+    const Str s = gstr(t);
+    const unsigned sx = s.x, sy = s.y, sz = s.z;
+    const double* QU_ = Q + PU * t.NC;
+    const double* QV_ = Q + PV * t.NC;
+    const double* QW_ = Q + PW * t.NC;
+    // a[r] = zone i-1, m[r] = zones (i, i+1) of row r: 0 (j,k), 1 (j,k-1), 2 (j-1,k), 3 (j-1,k-1)
+    const unsigned ro[4] = { 0u, sz, sy, sy + sz };
+    double ua[4], va[4], wa[4];
+    D2 um[4], vm[4], wm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        um[r] = ldg2(QU_, c - ro[r]); ua[r] = ldg(QU_, c - ro[r] - sx);
+        vm[r] = ldg2(QV_, c - ro[r]); va[r] = ldg(QV_, c - ro[r] - sx);
+        wm[r] = ldg2(QW_, c - ro[r]); wa[r] = ldg(QW_, c - ro[r] - sx);
+    }
+    double d[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        // hi = zone of the node's own column, lo = the column to its left
+#define HI(x, r) (w ? x##m[r].b : x##m[r].a)
+#define LO(x, r) (w ? x##m[r].a : x##a[r])
+        double ux = 0.25 * (HI(u, 0) - LO(u, 0) + HI(u, 1) - LO(u, 1) + HI(u, 2) - LO(u, 2) + HI(u, 3) - LO(u, 3)) * dxinv;
+        double vy = 0.25 * (HI(v, 0) - HI(v, 2) + HI(v, 1) - HI(v, 3) + LO(v, 0) - LO(v, 2) + LO(v, 1) - LO(v, 3)) * dyinv;
+        double wz = 0.25 * (HI(w, 0) - HI(w, 1) + HI(w, 2) - HI(w, 3) + LO(w, 0) - LO(w, 1) + LO(w, 2) - LO(w, 3)) * dzinv;
+#undef HI
+#undef LO
+        d[w] = ux + vy + wz;
+    }
+    if (v1) stg2(DIV, c, d[0], d[1]);
+    else stg(DIV, c, d[0]);
+}
+
 // ---------------------------------------------------------------------------------------
 // flattening + PPM + tracing.  Castro::uflatten (flatten.cpp:12-166) and Castro::trace_ppm
 // (trace_ppm.cpp:15-594, no sources) for the three directions of one zone of grow(bx,1).
@@ -1836,7 +1877,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             nhi[d][e] = (e == d) ? t.hi[e] + 1 : t.hi[e];
         }
 
-    KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, (P.hybrid_riemann == 1) ? S.SHK : (double*)nullptr, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+    if (P.hybrid_riemann == 1) { KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, S.SHK, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]); }
+    else { KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]); }
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
