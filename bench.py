@@ -102,15 +102,37 @@ def pmc_traffic_per_step(prof, steps):
     return tot
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup CPU quota (the GPU boxes expose 256 logical CPUs
+    behind a 16-CPU quota; oversubscribing them makes the OpenMP oracle several times slower)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(ncell, steps):
     """The CPU oracle (a port organised like the reference's CPU path: ~75 sweeps per tile,
     tiles 1024x16x16, OpenMP over tiles) timed on this host on a bounded Sedov sample."""
     from oracle import oracle_lib as O
     n = (ncell, ncell, ncell)
     ntiles = max(1, (ncell // 16)) ** 2
-    # one thread per tile at most; capped at 64 so the thread-private scratch (~220 MB per thread at
-    # 192^3) stays far below host memory
-    threads = max(1, min(os.cpu_count() or 1, ntiles, 64))
+    # one thread per usable CPU, one tile per thread at most (256 tiles at 256^3)
+    threads = max(1, min(usable_cpus(), ntiles))
     lev = O.Level(n, O.make_geom(n), O.default_params(), nthreads=threads)
     lev.init_sedov()
     lev.step(0.01)                    # untimed first step (page faults, scratch allocation)
@@ -133,8 +155,8 @@ def main():
     ap.add_argument("--ncell", type=int, default=256, help="global zones per side (strong scaling: fixed as N grows)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: ncell^3 zones PER GPU (config 3: 512^3 on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-ncell", type=int, default=192)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-ncell", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--periodic", action="store_true", help="periodic instead of outflow boundaries (exercises the halo "
                     "pack/exchange/unpack path even on one GPU)")

@@ -194,6 +194,7 @@ int ora_ctu_hydro_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], c
 
 /* ---------------- state maintenance (Source/driver) ---------------- */
 void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_params *P);
+void ora_set_state_threads(int n);
 double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P);
 double ora_min_density(const int lo[3], const int hi[3], ora_a4 u);
 void ora_bc_fill(ora_a4 u, const ora_geom *G);   /* physical-BC ghost fill, SURVEY D.2 */

@@ -94,6 +94,7 @@ void ora_level_post_init(ora_level *L)
 /* Castro::estTimeStep, Castro.cpp:1507-1626 (hydro limiter only; max_dt = 1e200) */
 double ora_level_est_time_step(ora_level *L)
 {
+    ora_set_state_threads(L->nthreads);
     ora_a4 S = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
     double estdt = 1.e200;
     double estdt_hydro = ora_estdt_cfl(L->lo, L->hi, S, &L->G, &L->P);
@@ -156,6 +157,7 @@ static void level_zero_fluxes(ora_level *L)
 static int level_do_advance(ora_level *L, double time, double dt)
 {
     const ora_params *P = &L->P;
+    ora_set_state_threads(L->nthreads);
     ora_a4 S_old = ora_make_a4(L->S_old, L->lo, L->hi, NUM_STATE);
     ora_a4 S_new = ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE);
     ora_a4 fl[3], mf[3], qe[3];

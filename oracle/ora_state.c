@@ -13,12 +13,20 @@
  */
 #include "ora_internal.h"
 
+/* The zone-local sweeps of this file run under OpenMP like the reference's MFIter loops (`#pragma omp parallel`,
+ * Castro.cpp:2902-3092, 3575-3775, timestep.cpp:31-140).  Default: one thread (unit tests); the level driver
+ * sets its own thread count. */
+static int ora_state_threads = 1;
+void ora_set_state_threads(int n) { ora_state_threads = n > 0 ? n : 1; }
+#define ORA_PFOR _Pragma("omp parallel for num_threads(ora_state_threads) schedule(static)")
+
 /* ------------------------------------------------------------------ */
 void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_params *P)
 {
     const double small_dens = P->small_dens;
 
     /* enforce_min_density */
+    ORA_PFOR
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -46,6 +54,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
 
     /* enforce_speed_limit (Castro.cpp:3049-3092) */
     if (P->speed_limit > 0.0) {
+        ORA_PFOR
         for (int k = lo[2]; k <= hi[2]; ++k)
         for (int j = lo[1]; j <= hi[1]; ++j)
         for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -68,6 +77,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
     }
 
     /* normalize_species */
+    ORA_PFOR
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -81,6 +91,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
     }
 
     /* computeTemp: reset_internal_energy ... */
+    ORA_PFOR
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -108,6 +119,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
     }
 
     /* ... then T from EOS(re) */
+    ORA_PFOR
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -125,6 +137,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
 double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P)
 {
     double estdt = 1.e200;
+    _Pragma("omp parallel for num_threads(ora_state_threads) schedule(static) reduction(min:estdt)")
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -155,6 +168,7 @@ double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom 
 double ora_min_density(const int lo[3], const int hi[3], ora_a4 u)
 {
     double m = 1.e300;
+    _Pragma("omp parallel for num_threads(ora_state_threads) schedule(static) reduction(min:m)")
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) m = amin(m, A4(u,i,j,k,URHO));
@@ -186,6 +200,7 @@ void ora_bc_fill(ora_a4 u, const ora_geom *G)
         for (int n = 0; n < u.nc; ++n) {
             const int klo = bc_kind(G->lo_bc[dir], n, dir);
             const int khi = bc_kind(G->hi_bc[dir], n, dir);
+            ORA_PFOR
             for (int k = u.lo[2]; k <= u.hi[2]; ++k)
             for (int j = u.lo[1]; j <= u.hi[1]; ++j)
             for (int i = u.lo[0]; i <= u.hi[0]; ++i) {
@@ -208,6 +223,7 @@ void ora_bc_fill(ora_a4 u, const ora_geom *G)
 void ora_fill_interior_copy(ora_a4 dst, ora_a4 src, const int lo[3], const int hi[3])
 {
     for (int n = 0; n < src.nc; ++n)
+    ORA_PFOR
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) A4(dst,i,j,k,n) = A4(src,i,j,k,n);
