@@ -72,7 +72,7 @@ def pmc_traffic(kernel):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup"}       # hipEvent label -> kernel symbol
+        alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup", "k_divu": "k_divu_pair"}       # hipEvent label -> kernel symbol
         k = d["kernels"].get(kernel) or d["kernels"][alias[kernel]]
         return k["bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     except (KeyError, ValueError):
@@ -87,7 +87,7 @@ def pmc_traffic_per_step(prof, steps):
     if not files:
         return None
     d = json.load(open(files[-1]))["kernels"]
-    alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup"}
+    alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup", "k_divu": "k_divu_pair"}
     tot = 0.0
     for name, (ms, launches) in prof.items():
         k = d.get(name) or d.get(alias.get(name, ""))
