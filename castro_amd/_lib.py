@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
-    "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab", "castro_amd_fillpatch_shell_fab",
+    "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab", "castro_amd_fillpatch_shell_fab", "castro_amd_apply_source_fab",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
@@ -131,6 +131,7 @@ def load():
                                                      C.c_double, C.c_void_p]
     L.castro_amd_saxpy_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]
     L.castro_amd_error_tag_fab.argtypes = [C.c_void_p, PF, C.c_int, PF, I3, I3, C.c_int, C.c_double, C.c_void_p]
+    L.castro_amd_apply_source_fab.argtypes = [C.c_void_p, PF, PF, C.c_double, PF, C.c_int, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]
     L.castro_amd_cc_interp_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.c_void_p]
     L.castro_amd_fillpatch_shell_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.POINTER(Params), C.c_int, C.c_void_p]
     L.castro_amd_lincomb_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]

@@ -471,16 +471,22 @@ class Castro:
         h = self.hydro
         lo, hi = self.lo, self.hi
         self.expand_state(S)
-        # MultiFab::Copy(S_new, Sborder) (:94)
-        h.copy(self.S_new_b, self.gbox, S, self.gbox, lo, hi)
-        # do_old_sources (:127-131): construct at t^n, apply with the full dt, clean_state; FillPatch the source
+        # MultiFab::Copy(S_new, Sborder) (:94); do_old_sources (:127-131): construct at t^n, apply with the full dt,
+        # clean_state -- the copy, the update and the cleaning in one pass where the backend has it
+        fused = hasattr(h, "apply_source")
+        if not fused:
+            h.copy(self.S_new_b, self.gbox, S, self.gbox, lo, hi)
         self.old_source.zero_()
         if self.do_grav:
             h.old_gravity_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.grav, self.grav_source_type, dt)
         if self.rotation is not None:
             h.old_rotation_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.rotation, self.geom, dt)
-        h.saxpy(self.S_new_b, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi)
-        h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+        if fused:
+            h.apply_source(self.S_new_b, self.gbox, S, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi, self.params, ntimes=1)
+        else:
+            h.saxpy(self.S_new_b, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi)
+            h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+        # FillPatch of the source for the tracing
         self.expand_state(self.old_source, self.sbox, self.src_neighbors)
         # hydro with the old source traced in the predictor; S_new += (it already holds the old source)
         self.construct_ctu_hydro_source(time, dt, src=self.old_source)
@@ -499,8 +505,12 @@ class Castro:
         if self.rotation is not None:
             h.new_rotation_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
                                   self.flux_boxes, lo, hi, self.rotation, self.geom, dt)
-        h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
-        h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+        if fused:
+            h.apply_source(self.S_new_b, self.gbox, self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi,
+                           self.params, ntimes=1)
+        else:
+            h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
+            h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
         # timestep validity check (:386-392)
         new_dt = self.estTimeStep()
         if self.params.change_max * new_dt < dt:

@@ -284,6 +284,38 @@ __global__ void __launch_bounds__(256) k_saxpy(DFab D, DFab S, Box3 b, double a,
     for (int n = 0; n < ncomp; ++n) D.p[cd + D.sn * n] += a * S.p[cs + S.sn * n];
 }
 
+// dst = base + a * src on the first nsrc components (the others copied), then clean_state x ntimes, in one pass:
+// MultiFab::Copy(S_new, Sborder) + apply_source_to_state + clean_state of do_advance_ctu (Castro_advance_ctu.cpp:94,
+// 127-131, 262-268).  base may be dst.
+__global__ void __launch_bounds__(256) k_apply_source(DFab D, DFab B, DFab S, Box3 b, double a, int nsrc, DevParams P, int ntimes)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const long cd = fidx(D, i, j, k, 0), cb = fidx(B, i, j, k, 0), cs = fidx(S, i, j, k, 0);
+    double u[NUM_STATE];
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) {
+        u[n] = B.p[cb + B.sn * n];
+        if (n < nsrc) u[n] += a * S.p[cs + S.sn * n];
+    }
+    if (ntimes > 0) clean_zone(P, ntimes, u[URHO], u[UMX], u[UMY], u[UMZ], u[UEDEN], u[UEINT], u[UTEMP], u[UFS]);
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) D.p[cd + D.sn * n] = u[n];
+}
+
+int launch_apply_source(const DFab& D, const DFab& B, const DFab& S, const int lo[3], const int hi[3], double a, int nsrc,
+                        const DevParams& P, int ntimes, hipStream_t stream, Profiler* prof)
+{
+    Box3 b;
+    long n = 1;
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
+    if (n <= 0) return 0;
+    prof_begin(prof, "k_apply_source", stream);
+    hipLaunchKernelGGL(k_apply_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, D, B, S, b, a, nsrc, P, ntimes);
+    prof_end(prof, stream);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // rotation source terms, state_in_rotating_frame = 1 (Source/rotation/Rotation.H:10-95,
 // Source/rotation/rotation_sources.cpp:9-500; math.H:9-17; position(): Castro_util.H:87-140)

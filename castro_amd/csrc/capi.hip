@@ -452,6 +452,18 @@ int castro_amd_saxpy_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a,
     return launch_saxpy(to_dfab(dst), to_dfab(src), lo, hi, a, ncomp, (hipStream_t)stream, &c->prof);
 }
 
+int castro_amd_apply_source_fab(castro_amd_ctx* c, const castro_amd_fab* dst, const castro_amd_fab* base, double a,
+                                const castro_amd_fab* src, int nsrc, const int lo[3], const int hi[3],
+                                const castro_amd_params* params, int clean_ntimes, void* stream)
+{
+    if (!c || !dst || !dst->p || !base || !base->p || !src || !src->p || !params || clean_ntimes < 0) return CASTRO_AMD_ERR_ARG;
+    if (dst->ncomp != NUM_STATE || base->ncomp != NUM_STATE || nsrc < 0 || nsrc > NUM_STATE || nsrc > src->ncomp) return CASTRO_AMD_ERR_ARG;
+    if (!fab_contains(dst, lo, hi) || !fab_contains(base, lo, hi) || !fab_contains(src, lo, hi)) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_apply_source(to_dfab(dst), to_dfab(base), to_dfab(src), lo, hi, a, nsrc, to_devparams(params), clean_ntimes,
+                               (hipStream_t)stream, &c->prof);
+}
+
 static bool fab_ok(const castro_amd_fab* f, int ncomp) { return f && f->p && f->ncomp >= ncomp; }
 
 int castro_amd_cc_interp_fab(castro_amd_ctx* c, const castro_amd_fab* crse, const castro_amd_fab* fine,

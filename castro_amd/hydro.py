@@ -140,6 +140,12 @@ class HipHydro:
         L.check(self.lib.castro_amd_saxpy_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(src, *src_box)),
                                               int(ncomp), L.i3(lo), L.i3(hi), _stream_ptr(stream)), "saxpy_fab")
 
+    def apply_source(self, dst, dst_box, base, base_box, a, src, src_box, nsrc, lo, hi, params, ntimes=1, stream=None):
+        """dst = base + a * src[:nsrc] (other components copied) followed by clean_state x ntimes, one pass."""
+        L.check(self.lib.castro_amd_apply_source_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), C.byref(L.fab_of(base, *base_box)),
+                                                     float(a), C.byref(L.fab_of(src, *src_box)), int(nsrc), L.i3(lo), L.i3(hi),
+                                                     C.byref(params), int(ntimes), _stream_ptr(stream)), "apply_source_fab")
+
     # ---- two-level AMR building blocks (include/castro_hydro_amd.h) ------------------------------
     def error_tag(self, field, field_box, comp, tags, tags_box, lo, hi, kind, value, stream=None):
         """kind: 0 value_greater, 1 value_less, 2 gradient, 3 relative_gradient (AMRErrorTag)."""

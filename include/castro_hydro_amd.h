@@ -213,6 +213,12 @@ int castro_amd_new_gravity_source_fab(castro_amd_ctx *ctx, const castro_amd_fab 
                                       const castro_amd_fab *source, const castro_amd_fab mass_fluxes[3],
                                       const int lo[3], const int hi[3], const double grav[3], int grav_source_type,
                                       double dt, const castro_amd_geom *geom, void *stream);
+/* dst = base + a * src[0:nsrc] (other components copied; base may be dst) followed by clean_state x clean_ntimes, one
+ * pass: MultiFab::Copy(S_new, Sborder) + apply_source_to_state + clean_state of do_advance_ctu
+ * (Castro_advance_ctu.cpp:94, 127-131, 262-268).  dst, base: ncomp 8. */
+int castro_amd_apply_source_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, const castro_amd_fab *base, double a,
+                                const castro_amd_fab *src, int nsrc, const int lo[3], const int hi[3],
+                                const castro_amd_params *params, int clean_ntimes, void *stream);
 int castro_amd_saxpy_fab(castro_amd_ctx *ctx, const castro_amd_fab *dst, double a, const castro_amd_fab *src, int ncomp,
                          const int lo[3], const int hi[3], void *stream);
 
