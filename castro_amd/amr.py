@@ -235,7 +235,8 @@ class CastroAmr:
         """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined box;
         patches = [entry, ...]: one entry per refined level, a box (lo, hi) or a list of boxes in the zones of the
         level below it (amr.max_level = len(patches)); or
-        refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name, kind:
+        refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name or a pointwise
+        derived field such as pressure, kind:
         value_greater | value_less | gradient | relative_gradient) for boxes that follow the tags up to
         amr.max_level = max_level: one bounding box per level, or with cluster=True the Berger-Rigoutsos boxes
         (amr.grid_eff, amr.blocking_factor and amr.max_grid_size in zones of the new level)."""
@@ -323,7 +324,16 @@ class CastroAmr:
         for b in lev.boxes:
             t = h.alloc(1, b.lo, b.hi)
             for field, kind, value in self.refine:
-                h.error_tag(b.S_new_b, b.gbox, _FIELDS[field], t, (b.lo, b.hi), b.lo, b.hi, _TAG_KINDS[kind], value)
+                if field in _FIELDS:
+                    h.error_tag(b.S_new_b, b.gbox, _FIELDS[field], t, (b.lo, b.hi), b.lo, b.hi, _TAG_KINDS[kind], value)
+                else:
+                    # a derived field (amr.refine.<name>.field_name = pressure, ...): evaluated with one ghost zone
+                    # for the gradient kinds, like the reference's derive on a grown box
+                    g1 = (tuple(x - 1 for x in b.lo), tuple(x + 1 for x in b.hi))
+                    d = h.alloc(1, *g1)
+                    center = [0.5 * (b.geom.problo[dd] + b.geom.probhi[dd]) for dd in range(3)]
+                    h.derive(field, b.S_new_b, b.gbox, d, g1, 0, g1[0], g1[1], b.geom, b.params, center)
+                    h.error_tag(d, g1, 0, t, (b.lo, b.hi), b.lo, b.hi, _TAG_KINDS[kind], value)
             sl = tuple(slice(b.lo[d] - olo[d], b.hi[d] - olo[d] + 1) for d in (2, 1, 0))
             tags[sl] = (t[0] > 0.5).to(tags.dtype)
             mask[sl] = 1.0

@@ -1356,3 +1356,27 @@ def test_sedov_amr_config_4_against_the_reference_analytic_table():
     assert abs(r["drift"][0]) <= 1e-12 and abs(r["drift"][1]) <= 1e-11
     assert abs(r["r_peak"] - r["r_shock"]) <= 1.5 * r["dx_fine"]
     assert r["l1"] < 0.025 and r["peak"] > 3.8, r          # measured 0.0184, 4.19
+
+
+@pytest.mark.parametrize("case,tol", [("sod", (0.01, 0.01, 0.01)), ("test2", (0.025, 0.03, 0.03)), ("test3", (0.12, 0.5, 0.025))])
+def test_reference_shock_tube_inputs_with_amr_against_exact_tables(case, tol):
+    """The reference's verification runs exactly as Exec/hydro_tests/Sod/inputs-{sod,test2,test3}-x specify them: 32 x 8 x 8
+    base zones, amr.max_level = 2 (regrid_int 2, blocking_factor 8, max_grid_size 64, n_error_buf 2, Berger-Rigoutsos
+    boxes), density / pressure (/ velocity) gradient indicators -- pressure and the velocities are derived fields --
+    outflow in x, slip walls in y and z; compared at stop_time with the 128-point exact solutions of
+    Exec/hydro_tests/Sod/Verification, to the tolerances of the uniform 128-zone runs of tests/test_oracle_known_answers.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sod_reference_inputs", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                                       "sod_reference_inputs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res, a = mod.run(case)
+    assert len(a.levels) == 3 and res["nregrid"] >= 3 and res["time"] == mod.CASES[case][2]
+    assert res["rho"] < tol[0] and res["u"] < tol[1] and res["p"] < tol[2], res
+    if case != "test2":                                   # test2's rarefactions leave through the outflow boundaries
+        assert abs(res["mass_drift"]) < 1e-10
+    # the solution stays one-dimensional on every level
+    for lev in a.levels:
+        for b in lev.boxes:
+            S = b.S_new()
+            assert float((S[0] - S[0][:1, :1, :]).abs().max()) == 0.0
