@@ -1380,3 +1380,21 @@ def test_reference_shock_tube_inputs_with_amr_against_exact_tables(case, tol):
         for b in lev.boxes:
             S = b.S_new()
             assert float((S[0] - S[0][:1, :1, :]).abs().max()) == 0.0
+
+
+def test_reference_sedov_testsuite_input_four_levels_plm():
+    """The reference's regression input Exec/hydro_tests/Sedov/inputs.3d.sph.testsuite as it is: 32^3 base zones,
+    amr.max_level = 3 (effective 256^3), ppm_type = 0 (PLM), regrid_int 2, blocking_factor 8, max_grid_size 32 (about 150
+    boxes on the finest level), density / pressure indicators, run to stop_time = 0.01: composite mass and energy to
+    round-off over ~130 coarse steps and ~40 regrids, shock within one finest zone of the analytic radius, composite
+    density within 4 % of the reference's table (measured 3.35 %; the uniform 256^3 PPM run gives 3.2 %)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("amr_sedov_validation", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                                         "amr_sedov_validation.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(verbose=False, **mod.TESTSUITE)
+    assert len(r["boxes"]) == 4 and r["boxes"][3] > 50 and r["nregrid"] >= 10 and 50 < r["nstep"] < 500
+    assert abs(r["drift"][0]) <= 1e-12 and abs(r["drift"][1]) <= 1e-11
+    assert abs(r["r_peak"] - r["r_shock"]) <= 1.5 * r["dx_fine"]
+    assert r["l1"] < 0.04 and r["peak"] > 3.0, r
