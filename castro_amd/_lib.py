@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
-    "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab", "castro_amd_fillpatch_shell_fab", "castro_amd_apply_source_fab",
+    "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab", "castro_amd_fillpatch_shell_fab", "castro_amd_apply_source_fab", "castro_amd_fab_ops",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
@@ -84,6 +84,14 @@ class Params(C.Structure):
         [("limit_fluxes_on_small_dens", C.c_int), ("limit_fluxes_on_large_vel", C.c_int), ("speed_limit", C.c_double)]
 
 
+class FabOp(C.Structure):
+    """castro_amd_fab_op (include/castro_hydro_amd.h)"""
+    _fields_ = [("kind", C.c_int), ("dir", C.c_int), ("ncomp", C.c_int), ("lo", C.c_int * 3), ("hi", C.c_int * 3),
+                ("a", C.c_double), ("b", C.c_double), ("dst", Fab), ("src", Fab), ("src2", Fab)]
+
+
+OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD = 0, 1, 2, 3
+
 _lib = None
 
 
@@ -131,6 +139,7 @@ def load():
                                                      C.c_double, C.c_void_p]
     L.castro_amd_saxpy_fab.argtypes = [C.c_void_p, PF, C.c_double, PF, C.c_int, I3, I3, C.c_void_p]
     L.castro_amd_error_tag_fab.argtypes = [C.c_void_p, PF, C.c_int, PF, I3, I3, C.c_int, C.c_double, C.c_void_p]
+    L.castro_amd_fab_ops.argtypes = [C.c_void_p, C.c_int, C.POINTER(FabOp), C.c_void_p]
     L.castro_amd_apply_source_fab.argtypes = [C.c_void_p, PF, PF, C.c_double, PF, C.c_int, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]
     L.castro_amd_cc_interp_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.c_void_p]
     L.castro_amd_fillpatch_shell_fab.argtypes = [C.c_void_p, PF, PF, I3, I3, C.c_int, C.POINTER(Params), C.c_int, C.c_void_p]

@@ -136,6 +136,20 @@ class _Level:
                         tg.append((p, (tuple(flo), tuple(fhi))))
                 b.reflux_to[(d, side)] = tg
             b.avg_to = [(p, it) for p in parents for it in [CL.intersect(b.pbox, p.bx)] if it]
+            # ghost zones outside the problem domain (only then the physical-BC fill has anything to do)
+            b.at_domain_edge = any(b.glo[d] < b.geom.domlo[d] or b.ghi[d] > b.geom.domhi[d] for d in range(3))
+        self._op_cache = {}
+        self.batched = hasattr(self.hydro, "make_ops")
+        if self.batched:
+            # flux-register operations never change between regrids (registers and flux FABs keep their storage)
+            mk = self.hydro.make_ops
+            self.ops_fine_add = mk([(L.OP_FLUXREG_FINE_ADD, d, NUM_STATE, rbox[0], rbox[1], 1.0, 0.0, (reg, rbox),
+                                     (b.fluxes[d], b.flux_boxes[d]), None)
+                                    for b in self.boxes for (d, side), (reg, rbox) in b.regs.items()])
+            self.ops_crse_init = mk([(L.OP_FLUXREG_CRSE_INIT, d, NUM_STATE, lo, hi, -1.0, 0.0, (reg, rbox),
+                                      (p.fluxes[d], p.flux_boxes[d]), None)
+                                     for b in self.boxes for (d, side), (reg, rbox) in b.regs.items()
+                                     for p, (lo, hi) in b.crse_init[(d, side)]])
 
     # ---- AmrLevel::FillPatch ---------------------------------------------------------------------
     def _interp_ghosts(self, b, S):
@@ -157,16 +171,58 @@ class _Level:
             h.copy(S, b.gbox, getattr(s, which), s.gbox, lo, hi)
         h.bc_fill(S, b.gbox, b.geom)                           # fine zones outside the domain
 
+    def _cached_ops(self, key, ptrs, build):
+        """Operation tables hold raw pointers: S_old_b / S_new_b swap at every advance, so a table is kept per
+        pointer configuration (two in the steady state)."""
+        ent = self._op_cache.get((key, ptrs))
+        if ent is None:
+            if len(self._op_cache) > 8:
+                self._op_cache.clear()
+            ent = build()
+            self._op_cache[(key, ptrs)] = ent
+        return ent
+
     def fill(self, which):
         """Ghost zones of S_old_b / S_new_b (`which`) of every box of the level."""
         if self.l == 0:
             for b in self.boxes:
                 b.expand_state(getattr(b, which))
             return
+        if not self.batched:
+            for b in self.boxes:
+                self._interp_ghosts(b, getattr(b, which))
+            for b in self.boxes:                               # valid zones are final only after every box's clean pass
+                self._copy_siblings(b, getattr(b, which), which)
+            return
+        h, a = self.hydro, self.alpha
+        parents = self.amr.lev[self.l - 1].boxes
+        # 1. time-interpolated coarse data under every box, all boxes in a few launches
+        pp = tuple(t.data_ptr() for p in parents for t in (p.S_old_b, p.S_new_b))
+        ops = self._cached_ops(("lincomb",), pp, lambda: h.make_ops(
+            [(L.OP_LINCOMB, 0, NUM_STATE, lo, hi, 0.0, 0.0, (b.ctmp, b.cbox), (p.S_old_b, p.gbox), (p.S_new_b, p.gbox))
+             for b in self.boxes for p, (lo, hi) in b.csrc + b.csrc_valid]))
+        arr, n = ops
+        for i in range(n):
+            arr[i].a, arr[i].b = 1.0 - a, a
+        # several parents of one box overlap in their ghost zones: the valid-zone pass must come after the ghost pass
+        if any(b.csrc_valid for b in self.boxes):
+            for b in self.boxes:
+                for p, (lo, hi) in b.csrc + b.csrc_valid:
+                    h.lincomb(b.ctmp, b.cbox, 1.0 - a, p.S_old_b, p.gbox, a, p.S_new_b, p.gbox, NUM_STATE, lo, hi)
+        else:
+            h.fab_ops(ops)
+        # 2. interpolation + clean_state of the ghost shell, one launch per box
         for b in self.boxes:
-            self._interp_ghosts(b, getattr(b, which))
-        for b in self.boxes:                                   # valid zones are final only after every box's clean pass
-            self._copy_siblings(b, getattr(b, which), which)
+            h.fillpatch_shell(b.ctmp, b.cbox, getattr(b, which), b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1)
+        # 3. valid zones of the siblings (final only after every box's clean pass), all boxes in a few launches
+        sp = tuple(getattr(b, which).data_ptr() for b in self.boxes)
+        h.fab_ops(self._cached_ops(("sib", which), sp, lambda: h.make_ops(
+            [(L.OP_COPY, 0, NUM_STATE, lo, hi, 0.0, 0.0, (getattr(b, which), b.gbox), (getattr(sb, which), sb.gbox), None)
+             for b in self.boxes for sb, (lo, hi) in b.sib])))
+        # 4. physical boundaries
+        for b in self.boxes:
+            if b.at_domain_edge:
+                h.bc_fill(getattr(b, which), b.gbox, b.geom)
 
     def fill_box(self, b, S):
         which = "S_new_b" if S is b.S_new_b else "S_old_b"
@@ -511,19 +567,25 @@ class CastroAmr:
         self.level_count[l] += 1
         if l > 0:
             # FluxRegFineAdd: + this level's fluxes (already dt x area) summed over the 4 fine faces
-            for b in lev.boxes:
-                for (d, side), (reg, rbox) in b.regs.items():
-                    h.fluxreg_fine_add(reg, rbox, b.fluxes[d], b.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
+            if lev.batched:
+                h.fab_ops(lev.ops_fine_add)
+            else:
+                for b in lev.boxes:
+                    for (d, side), (reg, rbox) in b.regs.items():
+                        h.fluxreg_fine_add(reg, rbox, b.fluxes[d], b.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
         if l < finest:
             fine = self.lev[l + 1]
             # ghost zones of the new data of this level, for the FillPatch of the next finer one
             lev.alpha = alpha + 0.5
             lev.fill("S_new_b")
             # FluxRegCrseInit: -1 x this level's fluxes through the faces of the finer boxes
-            for b in fine.boxes:
-                for (d, side), (reg, rbox) in b.regs.items():
-                    for p, (lo, hi) in b.crse_init[(d, side)]:
-                        h.fluxreg_crse_init(reg, rbox, p.fluxes[d], p.flux_boxes[d], lo, hi, NUM_STATE, -1.0)
+            if fine.batched:
+                h.fab_ops(fine.ops_crse_init)
+            else:
+                for b in fine.boxes:
+                    for (d, side), (reg, rbox) in b.regs.items():
+                        for p, (lo, hi) in b.crse_init[(d, side)]:
+                            h.fluxreg_crse_init(reg, rbox, p.fluxes[d], p.flux_boxes[d], lo, hi, NUM_STATE, -1.0)
             for it in range(2):
                 self._time_step(l + 1, t + it * (dt / 2), dt / 2, 0.5 * it)
             # post_timestep: reflux, avgDown, clean_state

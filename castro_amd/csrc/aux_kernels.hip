@@ -744,6 +744,76 @@ __global__ void __launch_bounds__(256) k_lincomb(DFab D, DFab X, DFab Y, Box3 b,
         D.p[fidx(D, i, j, k, n)] = a * X.p[fidx(X, i, j, k, n)] + bb * Y.p[fidx(Y, i, j, k, n)];
 }
 
+// up to FABOPS_MAX independent region operations in one launch (castro_amd_fab_ops); op r owns threads [start[r], start[r+1])
+#define FABOPS_MAX 16
+struct FabOp { DFab D, X, Y; int lo[3], n[3]; int kind, dir, ncomp; double a, b; };
+struct FabOps { int n; long start[FABOPS_MAX + 1]; FabOp op[FABOPS_MAX]; };
+
+__global__ void __launch_bounds__(256) k_fab_ops(FabOps T)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= T.start[T.n]) return;
+    int r = 0;
+    while (tid >= T.start[r + 1]) ++r;
+    const FabOp& o = T.op[r];
+    const long t = tid - T.start[r];
+    int c[3];
+    c[0] = o.lo[0] + (int)(t % o.n[0]);
+    const long q = t / o.n[0];
+    c[1] = o.lo[1] + (int)(q % o.n[1]);
+    c[2] = o.lo[2] + (int)(q / o.n[1]);
+    for (int n = 0; n < o.ncomp; ++n) {
+        const long cd = fidx(o.D, c[0], c[1], c[2], n);
+        if (o.kind == CASTRO_AMD_OP_COPY) {
+            o.D.p[cd] = o.X.p[fidx(o.X, c[0], c[1], c[2], n)];
+        } else if (o.kind == CASTRO_AMD_OP_LINCOMB) {
+            o.D.p[cd] = o.a * o.X.p[fidx(o.X, c[0], c[1], c[2], n)] + o.b * o.Y.p[fidx(o.Y, c[0], c[1], c[2], n)];
+        } else if (o.kind == CASTRO_AMD_OP_FLUXREG_CRSE_INIT) {
+            o.D.p[cd] = o.a * o.X.p[fidx(o.X, c[0], c[1], c[2], n)];
+        } else {
+            const int dir = o.dir, t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
+            int f[3];
+            double s = 0.0;
+            for (int bb = 0; bb < 2; ++bb)
+            for (int aa = 0; aa < 2; ++aa) {
+                f[dir] = 2 * c[dir];
+                f[t1] = 2 * c[t1] + aa;
+                f[t2] = 2 * c[t2] + bb;
+                s += o.X.p[fidx(o.X, f[0], f[1], f[2], n)];
+            }
+            o.D.p[cd] += o.a * s;
+        }
+    }
+}
+
+int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
+                   const int* dir, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof)
+{
+    int done = 0;
+    while (done < nops) {
+        FabOps T;
+        T.n = 0;
+        T.start[0] = 0;
+        for (; done < nops && T.n < FABOPS_MAX; ++done) {
+            long n = 1;
+            int nn[3];
+            for (int d = 0; d < 3; ++d) { nn[d] = hi[3 * done + d] - lo[3 * done + d] + 1; n *= nn[d] > 0 ? nn[d] : 0; }
+            if (n <= 0) continue;
+            FabOp& o = T.op[T.n];
+            o.D = D[done]; o.X = X[done]; o.Y = Y[done];
+            for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * done + d]; o.n[d] = nn[d]; }
+            o.kind = kind[done]; o.dir = dir[done]; o.ncomp = ncomp[done]; o.a = a[done]; o.b = b[done];
+            T.start[T.n + 1] = T.start[T.n] + n;
+            ++T.n;
+        }
+        if (T.n == 0) continue;
+        prof_begin(prof, "k_fab_ops", stream);
+        hipLaunchKernelGGL(k_fab_ops, dim3((unsigned)((T.start[T.n] + 255) / 256)), dim3(256), 0, stream, T);
+        prof_end(prof, stream);
+    }
+    return 0;
+}
+
 __global__ void __launch_bounds__(256) k_error_tag(DFab Q, int comp, DFab T, Box3 b, int kind, double value)
 {
     int i, j, k;

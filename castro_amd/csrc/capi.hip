@@ -1,6 +1,7 @@
 // capi.hip -- the C ABI (include/castro_hydro_amd.h) over the HIP kernels.
 // Plain pointers and sizes only; no torch, no AMReX.  One context per (device, stream).
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -478,6 +479,43 @@ int castro_amd_cc_interp_fab(castro_amd_ctx* c, const castro_amd_fab* crse, cons
     if (!fab_contains(crse, clo, chi)) return CASTRO_AMD_ERR_ARG;
     hipSetDevice(c->device);
     return launch_cc_interp(to_dfab(crse), to_dfab(fine), lo, hi, ncomp, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_fab_ops(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops, void* stream)
+{
+    if (!c || nops < 0 || (nops > 0 && !ops)) return CASTRO_AMD_ERR_ARG;
+    if (nops == 0) return CASTRO_AMD_OK;
+    std::vector<DFab> D(nops), X(nops), Y(nops);
+    std::vector<int> lo(3 * nops), hi(3 * nops), kind(nops), dir(nops), ncomp(nops);
+    std::vector<double> a(nops), b(nops);
+    for (int r = 0; r < nops; ++r) {
+        const castro_amd_fab_op& o = ops[r];
+        if (o.ncomp < 1 || !fab_ok(&o.dst, o.ncomp) || !fab_ok(&o.src, o.ncomp) || !fab_contains(&o.dst, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
+        switch (o.kind) {
+        case CASTRO_AMD_OP_LINCOMB:
+            if (!fab_ok(&o.src2, o.ncomp) || !fab_contains(&o.src2, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
+            /* fall through */
+        case CASTRO_AMD_OP_COPY:
+        case CASTRO_AMD_OP_FLUXREG_CRSE_INIT:
+            if (!fab_contains(&o.src, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
+            break;
+        case CASTRO_AMD_OP_FLUXREG_FINE_ADD: {
+            if (o.dir < 0 || o.dir > 2) return CASTRO_AMD_ERR_ARG;
+            int flo[3], fhi[3];
+            for (int d = 0; d < 3; ++d) { flo[d] = 2 * o.lo[d]; fhi[d] = (d == o.dir) ? 2 * o.hi[d] : 2 * o.hi[d] + 1; }
+            if (!fab_contains(&o.src, flo, fhi)) return CASTRO_AMD_ERR_ARG;
+            break; }
+        default:
+            return CASTRO_AMD_ERR_ARG;
+        }
+        D[r] = to_dfab(&o.dst); X[r] = to_dfab(&o.src);
+        Y[r] = (o.kind == CASTRO_AMD_OP_LINCOMB) ? to_dfab(&o.src2) : X[r];
+        for (int d = 0; d < 3; ++d) { lo[3 * r + d] = o.lo[d]; hi[3 * r + d] = o.hi[d]; }
+        kind[r] = o.kind; dir[r] = o.dir; ncomp[r] = o.ncomp; a[r] = o.a; b[r] = o.b;
+    }
+    hipSetDevice(c->device);
+    return launch_fab_ops(nops, D.data(), X.data(), Y.data(), lo.data(), hi.data(), kind.data(), dir.data(), ncomp.data(),
+                          a.data(), b.data(), (hipStream_t)stream, &c->prof);
 }
 
 int castro_amd_fillpatch_shell_fab(castro_amd_ctx* c, const castro_amd_fab* crse, const castro_amd_fab* fine,

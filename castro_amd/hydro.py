@@ -163,6 +163,24 @@ class HipHydro:
                                                         L.i3(vlo), L.i3(vhi), int(ngrow), C.byref(params), int(ntimes),
                                                         _stream_ptr(stream)), "fillpatch_shell_fab")
 
+    @staticmethod
+    def make_ops(specs):
+        """ctypes array of castro_amd_fab_op from (kind, dir, ncomp, lo, hi, a, b, (dst, box), (src, box), (src2, box) | None)."""
+        arr = (L.FabOp * max(len(specs), 1))()
+        for o, (kind, dir_, ncomp, lo, hi, a, b, dst, src, src2) in zip(arr, specs):
+            o.kind, o.dir, o.ncomp, o.a, o.b = kind, dir_, ncomp, a, b
+            for d in range(3):
+                o.lo[d], o.hi[d] = lo[d], hi[d]
+            o.dst, o.src = L.fab_of(dst[0], *dst[1]), L.fab_of(src[0], *src[1])
+            o.src2 = L.fab_of(src2[0], *src2[1]) if src2 is not None else o.src
+        return arr, len(specs)
+
+    def fab_ops(self, ops, stream=None):
+        """Independent FAB-to-FAB region operations (make_ops), sixteen per launch."""
+        arr, n = ops
+        if n:
+            L.check(self.lib.castro_amd_fab_ops(self.h, n, arr, _stream_ptr(stream)), "fab_ops")
+
     def lincomb(self, dst, dst_box, a, x, x_box, b, y, y_box, ncomp, lo, hi, stream=None):
         L.check(self.lib.castro_amd_lincomb_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(x, *x_box)),
                                                 float(b), C.byref(L.fab_of(y, *y_box)), int(ncomp), L.i3(lo), L.i3(hi),

@@ -263,6 +263,27 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
  *                                     zone of grow([vlo,vhi], ngrow) outside [vlo,vhi], followed by clean_state x
  *                                     clean_ntimes there (Castro_advance.cpp:186); ncomp 8
  * Register planes are ordinary FABs, one coarse face thick, in coarse face index space. */
+/* Several independent FAB-to-FAB region operations in one launch (a level of many small boxes is launch-bound
+ * otherwise: ~60 launches per box and advance).  The operations of one call must not write a zone that another one of
+ * the same call reads or writes.  Kinds and their single-operation equivalents:
+ *   CASTRO_AMD_OP_COPY               castro_amd_copy_fab              dst = src                (ncomp components)
+ *   CASTRO_AMD_OP_LINCOMB            castro_amd_lincomb_fab           dst = a src + b src2
+ *   CASTRO_AMD_OP_FLUXREG_CRSE_INIT  castro_amd_fluxreg_crse_init_fab dst = a src
+ *   CASTRO_AMD_OP_FLUXREG_FINE_ADD   castro_amd_fluxreg_fine_add_fab  dst += a (sum of the 4 fine faces of src), dir */
+#define CASTRO_AMD_OP_COPY 0
+#define CASTRO_AMD_OP_LINCOMB 1
+#define CASTRO_AMD_OP_FLUXREG_CRSE_INIT 2
+#define CASTRO_AMD_OP_FLUXREG_FINE_ADD 3
+typedef struct castro_amd_fab_op {
+    int kind;
+    int dir;                     /* FLUXREG_FINE_ADD only */
+    int ncomp;
+    int lo[3], hi[3];            /* region, in the index space of dst */
+    double a, b;
+    castro_amd_fab dst, src, src2;   /* src2: LINCOMB only */
+} castro_amd_fab_op;
+int castro_amd_fab_ops(castro_amd_ctx *ctx, int nops, const castro_amd_fab_op *ops, void *stream);
+
 int castro_amd_fillpatch_shell_fab(castro_amd_ctx *ctx, const castro_amd_fab *crse, const castro_amd_fab *fine,
                                    const int vlo[3], const int vhi[3], int ngrow, const castro_amd_params *params,
                                    int clean_ntimes, void *stream);
