@@ -907,6 +907,52 @@ def test_rccl_process_group_of_one_rank(tmp_path):
     assert np.array_equal(got["dts"], np.array(dts)) and np.array_equal(got["S"], c.S_new().cpu().numpy())
 
 
+def test_fab_ops_equal_the_single_operations(hip):
+    """castro_amd_fab_ops: 22 mixed copies, linear combinations and flux-register updates (more than one launch's worth)
+    give the bits of the one-operation entry points; a region that leaves its FAB is refused."""
+    import torch
+    from castro_amd import _lib as L
+    rng = np.random.default_rng(9)
+    box = ((-2, -1, 0), (13, 10, 9))
+    shp = (8, 10, 12, 16)
+    A, B = _to_dev(hip, rng.normal(size=shp)), _to_dev(hip, rng.normal(size=shp))
+    fbox = ((-4, -2, 0), (27, 21, 19))
+    Ffine = _to_dev(hip, rng.normal(size=(8, 20, 24, 32)))
+    one = [hip.alloc(8, *box) for _ in range(22)]
+    many = [hip.alloc(8, *box) for _ in range(22)]
+    for t in one + many:
+        t.copy_(_to_dev(hip, np.full(shp, 0.5)))
+    specs = []
+    for i in range(22):
+        lo = (box[0][0] + i % 3, box[0][1] + i % 2, box[0][2] + i % 4)
+        hi = (box[1][0] - i % 2, box[1][1] - i % 3, box[1][2] - i % 2)
+        kind = i % 4
+        if kind == L.OP_COPY:
+            hip.copy(one[i], box, A, box, lo, hi)
+            specs.append((kind, 0, 8, lo, hi, 0.0, 0.0, (many[i], box), (A, box), None))
+        elif kind == L.OP_LINCOMB:
+            hip.lincomb(one[i], box, 0.25, A, box, 0.75, B, box, 8, lo, hi)
+            specs.append((kind, 0, 8, lo, hi, 0.25, 0.75, (many[i], box), (A, box), (B, box)))
+        elif kind == L.OP_FLUXREG_CRSE_INIT:
+            hip.fluxreg_crse_init(one[i], box, B, box, lo, hi, 8, -1.0)
+            specs.append((kind, 0, 8, lo, hi, -1.0, 0.0, (many[i], box), (B, box), None))
+        else:
+            d = i % 3
+            flo = list(lo)
+            fhi = list(hi)
+            flo[d] = fhi[d] = lo[d]                              # one face plane, like a register
+            hip.fluxreg_fine_add(one[i], box, Ffine, fbox, flo, fhi, d, 8, 1.0)
+            specs.append((kind, d, 8, tuple(flo), tuple(fhi), 1.0, 0.0, (many[i], box), (Ffine, fbox), None))
+    hip.fab_ops(hip.make_ops(specs))
+    torch.cuda.synchronize()
+    for i in range(22):
+        assert torch.equal(one[i], many[i]), i
+        assert not torch.equal(many[i], torch.full_like(many[i], 0.5))
+    bad = hip.make_ops([(L.OP_COPY, 0, 8, (box[0][0] - 1, 0, 0), box[1], 0.0, 0.0, (many[0], box), (A, box), None)])
+    with pytest.raises(RuntimeError, match="bad argument"):
+        hip.fab_ops(bad)
+
+
 def test_fillpatch_shell_equals_interp_then_clean(hip, oracle):
     """castro_amd_fillpatch_shell_fab (one launch) == cc_interp on the six ghost slabs followed by clean_state there,
     on the device and in the oracle; the valid zones are not touched."""
