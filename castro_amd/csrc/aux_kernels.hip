@@ -7,6 +7,11 @@
 #include "ctu_kernels.h"
 
 namespace cad {
+// a launch that cannot be queued (bad configuration, lost device) is reported to the caller as CASTRO_AMD_ERR_HIP
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : CASTRO_AMD_ERR_HIP; }
+}
+
+namespace cad {
 
 __device__ __forceinline__ long fidx(const DFab& f, int i, int j, int k, int n)
 {
@@ -87,7 +92,7 @@ int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const De
     hipLaunchKernelGGL(k_clean_state<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, b, P, ntimes,
                        0.0, 0.0, 0.0, (double*)nullptr);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
@@ -103,7 +108,7 @@ int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], c
     hipLaunchKernelGGL(k_clean_state<true>, dim3((unsigned)nb), dim3(256), 0, stream, U, b, P, ntimes,
                        g.dx[0], g.dx[1], g.dx[2], d_out);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -154,7 +159,7 @@ int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom&
     hipLaunchKernelGGL(k_estdt, dim3((unsigned)nb), dim3(256), 0, stream, U, b,
                        g.dx[0], g.dx[1], g.dx[2], P, d_out);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -313,7 +318,7 @@ int launch_apply_source(const DFab& D, const DFab& B, const DFab& S, const int l
     prof_begin(prof, "k_apply_source", stream);
     hipLaunchKernelGGL(k_apply_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, D, B, S, b, a, nsrc, P, ntimes);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -511,7 +516,7 @@ int launch_old_grav_source(const DFab& U, const DFab& SRC, const int lo[3], cons
     hipLaunchKernelGGL(k_old_grav_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, SRC, b,
                        grav[0], grav[1], grav[2], type, dt);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
@@ -523,7 +528,7 @@ int launch_new_grav_source(const DFab& UO, const DFab& UN, const DFab& SRC, cons
     hipLaunchKernelGGL(k_new_grav_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, UO, UN, SRC, M[0], M[1], M[2], b,
                        grav[0], grav[1], grav[2], type, dt, dx[0], dx[1], dx[2]);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 static RotDev make_rotdev(const castro_amd_rotation* r, const castro_amd_geom* g, double dt)
@@ -565,7 +570,7 @@ int launch_old_rot_source(const DFab& U, const DFab& SRC, const int lo[3], const
     prof_begin(prof, "k_old_rot_source", stream);
     hipLaunchKernelGGL(k_old_rot_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, SRC, b, make_rotdev(r, g, dt), dt);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
@@ -577,7 +582,7 @@ int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const
     hipLaunchKernelGGL(k_new_rot_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, UO, UN, SRC, M[0], M[1], M[2], b,
                        make_rotdev(r, g, dt), dt);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
@@ -588,7 +593,7 @@ int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3],
     prof_begin(prof, "k_saxpy", stream);
     hipLaunchKernelGGL(k_saxpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, D, S, b, a, ncomp);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -684,7 +689,7 @@ int launch_fillpatch_shell(const DFab& C, const DFab& F, const int vlo[3], const
     prof_begin(prof, "k_fillpatch_shell", stream);
     hipLaunchKernelGGL(k_fillpatch_shell, dim3((unsigned)((S.start[6] + 255) / 256)), dim3(256), 0, stream, C, F, S, P, ntimes);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 __global__ void __launch_bounds__(256) k_avgdown(DFab F, DFab C, Box3 b, int ncomp)
@@ -811,7 +816,7 @@ int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const 
         hipLaunchKernelGGL(k_fab_ops, dim3((unsigned)((T.start[T.n] + 255) / 256)), dim3(256), 0, stream, T);
         prof_end(prof, stream);
     }
-    return 0;
+    return launch_status();
 }
 
 __global__ void __launch_bounds__(256) k_error_tag(DFab Q, int comp, DFab T, Box3 b, int kind, double value)
@@ -840,7 +845,7 @@ __global__ void __launch_bounds__(256) k_error_tag(DFab Q, int comp, DFab T, Box
     prof_begin(prof, name, stream);                                                                      \
     hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, __VA_ARGS__);      \
     prof_end(prof, stream);                                                                              \
-    return 0
+    return launch_status()
 
 int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof)
 { AMR_LAUNCH("k_cc_interp", k_cc_interp, C, F, b, ncomp); }
@@ -967,7 +972,7 @@ int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int 
     hipLaunchKernelGGL(k_derive, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, D, dcomp, b, which, P,
                        dx[0], dx[1], dx[2], problo[0], problo[1], problo[2], center[0], center[1], center[2]);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1025,7 +1030,7 @@ int launch_bc_fill(const DFab& U, const int flo[3], const int fhi[3], int ncomp,
             prof_end(prof, stream);
         }
     }
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1049,7 +1054,7 @@ int launch_copy(const DFab& dst, const DFab& src, const int lo[3], const int hi[
     prof_begin(prof, "k_copy", stream);
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, b, ncomp);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 __global__ void __launch_bounds__(256) k_pack(DFab f, Box3 b, int ncomp, double* buf, int unpack)
@@ -1076,7 +1081,7 @@ int launch_pack(const DFab& f, const int lo[3], const int hi[3], int ncomp, doub
     prof_begin(prof, unpack ? "k_unpack" : "k_pack", stream);
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, f, b, ncomp, buf, unpack);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // All halo regions of one FillBoundary in one launch: region r owns threads [start[r], start[r+1]) and the
@@ -1129,7 +1134,7 @@ int launch_pack_regions(const DFab& f, int nreg, const int* lo, const int* hi, c
     prof_begin(prof, unpack ? "k_unpack" : "k_pack", stream);
     hipLaunchKernelGGL(k_pack_regions, dim3((unsigned)((R.start[R.n] + 255) / 256)), dim3(256), 0, stream, f, R, ncomp, buf, unpack);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1197,7 +1202,7 @@ int launch_sedov_init(const DFab& U, const int lo[3], const int hi[3], const Dev
     hipLaunchKernelGGL(k_sedov_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, b, vdx, vlo, vc,
                        r_init, e_exp, e_ambient, temp_ambient, dens_ambient, nsub);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 // Sod initial data (Exec/hydro_tests/Sod/problem_initialize_state_data.H)
@@ -1240,7 +1245,7 @@ int launch_sod_init(const DFab& U, const int lo[3], const int hi[3], const doubl
     hipLaunchKernelGGL(k_sod_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, U, b, vdx, vlo, split,
                        idir0, rho_l, u_l, rhoe_l, T_l, rho_r, u_r, rhoe_r, T_r);
     prof_end(prof, stream);
-    return 0;
+    return launch_status();
 }
 
 } // namespace cad
