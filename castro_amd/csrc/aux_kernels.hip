@@ -981,22 +981,44 @@ int launch_derive(int which, const DFab& U, const DFab& D, int dcomp, const int 
 // Source/problems/Castro_bc_fill_nd.cpp:26-39).  One launch per (direction, side).
 // kind: 0 first-order extrapolation, +1 reflect even, -1 reflect odd (normal momentum).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_bc_fill(DFab U, Box3 b, int ncomp, int dir, int side, int edge, int wall)
+// One launch for all faces, edges and corners: the x, y, z sweeps of the reference (each over the full extent
+// already filled, so edges and corners inherit from filled neighbours) compose to an independent index map per
+// direction -- clamp to the nearest interior zone (FOEXTRAP) or mirror about the boundary (walls), with the normal
+// momentum of every mirrored direction negated -- applied to the zones outside the domain in a non-periodic direction.
+struct BcMap { int lo[3], hi[3]; int kind_lo[3], kind_hi[3]; };   // domain extent; kind 0 leave (interior), 1 extrapolate, 2 wall
+
+__global__ void __launch_bounds__(256) k_bc_fill(DFab U, Slabs S, int ncomp, BcMap M)
 {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= S.start[6]) return;
+    int r = 0;
+    while (tid >= S.start[r + 1]) ++r;
+    const long t = tid - S.start[r];
+    const int n0 = S.nn[r][0], n1 = S.nn[r][1];
     int ijk[3];
-    if (!box_thread3(b.lo, b.n, ijk[0], ijk[1], ijk[2])) return;
-    int s[3] = { ijk[0], ijk[1], ijk[2] };
-    const int cidx = ijk[dir];
-    if (!wall) {
-        s[dir] = edge;                       // FOEXTRAP: nearest interior zone
-    } else {
-        s[dir] = (side == 0) ? (2 * edge - cidx - 1) : (2 * edge - cidx + 1);
+    ijk[0] = S.lo[r][0] + (int)(t % n0);
+    const long q = t / n0;
+    ijk[1] = S.lo[r][1] + (int)(q % n1);
+    ijk[2] = S.lo[r][2] + (int)(q / n1);
+    int s[3];
+    bool flip[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        s[d] = ijk[d];
+        flip[d] = false;
+        if (ijk[d] < M.lo[d] && M.kind_lo[d] != 0) {
+            if (M.kind_lo[d] == 1) s[d] = M.lo[d];
+            else { s[d] = 2 * M.lo[d] - ijk[d] - 1; flip[d] = true; }
+        } else if (ijk[d] > M.hi[d] && M.kind_hi[d] != 0) {
+            if (M.kind_hi[d] == 1) s[d] = M.hi[d];
+            else { s[d] = 2 * M.hi[d] - ijk[d] + 1; flip[d] = true; }
+        }
     }
     const long cd = fidx(U, ijk[0], ijk[1], ijk[2], 0);
     const long cs = fidx(U, s[0], s[1], s[2], 0);
     for (int n = 0; n < ncomp; ++n) {
         double v = U.p[cs + U.sn * n];
-        if (wall && n == UMX + dir) v = -v;  // norm_vel_bc: REFLECT_ODD
+        if (n >= UMX && n <= UMZ && flip[n - UMX]) v = -v;      // norm_vel_bc: REFLECT_ODD
         U.p[cd + U.sn * n] = v;
     }
 }
@@ -1004,32 +1026,32 @@ __global__ void __launch_bounds__(256) k_bc_fill(DFab U, Box3 b, int ncomp, int 
 int launch_bc_fill(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const DevGeom& g,
                    const int lo_bc[3], const int hi_bc[3], hipStream_t stream, Profiler* prof)
 {
-    for (int dir = 0; dir < 3; ++dir) {
-        for (int side = 0; side < 2; ++side) {
-            const int bc = side == 0 ? lo_bc[dir] : hi_bc[dir];
-            if (bc == 0) continue;                       // Interior: filled by the halo exchange
-            Box3 b;
-            for (int d = 0; d < 3; ++d) { b.lo[d] = flo[d]; b.n[d] = fhi[d] - flo[d] + 1; }
-            int edge;
-            if (side == 0) {
-                edge = g.domlo[dir];
-                int hi = edge - 1 < fhi[dir] ? edge - 1 : fhi[dir];
-                b.n[dir] = hi - flo[dir] + 1;
-            } else {
-                edge = g.domhi[dir];
-                int lo = edge + 1 > flo[dir] ? edge + 1 : flo[dir];
-                b.lo[dir] = lo;
-                b.n[dir] = fhi[dir] - lo + 1;
-            }
-            if (b.n[dir] <= 0) continue;
-            long n = (long)b.n[0] * b.n[1] * b.n[2];
-            const int wall = (bc >= 3) ? 1 : 0;          // Symmetry, SlipWall, NoSlipWall
-            prof_begin(prof, "k_bc_fill", stream);
-            hipLaunchKernelGGL(k_bc_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                               U, b, ncomp, dir, side, edge, wall);
-            prof_end(prof, stream);
-        }
+    BcMap M;
+    int blo[3], bhi[3];        // the part of the FAB that needs no physical-boundary fill
+    for (int d = 0; d < 3; ++d) {
+        M.lo[d] = g.domlo[d]; M.hi[d] = g.domhi[d];
+        M.kind_lo[d] = lo_bc[d] == 0 ? 0 : (lo_bc[d] >= 3 ? 2 : 1);      // Symmetry, SlipWall, NoSlipWall mirror
+        M.kind_hi[d] = hi_bc[d] == 0 ? 0 : (hi_bc[d] >= 3 ? 2 : 1);
+        blo[d] = (M.kind_lo[d] != 0 && flo[d] < g.domlo[d]) ? g.domlo[d] : flo[d];
+        bhi[d] = (M.kind_hi[d] != 0 && fhi[d] > g.domhi[d]) ? g.domhi[d] : fhi[d];
+        if (blo[d] > bhi[d]) return 0;                                      // FAB entirely outside the domain: nothing to copy from
     }
+    // FAB box minus [blo, bhi] as six slabs (z slabs over the full x-y extent, then y, then x)
+    const int lo[6][3] = { { flo[0], flo[1], flo[2] }, { flo[0], flo[1], bhi[2] + 1 }, { flo[0], flo[1], blo[2] },
+                           { flo[0], bhi[1] + 1, blo[2] }, { flo[0], blo[1], blo[2] }, { bhi[0] + 1, blo[1], blo[2] } };
+    const int hi[6][3] = { { fhi[0], fhi[1], blo[2] - 1 }, { fhi[0], fhi[1], fhi[2] }, { fhi[0], blo[1] - 1, bhi[2] },
+                           { fhi[0], fhi[1], bhi[2] }, { blo[0] - 1, bhi[1], bhi[2] }, { fhi[0], bhi[1], bhi[2] } };
+    Slabs S;
+    S.start[0] = 0;
+    for (int r = 0; r < 6; ++r) {
+        long n = 1;
+        for (int d = 0; d < 3; ++d) { S.lo[r][d] = lo[r][d]; S.nn[r][d] = hi[r][d] - lo[r][d] + 1; n *= S.nn[r][d] > 0 ? S.nn[r][d] : 0; }
+        S.start[r + 1] = S.start[r] + n;
+    }
+    if (S.start[6] <= 0) return 0;
+    prof_begin(prof, "k_bc_fill", stream);
+    hipLaunchKernelGGL(k_bc_fill, dim3((unsigned)((S.start[6] + 255) / 256)), dim3(256), 0, stream, U, S, ncomp, M);
+    prof_end(prof, stream);
     return launch_status();
 }
 
