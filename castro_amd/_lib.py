@@ -87,10 +87,10 @@ class Params(C.Structure):
 class FabOp(C.Structure):
     """castro_amd_fab_op (include/castro_hydro_amd.h)"""
     _fields_ = [("kind", C.c_int), ("dir", C.c_int), ("ncomp", C.c_int), ("lo", C.c_int * 3), ("hi", C.c_int * 3),
-                ("a", C.c_double), ("b", C.c_double), ("dst", Fab), ("src", Fab), ("src2", Fab)]
+                ("side", C.c_int), ("a", C.c_double), ("b", C.c_double), ("dst", Fab), ("src", Fab), ("src2", Fab)]
 
 
-OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD = 0, 1, 2, 3
+OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX = 0, 1, 2, 3, 4
 
 _lib = None
 
@@ -205,14 +205,11 @@ def make_geom(n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2
     return g
 
 
+_I3 = C.c_int * 3
+
+
 def fab_desc(ptr, lo, hi, ncomp):
-    f = Fab()
-    f.p = ptr
-    for d in range(3):
-        f.lo[d] = int(lo[d])
-        f.hi[d] = int(hi[d])
-    f.ncomp = int(ncomp)
-    return f
+    return Fab(ptr, _I3(int(lo[0]), int(lo[1]), int(lo[2])), _I3(int(hi[0]), int(hi[1]), int(hi[2])), int(ncomp))
 
 
 def fab_of(tensor, lo, hi):
@@ -220,11 +217,11 @@ def fab_of(tensor, lo, hi):
     (C order of that shape == AMReX FAB layout: i fastest, component slowest)."""
     if tensor is None:
         return fab_desc(None, lo, hi, 0)
-    nx, ny, nz = hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1
-    assert tensor.is_contiguous(), "FAB tensors must be contiguous"
-    assert tuple(tensor.shape[-3:]) == (nz, ny, nx), (tuple(tensor.shape), (nz, ny, nx))
-    ncomp = tensor.numel() // (nx * ny * nz)
-    return fab_desc(tensor.data_ptr(), lo, hi, ncomp)
+    shp = tensor.shape
+    if not (tensor.is_contiguous() and shp[-1] == hi[0] - lo[0] + 1 and shp[-2] == hi[1] - lo[1] + 1 and shp[-3] == hi[2] - lo[2] + 1):
+        raise AssertionError("FAB tensors must be contiguous and shaped (ncomp, nz, ny, nx) of their box: %s for %s"
+                             % (tuple(shp), (lo, hi)))
+    return fab_desc(tensor.data_ptr(), lo, hi, shp[0] if len(shp) == 4 else 1)
 
 
 def check(rc, what):

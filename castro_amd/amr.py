@@ -176,7 +176,7 @@ class _Level:
         pointer configuration (two in the steady state)."""
         ent = self._op_cache.get((key, ptrs))
         if ent is None:
-            if len(self._op_cache) > 8:
+            if len(self._op_cache) > 64:
                 self._op_cache.clear()
             ent = build()
             self._op_cache[(key, ptrs)] = ent
@@ -196,20 +196,18 @@ class _Level:
             return
         h, a = self.hydro, self.alpha
         parents = self.amr.lev[self.l - 1].boxes
-        # 1. time-interpolated coarse data under every box, all boxes in a few launches
+        # 1. time-interpolated coarse data under every box, all boxes in a few launches.  Where a box has several parents
+        #    their grown boxes overlap: the ghost-zone pass goes first (overlapping entries carry identical values: a
+        #    ghost zone of one parent is a copy of the valid zone of another or the same interpolation), the valid-zone
+        #    pass second, as separate launches
         pp = tuple(t.data_ptr() for p in parents for t in (p.S_old_b, p.S_new_b))
-        ops = self._cached_ops(("lincomb",), pp, lambda: h.make_ops(
-            [(L.OP_LINCOMB, 0, NUM_STATE, lo, hi, 0.0, 0.0, (b.ctmp, b.cbox), (p.S_old_b, p.gbox), (p.S_new_b, p.gbox))
-             for b in self.boxes for p, (lo, hi) in b.csrc + b.csrc_valid]))
-        arr, n = ops
-        for i in range(n):
-            arr[i].a, arr[i].b = 1.0 - a, a
-        # several parents of one box overlap in their ghost zones: the valid-zone pass must come after the ghost pass
-        if any(b.csrc_valid for b in self.boxes):
-            for b in self.boxes:
-                for p, (lo, hi) in b.csrc + b.csrc_valid:
-                    h.lincomb(b.ctmp, b.cbox, 1.0 - a, p.S_old_b, p.gbox, a, p.S_new_b, p.gbox, NUM_STATE, lo, hi)
-        else:
+        for key, attr in (("lincomb_ghost", "csrc"), ("lincomb_valid", "csrc_valid")):
+            ops = self._cached_ops((key,), pp, lambda attr=attr: h.make_ops(
+                [(L.OP_LINCOMB, 0, NUM_STATE, lo, hi, 0.0, 0.0, (b.ctmp, b.cbox), (p.S_old_b, p.gbox), (p.S_new_b, p.gbox))
+                 for b in self.boxes for p, (lo, hi) in getattr(b, attr)]))
+            arr, n = ops
+            for i in range(n):
+                arr[i].a, arr[i].b = 1.0 - a, a
             h.fab_ops(ops)
         # 2. interpolation + clean_state of the ghost shell, one launch per box
         for b in self.boxes:
@@ -590,10 +588,21 @@ class CastroAmr:
                 self._time_step(l + 1, t + it * (dt / 2), dt / 2, 0.5 * it)
             # post_timestep: reflux, avgDown, clean_state
             vol = lev.geom.dx[0] * lev.geom.dx[1] * lev.geom.dx[2]
-            for b in fine.boxes:
-                for (d, side), (reg, rbox) in b.regs.items():
-                    for p, (lo, hi) in b.reflux_to[(d, side)]:
-                        h.reflux(p.S_new_b, p.gbox, reg, rbox, lo, hi, d, side, NUM_STATE, vol)
+            # face orientation by face orientation, like FluxRegister::Reflux's OrientationIter [3P]: the registers of one
+            # orientation touch disjoint coarse zones (two boxes with a common outside neighbour on the same side would
+            # overlap), so they can share launches; a zone next to several boxes gets its contributions in this order
+            for d in range(3):
+                for side in (0, 1):
+                    if fine.batched:
+                        pp = tuple(p.S_new_b.data_ptr() for p in lev.boxes)
+                        h.fab_ops(fine._cached_ops(("reflux", d, side), pp, lambda d=d, side=side: h.make_ops(
+                            [(L.OP_REFLUX, (d, side), NUM_STATE, lo, hi, vol, 0.0, (p.S_new_b, p.gbox), b.regs[(d, side)], None)
+                             for b in fine.boxes for p, (lo, hi) in b.reflux_to[(d, side)]])))
+                    else:
+                        for b in fine.boxes:
+                            reg, rbox = b.regs[(d, side)]
+                            for p, (lo, hi) in b.reflux_to[(d, side)]:
+                                h.reflux(p.S_new_b, p.gbox, reg, rbox, lo, hi, d, side, NUM_STATE, vol)
             self.avgDown(l + 1)
             lev.clean_new()
 

@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(256) k_lincomb(DFab D, DFab X, DFab Y, Box3 b,
 
 // up to FABOPS_MAX independent region operations in one launch (castro_amd_fab_ops); op r owns threads [start[r], start[r+1])
 #define FABOPS_MAX 16
-struct FabOp { DFab D, X, Y; int lo[3], n[3]; int kind, dir, ncomp; double a, b; };
+struct FabOp { DFab D, X, Y; int lo[3], n[3]; int kind, dir, ncomp, side; double a, b; };
 struct FabOps { int n; long start[FABOPS_MAX + 1]; FabOp op[FABOPS_MAX]; };
 
 __global__ void __launch_bounds__(256) k_fab_ops(FabOps T)
@@ -767,6 +767,14 @@ __global__ void __launch_bounds__(256) k_fab_ops(FabOps T)
     const long q = t / o.n[0];
     c[1] = o.lo[1] + (int)(q % o.n[1]);
     c[2] = o.lo[2] + (int)(q / o.n[1]);
+    if (o.kind == CASTRO_AMD_OP_REFLUX) {
+        int z[3] = { c[0], c[1], c[2] };
+        if (o.side == 0) z[o.dir] -= 1;
+        const double mult = o.side == 0 ? -1.0 : 1.0;
+        for (int n = 0; n < o.ncomp; ++n)
+            o.D.p[fidx(o.D, z[0], z[1], z[2], n)] += mult * o.X.p[fidx(o.X, c[0], c[1], c[2], n)] / o.a;
+        return;
+    }
     for (int n = 0; n < o.ncomp; ++n) {
         const long cd = fidx(o.D, c[0], c[1], c[2], n);
         if (o.kind == CASTRO_AMD_OP_COPY) {
@@ -792,7 +800,7 @@ __global__ void __launch_bounds__(256) k_fab_ops(FabOps T)
 }
 
 int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
-                   const int* dir, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof)
+                   const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof)
 {
     int done = 0;
     while (done < nops) {
@@ -807,7 +815,7 @@ int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const 
             FabOp& o = T.op[T.n];
             o.D = D[done]; o.X = X[done]; o.Y = Y[done];
             for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * done + d]; o.n[d] = nn[d]; }
-            o.kind = kind[done]; o.dir = dir[done]; o.ncomp = ncomp[done]; o.a = a[done]; o.b = b[done];
+            o.kind = kind[done]; o.dir = dir[done]; o.side = side[done]; o.ncomp = ncomp[done]; o.a = a[done]; o.b = b[done];
             T.start[T.n + 1] = T.start[T.n] + n;
             ++T.n;
         }

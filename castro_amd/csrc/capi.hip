@@ -486,12 +486,19 @@ int castro_amd_fab_ops(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops
     if (!c || nops < 0 || (nops > 0 && !ops)) return CASTRO_AMD_ERR_ARG;
     if (nops == 0) return CASTRO_AMD_OK;
     std::vector<DFab> D(nops), X(nops), Y(nops);
-    std::vector<int> lo(3 * nops), hi(3 * nops), kind(nops), dir(nops), ncomp(nops);
+    std::vector<int> lo(3 * nops), hi(3 * nops), kind(nops), dir(nops), side(nops), ncomp(nops);
     std::vector<double> a(nops), b(nops);
     for (int r = 0; r < nops; ++r) {
         const castro_amd_fab_op& o = ops[r];
-        if (o.ncomp < 1 || !fab_ok(&o.dst, o.ncomp) || !fab_ok(&o.src, o.ncomp) || !fab_contains(&o.dst, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
+        if (o.ncomp < 1 || !fab_ok(&o.dst, o.ncomp) || !fab_ok(&o.src, o.ncomp)) return CASTRO_AMD_ERR_ARG;
+        if (o.kind != CASTRO_AMD_OP_REFLUX && !fab_contains(&o.dst, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
         switch (o.kind) {
+        case CASTRO_AMD_OP_REFLUX: {
+            if (o.dir < 0 || o.dir > 2 || o.side < 0 || o.side > 1 || !fab_contains(&o.src, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
+            int zlo[3] = { o.lo[0], o.lo[1], o.lo[2] }, zhi[3] = { o.hi[0], o.hi[1], o.hi[2] };
+            if (o.side == 0) { zlo[o.dir] -= 1; zhi[o.dir] -= 1; }
+            if (!fab_contains(&o.dst, zlo, zhi)) return CASTRO_AMD_ERR_ARG;
+            break; }
         case CASTRO_AMD_OP_LINCOMB:
             if (!fab_ok(&o.src2, o.ncomp) || !fab_contains(&o.src2, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
             /* fall through */
@@ -511,10 +518,10 @@ int castro_amd_fab_ops(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops
         D[r] = to_dfab(&o.dst); X[r] = to_dfab(&o.src);
         Y[r] = (o.kind == CASTRO_AMD_OP_LINCOMB) ? to_dfab(&o.src2) : X[r];
         for (int d = 0; d < 3; ++d) { lo[3 * r + d] = o.lo[d]; hi[3 * r + d] = o.hi[d]; }
-        kind[r] = o.kind; dir[r] = o.dir; ncomp[r] = o.ncomp; a[r] = o.a; b[r] = o.b;
+        kind[r] = o.kind; dir[r] = o.dir; side[r] = o.side; ncomp[r] = o.ncomp; a[r] = o.a; b[r] = o.b;
     }
     hipSetDevice(c->device);
-    return launch_fab_ops(nops, D.data(), X.data(), Y.data(), lo.data(), hi.data(), kind.data(), dir.data(), ncomp.data(),
+    return launch_fab_ops(nops, D.data(), X.data(), Y.data(), lo.data(), hi.data(), kind.data(), dir.data(), side.data(), ncomp.data(),
                           a.data(), b.data(), (hipStream_t)stream, &c->prof);
 }
 

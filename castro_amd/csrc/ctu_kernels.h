@@ -85,7 +85,7 @@ int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
 int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
-                   const int* dir, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof);
+                   const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof);
 int launch_apply_source(const DFab& D, const DFab& B, const DFab& S, const int lo[3], const int hi[3], double a, int nsrc,
                         const DevParams& P, int ntimes, hipStream_t stream, Profiler* prof);
 int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);

@@ -12,8 +12,15 @@ import torch
 from . import _lib as L
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(stream):
+    """hipStream_t of `stream`, or of torch's current stream on the current device (the raw-handle query is ~20x cheaper
+    than torch.cuda.current_stream(), which matters when a level of small boxes issues thousands of calls per step)."""
     if stream is None:
+        if _raw_stream is not None:
+            return C.c_void_p(_raw_stream(torch.cuda.current_device()))
         stream = torch.cuda.current_stream()
     return C.c_void_p(stream.cuda_stream)
 
@@ -165,9 +172,12 @@ class HipHydro:
 
     @staticmethod
     def make_ops(specs):
-        """ctypes array of castro_amd_fab_op from (kind, dir, ncomp, lo, hi, a, b, (dst, box), (src, box), (src2, box) | None)."""
+        """ctypes array of castro_amd_fab_op from (kind, dir, ncomp, lo, hi, a, b, (dst, box), (src, box), (src2, box) | None);
+        for OP_REFLUX `dir` is the pair (dir, side) and `a` the zone volume."""
         arr = (L.FabOp * max(len(specs), 1))()
         for o, (kind, dir_, ncomp, lo, hi, a, b, dst, src, src2) in zip(arr, specs):
+            if isinstance(dir_, tuple):
+                dir_, o.side = dir_
             o.kind, o.dir, o.ncomp, o.a, o.b = kind, dir_, ncomp, a, b
             for d in range(3):
                 o.lo[d], o.hi[d] = lo[d], hi[d]
