@@ -168,6 +168,23 @@ class OracleBackend:
         sl = self._slices(box, lo, hi)
         state[sl] = buf.reshape(state[sl].shape)
 
+    # the one-launch forms of the device path (castro_amd_pack_regions_fab): same table / offset bookkeeping, so the gloo
+    # tests on CPU go through the same exchange plan as a multi-GPU run
+    @staticmethod
+    def region_table(boxes, offsets):
+        return [(tuple(b[0]), tuple(b[1]), int(o)) for b, o in zip(boxes, offsets)]
+
+    def pack_regions(self, state, box, table, buf, stream=None):
+        for lo, hi, off in table:
+            sl = state[self._slices(box, lo, hi)]
+            buf[off:off + sl.numel()] = sl.reshape(-1)
+
+    def unpack_regions(self, state, box, table, buf, stream=None):
+        for lo, hi, off in table:
+            sl = self._slices(box, lo, hi)
+            n = state[sl].numel()
+            state[sl] = buf[off:off + n].reshape(state[sl].shape)
+
     def copy(self, dst, dst_box, src, src_box, lo, hi, stream=None):
         dst[self._slices(dst_box, lo, hi)] = src[self._slices(src_box, lo, hi)]
 
