@@ -556,8 +556,66 @@ __device__ __forceinline__ void wsqge(double p, double v, double gam, double gdo
     wsq = amax(wsq, (0.5 * (gam - 1.0) / gam) * csq);
 }
 
-// riemann_solvers.H:225-581 -- Colella & Glaz (riemann_solver = 1), the reference's GPU
-// semantics: no pstar history, so cg_blend = 2 cannot bisect and keeps the last iterate
+// pstar_bisection, riemann.H:285-376: the cg_blend = 2 fall-back of the CPU path when the secant iteration has not
+// converged (rare)
+__device__ __forceinline__ void pstar_bisection(double pstar_lo, double pstar_hi,
+                                             double ul, double pl, double taul, double gamel, double clsql,
+                                             double ur, double pr, double taur, double gamer, double clsqr,
+                                             double gdot, double gmin, double gmax, int lcg_maxiter, double lcg_tol,
+                                             double& pstar, double& gamstar, bool& converged)
+{
+    constexpr int PSTAR_BISECT_FACTOR = 5;
+    double wlsq = 0.0;
+    wsqge(pl, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar_lo, wlsq);
+    double wrsq = 0.0;
+    wsqge(pr, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar_lo, wrsq);
+
+    double wl = 1.0 / sqrt(wlsq);
+    double wr = 1.0 / sqrt(wrsq);
+
+    double ustar_l = ul - (pstar_lo - pstar) * wl;
+    double ustar_r = ur + (pstar_lo - pstar) * wr;
+
+    double f_lo = ustar_l - ustar_r;
+
+    wsqge(pl, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar_hi, wlsq);
+    wsqge(pr, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar_hi, wrsq);
+
+    converged = false;
+    double pstar_c = 0.0;
+
+    for (int iter = 0; iter < PSTAR_BISECT_FACTOR * lcg_maxiter; iter++) {
+        pstar_c = 0.5 * (pstar_lo + pstar_hi);
+
+        wsqge(pl, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar_c, wlsq);
+        wsqge(pr, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar_c, wrsq);
+
+        wl = 1.0 / sqrt(wlsq);
+        wr = 1.0 / sqrt(wrsq);
+
+        ustar_l = ul - (pstar_c - pl) * wl;
+        ustar_r = ur - (pstar_c - pr) * wr;
+
+        double f_c = ustar_l - ustar_r;
+
+        if (0.5 * fabs(pstar_lo - pstar_hi) < lcg_tol * pstar_c) {
+            converged = true;
+            break;
+        }
+
+        if (f_lo * f_c < 0.0) {
+            pstar_hi = pstar_c;
+        } else {
+            pstar_lo = pstar_c;
+            f_lo = f_c;
+        }
+    }
+    pstar = pstar_c;
+}
+
+// riemann_solvers.H:225-581 -- Colella & Glaz (riemann_solver = 1) with the CPU path's handling of non-convergence:
+// cg_blend = 1 falls back to the two-shock guess, cg_blend = 2 bisects between the extremes of the last six iterates
+// (only their minimum and maximum are kept, not the whole pstar history)
 __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, const RAux& raux,
                                           RState& qint, const DevParams& P)
 {
@@ -608,6 +666,7 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
 
     bool converged = false;
     int iter = 0;
+    double hist_lo = 1.e200, hist_hi = -1.e200;          // over pstar_hist[cg_maxiter-6 .. cg_maxiter-1]
     while ((iter < P.cg_maxiter && !converged) || iter < 2) {
         wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
         wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
@@ -637,11 +696,17 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
         double err = fabs(pstar - pstar_old);
         if (err < P.cg_tol * pstar) converged = true;
 
+        if (iter >= P.cg_maxiter - 6) { hist_lo = amin(hist_lo, pstar); hist_hi = amax(hist_hi, pstar); }
         iter++;
     }
 
     if (!converged && P.cg_blend == 1) {
         pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    } else if (!converged && P.cg_blend == 2) {
+        double pstarl = amax(hist_lo, P.small_pres);
+        double pstaru = amax(hist_hi, P.small_pres);
+        pstar_bisection(pstarl, pstaru, ql.un, ql.p, taul, gamel, clsql, qr.un, qr.p, taur, gamer, clsqr,
+                        gdot, gmin, gmax, P.cg_maxiter, P.cg_tol, pstar, gamstar, converged);
     }
 
     ustar_r = qr.un - (qr.p - pstar) * wr;

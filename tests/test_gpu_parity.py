@@ -7,6 +7,7 @@ the test.  north_star's stated tolerance is rtol 1e-10 on the plotfile.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1444,3 +1445,17 @@ def test_reference_sedov_testsuite_input_four_levels_plm():
     assert abs(r["drift"][0]) <= 1e-12 and abs(r["drift"][1]) <= 1e-11
     assert abs(r["r_peak"] - r["r_shock"]) <= 1.5 * r["dx_fine"]
     assert r["l1"] < 0.04 and r["peak"] > 3.0, r
+
+
+def test_randomised_option_combinations_match_the_oracle():
+    """tools/fuzz_parity.py: 150 random boxes (1 to 14 zones a side, random index origin), states (smooth / noisy, with and
+    without a jump, cold kinetic-energy dominated ones), boundary types, sources and combinations of every option of
+    the path (PPM / PLM and its limiters, CGF / CG with all cg_blend values / HLLC, hybrid, first order, transverse_*,
+    ppm_temp_fix, flux limiters, speed limit, artificial viscosity, flux-assign mode): bit for bit.  (This is the
+    campaign that found the missing cg_blend = 2 bisection of the CPU reference path.)"""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "150", "7"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatching 0" in r.stdout
