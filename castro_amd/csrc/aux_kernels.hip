@@ -1031,17 +1031,43 @@ __global__ void __launch_bounds__(256) k_bc_fill(DFab U, Slabs S, int ncomp, BcM
     }
 }
 
+static int launch_bc_fill_map(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const BcMap& M,
+                              hipStream_t stream, Profiler* prof);
+
 int launch_bc_fill(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const DevGeom& g,
                    const int lo_bc[3], const int hi_bc[3], hipStream_t stream, Profiler* prof)
 {
     BcMap M;
-    int blo[3], bhi[3];        // the part of the FAB that needs no physical-boundary fill
+    bool degenerate = false;       // a mirrored ghost layer reaches past the other side of the domain
     for (int d = 0; d < 3; ++d) {
         M.lo[d] = g.domlo[d]; M.hi[d] = g.domhi[d];
         M.kind_lo[d] = lo_bc[d] == 0 ? 0 : (lo_bc[d] >= 3 ? 2 : 1);      // Symmetry, SlipWall, NoSlipWall mirror
         M.kind_hi[d] = hi_bc[d] == 0 ? 0 : (hi_bc[d] >= 3 ? 2 : 1);
-        blo[d] = (M.kind_lo[d] != 0 && flo[d] < g.domlo[d]) ? g.domlo[d] : flo[d];
-        bhi[d] = (M.kind_hi[d] != 0 && fhi[d] > g.domhi[d]) ? g.domhi[d] : fhi[d];
+        const int ndom = g.domhi[d] - g.domlo[d] + 1;
+        if (M.kind_lo[d] == 2 && g.domlo[d] - flo[d] > ndom) degenerate = true;
+        if (M.kind_hi[d] == 2 && fhi[d] - g.domhi[d] > ndom) degenerate = true;
+    }
+    if (!degenerate) return launch_bc_fill_map(U, flo, fhi, ncomp, M, stream, prof);
+    // a domain narrower than the ghost depth in a mirrored direction: the sweeps read zones that other sweeps
+    // write, so they are issued one (direction, side) at a time in the reference's order
+    for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+            BcMap one = M;
+            for (int e = 0; e < 3; ++e) { one.kind_lo[e] = 0; one.kind_hi[e] = 0; }
+            if (side == 0) one.kind_lo[d] = M.kind_lo[d]; else one.kind_hi[d] = M.kind_hi[d];
+            int rc = launch_bc_fill_map(U, flo, fhi, ncomp, one, stream, prof);
+            if (rc != 0) return rc;
+        }
+    return 0;
+}
+
+static int launch_bc_fill_map(const DFab& U, const int flo[3], const int fhi[3], int ncomp, const BcMap& M,
+                              hipStream_t stream, Profiler* prof)
+{
+    int blo[3], bhi[3];        // the part of the FAB that needs no physical-boundary fill
+    for (int d = 0; d < 3; ++d) {
+        blo[d] = (M.kind_lo[d] != 0 && flo[d] < M.lo[d]) ? M.lo[d] : flo[d];
+        bhi[d] = (M.kind_hi[d] != 0 && fhi[d] > M.hi[d]) ? M.hi[d] : fhi[d];
         if (blo[d] > bhi[d]) return 0;                                      // FAB entirely outside the domain: nothing to copy from
     }
     // FAB box minus [blo, bhi] as six slabs (z slabs over the full x-y extent, then y, then x)

@@ -1459,3 +1459,15 @@ def test_randomised_option_combinations_match_the_oracle():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatching 0" in r.stdout
+
+
+def test_randomised_auxiliary_entry_points_match_the_oracle():
+    """tools/fuzz_aux.py: clean_state x 1..3 (with small_dens / speed_limit / small_temp variations), estdt, the fused
+    clean + reduce, the physical-boundary fill with every boundary type on domains down to one zone wide, all derived
+    fields, cc_interp / avgdown / error tags, gravity and rotation sources -- 100 random boxes each, bit for bit."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_aux.py"), "100", "5"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout
