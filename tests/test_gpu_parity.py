@@ -1471,3 +1471,16 @@ def test_randomised_auxiliary_entry_points_match_the_oracle():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches 0" in r.stdout
+
+
+def test_randomised_amr_layouts_match_the_oracle_backend():
+    """tools/fuzz_amr.py: 40 random hierarchies (random base grid, up to three level-1 boxes anywhere in the domain --
+    adjacent, apart, at the physical boundary -- and up to two level-2 boxes, random boundary types, Sedov or Sod, PPM or
+    PLM, CGF or HLLC), a few coarse steps each: the device driver with its batched operations against the oracle-backed
+    driver issuing one operation at a time -- same dt sequence, every box of every level bit for bit."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_amr.py"), "40", "9"], cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatching 0" in r.stdout
