@@ -45,11 +45,23 @@ for case in range(ncases):
         src_box = (tuple(x - 3 for x in bxlo), tuple(x + 3 for x in bxhi))
         shp = (7,) + tuple(src_box[1][d] - src_box[0][d] + 1 for d in (2, 1, 0))
         src = rng.normal(scale=0.3, size=shp) * (rng.uniform(size=shp) < rng.choice([1.0, 0.05]))
+    tiles = None
+    if rng.integers(0, 3) == 0:                              # the box as several tiles of one FAB (mfi.nodaltilebox semantics)
+        cuts = [sorted(set([bxlo[d]] + ([int(x) for x in rng.integers(bxlo[d] + 1, bxhi[d] + 1, size=int(rng.integers(0, 3)))]
+                                        if bxhi[d] > bxlo[d] else []))) for d in range(3)]
+        tiles = []
+        for kz, z0 in enumerate(cuts[2]):
+            for ky, y0 in enumerate(cuts[1]):
+                for kx, x0 in enumerate(cuts[0]):
+                    hi = (cuts[0][kx + 1] - 1 if kx + 1 < len(cuts[0]) else bxhi[0],
+                          cuts[1][ky + 1] - 1 if ky + 1 < len(cuts[1]) else bxhi[1],
+                          cuts[2][kz + 1] - 1 if kz + 1 < len(cuts[2]) else bxhi[2])
+                    tiles.append(((x0, y0, z0), hi))
     dx = tuple(float(x) for x in rng.choice([0.01, 0.02, 0.05], size=3))
     dt = float(rng.choice([2e-4, 8e-4, 2e-3]))
     try:
         out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, dx=dx, pkw=pkw, src=src, src_box=src_box,
-                        geom_kw=dict(lo_bc=tuple(bcs[:3]), hi_bc=tuple(bcs[3:])), flux_assign=bool(rng.integers(0, 2)))
+                        geom_kw=dict(lo_bc=tuple(bcs[:3]), hi_bc=tuple(bcs[3:])), flux_assign=bool(rng.integers(0, 2)), hip_tiles=tiles)
     except AssertionError as e:                              # a state the reference would abort on (rho <= 0 in ctoprim)
         stats["skipped"] = stats.get("skipped", 0) + 1
         continue
@@ -64,6 +76,8 @@ for case in range(ncases):
             print("case %d %s: %d entries differ (max rel %.3e, NaN hip %d oracle %d)  n=%s bc=%s %s src=%s"
                   % (case, k, ne, rd, int(np.isnan(a).sum()), int(np.isnan(b).sum()), n, bcs, pkw, src is not None))
     bad += worst > 0
+    if tiles is not None:
+        stats["tiled"] = stats.get("tiled", 0) + 1
     key = (pkw["ppm_type"], pkw["riemann_solver"])
     stats[key] = stats.get(key, 0) + 1
 print("cases %d, mismatching %d, by (ppm_type, riemann_solver): %s" % (ncases, bad, stats))
