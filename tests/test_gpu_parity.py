@@ -993,7 +993,7 @@ def test_fillpatch_shell_equals_interp_then_clean(hip, oracle):
     assert np.array_equal(a, want)
 
 
-def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap):
+def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap, bc=(0, 2, 2)):
     import torch.distributed as dist
     import torch
     import castro_amd
@@ -1002,7 +1002,7 @@ def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        c = castro_amd.Castro(n, comm=castro_amd.DistComm(), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=overlap)
+        c = castro_amd.Castro(n, comm=castro_amd.DistComm(), lo_bc=bc, hi_bc=bc, overlap=overlap)
         c.initData("sedov", r_init=0.1, nsub=4)
         dts = [c.step(0.01) for _ in range(nsteps)]
         torch.cuda.synchronize()
@@ -1019,12 +1019,13 @@ def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap", [(2, False), (2, True), (8, False)])
-def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,bc", [(2, False, (0, 2, 2)), (2, True, (0, 2, 2)), (8, False, (0, 2, 2)),
+                                              (2, False, (2, 2, 2)), (4, False, (2, 2, 2)), (8, False, (2, 2, 2)), (8, True, (2, 4, 3))])
+def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, world, overlap, bc):
     """The N > 1 device path end to end (device pack -> inter-process exchange -> device unpack -> BC fill -> hydro,
     2-double allreduce), with two processes (z split) or eight (the 2x2x2 layout of an 8-GPU node: faces, edges and
-    corners to 7 peers, and two messages per peer pair across the periodic x direction) on the one GPU of the test
-    box.  The transport is gloo (RCCL needs one device per rank); everything else is the code that runs on a
+    corners to 7 peers, and two messages per peer pair across the periodic x direction; with outflow on all faces it is
+    the layout of the driver's strong-scaling runs at 2, 4 and 8 GPUs) on the one GPU of the test box.  The transport is gloo (RCCL needs one device per rank); everything else is the code that runs on a
     multi-GPU node."""
     import torch
     import torch.multiprocessing as mp
@@ -1032,9 +1033,9 @@ def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, world, overlap):
     from tests.test_driver_cpu import _free_port
     n, nsteps = (24, 16, 32), 4
     out = str(tmp_path / "two.npz")
-    mp.spawn(_two_rank_gpu_worker, args=(world, _free_port(), n, nsteps, out, overlap), nprocs=world, join=True)
+    mp.spawn(_two_rank_gpu_worker, args=(world, _free_port(), n, nsteps, out, overlap, bc), nprocs=world, join=True)
     got = np.load(out)
-    c = castro_amd.Castro(n, lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
+    c = castro_amd.Castro(n, lo_bc=bc, hi_bc=bc, overlap=False)
     c.initData("sedov", r_init=0.1, nsub=4)
     dts = [c.step(0.01) for _ in range(nsteps)]
     torch.cuda.synchronize()
