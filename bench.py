@@ -175,13 +175,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    # one rank per GPU; the modulo only matters for the functional check of this script on a box with fewer GPUs than
+    # ranks (CASTRO_AMD_BENCH_BACKEND=gloo, every rank on the same device -- timings are then meaningless)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CASTRO_AMD_BENCH_BACKEND", "nccl")         # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
         comm = castro_amd.DistComm()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
@@ -218,7 +225,7 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     if comm is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        w = torch.tensor([wall], dtype=torch.float64, device="cpu" if comm.dist.get_backend() == "gloo" else "cuda")
         comm.dist.all_reduce(w, op=comm.dist.ReduceOp.MAX)
         wall = w.item()
     prof = c.hydro.profile_report()
