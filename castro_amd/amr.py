@@ -27,10 +27,13 @@ generation classes [3P] is orchestrated here on top of `Castro` objects, one per
 
 Fixed hierarchies: `patches=[...]`, one entry per refined level: a box (lo, hi) or a list of boxes, in the zones of
 the level below.  Level 0 is one box (per rank; this driver is single-rank).
-Not provided: multi-rank AMR, gravity / rotation on AMR levels.  The interpolation,
+Periodic domains: the periodic images of the boxes of a level enter the same-level copies and the reflux as boxes shifted
+by the domain extent.  Not provided: multi-rank AMR, gravity / rotation on AMR levels.  The interpolation,
 flux-register and clustering arithmetic is AMReX's, restated from its published description
 (include/castro_hydro_amd.h, castro_amd/cluster.py): parity with an AMReX build is unpinned.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -41,6 +44,12 @@ from .castro import Castro, NUM_GROW, NUM_STATE
 
 def _coarsen(i):
     return i // 2            # floor division is AMReX's coarsen() for negative indices too
+
+
+def _shift(box, sh):
+    """The box (lo, hi) moved by sh zones.  A FAB described with a shifted box is read at index - sh: this is how the
+    periodic images of a box enter the same-index copy / reflux operations without any kernel knowing about them."""
+    return tuple(box[0][d] + sh[d] for d in range(3)), tuple(box[1][d] + sh[d] for d in range(3))
 
 
 def _is_box(x):
@@ -106,8 +115,14 @@ class _Level:
         if self.l == 0:
             return
         parents = self.amr.lev[self.l - 1].boxes
+        # periodic images: shifts by the domain extent (in zones of this level / of the parent level)
+        per = self.amr.periodic
+        ext = [(2 ** self.l) * self.amr.n_cell[d] for d in range(3)]
+        shifts = list(itertools.product(*[(-ext[d], 0, ext[d]) if per[d] else (0,) for d in range(3)]))
+        cshifts = [tuple(x // 2 for x in sh) for sh in shifts]
         for b in self.boxes:
-            b.sib = [(s, it) for s in self.boxes if s is not b for it in [CL.intersect(b.gbox, s.bx)] if it]
+            b.sib = [(s, it, sh) for s in self.boxes for sh in shifts if not (s is b and sh == (0, 0, 0))
+                     for it in [CL.intersect(b.gbox, _shift(s.bx, sh))] if it]
             b.csrc = [(p, it) for p in parents for it in [CL.intersect(b.cbox, p.gbox)] if it]
             if len(b.csrc) == 1:
                 assert b.csrc[0][1] == b.cbox, "box not properly nested: its ghost zones need parent data beyond the parent's own ghost zones"
@@ -129,12 +144,23 @@ class _Level:
                 zlo[d] += sh; zhi[d] += sh
                 tg = []
                 for p in parents:
-                    it = CL.intersect((tuple(zlo), tuple(zhi)), p.bx)
-                    if it:
-                        flo, fhi = list(it[0]), list(it[1])
-                        flo[d] -= sh; fhi[d] -= sh
-                        tg.append((p, (tuple(flo), tuple(fhi))))
+                    for csh in cshifts:                  # a coarse zone beyond a periodic boundary is its image inside
+                        it = CL.intersect((tuple(zlo), tuple(zhi)), _shift(p.bx, csh))
+                        if it:
+                            flo, fhi = list(it[0]), list(it[1])
+                            flo[d] -= sh; fhi[d] -= sh
+                            tg.append((p, (tuple(flo), tuple(fhi)), csh))
                 b.reflux_to[(d, side)] = tg
+                # proper nesting (AMReX's Amr::grid_places guarantees it): every parent-level zone next to a face of
+                # this box is a valid zone of the parent level (or lies outside a non-periodic domain); a face that
+                # touched a still coarser level directly would lose its flux correction
+                cdom = [(2 ** (self.l - 1)) * self.amr.n_cell[x] for x in range(3)]
+                if not per[d]:
+                    zlo[d], zhi[d] = max(zlo[d], 0), min(zhi[d], cdom[d] - 1)
+                want = int(np.prod([max(zhi[x] - zlo[x] + 1, 0) for x in range(3)]))
+                have = sum(int(np.prod([fhi[x] - flo[x] + 1 for x in range(3)])) for _, (flo, fhi), _ in tg)
+                assert have == want, "box %s of level %d not properly nested: zones of level %d next to its %s face " \
+                    "belong to no box of that level" % (b.bx, self.l, self.l - 1, "xyz"[d] + "-+"[side])
             b.avg_to = [(p, it) for p in parents for it in [CL.intersect(b.pbox, p.bx)] if it]
             # ghost zones outside the problem domain (only then the physical-BC fill has anything to do)
             b.at_domain_edge = any(b.glo[d] < b.geom.domlo[d] or b.ghi[d] > b.geom.domhi[d] for d in range(3))
@@ -167,8 +193,8 @@ class _Level:
 
     def _copy_siblings(self, b, S, which):
         h = self.hydro
-        for s, (lo, hi) in b.sib:
-            h.copy(S, b.gbox, getattr(s, which), s.gbox, lo, hi)
+        for s, (lo, hi), sh in b.sib:
+            h.copy(S, b.gbox, getattr(s, which), _shift(s.gbox, sh), lo, hi)
         h.bc_fill(S, b.gbox, b.geom)                           # fine zones outside the domain
 
     def _cached_ops(self, key, ptrs, build):
@@ -215,8 +241,8 @@ class _Level:
         # 3. valid zones of the siblings (final only after every box's clean pass), all boxes in a few launches
         sp = tuple(getattr(b, which).data_ptr() for b in self.boxes)
         h.fab_ops(self._cached_ops(("sib", which), sp, lambda: h.make_ops(
-            [(L.OP_COPY, 0, NUM_STATE, lo, hi, 0.0, 0.0, (getattr(b, which), b.gbox), (getattr(sb, which), sb.gbox), None)
-             for b in self.boxes for sb, (lo, hi) in b.sib])))
+            [(L.OP_COPY, 0, NUM_STATE, lo, hi, 0.0, 0.0, (getattr(b, which), b.gbox), (getattr(sb, which), _shift(sb.gbox, sh)), None)
+             for b in self.boxes for sb, (lo, hi), sh in b.sib])))
         # 4. physical boundaries
         for b in self.boxes:
             if b.at_domain_edge:
@@ -302,6 +328,7 @@ class CastroAmr:
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
         self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
         self.n_cell = tuple(n_cell)
+        self.periodic = tuple(lo_bc[d] == 0 and hi_bc[d] == 0 for d in range(3))
         self._hydros = []
         base = Castro(n_cell, hydro=self._hydro_for(0), **self._kw)
         self.lev = [_Level(self, 0, [base])]                          # lev[0] covers the domain
@@ -393,11 +420,67 @@ class CastroAmr:
             mask[sl] = 1.0
         return tags, mask, olo
 
-    def tag_boxes(self, l=0, ghosts_filled=False, cover=()):
+    def _cell_images(self, l, a):
+        """Shifts (in blocking cells of level l) to the periodic images of the domain."""
+        ext = [(2 ** l) * self.n_cell[d] // a for d in range(3)]
+        return list(itertools.product(*[(-ext[d], 0, ext[d]) if self.periodic[d] else (0,) for d in range(3)]))
+
+    def _erode_cells(self, p, o, l, a):
+        """p (bool, [z, y, x], origin o in cells of a zones of level l) with every cell removed that has a neighbour
+        outside p.  Beyond a physical boundary everything counts as inside; beyond a periodic one lies the other end
+        of p when p spans the domain."""
+        for d in range(3):
+            ax = 2 - d
+            n = p.shape[ax]
+            nd = (2 ** l) * self.n_cell[d] // a
+            at_lo, at_hi = o[d] == 0, o[d] + n == nd
+            first, last = np.take(p, [0], axis=ax), np.take(p, [n - 1], axis=ax)
+            if self.periodic[d]:
+                wrap = at_lo and at_hi
+                below, above = (last, first) if wrap else (np.zeros_like(first), np.zeros_like(first))
+            else:
+                below = np.ones_like(first) if at_lo else np.zeros_like(first)
+                above = np.ones_like(first) if at_hi else np.zeros_like(first)
+            q = np.concatenate([below, p, above], axis=ax)
+            sl = lambda a0, a1: tuple(slice(a0, a1) if x == ax else slice(None) for x in range(3))
+            p = q[sl(0, n)] & q[sl(1, n + 1)] & q[sl(2, n + 2)]
+        return p
+
+    def _nesting_cells(self, l, lbase, o, shape, a):
+        """Amr::grid_places' proper nesting domain [3P] for the tags of level l when level lbase and everything below
+        it keep their boxes: the region of level lbase shrunk by one blocking cell, refined and shrunk by another cell
+        for every level up to l -- so that each new level fits around the next with a cell to spare.  Returned over
+        the cells (of a zones of level l) of the region (o, shape); None when there is nothing to respect (level 0
+        covers the domain)."""
+        if lbase == 0:
+            return None
+        assert all(((2 ** lbase) * self.n_cell[d]) % a == 0 for d in range(3))
+        bl = self.lev[lbase].box_list()
+        olo = [min(b[0][d] for b in bl) // a for d in range(3)]
+        ohi = [max(b[1][d] for b in bl) // a for d in range(3)]
+        p = np.zeros(tuple(ohi[d] - olo[d] + 1 for d in (2, 1, 0)), dtype=bool)
+        for lo, hi in bl:
+            p[tuple(slice(lo[d] // a - olo[d], hi[d] // a - olo[d] + 1) for d in (2, 1, 0))] = True
+        p = self._erode_cells(p, olo, lbase, a)
+        for i in range(lbase + 1, l + 1):
+            p = p.repeat(2, axis=0).repeat(2, axis=1).repeat(2, axis=2)
+            olo = [2 * x for x in olo]
+            p = self._erode_cells(p, olo, i, a)
+        out = np.zeros(shape, dtype=bool)
+        src = ((tuple(olo), tuple(olo[d] + p.shape[2 - d] - 1 for d in range(3))))
+        it = CL.intersect(src, (tuple(o), tuple(o[d] + shape[2 - d] - 1 for d in range(3))))
+        if it:
+            out[tuple(slice(it[0][d] - o[d], it[1][d] - o[d] + 1) for d in (2, 1, 0))] = \
+                p[tuple(slice(it[0][d] - olo[d], it[1][d] - olo[d] + 1) for d in (2, 1, 0))]
+        return out
+
+    def tag_boxes(self, l=0, ghosts_filled=False, cover=(), lbase=None, nest=()):
         """New boxes of level l+1 in level-l zones: clustered, buffered tags of level l, also covering `cover`
-        (boxes in level-l zones that the new boxes must contain: the footprint of the level above).  Buffering and
-        the reduction to blocking_factor/2-sized cells run where the tags are (max-pooling); only the reduced arrays
-        go to the host for the clustering."""
+        (boxes in level-l zones that the new boxes must contain: the footprint of the level above) and the blocking
+        cells of and around `nest` (that footprint without buffer: proper nesting), all inside the proper nesting
+        domain of a regrid that leaves levels <= lbase (default l) alone.  Buffering and the reduction to
+        blocking_factor/2-sized cells run where the tags are (max-pooling); only the reduced arrays go to the host
+        for the clustering."""
         import torch.nn.functional as F
         if not ghosts_filled:
             self._fill_ghosts_new(l)
@@ -419,9 +502,21 @@ class CastroAmr:
         else:
             ct, cm = tags, mask
         ct = (ct > 0.5).cpu().numpy()
+        oc = tuple(x // a for x in o)
+        for lo, hi in nest:                                     # one cell around the footprint of level l+2
+            for sh in self._cell_images(l, a):
+                it = CL.intersect((tuple(lo[d] // a - 1 + sh[d] for d in range(3)), tuple(hi[d] // a + 1 + sh[d] for d in range(3))),
+                                  (oc, tuple(oc[d] + ct.shape[2 - d] - 1 for d in range(3))))
+                if it:
+                    ct[tuple(slice(it[0][d] - oc[d], it[1][d] - oc[d] + 1) for d in (2, 1, 0))] = True
         if not ct.any():
             return []
         cm = (cm > 0.5).cpu().numpy()
+        pn = self._nesting_cells(l, l if lbase is None else lbase, oc, ct.shape, a)
+        if pn is not None:
+            cm &= pn
+            if not (ct & cm).any():
+                return []
         return CL.boxes_from_coarse(ct, cm, o, a, grid_eff=self.grid_eff,
                                     max_size=None if self.max_grid_size is None else max(self.max_grid_size // 2, a))
 
@@ -437,11 +532,12 @@ class CastroAmr:
         self._fill_ghosts_new(top, lbase, alpha)
         new = {l: self.boxes[l] for l in range(1, lbase + 1)}   # levels up to lbase keep their boxes
         for l in range(top, lbase - 1, -1):
-            cover = []
+            cover, nest = [], []
             for lo, hi in new.get(l + 2, []):                   # proper nesting: contain the level above + a buffer
+                nest.append((tuple(_coarsen(lo[d]) for d in range(3)), tuple(_coarsen(hi[d]) for d in range(3))))
                 cover.append((tuple(_coarsen(lo[d]) - self.n_error_buf for d in range(3)),
                               tuple(_coarsen(hi[d]) + self.n_error_buf for d in range(3))))
-            new[l + 1] = self.tag_boxes(l, ghosts_filled=True, cover=cover)
+            new[l + 1] = self.tag_boxes(l, ghosts_filled=True, cover=cover, lbase=lbase, nest=nest)
         out = []
         for l in range(1, top + 2):
             if not new.get(l):
@@ -506,6 +602,22 @@ class CastroAmr:
                 self._push_level(bl)
                 for b in self.lev[-1].boxes:
                     b.initData(problem, **kw)                   # fine levels start from the problem initialiser
+            # Amr::bldFineLevels' closing loop [3P]: each level above was placed inside the one before it; regrid from
+            # level 0 (initial data from the initialiser again) until the coarser levels have grown around the finer
+            # ones and the box lists stay as they are
+            for _ in range(4):
+                if len(self.lev) == 1:
+                    break
+                for l in range(len(self.lev) - 1, 0, -1):
+                    self.avgDown(l)
+                new = self._grid_places(0)
+                if new == self.boxes[1:]:
+                    break
+                self._drop_fine()
+                for bl in new:
+                    self._push_level(bl)
+                    for b in self.lev[-1].boxes:
+                        b.initData(problem, **kw)
         else:
             for lev in self.lev[1:]:
                 for b in lev.boxes:
@@ -596,13 +708,13 @@ class CastroAmr:
                     if fine.batched:
                         pp = tuple(p.S_new_b.data_ptr() for p in lev.boxes)
                         h.fab_ops(fine._cached_ops(("reflux", d, side), pp, lambda d=d, side=side: h.make_ops(
-                            [(L.OP_REFLUX, (d, side), NUM_STATE, lo, hi, vol, 0.0, (p.S_new_b, p.gbox), b.regs[(d, side)], None)
-                             for b in fine.boxes for p, (lo, hi) in b.reflux_to[(d, side)]])))
+                            [(L.OP_REFLUX, (d, side), NUM_STATE, lo, hi, vol, 0.0, (p.S_new_b, _shift(p.gbox, csh)), b.regs[(d, side)], None)
+                             for b in fine.boxes for p, (lo, hi), csh in b.reflux_to[(d, side)]])))
                     else:
                         for b in fine.boxes:
                             reg, rbox = b.regs[(d, side)]
-                            for p, (lo, hi) in b.reflux_to[(d, side)]:
-                                h.reflux(p.S_new_b, p.gbox, reg, rbox, lo, hi, d, side, NUM_STATE, vol)
+                            for p, (lo, hi), csh in b.reflux_to[(d, side)]:
+                                h.reflux(p.S_new_b, _shift(p.gbox, csh), reg, rbox, lo, hi, d, side, NUM_STATE, vol)
             self.avgDown(l + 1)
             lev.clean_new()
 

@@ -142,9 +142,9 @@ class Castro:
             self.hi.append(self.lo[d] + nloc - 1)
         self.lo, self.hi = tuple(self.lo), tuple(self.hi)
         if box is not None:
-            # a single box that does not tile the domain (a refined patch, castro_amd/amr.py): one rank, no
-            # same-level neighbours; its ghost zones come from the coarser level
-            assert self.comm.size == 1 and not any(self.periodic)
+            # a single box that does not tile the domain (a refined patch, castro_amd/amr.py): one rank; its ghost zones
+            # come from the coarser level and from the other boxes of its level (periodic images included)
+            assert self.comm.size == 1
             self.lo, self.hi = tuple(int(x) for x in box[0]), tuple(int(x) for x in box[1])
         self.n = tuple(self.hi[d] - self.lo[d] + 1 for d in range(3))
         self.glo = tuple(x - NUM_GROW for x in self.lo)
