@@ -28,7 +28,8 @@ generation classes [3P] is orchestrated here on top of `Castro` objects, one per
 Fixed hierarchies: `patches=[...]`, one entry per refined level: a box (lo, hi) or a list of boxes, in the zones of
 the level below.  Level 0 is one box (per rank; this driver is single-rank).
 Periodic domains: the periodic images of the boxes of a level enter the same-level copies and the reflux as boxes shifted
-by the domain extent.  Not provided: multi-rank AMR, gravity / rotation on AMR levels.  The interpolation,
+by the domain extent.  Constant gravity and rotation sources on every level (the Source_Type FillPatch of a refined level
+interpolates the coarse sources like the state).  Not provided: multi-rank AMR.  The interpolation,
 flux-register and clustering arithmetic is AMReX's, restated from its published description
 (include/castro_hydro_amd.h, castro_amd/cluster.py): parity with an AMReX build is unpinned.
 """
@@ -40,6 +41,8 @@ import torch
 from . import _lib as L
 from . import cluster as CL
 from .castro import Castro, NUM_GROW, NUM_STATE
+
+NSRC = 7                     # components of Source_Type (Castro_setup.cpp:317-327)
 
 
 def _coarsen(i):
@@ -69,6 +72,8 @@ class _Patch(Castro):
         self.shell = [((glo[0], glo[1], glo[2]), (ghi[0], ghi[1], lo[2] - 1)), ((glo[0], glo[1], hi[2] + 1), (ghi[0], ghi[1], ghi[2])),
                       ((glo[0], glo[1], lo[2]), (ghi[0], lo[1] - 1, hi[2])), ((glo[0], hi[1] + 1, lo[2]), (ghi[0], ghi[1], hi[2])),
                       ((glo[0], lo[1], lo[2]), (lo[0] - 1, hi[1], hi[2])), ((hi[0] + 1, lo[1], lo[2]), (ghi[0], hi[1], hi[2]))]
+        if self.have_sources:
+            self._bind_sources()
         # flux registers: the coarse faces on the six sides of this box
         plo, phi = pbox
         self.regs = {}
@@ -78,8 +83,19 @@ class _Patch(Castro):
                 rlo[d] = rhi[d] = (plo[d] if side == 0 else phi[d] + 1)
                 self.regs[(d, side)] = (self.hydro.alloc(NUM_STATE, rlo, rhi), (tuple(rlo), tuple(rhi)))
 
+    def _bind_sources(self):
+        """Source_Type data (NUM_GROW_SRC ghost zones): the coarse zones under the grown box, and the ghost shell."""
+        slo, shi = self.sbox
+        self.scbox = (tuple(_coarsen(slo[d]) - 1 for d in range(3)), tuple(_coarsen(shi[d]) + 1 for d in range(3)))
+        self.stmp = self.hydro.alloc(NSRC, *self.scbox)
+        self.new_source_g = self.hydro.alloc(NSRC, *self.sbox)
+        lo, hi = self.lo, self.hi
+        self.sshell = [((slo[0], slo[1], slo[2]), (shi[0], shi[1], lo[2] - 1)), ((slo[0], slo[1], hi[2] + 1), (shi[0], shi[1], shi[2])),
+                       ((slo[0], slo[1], lo[2]), (shi[0], lo[1] - 1, hi[2])), ((slo[0], hi[1] + 1, lo[2]), (shi[0], shi[1], hi[2])),
+                       ((slo[0], lo[1], lo[2]), (lo[0] - 1, hi[1], hi[2])), ((hi[0] + 1, lo[1], lo[2]), (shi[0], hi[1], hi[2]))]
+
     def expand_state(self, S, box=None, neighbors=None):
-        assert box is None, "refined boxes carry no Source_Type data"
+        assert box is None, "the Source_Type FillPatch of a refined level is level-wide: _Level.fill_source"
         self.level.fill_box(self, S)
 
 
@@ -94,7 +110,7 @@ class _Level:
         self.red = b0.red
         for b in self.boxes:
             b.red = self.red      # one [min dt, min rho] pair for the level: every box reduces into it
-        for k in ("use_retry", "retry_subcycle_factor", "max_subcycles", "dt_cutoff", "max_dt", "fixed_dt"):
+        for k in ("use_retry", "retry_subcycle_factor", "max_subcycles", "dt_cutoff", "max_dt", "fixed_dt", "have_sources"):
             setattr(self, k, getattr(b0, k))
         self.fuse_clean = b0.fuse_clean
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
@@ -162,6 +178,11 @@ class _Level:
                 assert have == want, "box %s of level %d not properly nested: zones of level %d next to its %s face " \
                     "belong to no box of that level" % (b.bx, self.l, self.l - 1, "xyz"[d] + "-+"[side])
             b.avg_to = [(p, it) for p in parents for it in [CL.intersect(b.pbox, p.bx)] if it]
+            if self.have_sources:                                # the same tables for the Source_Type FillPatch
+                b.ssib = [(sb, it, sh) for sb in self.boxes for sh in shifts if not (sb is b and sh == (0, 0, 0))
+                          for it in [CL.intersect(b.sbox, _shift(sb.bx, sh))] if it]
+                b.ssrc = [(p, it) for p in parents for it in [CL.intersect(b.scbox, p.sbox)] if it]
+                b.ssrc_valid = [(p, it) for p in parents for it in [CL.intersect(b.scbox, p.bx)] if it]
             # ghost zones outside the problem domain (only then the physical-BC fill has anything to do)
             b.at_domain_edge = any(b.glo[d] < b.geom.domlo[d] or b.ghi[d] > b.geom.domhi[d] for d in range(3))
         self._op_cache = {}
@@ -254,6 +275,79 @@ class _Level:
         self._interp_ghosts(b, S)
         self._copy_siblings(b, S, which)
 
+    # ---- AmrLevel::FillPatch of Source_Type (Castro_advance_ctu.cpp:138-140) ------------------------------
+    def fill_source(self, name):
+        """Ghost zones of the Source_Type data `name` (old_source / new_source_g) of every box: coarse Source_Type data
+        interpolated in time ((1 - alpha) old + alpha new, StateData's rule) and space (cell_cons_interp,
+        Castro_setup.cpp:317-327), valid data of the other boxes of the level, physical boundaries."""
+        if self.l == 0:
+            for b in self.boxes:
+                b.expand_state(getattr(b, name), b.sbox, b.src_neighbors)
+            return
+        h, a = self.hydro, self.alpha
+        for b in self.boxes:
+            for p, (lo, hi) in b.ssrc + b.ssrc_valid:           # ghost zones of the parents first, valid zones last
+                h.lincomb(b.stmp, b.scbox, 1.0 - a, p.old_source, p.sbox, a, p.new_source_g, p.sbox, NSRC, lo, hi)
+            for lo, hi in b.sshell:
+                h.cc_interp(b.stmp, b.scbox, getattr(b, name), b.sbox, lo, hi, NSRC)
+        for b in self.boxes:
+            for sb, (lo, hi), sh in b.ssib:
+                h.copy(getattr(b, name), b.sbox, getattr(sb, name), _shift(sb.sbox, sh), lo, hi)
+            h.bc_fill(getattr(b, name), b.sbox, b.geom)
+
+    def fill_new_source(self):
+        """The new-time Source_Type data with ghost zones, for the FillPatch of the next finer level."""
+        h = self.hydro
+        for b in self.boxes:
+            h.copy(b.new_source_g, b.sbox, b.new_source, b.bx, b.lo, b.hi)
+        self.fill_source("new_source_g")
+
+    def _advance_with_sources(self, time, dt):
+        """do_advance_ctu with old- and new-time gravity / rotation sources (Castro_advance_ctu.cpp:94-143, 156-274),
+        stage by stage over the boxes of the level; the per-box arithmetic is Castro._do_advance_with_sources'."""
+        h = self.hydro
+        fused = hasattr(h, "apply_source")
+        for b in self.boxes:
+            S, lo, hi = b.S_old_b, b.lo, b.hi
+            b.old_source.zero_()
+            if b.do_grav:
+                h.old_gravity_source(S, b.gbox, b.old_source, b.sbox, lo, hi, b.grav, b.grav_source_type, dt)
+            if b.rotation is not None:
+                h.old_rotation_source(S, b.gbox, b.old_source, b.sbox, lo, hi, b.rotation, b.geom, dt)
+            if fused:
+                h.apply_source(b.S_new_b, b.gbox, S, b.gbox, dt, b.old_source, b.sbox, NSRC, lo, hi, b.params, ntimes=1)
+            else:
+                h.copy(b.S_new_b, b.gbox, S, b.gbox, lo, hi)
+                h.saxpy(b.S_new_b, b.gbox, dt, b.old_source, b.sbox, NSRC, lo, hi)
+                h.clean_state(b.S_new_b, b.gbox, lo, hi, b.params, ntimes=1)
+        self.fill_source("old_source")
+        for b in self.boxes:
+            b.construct_ctu_hydro_source(time, dt, src=b.old_source)
+            b._flux_clear = False
+        for b in self.boxes:
+            h.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
+        _, rho_min = self.red.tolist()
+        if rho_min < self.params.small_dens:
+            return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
+        for b in self.boxes:
+            S, lo, hi = b.S_old_b, b.lo, b.hi
+            b.new_source.zero_()
+            if b.do_grav:
+                h.new_gravity_source(S, b.gbox, b.S_new_b, b.gbox, b.new_source, (lo, hi), b.mass_fluxes, b.flux_boxes,
+                                     lo, hi, b.grav, b.grav_source_type, dt, b.geom)
+            if b.rotation is not None:
+                h.new_rotation_source(S, b.gbox, b.S_new_b, b.gbox, b.new_source, (lo, hi), b.mass_fluxes, b.flux_boxes,
+                                      lo, hi, b.rotation, b.geom, dt)
+            if fused:
+                h.apply_source(b.S_new_b, b.gbox, b.S_new_b, b.gbox, dt, b.new_source, (lo, hi), NSRC, lo, hi, b.params, ntimes=1)
+            else:
+                h.saxpy(b.S_new_b, b.gbox, dt, b.new_source, (lo, hi), NSRC, lo, hi)
+                h.clean_state(b.S_new_b, b.gbox, lo, hi, b.params, ntimes=1)
+        new_dt = self.estTimeStep()
+        if self.params.change_max * new_dt < dt:
+            return False, "timestep validity check failed", None
+        return True, "", new_dt
+
     # ---- Castro::advance over the boxes of the level (Castro_advance.cpp:19-121) ----------------------
     def _swap_state_time_levels(self):
         for b in self.boxes:
@@ -279,6 +373,8 @@ class _Level:
             b.clean_state(b.S_old_b, 2)
         self.red.fill_(1.e200)
         self.fill("S_old_b")
+        if self.have_sources:
+            return self._advance_with_sources(time, dt)
         for b in self.boxes:
             b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
             b._flux_clear = False
@@ -311,7 +407,8 @@ _FIELDS = {"density": 0, "xmom": 1, "ymom": 2, "zmom": 3, "rho_E": 4, "rho_e": 5
 class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
-                 blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128):
+                 blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128,
+                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None):
         """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined box;
         patches = [entry, ...]: one entry per refined level, a box (lo, hi) or a list of boxes in the zones of the
         level below it (amr.max_level = len(patches)); or
@@ -326,11 +423,14 @@ class CastroAmr:
         assert (patches is None) != (refine is None), "give either fixed patches or refinement indicators"
         self._mk = (lambda: None) if make_hydro is None else make_hydro
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
-        self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False)
+        self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False,
+                        do_grav=do_grav, const_grav=const_grav, grav_source_type=grav_source_type, rotation=rotation)
         self.n_cell = tuple(n_cell)
         self.periodic = tuple(lo_bc[d] == 0 and hi_bc[d] == 0 for d in range(3))
         self._hydros = []
         base = Castro(n_cell, hydro=self._hydro_for(0), **self._kw)
+        if base.have_sources:
+            base.new_source_g = base.hydro.alloc(NSRC, *base.sbox)
         self.lev = [_Level(self, 0, [base])]                          # lev[0] covers the domain
         self.refine = refine
         self.regrid_int, self.n_error_buf, self.blocking_factor = int(regrid_int), int(n_error_buf), int(blocking_factor)
@@ -688,6 +788,8 @@ class CastroAmr:
             # ghost zones of the new data of this level, for the FillPatch of the next finer one
             lev.alpha = alpha + 0.5
             lev.fill("S_new_b")
+            if lev.have_sources:
+                lev.fill_new_source()
             # FluxRegCrseInit: -1 x this level's fluxes through the faces of the finer boxes
             if fine.batched:
                 h.fab_ops(fine.ops_crse_init)

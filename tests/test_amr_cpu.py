@@ -416,3 +416,60 @@ def test_a_box_that_touches_a_level_two_below_is_refused(oracle):
     for _ in range(2):
         a.step()
     assert abs(a.composite_sum(0) - m0) <= 1e-12 * m0
+
+
+def test_source_fillpatch_of_a_refined_level(oracle):
+    """AmrLevel::FillPatch of Source_Type on a refined level (Castro_advance_ctu.cpp:138-140): ghost zones under another
+    box of the level take its valid data, the others the coarse Source_Type data interpolated in time ((1 - alpha) old
+    + alpha new) and space -- exact for fields linear in space."""
+    import castro_amd
+    a = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(), make_hydro=OracleBackend, do_grav=True,
+                             const_grav=-1.0, patches=[[((4, 4, 4), (7, 11, 11)), ((8, 4, 4), (11, 11, 11))]])
+    c = a.crse.boxes[0]
+    (x0, y0, z0), (x1, y1, z1) = c.sbox
+    z, y, x = np.meshgrid(np.arange(z0, z1 + 1) + 0.5, np.arange(y0, y1 + 1) + 0.5, np.arange(x0, x1 + 1) + 0.5, indexing="ij")
+    for n in range(7):
+        c.old_source[n] = torch.from_numpy((n + 1) * (1.0 + 0.5 * x - 0.25 * y + 0.125 * z))
+        c.new_source_g[n] = torch.from_numpy((n + 1) * (-2.0 + 0.25 * x + 0.5 * y - 0.75 * z))
+    fine = a.fine
+    for i, b in enumerate(fine.boxes):
+        b.old_source[:] = 100.0 + i
+    fine.alpha = 0.5
+    fine.fill_source("old_source")
+    for i, b in enumerate(fine.boxes):
+        (x0, y0, z0), (x1, y1, z1) = b.sbox
+        z, y, x = np.meshgrid(*[(np.arange(p, q + 1) + 0.5) / 2 for p, q in ((z0, z1), (y0, y1), (x0, x1))], indexing="ij")
+        got = b.old_source.numpy()
+        other = fine.boxes[1 - i]
+        for n in range(7):
+            want = (n + 1) * 0.5 * ((1.0 + 0.5 * x - 0.25 * y + 0.125 * z) + (-2.0 + 0.25 * x + 0.5 * y - 0.75 * z))
+            for (lo, hi), val in ((b.bx, 100.0 + i), (other.bx, 100.0 + 1 - i)):
+                it = castro_amd.cluster.intersect((lo, hi), b.sbox)
+                want[it[0][2] - z0:it[1][2] - z0 + 1, it[0][1] - y0:it[1][1] - y0 + 1, it[0][0] - x0:it[1][0] - x0 + 1] = val
+            assert np.abs(got[n] - want).max() <= 1e-13 * np.abs(want).max()
+
+
+def test_gravity_and_rotation_on_refined_levels(oracle):
+    """Constant gravity and rotation on three levels: level 1 in one box or in two (the Source_Type ghost zones of a box
+    then come from its neighbour and from both parents) -- bit for bit the same; mass is conserved, the momentum gained
+    is the impulse of gravity to first order, and the sources are felt on every level."""
+    import castro_amd
+    rot = oracle.make_rotation(rotational_period=20.0, rot_axis=3)
+    kw = dict(params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend, do_grav=True, const_grav=-3.0, rotation=rot,
+              lo_bc=(0, 0, 0), hi_bc=(0, 0, 0))
+    l2 = ((12, 12, 12), (19, 19, 19))
+    one = castro_amd.CastroAmr((16, 16, 16), patches=[((4, 4, 4), (11, 11, 11)), l2], **kw)
+    two = castro_amd.CastroAmr((16, 16, 16), patches=[[((4, 4, 4), (11, 7, 11)), ((4, 8, 4), (11, 11, 11))], l2], **kw)
+    for a in (one, two):
+        a.initData("sedov", r_init=0.08, nsub=4)
+    m0 = one.composite_sum(0)
+    for _ in range(6):
+        assert one.step(0.05) == two.step(0.05)
+    assert np.array_equal(two.crse.S_new().numpy(), one.crse.S_new().numpy())
+    assert np.array_equal(_assemble(two.levels[1], (8, 8, 8), (16, 16, 16)), one.levels[1].S_new().numpy())
+    assert np.array_equal(two.levels[2].S_new().numpy(), one.levels[2].S_new().numpy())
+    assert abs(one.composite_sum(0) - m0) <= 1e-12 * m0            # periodic: the falling gas stays in the box
+    pz = one.composite_sum(3)
+    assert abs(pz / (m0 * -3.0 * one.time) - 1.0) < 0.02
+    far = one.levels[2].S_new().numpy()[:, 0, 0, 0]                 # a quiet corner zone of the finest level falls freely
+    assert abs(far[3] / (far[0] * -3.0 * one.time) - 1.0) < 1e-3

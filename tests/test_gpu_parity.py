@@ -1212,6 +1212,33 @@ def test_periodic_amr_on_the_device_matches_oracle_backend(oracle):
     assert np.abs(pairs["L1 box 0"][0][0] - 1.0).max() > 1e-3          # the blast has reached the boxes at the boundary
 
 
+def test_amr_with_gravity_and_rotation_on_the_device_matches_oracle_backend(oracle):
+    """Constant gravity and rotation on three levels with several boxes, periodic in z: the Source_Type FillPatch of the
+    refined levels (time / space interpolation of the coarse sources with seven components, copies between boxes,
+    boundary fill) and the fused source updates on the device against the oracle-backed driver, bit for bit."""
+    import torch
+    import castro_amd
+    from tests.oracle_backend import OracleBackend
+    kw = dict(patches=[[((4, 4, 0), (11, 7, 7)), ((4, 8, 0), (11, 11, 7)), ((4, 4, 12), (11, 11, 15))], ((12, 10, 4), (19, 19, 11))],
+              lo_bc=(2, 4, 0), hi_bc=(3, 2, 0), do_grav=True, const_grav=-3.0)
+    for gst, rst in ((4, 4), (2, 1)):
+        a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1), grav_source_type=gst,
+                                 rotation=castro_amd.make_rotation(20.0, 3, rot_source_type=rst), **kw)
+        b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+                                 grav_source_type=gst, rotation=oracle.make_rotation(20.0, 3, rot_source_type=rst), **kw)
+        for x in (a, b):
+            x.initData("sedov", r_init=0.12, nsub=4)
+        for _ in range(5):
+            assert a.step() == b.step()
+        torch.cuda.synchronize()
+        pairs = {}
+        for l in range(3):
+            for i, (x, y) in enumerate(zip(a.levels[l].boxes, b.levels[l].boxes)):
+                pairs["L%d box %d" % (l, i)] = (x.S_new().cpu().numpy(), y.S_new().numpy())
+        _assert_exact(pairs, "AMR with sources (grav_source_type %d, rot_source_type %d)" % (gst, rst))
+        assert np.abs(pairs["L2 box 0"][0][3]).max() > 1e-6
+
+
 def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
     """amr.max_level = 2 (1 + 2 + 4 advances per coarse step) on the device vs the oracle-backed orchestration."""
     import torch
