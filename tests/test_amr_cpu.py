@@ -473,3 +473,36 @@ def test_gravity_and_rotation_on_refined_levels(oracle):
     assert abs(pz / (m0 * -3.0 * one.time) - 1.0) < 0.02
     far = one.levels[2].S_new().numpy()[:, 0, 0, 0]                 # a quiet corner zone of the finest level falls freely
     assert abs(far[3] / (far[0] * -3.0 * one.time) - 1.0) < 1e-3
+
+
+def test_proper_nesting_domain(oracle):
+    """Amr::grid_places' proper nesting domain restated (CastroAmr._nesting_cells): the region of the level that keeps its
+    boxes, shrunk by one blocking cell -- not at a physical boundary, and not across a periodic one when the level
+    continues on the other side -- then refined and shrunk again for every level above."""
+    import castro_amd
+    kw = dict(params=oracle.default_params(), make_hydro=OracleBackend, blocking_factor=4)
+    # level 1 (zones of level 1: x 0..15 and 24..31, y 8..23, z 0..31): walls in x, periodic in y and z
+    a = castro_amd.CastroAmr((16, 16, 16), patches=[[((0, 4, 0), (7, 11, 15)), ((12, 4, 0), (15, 11, 15))]],
+                             lo_bc=(4, 0, 0), hi_bc=(4, 0, 0), **kw)
+    cells = a._nesting_cells(1, 1, (0, 4, 0), (16, 8, 16), 2)          # cells of 2 zones of level 1, [z, y, x]
+    want = np.zeros((16, 8, 16), dtype=bool)
+    want[:, 1:7, 0:7] = True        # x: flush with the wall at 0, one cell in from the edge at cell 7; y: one cell in on both sides
+    want[:, 1:7, 13:16] = True      # the second box: one cell in from its inner edge, flush with the wall at the top
+    assert np.array_equal(cells, want)                                   # z: the level spans the periodic domain, nothing lost
+    # one level up: refined, and another cell (of 2 zones of level 2) taken off
+    up = a._nesting_cells(2, 1, (0, 8, 0), (32, 16, 32), 2)
+    want2 = np.zeros((32, 16, 32), dtype=bool)
+    want2[:, 3:13, 0:13] = True
+    want2[:, 3:13, 27:32] = True
+    assert np.array_equal(up, want2)
+    # periodic in x with the level on both sides of the boundary: the boxes continue into each other
+    b = castro_amd.CastroAmr((16, 16, 16), patches=[[((0, 4, 0), (7, 11, 15)), ((12, 4, 0), (15, 11, 15))]],
+                             lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), **kw)
+    assert np.array_equal(b._nesting_cells(1, 1, (0, 4, 0), (16, 8, 16), 2), want)
+    # ... and with the level on one side only, the periodic boundary is an edge like any other
+    c = castro_amd.CastroAmr((16, 16, 16), patches=[[((0, 4, 0), (7, 11, 15))]], lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), **kw)
+    one = c._nesting_cells(1, 1, (0, 4, 0), (16, 8, 8), 2)
+    want3 = np.zeros((16, 8, 8), dtype=bool)
+    want3[:, 1:7, 1:7] = True
+    assert np.array_equal(one, want3)
+    assert a._nesting_cells(1, 0, (0, 4, 0), (16, 8, 16), 2) is None     # level 0 covers the domain: nothing to respect
