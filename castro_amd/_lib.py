@@ -25,7 +25,7 @@ DERIVE_IDS = {"pressure": 0, "kineng": 1, "soundspeed": 2, "Gamma_1": 3, "MachNu
 EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
-    "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status",
+    "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status", "castro_amd_ctx_poison_scratch",
     "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab",
     "castro_amd_error_tag_fab", "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
+    "castro_amd_cmpflx_points", "castro_amd_ppm_points", "castro_amd_flatten_points", "castro_amd_trans_points",
 )
 
 
@@ -116,6 +117,7 @@ def load():
     L.castro_amd_ctx_scratch_bytes.restype = C.c_longlong
     L.castro_amd_ctx_scratch_bytes.argtypes = [C.c_void_p]
     L.castro_amd_ctx_status.argtypes = [C.c_void_p, C.c_void_p]
+    L.castro_amd_ctx_poison_scratch.argtypes = [C.c_void_p, C.c_void_p]
     L.castro_amd_ctu_hydro_fab.argtypes = [
         C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
         C.c_double, C.c_double, C.c_int, C.c_void_p]
@@ -163,6 +165,12 @@ def load():
     L.castro_amd_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int,
                                              C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.castro_amd_ctx_profile_reset.argtypes = [C.c_void_p]
+    V = C.c_void_p
+    L.castro_amd_cmpflx_points.argtypes = [C.c_longlong, C.c_int, V, V, V, V, V, V, C.POINTER(Params), V, V]
+    L.castro_amd_ppm_points.argtypes = [C.c_longlong, V, V, V, V, C.c_double, V, V]
+    L.castro_amd_flatten_points.argtypes = [C.c_longlong, V, V, V, V]
+    L.castro_amd_trans_points.argtypes = [C.c_longlong, C.c_int, C.c_int, V, V, V, V, V, C.c_double, C.c_double,
+                                          C.POINTER(Params), V, V]
     _lib = L
     return L
 

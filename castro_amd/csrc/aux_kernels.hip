@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     double eint = U.p[c + U.sn * UEINT];
     double temp = U.p[c + U.sn * UTEMP];
     double rX = U.p[c + U.sn * UFS];
-    if (REDUCE) rmin_raw = fmin(rmin_raw, rho);
+    if (REDUCE) rmin_raw = fmin(rmin_raw, nan_guard(rho));
 
     clean_zone(P, ntimes, rho, mx, my, mz, eden, eint, temp, rX);
 
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     U.p[c + U.sn * UTEMP] = temp;
     U.p[c + U.sn * UFS] = rX;
 
-    if (REDUCE) dtmin = fmin(dtmin, zone_dt_cfl(P, dx0, dx1, dx2, rho, mx, my, mz, eint));
+    if (REDUCE) dtmin = fmin(dtmin, nan_guard(zone_dt_cfl(P, dx0, dx1, dx2, rho, mx, my, mz, eint)));
     }
     if (REDUCE) block_min2_atomic(dtmin, rmin_raw, red);
 }
@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, doubl
         double dt2 = dx1 / (cs + fabs(uy));
         double dt3 = dx2 / (cs + fabs(uz));
 
-        dtmin = fmin(dtmin, amin(amin(dt1, dt2), dt3));
-        rmin = fmin(rmin, rho);
+        dtmin = fmin(dtmin, nan_guard(amin(amin(dt1, dt2), dt3)));
+        rmin = fmin(rmin, nan_guard(rho));
     }
     block_min2_atomic(dtmin, rmin, out);
 }

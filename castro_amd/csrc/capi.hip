@@ -112,6 +112,8 @@ static DevParams to_devparams(const castro_amd_params* p)
     return P;
 }
 
+namespace cad { DevParams unit_devparams(const castro_amd_params* p) { return to_devparams(p); } }
+
 static DevGeom to_devgeom(const castro_amd_geom* g)
 {
     DevGeom G;
@@ -138,7 +140,7 @@ static constexpr int kPlanesResetRhoe = 9;     // F1E[3] + F2E[6], only with tra
 
 extern "C" {
 
-const char* castro_amd_version(void) { return "castro_hydro_amd 0.1 (gfx950, round 1)"; }
+const char* castro_amd_version(void) { return "castro_hydro_amd 0.2 (gfx950, round 2)"; }
 
 // Source/driver/_cpp_parameters defaults + Exec/hydro_tests/Sedov/inputs.3d.sph(.testsuite)
 void castro_amd_default_params(castro_amd_params* p)
@@ -714,6 +716,16 @@ int castro_amd_sod_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, cons
     hipSetDevice(c->device);
     return launch_sod_init(to_dfab(state), lo, hi, geom->dx, geom->problo, split, idir - 1,
                            rho_l, u_l, rho_l * e_l, T_l, rho_r, u_r, rho_r * e_r, T_r, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_ctx_poison_scratch(castro_amd_ctx* c, void* stream)
+{
+    if (!c) return CASTRO_AMD_ERR_ARG;
+    if (!c->arena) return CASTRO_AMD_OK;
+    hipSetDevice(c->device);
+    // all-ones bytes are a NaN in every double
+    return hipMemsetAsync(c->arena, 0xFF, c->arena_doubles * sizeof(double), (hipStream_t)stream) == hipSuccess
+        ? CASTRO_AMD_OK : CASTRO_AMD_ERR_HIP;
 }
 
 int castro_amd_ctx_profile(castro_amd_ctx* c, int enable)

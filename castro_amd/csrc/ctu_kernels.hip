@@ -1729,9 +1729,9 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
     }
 
     if (CLEAN) {
-        rmin_raw = un[URHO];
+        rmin_raw = nan_guard(un[URHO]);
         clean_zone(P, ntimes, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEDEN], un[UEINT], un[UTEMP], un[UFS]);
-        dtmin = zone_dt_cfl(P, dx0, dx1, dx2, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEINT]);
+        dtmin = nan_guard(zone_dt_cfl(P, dx0, dx1, dx2, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEINT]));
     }
 #pragma unroll
     for (int m = 0; m < NUM_STATE; ++m) {
@@ -1823,7 +1823,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // Only the no-source PPM path is split; otherwise A is empty and B is the whole update.
     // ppm_temp_fix = 2: the first solves go through k_riemann1<D, TFIX>: no fused x solve, no staging
     const bool tfix = P.ppm_temp_fix == 2 && P.riemann_solver != 2;
-    const bool splittable = !Src.p && P.ppm_type == 1 && !tfix;
+    // hybrid_riemann = 1: the fused x solve of stage A would read the shock flags, which k_divu writes in stage B
+    const bool splittable = !Src.p && P.ppm_type == 1 && !tfix && P.hybrid_riemann != 1;
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
     const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
     SkipBox valid_box, inner_box;

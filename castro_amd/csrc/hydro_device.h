@@ -49,6 +49,14 @@ struct DevParams {
 // amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument
 __device__ __forceinline__ double amin(double a, double b) { return (b < a) ? b : a; }
 __device__ __forceinline__ double amax(double a, double b) { return (a < b) ? b : a; }
+// copysign(1.0, x) as the reference's x86-64 CPU build evaluates it when x is a NaN.  The sign of a NaN is outside
+// IEEE 754's value semantics, but the Riemann solvers branch on it: `sgnm = copysign(1.0, ustar)` decides
+// `spout = co - sgnm*uo`, and `spout < 0` returns the (finite) upwind state even when ustar is a NaN (met with
+// cg_blend = 1, whose fall-back evaluates the two-shock guess with the INVERSE wave speeds and can drive pstar
+// negative, riemann_solvers.H:437-441).  SSE2 produces the "real indefinite" QNaN -- sign bit SET -- for every
+// invalid operation (sqrt of a negative, 0*inf, inf-inf) and add/sub/mul/div hand a NaN operand on with its sign,
+// so on the host that NaN is negative and sgnm = -1; gfx950 produces +NaN.  tests: fuzz_parity 4000/201 cases 436, 2315.
+__device__ __forceinline__ double sign_of(double x) { return (x != x) ? -1.0 : copysign(1.0, x); }
 
 // ---------------------------------------------------------------------------------------
 // gamma-law EOS (Microphysics EOS/gamma_law restated)
@@ -292,6 +300,10 @@ __device__ __forceinline__ void atomic_min_double(double* addr, double v)
     __hip_atomic_fetch_min(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A NaN enters the density / time-step minima as -1e300, so that the step is rejected and retried instead of being
+// accepted silently (the reference's std::min folds drop NaNs; deliberate deviation).
+__device__ __forceinline__ double nan_guard(double x) { return (x != x) ? -1.e300 : x; }
+
 // block-wide min of two values (wave shuffle -> LDS -> one atomic per block)
 __device__ __forceinline__ void block_min2_atomic(double a, double b, double* out)
 {
@@ -457,7 +469,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
         ustar = 0.0;
     }
 
-    double sgnm = copysign(1.0, ustar);
+    double sgnm = sign_of(ustar);
     if (ustar == 0.0) sgnm = 0.0;
 
     double fp = 0.5 * (1.0 + sgnm);
@@ -740,7 +752,7 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     double wosq = 0.0;
     wsqge(po, tauo, gameo, gdot, gamstar, gmin, gmax, clsq, pstar, wosq);
 
-    double sgnm = copysign(1.0, ustar);
+    double sgnm = sign_of(ustar);
 
     double wo = sqrt(wosq);
     double dpjmp = pstar - po;
@@ -877,7 +889,7 @@ __device__ __forceinline__ void hllc_flux(const RState& ql, const RState& qr, do
     double cstar = sqrt(fabs(gamco * pstar / rstar));
     cstar = amax(cstar, csmall);
 
-    double sgnm = copysign(1.0, ustar);
+    double sgnm = sign_of(ustar);
     double spout = co - sgnm * uo;
     double spin = cstar - sgnm * ustar;
     double ushock = 0.5 * (spin + spout);
@@ -1072,7 +1084,7 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
         F.utt = qint.utt;
         F.pgd = qint.p;
 
-        double sgnm = copysign(1.0, qint.un);
+        double sgnm = sign_of(qint.un);
         if (qint.un == 0.0) sgnm = 0.0;
 
         double fp = 0.5 * (1.0 + sgnm);

@@ -66,6 +66,46 @@ class HipHydro:
     def status(self, stream=None):
         return int(self.lib.castro_amd_ctx_status(self.h, _stream_ptr(stream)))
 
+    def poison_scratch(self, stream=None):
+        """NaN-fill the scratch arena (tests: a call must not read what an earlier call left there)."""
+        L.check(self.lib.castro_amd_ctx_poison_scratch(self.h, _stream_ptr(stream)), "ctx_poison_scratch")
+
+    # ---- pointwise forms (known-answer vectors at the level of the reference's own functions) ----
+    def cmpflx_points(self, idir, qm, qp, cl, cr, params, bnd_fac=None, is_shock=None):
+        """Castro::cmpflx_plus_godunov's body on n interfaces: qm, qp (7, n); returns (11, n)."""
+        n = qm.shape[1]
+        out = torch.empty((11, n), dtype=torch.float64, device=self.device)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        L.check(self.lib.castro_amd_cmpflx_points(n, int(idir), ptr(qm), ptr(qp), ptr(cl), ptr(cr), ptr(bnd_fac), ptr(is_shock),
+                                                  C.byref(params), ptr(out), _stream_ptr(None)), "cmpflx_points")
+        return out
+
+    def ppm_points(self, s, flatn, u, c, dtdx):
+        """ppm_reconstruct + ppm_int_profile: s (5, n) -> (sm, sp, Ip[3], Im[3]) as (8, n)."""
+        n = s.shape[1]
+        out = torch.empty((8, n), dtype=torch.float64, device=self.device)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.castro_amd_ppm_points(n, ptr(s), ptr(flatn), ptr(u), ptr(c), float(dtdx), ptr(out), _stream_ptr(None)),
+                "ppm_points")
+        return out
+
+    def flatten_points(self, p7, u5):
+        n = p7.shape[1]
+        out = torch.empty((n,), dtype=torch.float64, device=self.device)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.castro_amd_flatten_points(n, ptr(p7), ptr(u5), ptr(out), _stream_ptr(None)), "flatten_points")
+        return out
+
+    def trans_points(self, q, f1r, f1l, cdtdx1, params, tdir=0, f2r=None, f2l=None, cdtdx2=0.0):
+        """actual_trans_single (f2r is None) / actual_trans_final: q (7, n), flux records (8, n) -> (7, n)."""
+        n = q.shape[1]
+        out = torch.empty((7, n), dtype=torch.float64, device=self.device)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        L.check(self.lib.castro_amd_trans_points(n, 2 if f2r is not None else 1, int(tdir), ptr(q), ptr(f1r), ptr(f1l), ptr(f2r),
+                                                 ptr(f2l), float(cdtdx1), float(cdtdx2), C.byref(params), ptr(out),
+                                                 _stream_ptr(None)), "trans_points")
+        return out
+
     # ---- the hot path: Castro::construct_ctu_hydro_source, one FAB/tile --------------------
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,

@@ -119,6 +119,9 @@ long long castro_amd_ctx_scratch_bytes(const castro_amd_ctx *ctx);
 /* Synchronises `stream`, returns and clears the latched device status bits:
  * bit0 = rho <= 0 or rho < small_dens met in ctoprim (advection_util.cpp:56-68). */
 int castro_amd_ctx_status(castro_amd_ctx *ctx, void *stream);
+/* Fill the scratch arena with NaNs (asynchronous on `stream`): lets a caller or a test prove that a call reads
+ * nothing a previous call left behind. */
+int castro_amd_ctx_poison_scratch(castro_amd_ctx *ctx, void *stream);
 
 /* flags for castro_amd_ctu_hydro_fab */
 #define CASTRO_AMD_UPDATE_ADD 0      /* S_new += dt*div(F)...   (reference semantics: S_new holds a copy of Sborder) */
@@ -402,6 +405,34 @@ int castro_amd_ctx_profile_count(castro_amd_ctx *ctx);
 int castro_amd_ctx_profile_get(castro_amd_ctx *ctx, int idx, char *name, int name_len,
                                double *total_ms, long long *launches);
 void castro_amd_ctx_profile_reset(castro_amd_ctx *ctx);
+
+/*
+ * Pointwise forms of the per-interface / per-zone functions of the path, for known-answer vectors recorded at the level
+ * of the reference's own functions.  Flat lists of n points, device pointers, component-major: a[comp * n + point].
+ * No context: nothing is allocated.
+ *   castro_amd_cmpflx_points   body of Castro::cmpflx_plus_godunov for one interface (Source/hydro/riemann.cpp:62-203):
+ *                              load_input_states (riemann.H:66-246), riemannus / riemanncg / HLLC (riemann_solvers.H),
+ *                              compute_flux_q (:14-211), passive upwinding, HLL in shocked zones.
+ *                              qm, qp: 7 comps (rho,u,v,w,p,rhoe,X); cl, cr: sound speed of the zones either side;
+ *                              bnd_fac (NULL = 1) and is_shock (NULL = 0) per interface;
+ *                              out: 11 comps (F_rho, F_mom normal/t/tt, F_E, F_eint, F_X, Godunov un, ut, utt, p)
+ *   castro_amd_ppm_points      ppm_reconstruct (ppm.H:54-139) + ppm_int_profile (:157-252) of a five-point stencil
+ *                              s (5 comps): out = (sm, sp, Ip[3], Im[3]) under the waves u-c, u, u+c
+ *   castro_amd_flatten_points  the one-direction flattening coefficient of Castro::uflatten (flatten.cpp:12-166):
+ *                              p7 = pressure at i-3..i+3, u5 = normal velocity at i-2..i+2
+ *   castro_amd_trans_points    actual_trans_single (trans.cpp:66-437, ntrans = 1, tdir = transverse direction) or
+ *                              actual_trans_final (:498-862, ntrans = 2): q 7 comps, flux records 8 comps
+ *                              (rho, mx, my, mz, E, X fluxes, Godunov un, Godunov p) at the high (r) / low (l) face
+ */
+int castro_amd_cmpflx_points(long long n, int idir, const double *qm, const double *qp, const double *cl, const double *cr,
+                             const double *bnd_fac, const int *is_shock, const castro_amd_params *params, double *out,
+                             void *stream);
+int castro_amd_ppm_points(long long n, const double *s, const double *flatn, const double *u, const double *c, double dtdx,
+                          double *out, void *stream);
+int castro_amd_flatten_points(long long n, const double *p7, const double *u5, double *out, void *stream);
+int castro_amd_trans_points(long long n, int ntrans, int tdir, const double *q, const double *f1r, const double *f1l,
+                            const double *f2r, const double *f2l, double cdtdx1, double cdtdx2,
+                            const castro_amd_params *params, double *out, void *stream);
 
 #ifdef __cplusplus
 }

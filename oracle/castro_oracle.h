@@ -151,6 +151,8 @@ void ora_plm_reflect_fix(const int lo[3], const int hi[3], int idir, ora_a4 qm, 
 void ora_cmpflx_plus_godunov(const int lo[3], const int hi[3], ora_a4 qm, ora_a4 qp, ora_a4 flx,
                              ora_a4 qgdnv, ora_a4 qaux, ora_a4 shk, int idir,
                              const ora_geom *G, const ora_params *P);
+void ora_cmpflx_points(long n, int idir, const double *qm, const double *qp, const double *cl, const double *cr,
+                       const double *bnd_fac, const int *is_shock, const ora_params *P, double *out);
 void ora_trans_single(const int lo[3], const int hi[3], int idir_t, int idir_n, ora_a4 qm, ora_a4 qmo,
                       ora_a4 qp, ora_a4 qpo, ora_a4 qaux, ora_a4 flux_t, ora_a4 q_t,
                       double hdt, double cdtdx, const ora_params *P);

@@ -15,6 +15,11 @@
  * resolve to the FIRST argument.  Keep that exactly. */
 static inline double amin(double a, double b) { return (b < a) ? b : a; }
 static inline double amax(double a, double b) { return (a < b) ? b : a; }
+/* Deliberate deviation from the reference, on both sides of every parity test: the reference's reductions
+ * (S_new.min(URHO), the CFL minimum) are std::min folds, which DROP a NaN, so a NaN state passes its density and
+ * time-step checks silently.  Here a NaN enters the minimum as -1e300 and the step is rejected (negative density /
+ * time-step validity), which hands it to the retry logic. */
+static inline double ora_nan_guard(double x) { return (x != x) ? -1.e300 : x; }
 static inline double amin3(double a, double b, double c) { return amin(amin(a, b), c); }
 
 /* Castro_util.H:24-50 with NumAdv=0, NumSpec=1, NumAux=0 */

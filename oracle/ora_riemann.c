@@ -5,6 +5,7 @@
  * riemanncg (CG) + wsqge + pstar_bisection, HLLC, HLL, compute_flux_q.
  */
 #include <stdio.h>
+#include <string.h>
 #include "ora_internal.h"
 
 /* riemann.H:66-246 */
@@ -829,4 +830,43 @@ void ora_riemann_single(int solver, const double qlv[7], const double qrv[7], do
     else ora_riemanncg(&ql, &qr, &raux, &qi, P);
     out[0] = qi.rho; out[1] = qi.un; out[2] = qi.ut; out[3] = qi.utt; out[4] = qi.p; out[5] = qi.rhoe;
     out[6] = 0.0;
+}
+
+/* Pointwise driver of ora_cmpflx_plus_godunov for known-answer vectors: interface `p` of n lies between two zones of
+ * its own (qaux QC = cl, cr; QGAMC = eos_gamma), arrays component-major a[comp * n + p]; qm, qp: 7 comps
+ * (rho,u,v,w,p,rhoe,X); bnd_fac 0 puts the interface on a SlipWall; out: 11 comps (flux rho, normal / first / second
+ * transverse momentum, E, eint, X, Godunov un, ut, utt, p) -- the layout of castro_amd_cmpflx_points. */
+void ora_cmpflx_points(long n, int idir, const double *qm, const double *qp, const double *cl, const double *cr,
+                       const double *bnd_fac, const int *is_shock, const ora_params *P, double *out)
+{
+    const int it = (idir == 0) ? 1 : 0, itt = (idir == 2) ? 1 : 2;
+    for (long p = 0; p < n; ++p) {
+        int zlo[3] = {0, 0, 0}, zhi[3] = {0, 0, 0}, flo[3] = {0, 0, 0};
+        zlo[idir] = -1;
+        double qmv[NQ * 2] = {0}, qpv[NQ * 2] = {0}, aux[NQAUX * 2], shk[2] = {0, 0}, flx[NUM_STATE * 2] = {0}, gd[NGDNV * 2] = {0};
+        /* the face 0 of direction idir sits between zones -1 and 0; face arrays cover [-1,0] too, index 1 = face 0 */
+        const int src[7] = {QRHO, QU, QV, QW, QPRES, QREINT, QFS};
+        for (int m = 0; m < 7; ++m) { qmv[src[m] * 2 + 1] = qm[m * n + p]; qpv[src[m] * 2 + 1] = qp[m * n + p]; }
+        aux[QGAMC * 2 + 0] = P->eos_gamma; aux[QGAMC * 2 + 1] = P->eos_gamma;
+        aux[QC * 2 + 0] = cl[p]; aux[QC * 2 + 1] = cr[p];
+        if (is_shock && is_shock[p]) shk[1] = 1.0;
+        ora_geom G;
+        memset(&G, 0, sizeof(G));
+        for (int d = 0; d < 3; ++d) { G.dx[d] = 1.0; G.domlo[d] = -100; G.domhi[d] = 100; G.lo_bc[d] = BC_OUTFLOW; G.hi_bc[d] = BC_OUTFLOW; }
+        if (bnd_fac && bnd_fac[p] == 0.0) { G.domlo[idir] = 0; G.lo_bc[idir] = BC_SLIPWALL; }
+        ora_cmpflx_plus_godunov(flo, flo, ora_make_a4(qmv, zlo, zhi, NQ), ora_make_a4(qpv, zlo, zhi, NQ),
+                                ora_make_a4(flx, zlo, zhi, NUM_STATE), ora_make_a4(gd, zlo, zhi, NGDNV),
+                                ora_make_a4(aux, zlo, zhi, NQAUX), ora_make_a4(shk, zlo, zhi, 1), idir, &G, P);
+        out[0 * n + p] = flx[URHO * 2 + 1];
+        out[1 * n + p] = flx[(UMX + idir) * 2 + 1];
+        out[2 * n + p] = flx[(UMX + it) * 2 + 1];
+        out[3 * n + p] = flx[(UMX + itt) * 2 + 1];
+        out[4 * n + p] = flx[UEDEN * 2 + 1];
+        out[5 * n + p] = flx[UEINT * 2 + 1];
+        out[6 * n + p] = flx[UFS * 2 + 1];
+        out[7 * n + p] = gd[(GDU + idir) * 2 + 1];
+        out[8 * n + p] = gd[(GDU + it) * 2 + 1];
+        out[9 * n + p] = gd[(GDU + itt) * 2 + 1];
+        out[10 * n + p] = gd[GDPRES * 2 + 1];
+    }
 }

@@ -160,6 +160,7 @@ double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom 
         double dt3 = G->dx[2] / (c + fabs(uz));
 
         double d = amin3(dt1, dt2, dt3);
+        d = ora_nan_guard(d);
         estdt = amin(estdt, d);
     }
     return estdt;
@@ -171,7 +172,7 @@ double ora_min_density(const int lo[3], const int hi[3], ora_a4 u)
     _Pragma("omp parallel for num_threads(ora_state_threads) schedule(static) reduction(min:m)")
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
-    for (int i = lo[0]; i <= hi[0]; ++i) m = amin(m, A4(u,i,j,k,URHO));
+    for (int i = lo[0]; i <= hi[0]; ++i) m = amin(m, ora_nan_guard(A4(u,i,j,k,URHO)));
     return m;
 }
 

@@ -101,6 +101,8 @@ def lib():
         L.ora_riemann_single.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.c_double, C.c_double, C.c_double, C.POINTER(Params),
                                          C.POINTER(C.c_double)]
+        PD = C.POINTER(C.c_double)
+        L.ora_cmpflx_points.argtypes = [C.c_long, C.c_int, PD, PD, PD, PD, PD, C.POINTER(C.c_int), C.POINTER(Params), PD]
         L.ora_ppm_reconstruct.argtypes = [C.POINTER(C.c_double), C.c_double,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ora_ppm_int_profile.argtypes = [C.c_double] * 6 + [C.POINTER(C.c_double)] * 2
@@ -347,3 +349,17 @@ class Level:
 
     def last_hydro_seconds(self):
         return lib().ora_level_last_hydro_seconds(self.h)
+
+
+def cmpflx_points(idir, qm, qp, cl, cr, bnd_fac, P, is_shock=None):
+    """ora_cmpflx_plus_godunov one interface at a time: qm, qp (7, n) -> (11, n), the layout of castro_amd_cmpflx_points"""
+    n = qm.shape[1]
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    qm, qp, cl, cr = c(qm), c(qp), c(cl), c(cr)
+    bf = c(bnd_fac) if bnd_fac is not None else np.ones(n)
+    sh = np.ascontiguousarray(is_shock, dtype=np.int32) if is_shock is not None else None
+    out = np.empty((11, n))
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    lib().ora_cmpflx_points(n, int(idir), pd(qm), pd(qp), pd(cl), pd(cr), pd(bf),
+                            sh.ctypes.data_as(C.POINTER(C.c_int)) if sh is not None else None, C.byref(P), pd(out))
+    return out

@@ -2,7 +2,8 @@
 """Randomised driver-level campaign: castro_amd.Castro on the device against the oracle's own level driver (C, an
 independent restatement of Castro::advance / do_advance_ctu / retry / dt control): random grids, boundaries (inflow /
 outflow, walls), options, problems, constant gravity and rotation on or off, several steps -- same dt sequence, same
-retry counts, same state, bit for bit.  usage: tools/fuzz_driver.py [ncases] [seed]"""
+retry counts, same state, bit for bit.  usage: tools/fuzz_driver.py [ncases] [seed] [only]
+`only` = comma-separated case numbers: the random stream is replayed, the other cases are not computed."""
 import sys
 
 import numpy as np
@@ -14,6 +15,7 @@ from oracle import oracle_lib as oracle
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+only = set(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
 bad = 0
 for case in range(ncases):
     n = tuple(int(rng.integers(8, 17)) for _ in range(3))
@@ -28,6 +30,11 @@ for case in range(ncases):
     rkw = dict(center=(0.5, 0.5, 0.5), rot_source_type=int(rng.integers(1, 5)), implicit_rotation_update=int(rng.integers(0, 2)))
     per, ax = float(rng.choice([0.05, 1.0])), int(rng.integers(1, 4))
     ckw = dict(lo_bc=tuple(bcs[:3]), hi_bc=tuple(bcs[3:]))
+    if only is not None and case not in only:      # replay the draws below without computing
+        if str(rng.choice(["sedov", "sod"])) == "sod":
+            rng.integers(1, 4)
+        rng.integers(3, 9)
+        continue
     c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), do_grav=grav, const_grav=cg, grav_source_type=gst,
                           rotation=castro_amd.make_rotation(per, ax, **rkw) if rot else None, **ckw)
     lev = oracle.Level(n, oracle.make_geom(n, **ckw), oracle.default_params(**pkw), nthreads=4)
