@@ -29,21 +29,32 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PATH_BYTES_CONTRACT = 600.0
 PATH_BYTES_ASSIGN = 344.0
 
-# algorithmic (compulsory) bytes per processed unit of each hot-path kernel: every input and
-# output array element exactly once (DESIGN.md "Kernels").  Unit = one zone/face of the kernel's box.
+# compulsory bytes per processed unit of each hot-path kernel: every input and output array element exactly once
+# (DESIGN.md "Kernels").  Unit = one zone/face of the kernel's box.  These give the per-kernel HBM utilisation
+# (roofline.kernel_utilisation); the roofline figure itself is the SURVEY 8(d) contract above.
 KERNEL_BYTES_PER_UNIT = {
     "k_ctoprim": 8 * (8 + 8),
     "k_divu": 8 * (3 + 1),
     "k_trace": 8 * (8 + 42 + 8),                          # + F1[x]: the first x Riemann solve is fused in
     "k_riemann1": 8 * (14 + 1 + 8),
     "k_trans1": 8 * (42 + 24 + 1 + 48),                   # all three normal directions in one launch
-    "k_final": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),        # fluxes read-modify-write (8 read + 8 write + mass)
+    "k_final_rmw": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),    # fluxes read-modify-write (8 read + 8 write + mass)
     "k_final_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 9),  # fluxes written only
+    "k_finalx_consup_rmw": 8 * (14 + 16 + 1 + 1 + 8 + 17 + 18 + 8),   # x faces + consup: + FL[y], FL[z] read, S_new written
+    "k_finalx_consup_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 18 + 8),
     "k_consup": 8 * (27 + 8 + 8),
     "k_consup_clean": 8 * (27 + 8 + 8),
     "k_clean_state": 8 * (8 + 8),
     "k_estdt": 8 * 5,
 }
+
+
+def kernel_bytes_per_unit(name, contract):
+    if name in ("k_final_x", "k_final_y", "k_final_z"):
+        return KERNEL_BYTES_PER_UNIT["k_final_rmw" if contract else "k_final_assign"]
+    if name == "k_finalx_consup":
+        return KERNEL_BYTES_PER_UNIT["k_finalx_consup_rmw" if contract else "k_finalx_consup_assign"]
+    return KERNEL_BYTES_PER_UNIT.get(name, 0)
 
 
 def kernel_units(name, n):
@@ -52,54 +63,42 @@ def kernel_units(name, n):
         "k_ctoprim": (nx + 8) * (ny + 8) * (nz + 8),
         "k_divu": (nx + 2) * (ny + 2) * (nz + 2),
         "k_trace": (nx + 2) * (ny + 2) * (nz + 2),
-        "k_riemann1": ((nx + 1) * (ny + 2) * (nz + 2) + (nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 3.0,
+        "k_riemann1": ((nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 2.0,     # y and z launches
         "k_trans1": (nx + 2) * (ny + 2) * (nz + 2),
-        "k_final": ((nx + 1) * ny * nz + nx * (ny + 1) * nz + nx * ny * (nz + 1)) / 3.0,
-        "k_consup": nx * ny * nz,
-        "k_consup_clean": nx * ny * nz,
-        "k_clean_state": nx * ny * nz,
-        "k_estdt": nx * ny * nz,
+        "k_final_x": (nx + 1) * ny * nz,
+        "k_final_y": nx * (ny + 1) * nz,
+        "k_final_z": nx * ny * (nz + 1),
+        "k_finalx_consup": (nx + 1) * ny * nz,
     }.get(name, nx * ny * nz)
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed PMC pass (profiles/*_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 correction on FETCH_SIZE).
-    Counters cannot be collected from inside this process, so None if no profile is committed."""
+def source_stamp():
+    """sha1 over the kernel sources: ties a committed PMC profile to the code it was taken from"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "castro_amd", "csrc")
+    for f in ("hydro_device.h", "ctu_kernels.h", "ctu_kernels.hip", "aux_kernels.hip", "capi.hip"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_per_step():
+    """L2->fabric bytes of one 256^3 step from the newest committed PMC pass (profiles/*_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction on FETCH_SIZE, tools/pmc.sh).  Counters cannot be
+    collected from inside this process; the profile is used only if it carries the stamp of the kernel sources this
+    run was built from, otherwise (None, reason)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
-        return None, None
+        return None, "no committed profile"
     try:
         d = json.load(open(files[-1]))
-        alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup", "k_divu": "k_divu_pair"}       # hipEvent label -> kernel symbol
-        k = d["kernels"].get(kernel) or d["kernels"][alias[kernel]]
-        return k["bytes_per_launch"], os.path.relpath(files[-1], ROOT)
-    except (KeyError, ValueError):
-        return None, None
-
-
-def pmc_traffic_per_step(prof, steps):
-    """Sum over the hot-path kernels of (PMC bytes per launch from the committed profile) x (launches per step
-    counted live): the L2->fabric traffic of one step.  None without a committed profile."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))["kernels"]
-    alias = {"k_trace": "k_trace_pair", "k_consup_clean": "k_consup", "k_divu": "k_divu_pair"}
-    tot = 0.0
-    for name, (ms, launches) in prof.items():
-        k = d.get(name) or d.get(alias.get(name, ""))
-        if k is None:
-            continue
-        if name == "k_riemann1" and "k_riemann1_blockstart" in d:
-            # two full launches + one block-start launch per step share the label
-            per_step = 2 * k["bytes_per_launch"] + d["k_riemann1_blockstart"]["bytes_per_launch"]
-            tot += per_step
-            continue
-        tot += k["bytes_per_launch"] * launches / max(steps, 1)
-    return tot
+    except ValueError:
+        return None, "unreadable profile"
+    if d.get("source_stamp") != source_stamp():
+        return None, "%s was taken from other kernel sources (stamp %s, now %s)" % (
+            os.path.relpath(files[-1], ROOT), d.get("source_stamp"), source_stamp())
+    return d.get("bytes_per_step"), os.path.relpath(files[-1], ROOT)
 
 
 def usable_cpus():
@@ -163,6 +162,7 @@ def main():
     ap.add_argument("--force-overlap", action="store_true", help="staged overlap (ghost-free part of the update while the halo "
                     "exchange runs on the communication stream), as every rank of a multi-GPU run does")
     ap.add_argument("--overlap-tiles", action="store_true", help="the older interior tile + 6 boundary slabs form of the overlap")
+    ap.add_argument("--no-contract-leg", action="store_true", help="skip the 600-B contract leg of the default run")
     ap.add_argument("--reference-contract", action="store_true",
                     help="zero-fill + accumulate fluxes and run clean_state/estdt as separate passes (600 B/cell form)")
     args = ap.parse_args()
@@ -200,14 +200,7 @@ def main():
 
     contract = args.reference_contract
     bc = (0, 0, 0) if args.periodic else (2, 2, 2)
-    c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc,
-                          overlap=(False if args.no_overlap else ("tiles" if args.overlap_tiles else
-                                                                  (True if args.force_overlap else None))),
-                          fuse_clean=not contract, flux_assign=not contract)
-    PATH_BYTES_PER_CELL = PATH_BYTES_CONTRACT if contract else PATH_BYTES_ASSIGN
-    c.initData("sedov")                      # synthetic input, generated on the device
-    for _ in range(args.warmup):
-        c.step()
+    overlap = (False if args.no_overlap else ("tiles" if args.overlap_tiles else (True if args.force_overlap else None)))
 
     def sync():
         torch.cuda.synchronize()
@@ -215,51 +208,76 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    c.hydro.profile(True)
-    c.hydro.profile_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        c.step()
-    sync()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    if comm is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device="cpu" if comm.dist.get_backend() == "gloo" else "cuda")
-        comm.dist.all_reduce(w, op=comm.dist.ReduceOp.MAX)
-        wall = w.item()
-    prof = c.hydro.profile_report()
-    c.hydro.profile(False)
+    def run(contract_mode, steps, warmup, kernel_pass):
+        """W untimed warm-up steps, K timed steps (no profiling events in the timed region), then -- untimed -- a second
+        pass of min(K, 5) steps with hipEvents around every kernel on its launch stream for the per-kernel table."""
+        c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc, overlap=overlap,
+                              fuse_clean=not contract_mode, flux_assign=not contract_mode)
+        c.initData("sedov")                      # synthetic input, generated on the device
+        for _ in range(warmup):
+            c.step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.step()
+        sync()
+        wall = time.perf_counter() - t0
+        if comm is not None:
+            w = torch.tensor([wall], dtype=torch.float64, device="cpu" if comm.dist.get_backend() == "gloo" else "cuda")
+            comm.dist.all_reduce(w, op=comm.dist.ReduceOp.MAX)
+            wall = w.item()
+        prof, ksteps = {}, 0
+        if kernel_pass:
+            ksteps = min(steps, 5)
+            c.hydro.profile(True)
+            c.hydro.profile_reset()
+            for _ in range(ksteps):
+                c.step()
+            sync()
+            prof = c.hydro.profile_report()
+            c.hydro.profile(False)
+        info = {"zones_per_gpu": c.n[0] * c.n[1] * c.n[2], "sim_time": c.time, "nstep": c.nstep, "n": c.n,
+                "overlap_halo": ("tiles" if c.overlap == "tiles" else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
+                "halo": c.halo_stats() if hasattr(c, "halo_stats") else None}
+        del c
+        torch.cuda.empty_cache()
+        return wall, prof, ksteps, info
 
+    wall, prof, ksteps, info = run(contract, args.steps, args.warmup, True)
     total_cells = n_cell[0] * n_cell[1] * n_cell[2]
     value = total_cells * args.steps / wall
+    bytes_per_cell = PATH_BYTES_CONTRACT if contract else PATH_BYTES_ASSIGN
 
-    # dominant kernel (largest total device time over the timed region), hipEvent-timed on its stream
-    roof = None
-    if prof:
-        name, (tot_ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
-        avg_s = tot_ms / launches / 1e3
-        units = kernel_units(name, c.n)
-        alg_bytes = KERNEL_BYTES_PER_UNIT.get(name + "_assign" if (name == "k_final" and not contract) else name, 0) * units
-        achieved = alg_bytes / avg_s / 1e9
-        traffic, traffic_src = pmc_traffic(name)
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": name, "avg_launch_ms": avg_s * 1e3, "launches": launches,
-                "algorithmic_bytes_per_launch": alg_bytes}
-    hydro_ms = sum(v[0] for k, v in prof.items() if k in ("k_ctoprim", "k_divu", "k_trace", "k_riemann1", "k_trans1",
-                                                          "k_final", "k_consup", "k_consup_clean")) / max(args.steps, 1)
-    traffic_step = pmc_traffic_per_step(prof, args.steps) if prof else None
-    path = {"bytes_per_cell_update": PATH_BYTES_PER_CELL,
-            "achieved_GBs_per_gpu": value / world * PATH_BYTES_PER_CELL / 1e9,
-            "frac_of_hbm_peak": value / world * PATH_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS,
-            "hydro_kernels_ms_per_step": hydro_ms,
-            # hardware utilisation: PMC traffic of one step (committed rocprofv3 profile of this command) over the
-            # measured step time, against the 8 TB/s peak
-            "pmc_traffic_bytes_per_step": traffic_step,
-            "pmc_traffic_GBs": (traffic_step / (wall / args.steps) / 1e9) if traffic_step and world == 1 and c.n == (256, 256, 256) else None,
-            "pmc_traffic_frac_of_hbm_peak": (traffic_step / (wall / args.steps) / 1e9 / HBM_PEAK_GBS) if traffic_step and world == 1 and c.n == (256, 256, 256) else None,
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())}}
+    # per-kernel HBM utilisation: compulsory bytes of a launch over its hipEvent-timed duration
+    kutil = {}
+    for name, (tot_ms, launches) in sorted(prof.items()):
+        bpu = kernel_bytes_per_unit(name, contract)
+        avg_ms = tot_ms / launches
+        e = {"avg_launch_ms": avg_ms, "launches_per_step": launches / ksteps, "ms_per_step": tot_ms / ksteps}
+        if bpu:
+            nb = bpu * kernel_units(name, info["n"])
+            e.update({"compulsory_bytes_per_launch": nb, "GBs": nb / avg_ms / 1e6, "frac_of_hbm_peak": nb / avg_ms / 1e6 / HBM_PEAK_GBS})
+        kutil[name] = e
+    traffic_step, traffic_src = pmc_traffic_per_step() if (world == 1 and info["n"] == (256, 256, 256) and not contract) else (None, "n/a for this configuration")
+
+    # SURVEY 8(d): roofline = cell-updates/s x declared bytes per cell-update over the 8 TB/s HBM peak (per GPU)
+    achieved = value / world * bytes_per_cell / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic_step, "traffic_source": traffic_src,
+            "bytes_per_cell_update": bytes_per_cell,
+            "definition": "SURVEY 8(d): cell-updates/s x declared contract bytes per cell-update / 8 TB/s; traffic = L2->fabric "
+                          "bytes of one step (PMC, committed profile of the same sources)",
+            "kernel_utilisation": kutil}
+    if traffic_step:
+        roof["traffic_GBs"] = traffic_step / (wall / args.steps) / 1e9
+        roof["traffic_over_algorithmic"] = traffic_step / (bytes_per_cell * total_cells)
+    if not contract and world == 1 and not args.no_contract_leg:
+        # the reference's full output contract (zero-filled fluxes accumulated with +=, S_new read-modify-write,
+        # clean_state / estdt as separate passes) timed in the same run
+        w6, _, _, _ = run(True, max(5, args.steps // 2), 2, False)
+        v6 = total_cells * max(5, args.steps // 2) / w6
+        roof["contract_600B"] = {"ms_per_step": w6 / max(5, args.steps // 2) * 1e3, "value": v6,
+                                 "achieved": v6 * PATH_BYTES_CONTRACT / 1e9, "frac": v6 * PATH_BYTES_CONTRACT / 1e9 / HBM_PEAK_GBS}
 
     out = {
         "metric": "cell-updates/sec, Sedov 3D 256\u00b3 single-level at 1/2/4/8 MI355X; % HBM roofline",
@@ -268,12 +286,11 @@ def main():
         "scaling": "weak" if args.weak else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Sedov 3D %dx%dx%d single level, gamma-law EOS, PPM + CGF Riemann, CTU" % n_cell,
-                   "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": c.n[0] * c.n[1] * c.n[2],
-                   "overlap_halo": ("tiles" if c.overlap == "tiles" else bool(c.overlap and c._comm_stream is not None and c.neighbors)), "sim_time": c.time, "nstep": c.nstep,
+                   "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": info["zones_per_gpu"],
+                   "overlap_halo": info["overlap_halo"], "sim_time": info["sim_time"], "nstep": info["nstep"],
                    "flux_mode": "accumulate (600 B/cell contract)" if contract else "assign (344 B/cell, declared)",
-                   "fused_clean_state": not contract},
+                   "fused_clean_state": not contract, "halo": info["halo"]},
         "roofline": roof,
-        "path_roofline": path,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_ncell, args.cpu_steps)

@@ -17,6 +17,8 @@ sub-box, which needs no remote data, on the compute stream.
 """
 import itertools
 
+import time
+
 import torch
 
 from . import _lib as L
@@ -316,6 +318,23 @@ class Castro:
         for nb in neighbors:
             h.unpack(S, box, nb["rbox"][0], nb["rbox"][1], nb["rbuf"])
         h.bc_fill(S, box, self.geom)
+
+    def halo_stats(self, repeats=5):
+        """What one FillBoundary of the state costs this rank: bytes sent to other ranks per step, the number of
+        neighbour regions, and the wall time of pack + exchange + unpack + BC fill measured on an idle stream
+        (bench.py --gpus N reports it; Castro.cpp:4201-4209 expand_state)."""
+        remote = [nb for nb in self.neighbors if nb["peer"] != self.comm.rank]
+        nbytes = sum(nb["sbuf"].numel() * 8 for nb in remote)
+        torch.cuda.synchronize()
+        self.comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            self.expand_state(self.S_old_b)
+        torch.cuda.synchronize()
+        self.comm.barrier()
+        ms = (time.perf_counter() - t0) / repeats * 1e3
+        return {"regions": len(self.neighbors), "remote_regions": len(remote), "bytes_sent_per_step": nbytes,
+                "fillboundary_ms": ms}
 
     # ---- Castro::clean_state ---------------------------------------------------------------
     def clean_state(self, S, ntimes=1):

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; }
+namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; }
 
 using namespace cad;
 
@@ -128,9 +128,13 @@ static DevGeom to_devgeom(const castro_amd_geom* g)
     return G;
 }
 
+// x extent of a scratch plane: the tile grown by 4, preceded by g_xpad unused columns and rounded up to a multiple of
+// 16 doubles when g_xpad > 0, so that zone lo[0] - 4 + (4 + g_xpad) starts a 128-byte line in every row
+static int scratch_nx(int nx) { return cad::g_xpad > 0 ? ((nx + 8 + cad::g_xpad + 15) & ~15) : nx + 8; }
+
 static size_t plane_doubles(int nx, int ny, int nz)
 {
-    size_t n = (size_t)(nx + 8) * (ny + 8) * (nz + 8);
+    size_t n = (size_t)scratch_nx(nx) * (ny + 8) * (nz + 8);
     return (n + 31) & ~(size_t)31;     // keep every component plane 256-byte aligned
 }
 
@@ -192,6 +196,16 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
     if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
+    if (const char* e = std::getenv("CASTRO_AMD_FUSE_CONSUP")) g_fuse_consup = std::atoi(e);   // 0: k_final<x> + k_consup
+    if (const char* e = std::getenv("CASTRO_AMD_FINAL_LDS")) g_final_lds = std::atoi(e);   // 0: the plain k_final
+    if (const char* e = std::getenv("CASTRO_AMD_XPAD")) g_xpad = std::atoi(e);             // unused columns in front of every scratch row
+    if (const char* e = std::getenv("CASTRO_AMD_BRICK_LDS")) g_brick_lds_budget = std::atoi(e);   // bytes per workgroup
+    if (const char* e = std::getenv("CASTRO_AMD_BRICK")) {                                   // "tx2,ty,tz" of the brick kernels
+        int a = 0, b = 0, c2 = 0;
+        if (std::sscanf(e, "%d,%d,%d", &a, &b, &c2) == 3 && a >= 0 && b >= 0 && c2 >= 0 && a * b * c2 <= 256) {
+            g_brick[0] = a; g_brick[1] = b; g_brick[2] = c2;          // 0,0,0: chosen per launch
+        }
+    }
     *out = c;
     return CASTRO_AMD_OK;
 }
@@ -280,7 +294,8 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
         ghi[d] = bxhi[d] + CASTRO_AMD_NUM_GROW;
     }
     const int nx = bxhi[0] - bxlo[0] + 1, ny = bxhi[1] - bxlo[1] + 1, nz = bxhi[2] - bxlo[2] + 1;
-    t.NX = nx + 8; t.NY = ny + 8; t.NZ = nz + 8;
+    t.glo[0] -= g_xpad;
+    t.NX = scratch_nx(nx); t.NY = ny + 8; t.NZ = nz + 8;
     t.NC = (long)plane_doubles(nx, ny, nz);
 
     if (!fab_contains(Sborder, glo, ghi)) return CASTRO_AMD_ERR_ARG;

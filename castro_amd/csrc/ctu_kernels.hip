@@ -1444,8 +1444,16 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     double fr[2][NF1], fl[2][NF1], qmo[2][NEDGE], qpo[2][NEDGE];
 
     // minus states live in zones c - sn; their T-faces are (c - sn) and (c - sn + st)
+#ifdef DIAG_F1_REUSE      // timing diagnostic (wrong results): one record load per (N,T) instead of four
+    load_f1_2(S.F1[T], t.NC, c, fl);
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int n = 0; n < NF1; ++n) fr[w][n] = fl[w][n] * 1.01;
+#else
     load_f1_2(S.F1[T], t.NC, c - sn + st, fr);
     load_f1_2(S.F1[T], t.NC, c - sn, fl);
+#endif
     if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
         const D2 er = ldg2(S.F1E[T], c - sn + st), el = ldg2(S.F1E[T], c - sn);
         trans_single<T>(qm[0], fr[0], fl[0], P.gamma, cdtdx, P, qmo[0], er.a, el.a);
@@ -1456,8 +1464,10 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     }
 
     // plus states live in zones c
+#ifndef DIAG_F1_REUSE
     load_f1_2(S.F1[T], t.NC, c + st, fr);
     load_f1_2(S.F1[T], t.NC, c, fl);
+#endif
     if (RE && P.reset_rhoe == 1) {
         const D2 er = ldg2(S.F1E[T], c + st), el = ldg2(S.F1E[T], c);
         trans_single<T>(qp[0], fr[0], fl[0], P.gamma, cdtdx, P, qpo[0], er.a, el.a);
@@ -1556,16 +1566,18 @@ __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* 
 
 // one normal direction of the final stage for the faces (ijk) and (ijk + x); v0 / v1: the faces belong to
 // nodal(bx, N)
-template <int N, bool RE, bool LIM>
+// c0 / c1: compute face 0 / 1 of the pair; v0 / v1: store its outputs (fluxes, mass_fluxes, qe and, with STORE_FL, the
+// record for consup).  R returns the records of both faces.
+template <int N, bool RE, bool LIM, bool STORE_FL = true>
 __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool v0, bool v1, unsigned c,
                                            const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                            const DFab& U, const DFab& fluxes, const DFab& mass, const DFab& qe,
                                            double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
-                                           int acc_hi, int assign, const DevParams& P)
+                                           int acc_hi, int assign, const DevParams& P, double R[2][NFIN])
 {
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
-    if (!v0 && !v1) return;
+    if (STORE_FL && !v0 && !v1) return;
     const Str s = gstr(t);
     const unsigned sn = dstr(s, N), s1 = dstr(s, T1), s2 = dstr(s, T2);
     const long NC = t.NC;
@@ -1578,10 +1590,19 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     // minus states (zones c - sn)
     load_edge_2(S.QM[N], NC, c, q);
     if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }   // changed by its first solve
+#ifdef DIAG_F2_REUSE      // timing diagnostic (wrong results): two record loads per face pair instead of eight
+    load_f1_2(F12, NC, c, f1l);
+    load_f1_2(F21, NC, c, f2l);
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int n = 0; n < NF1; ++n) { f1r[w][n] = f1l[w][n] * 1.01; f2r[w][n] = f2l[w][n] * 0.99; }
+#else
     load_f1_2(F12, NC, c - sn + s1, f1r);
     load_f1_2(F12, NC, c - sn, f1l);
     load_f1_2(F21, NC, c - sn + s2, f2r);
     load_f1_2(F21, NC, c - sn, f2l);
+#endif
     if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
         const double* E12 = S.F2E[f2_slot(T1, T2)];
         const double* E21 = S.F2E[f2_slot(T2, T1)];
@@ -1596,10 +1617,12 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     // plus states (zones c)
     load_edge_2(S.QP[N], NC, c, q);
     if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }
+#ifndef DIAG_F2_REUSE
     load_f1_2(F12, NC, c + s1, f1r);
     load_f1_2(F12, NC, c, f1l);
     load_f1_2(F21, NC, c + s2, f2r);
     load_f1_2(F21, NC, c, f2l);
+#endif
     if (RE && P.reset_rhoe == 1) {
         const double* E12 = S.F2E[f2_slot(T1, T2)];
         const double* E21 = S.F2E[f2_slot(T2, T1)];
@@ -1619,7 +1642,6 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 #pragma unroll
         for (int w = 0; w < 2; ++w) { temp_fix_edge(ql[w], P); temp_fix_edge(qr[w], P); }
     }
-    double R[2][NFIN];
     IFlux f[2];
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
@@ -1633,6 +1655,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     }
     final_flux_tail<N, LIM>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
                             ijk[0], ijk[1], ijk[2], dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
+    if (!STORE_FL) return;
     double* FL = S.FL[N];
     if (v0 && v1) {
 #pragma unroll
@@ -1658,7 +1681,165 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    final_body<N, RE, LIM>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P);
+    double R[2][NFIN];
+    final_body<N, RE, LIM>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R);
+}
+
+// ---------------------------------------------------------------------------------------
+// Brick launches: a workgroup owns a tile of tx2 x-pairs by ty by tz faces (or zones) and stages the flux records its
+// threads share -- every record of the transverse stage is read by eight threads -- in LDS, once, with 16-byte loads
+// along the x pencil.  The records of one array are kept component by component (SoA like the scratch planes), the x
+// extent padded to an even number of doubles so that a thread's two faces are one 16-byte LDS access.
+// Workgroup ids map to tiles XCD by XCD like LinBox does: id -> (id % 8) * (nb / 8) + id / 8, tiles x fastest.
+// ---------------------------------------------------------------------------------------
+struct Brick {
+    int lo[3], hi[3];      // faces (zones) the launch covers
+    int tx2, ty, tz;       // pair-threads along x, rows in y and z of one workgroup (tx2 * ty * tz <= 256)
+    int ntx, nty, ntz;     // tiles per direction
+    unsigned nb;           // workgroups launched, a multiple of 8
+    int exs[2], ey[2], ez[2];   // LDS extents of the two staged arrays (exs even)
+};
+
+// stage the records of plane set A (NF1 components) for the region [o, o + e) into LDS: rows of e0 doubles as
+// ceil(e0 / 2) 16-byte loads; 32 lanes per row, 8 rows per pass
+__device__ __forceinline__ void brick_stage(const Tile& t, const double* __restrict__ A, double* __restrict__ L,
+                                            const int o[3], const int e[3], int exs, int ey, int ez)
+{
+    const int lane = threadIdx.x & 31, rsel = threadIdx.x >> 5;      // 8 row slots of 32 lanes
+    const int units = (e[0] + 1) >> 1;
+    const int nrow = e[1] * e[2];
+    const int cs = exs * ey * ez;
+    for (int u0 = 0; u0 < units; u0 += 32) {
+        const int u = u0 + lane;
+        for (int r = rsel; r < nrow; r += 8) {
+            const int z = r / e[1], y = r - z * e[1];
+            if (u < units) {
+                const unsigned c = goff(t, o[0] + 2 * u, o[1] + y, o[2] + z);
+                const int li = (z * ey + y) * exs + 2 * u;
+#pragma unroll
+                for (int n = 0; n < NF1; ++n) {
+                    const D2 v = ldg2(A + (long)n * t.NC, c);
+                    L[n * cs + li] = v.a;
+                    L[n * cs + li + 1] = v.b;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void lds_rec2(const double* __restrict__ L, int cs, int idx, double r[2][NF1])
+{
+#pragma unroll
+    for (int n = 0; n < NF1; ++n) { r[0][n] = L[n * cs + idx]; r[1][n] = L[n * cs + idx + 1]; }
+}
+
+// k_final<N> with the two transverse flux arrays F^{T1|T2}, F^{T2|T1} staged in LDS (default options only: the
+// transverse_reset_rhoe / ppm_temp_fix instantiations keep the plain kernel)
+template <int N, bool LIM>
+__global__ void __launch_bounds__(256) k_final_lds(Tile t, Brick b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                   DFab U, DFab fluxes, DFab mass, DFab qe,
+                                                   double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
+                                                   int acc_hi, int assign, DevParams P)
+{
+    constexpr int T1 = (N == 0) ? 1 : 0;
+    constexpr int T2 = (N == 2) ? 1 : 2;
+    extern __shared__ double lds[];
+
+    unsigned bid = blockIdx.x;
+    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
+    if (bid >= (unsigned)(b.ntx * b.nty * b.ntz)) return;
+    const int tX = (int)(bid % (unsigned)b.ntx);
+    const unsigned rr = bid / (unsigned)b.ntx;
+    const int tY = (int)(rr % (unsigned)b.nty), tZ = (int)(rr / (unsigned)b.nty);
+    int l[3] = { b.lo[0] + tX * 2 * b.tx2, b.lo[1] + tY * b.ty, b.lo[2] + tZ * b.tz };
+    int n[3] = { 2 * b.tx2, b.ty, b.tz };
+#pragma unroll
+    for (int d = 0; d < 3; ++d) if (l[d] + n[d] - 1 > b.hi[d]) n[d] = b.hi[d] - l[d] + 1;
+
+    // staged regions: zones c - sn and c of every face of the tile, low and high face of the array's own direction
+    int o0[3], e0[3], o1[3], e1[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        o0[d] = o1[d] = l[d] - (d == N ? 1 : 0);
+        e0[d] = n[d] + (d == N ? 1 : 0) + (d == T1 ? 1 : 0);
+        e1[d] = n[d] + (d == N ? 1 : 0) + (d == T2 ? 1 : 0);
+    }
+    double* L0 = lds;
+    const int cs0 = b.exs[0] * b.ey[0] * b.ez[0], cs1 = b.exs[1] * b.ey[1] * b.ez[1];
+    double* L1 = lds + NF1 * cs0;
+    brick_stage(t, S.F2[f2_slot(T1, T2)], L0, o0, e0, b.exs[0], b.ey[0], b.ez[0]);
+    brick_stage(t, S.F2[f2_slot(T2, T1)], L1, o1, e1, b.exs[1], b.ey[1], b.ez[1]);
+
+    // this thread's faces
+    const int px = (int)(threadIdx.x % (unsigned)b.tx2);
+    const int rw = (int)(threadIdx.x / (unsigned)b.tx2);
+    const int ry = rw % b.ty, rz = rw / b.ty;
+    const int i = l[0] + 2 * px, j = l[1] + ry, k = l[2] + rz;
+    const bool v0 = 2 * px < n[0] && ry < n[1] && rz < n[2];
+    const bool v1 = v0 && 2 * px + 1 < n[0];
+
+    const Str s = gstr(t);
+    const unsigned sn = dstr(s, N), s1 = dstr(s, T1), s2 = dstr(s, T2);
+    const long NC = t.NC;
+    const unsigned c = goff(t, i, j, k);
+    double qm[2][NEDGE], qp[2][NEDGE];
+    D2 cl, cr;
+    if (v0) {
+        // issued before the barrier: in flight while the tile is being staged
+        load_edge_2(S.QM[N], NC, c, qm);
+        load_edge_2(S.QP[N], NC, c, qp);
+        cl = ldg2(Q + PC * NC, c - sn);
+        cr = ldg2(Q + PC * NC, c);
+    }
+    __syncthreads();
+    if (!v0) return;
+
+    // LDS index of (face i, j, k) in the two arrays; the offsets of the four records around it
+    const int b0 = ((k - o0[2]) * b.ey[0] + (j - o0[1])) * b.exs[0] + (i - o0[0]);
+    const int b1 = ((k - o1[2]) * b.ey[1] + (j - o1[1])) * b.exs[1] + (i - o1[0]);
+    const int st0[3] = { 1, b.exs[0], b.exs[0] * b.ey[0] }, st1[3] = { 1, b.exs[1], b.exs[1] * b.ey[1] };
+    const int n0 = st0[N], n1 = st1[N], h0 = st0[T1], h1 = st1[T2];
+
+    double ql[2][NEDGE], qr[2][NEDGE];
+    double f1r[2][NF1], f1l[2][NF1], f2r[2][NF1], f2l[2][NF1];
+    // minus states (zones c - sn)
+    lds_rec2(L0, cs0, b0 - n0 + h0, f1r);
+    lds_rec2(L0, cs0, b0 - n0, f1l);
+    lds_rec2(L1, cs1, b1 - n1 + h1, f2r);
+    lds_rec2(L1, cs1, b1 - n1, f2l);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) trans_final(qm[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[w]);
+    // plus states (zones c)
+    lds_rec2(L0, cs0, b0 + h0, f1r);
+    lds_rec2(L0, cs0, b0, f1l);
+    lds_rec2(L1, cs1, b1 + h1, f2r);
+    lds_rec2(L1, cs1, b1, f2l);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) trans_final(qp[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[w]);
+
+    const unsigned usn = 8u * (N == 0 ? 1u : N == 1 ? (unsigned)U.sy : (unsigned)U.sz);
+    double R[2][NFIN];
+    IFlux f[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState rl, rrs;
+        double Xl, Xr;
+        rstate_from_edge<N>(ql[w], P.gamma, rl, Xl);
+        rstate_from_edge<N>(qr[w], P.gamma, rrs, Xr);
+        const int idxN = (N == 0) ? i + w : (N == 1) ? j : k;
+        interface_flux<N>(rl, rrs, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
+                          face_shock(S, P, c + 8u * w, sn), P, f[w]);
+    }
+    final_flux_tail<N, LIM>(t, S, f, c, s1, s2, U, foff(U, i, j, k), usn, fluxes, mass, qe,
+                            i, j, k, dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
+    double* FL = S.FL[N];
+    if (v1) {
+#pragma unroll
+        for (int m = 0; m < NFIN; ++m) stg2(FL + (long)m * NC, c, R[0][m], R[1][m]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < NFIN; ++m) stg(FL + (long)m * NC, c, R[0][m]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1743,6 +1924,109 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 }
 
 // ---------------------------------------------------------------------------------------
+// k_final<x> and consup_hydro in one kernel: the x fluxes of a zone never leave the chip.
+//   A thread owns the x-faces (i, i+1) like k_final<0> and the zones (i, i+1): their low x fluxes are its own two
+//   records, the high flux of zone i+1 is the first record of the NEXT lane (one wave shuffle per component).  So that
+//   no zone straddles two wavefronts, consecutive waves overlap by one slot: a wave advances 63 slots and its lane 63
+//   only repeats the first slot of the next wave (1.6 % redundant solves, no LDS, no barrier).  A row of nx zones has
+//   ceil(nx/2) zone slots and one more for the face hi+1.  The y and z flux records come from FL[1], FL[2], which
+//   k_final<1>, k_final<2> have written before this launch.  Saves, per zone and step: FL[0] written and read (18
+//   plane passes), Sborder read once instead of twice, one launch.
+// ---------------------------------------------------------------------------------------
+struct XRows { int lo[3]; int hi0; int nslot, ny, nz; unsigned nb; };
+
+template <bool LIM, bool CLEAN>
+__global__ void __launch_bounds__(256) k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                       DFab U, DFab fluxes, DFab mass, DFab qe, DFab Unew,
+                                                       double hdtdy, double hdtdz, double dt,
+                                                       double area0, double area1, double area2, double vol,
+                                                       int acc_hi, int assign, int from_sborder, DevParams P, int ntimes,
+                                                       double* red)
+{
+    unsigned bid = blockIdx.x;
+    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
+    const int lane = threadIdx.x & 63;
+    const unsigned total = (unsigned)b.nslot * (unsigned)b.ny * (unsigned)b.nz;
+    unsigned sl = (bid * 4u + (threadIdx.x >> 6)) * 63u + (unsigned)lane;
+    const bool live = sl < total;
+    if (!live) sl = total - 1u;                       // keeps every lane inside the arrays; it stores nothing
+    const unsigned row = sl / (unsigned)b.nslot;
+    const int p = (int)(sl - row * (unsigned)b.nslot);
+    int ijk[3];
+    ijk[0] = b.lo[0] + 2 * p;
+    ijk[1] = b.lo[1] + (int)(row % (unsigned)b.ny);
+    ijk[2] = b.lo[2] + (int)(row / (unsigned)b.ny);
+    const bool owner = live && lane < 63;
+    const bool f0 = ijk[0] <= b.hi0 + 1, f1 = ijk[0] + 1 <= b.hi0 + 1;          // faces of nodal(bx, x)
+    const bool zA = owner && ijk[0] <= b.hi0, zB = owner && ijk[0] + 1 <= b.hi0; // zones of bx
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+
+    double R[2][NFIN];
+    final_body<0, false, LIM, false>(t, ijk, owner && f0, owner && f1, c, Q, S, g, U, fluxes, mass, qe, hdtdy, hdtdz, dt,
+                                     area0, g.dx[0], acc_hi, assign, P, R);
+    double Rn[NFIN];                                   // face i+2
+#pragma unroll
+    for (int m = 0; m < NFIN; ++m) Rn[m] = __shfl_down(R[0][m], 1, 64);
+
+    // Castro::consup_hydro (Castro_ctu.cpp:11-86) for the zones i and i+1
+    double dtmin = 1.e200, rmin_raw = 1.e300;
+    if (zA) {
+        const Str s = gstr(t);
+        const unsigned sy = s.y, sz = s.z;
+        const long NC = t.NC;
+        const double volinv = 1.0 / vol;
+        const double* F1 = S.FL[1];
+        const double* F2 = S.FL[2];
+        const unsigned cn = foff(Unew, ijk[0], ijk[1], ijk[2]);
+        const unsigned ci = foff(U, ijk[0], ijk[1], ijk[2]);
+        constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
+        double un[2][NUM_STATE];
+#pragma unroll
+        for (int m = 0; m < NUM_STATE; ++m) {
+            const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
+            if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }       // zero flux
+            const int r = rec[m];
+            const D2 y0 = ldg2(F1 + (long)r * NC, c), y1 = ldg2(F1 + (long)r * NC, c + sy);
+            const D2 z0 = ldg2(F2 + (long)r * NC, c), z1 = ldg2(F2 + (long)r * NC, c + sz);
+            un[0][m] = u0.a + dt * (R[0][r] * area0 - R[1][r] * area0 + y0.a * area1 - y1.a * area1 + z0.a * area2 - z1.a * area2) * volinv;
+            un[1][m] = u0.b + dt * (R[1][r] * area0 - Rn[r] * area0 + y0.b * area1 - y1.b * area1 + z0.b * area2 - z1.b * area2) * volinv;
+            if (m == UEINT) {
+                const D2 py0 = ldg2(F1 + GPG * NC, c), py1 = ldg2(F1 + GPG * NC, c + sy);
+                const D2 uy0 = ldg2(F1 + GUG * NC, c), uy1 = ldg2(F1 + GUG * NC, c + sy);
+                const D2 pz0 = ldg2(F2 + GPG * NC, c), pz1 = ldg2(F2 + GPG * NC, c + sz);
+                const D2 uz0 = ldg2(F2 + GUG * NC, c), uz1 = ldg2(F2 + GUG * NC, c + sz);
+                double pdu = (R[1][GPG] + R[0][GPG]) * (R[1][GUG] * area0 - R[0][GUG] * area0);
+                pdu += (py1.a + py0.a) * (uy1.a * area1 - uy0.a * area1);
+                pdu += (pz1.a + pz0.a) * (uz1.a * area2 - uz0.a * area2);
+                pdu = 0.5 * pdu * volinv;
+                un[0][m] = un[0][m] - dt * pdu;
+                pdu = (Rn[GPG] + R[1][GPG]) * (Rn[GUG] * area0 - R[1][GUG] * area0);
+                pdu += (py1.b + py0.b) * (uy1.b * area1 - uy0.b * area1);
+                pdu += (pz1.b + pz0.b) * (uz1.b * area2 - uz0.b * area2);
+                pdu = 0.5 * pdu * volinv;
+                un[1][m] = un[1][m] - dt * pdu;
+            }
+        }
+        if (CLEAN) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                if (w == 1 && !zB) continue;
+                rmin_raw = fmin(rmin_raw, nan_guard(un[w][URHO]));
+                clean_zone(P, ntimes, un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS]);
+                dtmin = fmin(dtmin, nan_guard(zone_dt_cfl(P, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEINT])));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NUM_STATE; ++m) {
+            if (m == UTEMP && !CLEAN && !from_sborder) continue;     // unchanged in place
+            if (zB) stg2(Unew.p + m * Unew.sn, cn, un[0][m], un[1][m]);
+            else stg(Unew.p + m * Unew.sn, cn, un[0][m]);
+        }
+    }
+    if (CLEAN && red) block_min2_atomic(dtmin, rmin_raw, red);
+}
+
+// ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
@@ -1794,6 +2078,54 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         }                                                                                    \
     } while (0)
 
+// brick geometry for a launch over [lo,hi]: x-tiles of equal width (at most 64 faces), the rows of a 256-thread
+// workgroup arranged ty x tz as squarely as the box allows; CASTRO_AMD_BRICK="tx2,ty,tz" overrides.
+// grow[a][d]: extra extent of staged array a in direction d (0, 1 or 2)
+int g_brick[3] = { 0, 0, 0 };
+int g_xpad = 0;            // see capi.hip scratch_nx
+int g_final_lds = 0;       // 1: k_final_lds (transverse flux records staged in LDS; measured slower)
+int g_fuse_consup = 1;    // 1: k_finalx_consup (the x faces of the final stage and consup_hydro in one kernel)
+int g_brick_lds_budget = 80 * 1024;     // bytes of LDS per workgroup: two workgroups per CU
+static Brick make_brick(const int lo[3], const int hi[3], const int grow[2][3], size_t& lds_bytes)
+{
+    Brick b;
+    int n[3];
+    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.hi[d] = hi[d]; n[d] = hi[d] - lo[d] + 1; }
+    auto lds_of = [&](int tx2, int ty, int tz) {
+        size_t doubles = 0;
+        for (int a = 0; a < 2; ++a)
+            doubles += (size_t)NF1 * ((2 * tx2 + grow[a][0] + 1) & ~1) * (ty + grow[a][1]) * (tz + grow[a][2]);
+        return doubles * sizeof(double);
+    };
+    if (g_brick[0] > 0) { b.tx2 = g_brick[0]; b.ty = g_brick[1]; b.tz = g_brick[2]; }
+    else {
+        const int pairs = (n[0] + 1) / 2;
+        const int ntx = (pairs + 31) / 32;
+        b.tx2 = (pairs + ntx - 1) / ntx;
+        const int rows = 256 / b.tx2;
+        double best = -1.0;
+        b.ty = b.tz = 1;
+        for (int tz = 1; tz <= rows && tz <= n[2]; ++tz)
+            for (int ty = 1; ty * tz <= rows && ty <= n[1]; ++ty) {
+                if (lds_of(b.tx2, ty, tz) > (size_t)g_brick_lds_budget) continue;
+                // faces per workgroup over the halo factor of the staged records
+                const double score = (double)(ty * tz) * (double)(ty * tz) / (double)((ty + 1) * (tz + 1));
+                if (score > best) { best = score; b.ty = ty; b.tz = tz; }
+            }
+    }
+    b.ntx = (n[0] + 2 * b.tx2 - 1) / (2 * b.tx2);
+    b.nty = (n[1] + b.ty - 1) / b.ty;
+    b.ntz = (n[2] + b.tz - 1) / b.tz;
+    b.nb = ((unsigned)(b.ntx * b.nty * b.ntz) + 7u) & ~7u;
+    for (int a = 0; a < 2; ++a) {
+        b.exs[a] = (2 * b.tx2 + grow[a][0] + 1) & ~1;
+        b.ey[a] = b.ty + grow[a][1];
+        b.ez[a] = b.tz + grow[a][2];
+    }
+    lds_bytes = lds_of(b.tx2, b.ty, b.tz);
+    return b;
+}
+
 // outer box minus inner box as up to six slabs: z slabs over the full x,y extent, y slabs over the inner z range,
 // x slabs over the inner y,z range (thin in x: a wavefront then covers many rows, no idle lanes)
 static int shell_boxes(const int olo[3], const int ohi[3], const int ilo[3], const int ihi[3], int lo[6][3], int hi[6][3])
@@ -1837,7 +2169,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // boxes
     const int olo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 };
     const int ohi[3] = { t.hi[0] + 1, t.hi[1] + 1, t.hi[2] + 1 };
-    const int qhi[3] = { t.glo[0] + t.NX - 1, t.glo[1] + t.NY - 1, t.glo[2] + t.NZ - 1 };
+    const int qlo[3] = { t.lo[0] - 4, t.lo[1] - 4, t.lo[2] - 4 };     // grow(bx, 4): the zones of Sborder the path reads
+    const int qhi[3] = { t.hi[0] + 4, t.hi[1] + 4, t.hi[2] + 4 };
 
     // PPM tracing of the zones of [lo,hi] with the first x Riemann solve fused in, for the faces whose two zones the
     // launch covers; the faces at the workgroup starts follow in a one-thread-per-workgroup launch, those on the
@@ -1847,7 +2180,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         long n_;
         LinBox b_ = linbox2(lo, hi, n_);
         if (n_ > 0) {
-            prof_begin(prof, "k_riemann1", stream);
+            prof_begin(prof, "k_riemann1_blockstart", stream);
             hipLaunchKernelGGL(k_riemann1_blockstart, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
             prof_end(prof, stream);
         }
@@ -1863,10 +2196,10 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     const bool second_half = stage_b && splittable;     // stage A has run on this tile
     int slo[6][3], shi[6][3];
     if (second_half) {
-        const int ns = shell_boxes(t.glo, qhi, t.lo, t.hi, slo, shi);
+        const int ns = shell_boxes(qlo, qhi, t.lo, t.hi, slo, shi);
         for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim, slo[m], shi[m], Sborder, S.Q, P, d_status, none);
     } else {
-        KL("k_ctoprim", k_ctoprim, t.glo, qhi, Sborder, S.Q, P, d_status, none);
+        KL("k_ctoprim", k_ctoprim, qlo, qhi, Sborder, S.Q, P, d_status, none);
     }
 
     int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
@@ -1930,17 +2263,69 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 #define TRANSVERSE_STAGES(RE, LIM)                                                                                \
     do {                                                                                                          \
         KL2("k_trans1", k_trans1<RE>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);                              \
-        KL2("k_final", (k_final<0, RE, LIM>), nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],      \
+        KL2("k_final_x", (k_final<0, RE, LIM>), nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],      \
             hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P);                                 \
-        KL2("k_final", (k_final<1, RE, LIM>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],      \
+        KL2("k_final_y", (k_final<1, RE, LIM>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],      \
             hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);                                 \
-        KL2("k_final", (k_final<2, RE, LIM>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],      \
+        KL2("k_final_z", (k_final<2, RE, LIM>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],      \
             hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);                                 \
     } while (0)
     // the flux limiters (non-default too) share one extra pair of instantiations: both flags are tested inside
     const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
+    // default options: the final stage stages its transverse flux records in LDS (k_final_lds)
+#define FINAL_LDS(NN, LIM, h1, h2, ar)                                                                           \
+    do {                                                                                                          \
+        constexpr int T1_ = (NN == 0) ? 1 : 0, T2_ = (NN == 2) ? 1 : 2;                                           \
+        int grow_[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };                                                           \
+        grow_[0][NN] += 1; grow_[0][T1_] += 1; grow_[1][NN] += 1; grow_[1][T2_] += 1;                             \
+        size_t lds_;                                                                                              \
+        Brick b_ = make_brick(nlo[NN], nhi[NN], grow_, lds_);                                                     \
+        static const bool attr_ = (hipFuncSetAttribute((const void*)k_final_lds<NN, LIM>,                         \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
+        (void)attr_;                                                                                              \
+        prof_begin(prof, NN == 0 ? "k_final_x" : NN == 1 ? "k_final_y" : "k_final_z", stream);                    \
+        hipLaunchKernelGGL((k_final_lds<NN, LIM>), dim3(b_.nb), dim3(256), lds_, stream, t, b_, S.Q, S, g, Sborder, \
+                           fluxes[NN], mass[NN], qe[NN], h1, h2, dt, ar, g.dx[NN], acc_hi[NN], (flags & 2) ? 1 : 0, P); \
+        prof_end(prof, stream);                                                                                   \
+    } while (0)
     if (P.reset_rhoe == 1 || tfix) { if (lim) TRANSVERSE_STAGES(true, true); else TRANSVERSE_STAGES(true, false); }
+    else if (g_fuse_consup) {
+        // y and z first (they write FL[1], FL[2]), then the x faces with the conservative update fused in
+        KL2("k_trans1", k_trans1<false>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+        if (lim) {
+            KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
+            KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+        } else {
+            KL2("k_final_y", (k_final<1, false, false>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
+            KL2("k_final_z", (k_final<2, false, false>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+        }
+        XRows xr;
+        for (int d = 0; d < 3; ++d) xr.lo[d] = t.lo[d];
+        xr.hi0 = t.hi[0];
+        const int nx = t.hi[0] - t.lo[0] + 1;
+        xr.nslot = (nx + 1) / 2 + 1; xr.ny = t.hi[1] - t.lo[1] + 1; xr.nz = t.hi[2] - t.lo[2] + 1;
+        const long slots = (long)xr.nslot * xr.ny * xr.nz;
+        const long waves = (slots + 62) / 63;
+        xr.nb = ((unsigned)((waves + 3) / 4) + 7u) & ~7u;
+        const double vol_ = g.dx[0] * g.dx[1] * g.dx[2];
+        prof_begin(prof, "k_finalx_consup", stream);
+#define FXC(LIM, CLEAN, nt, rd)                                                                                         \
+        hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN>), dim3(xr.nb), dim3(256), 0, stream, t, xr, S.Q, S, g, Sborder,      \
+                           fluxes[0], mass[0], qe[0], Snew, hdtdy, hdtdz, dt, area0, area1, area2, vol_, acc_hi[0],      \
+                           (flags & 2) ? 1 : 0, (flags & 1) ? 1 : 0, P, nt, rd)
+        if (clean_ntimes > 0) { if (lim) FXC(true, true, clean_ntimes, red); else FXC(false, true, clean_ntimes, red); }
+        else { if (lim) FXC(true, false, 0, (double*)nullptr); else FXC(false, false, 0, (double*)nullptr); }
+#undef FXC
+        prof_end(prof, stream);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    else if (g_final_lds) {
+        KL2("k_trans1", k_trans1<false>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+        if (lim) { FINAL_LDS(0, true, hdtdy, hdtdz, area0); FINAL_LDS(1, true, hdtdx, hdtdz, area1); FINAL_LDS(2, true, hdtdx, hdtdy, area2); }
+        else { FINAL_LDS(0, false, hdtdy, hdtdz, area0); FINAL_LDS(1, false, hdtdx, hdtdz, area1); FINAL_LDS(2, false, hdtdx, hdtdy, area2); }
+    }
     else { if (lim) TRANSVERSE_STAGES(false, true); else TRANSVERSE_STAGES(false, false); }
+#undef FINAL_LDS
 #undef TRANSVERSE_STAGES
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];

@@ -1522,6 +1522,56 @@ def test_randomised_option_combinations_match_the_oracle():
     assert "mismatching 0" in r.stdout
 
 
+@pytest.mark.parametrize("env", [{"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "0"},
+                                 {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1"},
+                                 {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1", "CASTRO_AMD_BRICK": "5,3,2"},
+                                 {"CASTRO_AMD_FUSE_CONSUP": "1", "CASTRO_AMD_XPAD": "12"}],
+                         ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows"])
+def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
+    """The final stage has three forms: k_final<x,y,z> + k_consup (round 1), k_final_lds (transverse flux records staged
+    in LDS bricks; measured slower, kept as the measured experiment of DESIGN.md section 9) and the default
+    k_final<y,z> + k_finalx_consup.  Each must match the oracle bit for bit, odd extents and several tiles included."""
+    import castro_amd
+    from castro_amd.hydro import HipHydro
+    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        os.environ.update(env)
+        h = HipHydro(0)                       # the knobs are read when a context is created
+        for shape, seed in (((37, 9, 11), 5), ((8, 8, 8), 6), ((1, 5, 3), 7), ((130, 4, 3), 8)):
+            rng = np.random.default_rng(seed)
+            bxlo = (2, -3, 1)
+            bxhi = tuple(bxlo[d] + shape[d] - 1 for d in range(3))
+            sb_lo, sb_hi = tuple(x - 4 for x in bxlo), tuple(x + 4 for x in bxhi)
+            U = physical_state(rng, sb_lo, sb_hi, jump=True)
+            for fa in (False, True):
+                out = _run_both(h, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 6.0e-4, dx=(0.02, 0.015, 0.03), flux_assign=fa)
+                _assert_exact(out, "%s shape %s assign %s" % (env, shape, fa))
+        # as two tiles of one FAB
+        rng = np.random.default_rng(9)
+        bxlo, bxhi = (0, 0, 0), (20, 9, 7)
+        sb_lo, sb_hi = (-4, -4, -4), (24, 13, 11)
+        U = physical_state(rng, sb_lo, sb_hi)
+        out = _run_both(h, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 5.0e-4, dx=(0.02, 0.02, 0.02),
+                        hip_tiles=[((0, 0, 0), (10, 9, 7)), ((11, 0, 0), (20, 9, 7))])
+        _assert_exact(out, "%s tiled" % (env,))
+        h.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        os.environ.setdefault("CASTRO_AMD_XPAD", "0")
+        for k, v in (("CASTRO_AMD_FUSE_CONSUP", "1"), ("CASTRO_AMD_FINAL_LDS", "0")):
+            os.environ[k] = v
+        os.environ["CASTRO_AMD_BRICK"] = "0,0,0"
+        HipHydro(0).close()                   # restore the library's defaults for the tests that follow
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+
+
 def test_colella_glaz_nan_sign_seeds_are_bit_exact():
     """Round 1's open parity failure, by seed: tools/fuzz_parity.py 4000 201 cases 436 and 2315 and tools/fuzz_driver.py
     700 203 case 313 -- riemann_solver = 1 with cg_blend = 1, whose non-convergence fall-back evaluates the two-shock guess

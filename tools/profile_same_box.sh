@@ -16,11 +16,19 @@ find $OUT/${TAG}_samebox_stats -type f -size +8M -delete 2>/dev/null
 python3 - <<PY
 import csv, glob, json
 d = json.load(open("$OUT/${TAG}_bench.json"))
-print("bench: ms/step %.3f, %s avg launch %.4f ms (hipEvent), frac %.3f" % (d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"]))
+ku = d["roofline"]["kernel_utilisation"]
+print("bench: ms/step %.3f, contract roofline frac %.4f" % (d["ms_per_step"], d["roofline"]["frac"]))
 f = glob.glob("$OUT/${TAG}_samebox_stats/**/*kernel_stats.csv", recursive=True)[0]
-tot = n = 0
-for r in csv.DictReader(open(f)):
-    if "k_final" in r["Name"]:
-        tot += float(r["TotalDurationNs"]); n += int(r["Calls"])
-print("rocprofv3: k_final avg %.4f ms over %d launches" % (tot / n / 1e6, n))
+rows = list(csv.DictReader(open(f)))
+def prof(sub):
+    tot = n = 0
+    for r in rows:
+        if sub in r["Name"]:
+            tot += float(r["TotalDurationNs"]); n += int(r["Calls"])
+    return (tot / n / 1e6, n) if n else (float("nan"), 0)
+for label, sub in (("k_trans1", "k_trans1"), ("k_trace", "k_trace_pair"), ("k_finalx_consup", "k_finalx_consup"),
+                   ("k_final_y", "k_final<1"), ("k_final_z", "k_final<2")):
+    if label in ku:
+        a, n = prof(sub)
+        print("%-16s hipEvent avg %.4f ms | rocprofv3 avg %.4f ms over %d launches" % (label, ku[label]["avg_launch_ms"], a, n))
 PY

@@ -49,13 +49,16 @@ for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         print("%-60s %8d %16.1f" % (k[:60], n, v / n))
 
 
-# per-kernel HBM-side traffic per launch, gfx950 correction applied (MI355X_MICROARCH.md, HBM section):
+# per-kernel HBM-side traffic per launch and per step, gfx950 correction applied (MI355X_MICROARCH.md, HBM section):
 # FETCH_SIZE is reported in KiB and counts 128-B requests as 64 B for coalesced streams (x2);
-# WRITE_SIZE (KiB) is exact.  Kernel template instances are merged by base name.
+# WRITE_SIZE (KiB) is exact.  Kernel template instances are kept apart (k_final<0|1|2>); steps = launches of k_trans1.
 import json
 import re
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_stamp
 traffic = {}
 vals = {}
+nsteps = {}
 for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = find(tag + "_" + which, "*counter_collection.csv")
     if not f:
@@ -64,15 +67,23 @@ for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     for r in csv.DictReader(open(f)):
         if r.get("Counter_Name") != ctr:
             continue
-        k = re.sub(r"<.*", "", short(r["Kernel_Name"])).strip()
+        k = short(r["Kernel_Name"]).strip()
+        k = re.sub(r"<(\d).*", r"<\1>", k) if k.startswith("k_final<") or k.startswith("k_riemann1<") else re.sub(r"<.*", "", k)
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1] += 1
+    nsteps[ctr] = max(1, acc.get("k_trans1", [0, 1])[1])
     for k, (v, n) in acc.items():
-        vals.setdefault(k, {})[ctr] = v / n
+        vals.setdefault(k, {})[ctr] = (v / n, n)
+step_bytes = 0.0
 for k, d in vals.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d and k.startswith("k_"):
-        traffic[k] = {"read_bytes_per_launch": d["FETCH_SIZE"] * 1024 * 2, "write_bytes_per_launch": d["WRITE_SIZE"] * 1024,
-                      "bytes_per_launch": d["FETCH_SIZE"] * 1024 * 2 + d["WRITE_SIZE"] * 1024}
+        rd, wr = d["FETCH_SIZE"][0] * 1024 * 2, d["WRITE_SIZE"][0] * 1024
+        per_step = d["FETCH_SIZE"][1] / nsteps["FETCH_SIZE"]
+        traffic[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
+                      "launches_per_step": per_step}
+        step_bytes += (rd + wr) * per_step
 json.dump({"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), "
-           "same command as bench.py --steps 5 --warmup 2", "kernels": traffic},
+           "same command as bench.py --steps 5 --warmup 2 --no-contract-leg", "source_stamp": source_stamp(),
+           "bytes_per_step": step_bytes, "steps_profiled": nsteps.get("FETCH_SIZE"), "kernels": traffic},
           open(os.path.join(root, tag + "_traffic.json"), "w"), indent=1)
+print("\nL2->fabric bytes per step: %.2f GB (%d steps profiled)" % (step_bytes / 1e9, nsteps.get("FETCH_SIZE", 0)))

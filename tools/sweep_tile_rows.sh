@@ -4,10 +4,10 @@ mkdir -p gpurun_out
 CASTRO_AMD_TILE_ROWS=8 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
 for ty in 0 4 8 16 32 64; do
   echo "== TILE_ROWS=$ty"
-  CASTRO_AMD_TILE_ROWS=$ty python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/sweep_ty$ty.json 2> gpurun_out/sweep_ty$ty.err
+  CASTRO_AMD_TILE_ROWS=$ty python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-contract-leg > gpurun_out/sweep_ty$ty.json 2> gpurun_out/sweep_ty$ty.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/sweep_ty$ty.json"))
-print("ms/step %.2f" % d["ms_per_step"], {k: round(v,2) for k,v in d["path_roofline"]["kernel_ms_per_step"].items()})
+print("ms/step %.2f" % d["ms_per_step"], {k: round(v,2) for k,v in {a: b["ms_per_step"] for a, b in d["roofline"]["kernel_utilisation"].items()}.items()})
 PY
 done
