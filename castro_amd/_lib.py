@@ -169,7 +169,7 @@ def load():
     L.castro_amd_cmpflx_points.argtypes = [C.c_longlong, C.c_int, V, V, V, V, V, V, C.POINTER(Params), V, V]
     L.castro_amd_ppm_points.argtypes = [C.c_longlong, V, V, V, V, C.c_double, V, V]
     L.castro_amd_flatten_points.argtypes = [C.c_longlong, V, V, V, V]
-    L.castro_amd_trans_points.argtypes = [C.c_longlong, C.c_int, C.c_int, V, V, V, V, V, C.c_double, C.c_double,
+    L.castro_amd_trans_points.argtypes = [C.c_longlong, C.c_int, C.c_int, V, V, V, V, V, V, C.c_double, C.c_double,
                                           C.POINTER(Params), V, V]
     _lib = L
     return L

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; }
+namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; }
 
 using namespace cad;
 
@@ -173,7 +173,9 @@ void castro_amd_finalize_params(castro_amd_params* p)
     if (p->small_pres < 0.0) p->small_pres = 1.e-100;
     if (p->small_ener < 0.0) p->small_ener = 1.e-100;
     // eos(eos_input_rt) at (small_dens, small_temp)
-    double e = K_B * p->small_temp / ((p->eos_gamma - 1.0) * (p->abar * M_U));
+    // xn = 1 / NumSpec (Castro_setup.cpp:279): mu = abar = 1 / sum_k(xn_k / A_k)
+    const double mu = 1.0 / (1.0 * (1.0 / p->abar));
+    double e = K_B * p->small_temp / ((p->eos_gamma - 1.0) * (mu * M_U));
     double pr = (p->eos_gamma - 1.0) * p->small_dens * e;
     if (p->small_pres < pr) p->small_pres = pr;
     if (p->small_ener < e) p->small_ener = e;
@@ -196,6 +198,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
     if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
+    if (const char* e = std::getenv("CASTRO_AMD_FUSED_TILE_ROWS")) g_fused_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FUSE_CONSUP")) g_fuse_consup = std::atoi(e);   // 0: k_final<x> + k_consup
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_LDS")) g_final_lds = std::atoi(e);   // 0: the plain k_final
     if (const char* e = std::getenv("CASTRO_AMD_XPAD")) g_xpad = std::atoi(e);             // unused columns in front of every scratch row
@@ -708,7 +711,8 @@ int castro_amd_sedov_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, co
     // eos(eos_input_rp)
     const double g = params->eos_gamma;
     const double e_ambient = p_ambient / ((g - 1.0) * dens_ambient);
-    const double temp_ambient = (g - 1.0) * e_ambient * (params->abar * M_U) / K_B;
+    const double mu = 1.0 / (1.0 * (1.0 / params->abar));          // xn = 1 (problem_initialize.H:25-29)
+    const double temp_ambient = (g - 1.0) * e_ambient * (mu * M_U) / K_B;
     const double vctr = (4.0 / 3.0) * M_PI * r_init * r_init * r_init;
     const double e_exp = exp_energy / vctr / dens_ambient;
     hipSetDevice(c->device);
@@ -726,8 +730,9 @@ int castro_amd_sod_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, cons
     const double g = params->eos_gamma;
     const double split = frac * (geom->problo[idir - 1] + geom->probhi[idir - 1]);
     const double e_l = p_l / ((g - 1.0) * rho_l), e_r = p_r / ((g - 1.0) * rho_r);
-    const double T_l = (g - 1.0) * e_l * (params->abar * M_U) / K_B;
-    const double T_r = (g - 1.0) * e_r * (params->abar * M_U) / K_B;
+    const double mu = 1.0 / (1.0 * (1.0 / params->abar));          // xn = 1
+    const double T_l = (g - 1.0) * e_l * (mu * M_U) / K_B;
+    const double T_r = (g - 1.0) * e_r * (mu * M_U) / K_B;
     hipSetDevice(c->device);
     return launch_sod_init(to_dfab(state), lo, hi, geom->dx, geom->problo, split, idir - 1,
                            rho_l, u_l, rho_l * e_l, T_l, rho_r, u_r, rho_r * e_r, T_r, (hipStream_t)stream, &c->prof);

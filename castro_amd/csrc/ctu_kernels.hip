@@ -1933,7 +1933,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 //   k_final<1>, k_final<2> have written before this launch.  Saves, per zone and step: FL[0] written and read (18
 //   plane passes), Sborder read once instead of twice, one launch.
 // ---------------------------------------------------------------------------------------
-struct XRows { int lo[3]; int hi0; int nslot, ny, nz; unsigned nb; };
+struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; };
 
 template <bool LIM, bool CLEAN>
 __global__ void __launch_bounds__(256) k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
@@ -1954,8 +1954,21 @@ __global__ void __launch_bounds__(256) k_finalx_consup(Tile t, XRows b, const do
     const int p = (int)(sl - row * (unsigned)b.nslot);
     int ijk[3];
     ijk[0] = b.lo[0] + 2 * p;
-    ijk[1] = b.lo[1] + (int)(row % (unsigned)b.ny);
-    ijk[2] = b.lo[2] + (int)(row / (unsigned)b.ny);
+    if (b.ty > 0) {
+        // rows y-tile by y-tile, z-plane by z-plane inside a tile (like LinBox): the y and z neighbours of the rows an
+        // XCD works on at one time stay in its L2
+        const unsigned rpt = (unsigned)b.ty * (unsigned)b.nz;
+        const unsigned yt = row / rpt;
+        const unsigned rem = row - yt * rpt;
+        const unsigned left = (unsigned)b.ny - yt * (unsigned)b.ty;
+        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
+        const unsigned kk = rem / tyh;
+        ijk[1] = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - kk * tyh));
+        ijk[2] = b.lo[2] + (int)kk;
+    } else {
+        ijk[1] = b.lo[1] + (int)(row % (unsigned)b.ny);
+        ijk[2] = b.lo[2] + (int)(row / (unsigned)b.ny);
+    }
     const bool owner = live && lane < 63;
     const bool f0 = ijk[0] <= b.hi0 + 1, f1 = ijk[0] + 1 <= b.hi0 + 1;          // faces of nodal(bx, x)
     const bool zA = owner && ijk[0] <= b.hi0, zB = owner && ijk[0] + 1 <= b.hi0; // zones of bx
@@ -2084,6 +2097,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
 int g_brick[3] = { 0, 0, 0 };
 int g_xpad = 0;            // see capi.hip scratch_nx
 int g_final_lds = 0;       // 1: k_final_lds (transverse flux records staged in LDS; measured slower)
+int g_fused_tile_rows = 16; // rows per y-tile of the k_finalx_consup row order (0: plain)
 int g_fuse_consup = 1;    // 1: k_finalx_consup (the x faces of the final stage and consup_hydro in one kernel)
 int g_brick_lds_budget = 80 * 1024;     // bytes of LDS per workgroup: two workgroups per CU
 static Brick make_brick(const int lo[3], const int hi[3], const int grow[2][3], size_t& lds_bytes)
@@ -2304,6 +2318,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         xr.hi0 = t.hi[0];
         const int nx = t.hi[0] - t.lo[0] + 1;
         xr.nslot = (nx + 1) / 2 + 1; xr.ny = t.hi[1] - t.lo[1] + 1; xr.nz = t.hi[2] - t.lo[2] + 1;
+        xr.ty = g_fused_tile_rows;
         const long slots = (long)xr.nslot * xr.ny * xr.nz;
         const long waves = (slots + 62) / 63;
         xr.nb = ((unsigned)((waves + 3) / 4) + 7u) & ~7u;

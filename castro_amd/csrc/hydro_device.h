@@ -61,13 +61,20 @@ __device__ __forceinline__ double sign_of(double x) { return (x != x) ? -1.0 : c
 // ---------------------------------------------------------------------------------------
 // gamma-law EOS (Microphysics EOS/gamma_law restated)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double eos_e_of_T(const DevParams& P, double T)
+// mean molecular weight with eos_assume_neutral = 1: mu = abar = 1 / sum_k(X_k / A_k) (composition(), one species of
+// mass number P.abar), so e(T) and T(e) depend on the mass fraction xn the reference hands to the EOS at each call site
+__device__ __forceinline__ double eos_mu(const DevParams& P, double xn)
 {
-    return K_B * T / ((P.gamma - 1.0) * (P.abar * M_U));
+    double sum = xn * (1.0 / P.abar);
+    return 1.0 / sum;
 }
-__device__ __forceinline__ double eos_T_of_e(const DevParams& P, double e)
+__device__ __forceinline__ double eos_e_of_T(const DevParams& P, double T, double xn)
 {
-    return (P.gamma - 1.0) * e * (P.abar * M_U) / K_B;
+    return K_B * T / ((P.gamma - 1.0) * (eos_mu(P, xn) * M_U));
+}
+__device__ __forceinline__ double eos_T_of_e(const DevParams& P, double e, double xn)
+{
+    return (P.gamma - 1.0) * e * (eos_mu(P, xn) * M_U) / K_B;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -210,7 +217,7 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
         // enforce_min_density
         if (rho < P.small_dens) {
             rX *= (P.small_dens / rho);
-            double e = eos_e_of_T(P, P.small_temp);
+            double e = eos_e_of_T(P, P.small_temp, rX / P.small_dens);       // advection_util.cpp:1127
             rho = P.small_dens;
             temp = P.small_temp;
             mx = 0.0; my = 0.0; mz = 0.0;
@@ -253,7 +260,7 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
             double Wp = mz * rhoInv;
             double ke = 0.5 * (Up * Up + Vp * Vp + Wp * Wp);
 
-            double small_e = eos_e_of_T(P, P.small_temp);
+            double small_e = eos_e_of_T(P, P.small_temp, rX * rhoInv);       // Castro.cpp:3376
 
             eint = amax(eint, rho * small_e);
             eden = amax(eden, rho * (small_e + ke) + 0.0);
@@ -269,7 +276,7 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
         {
             double rhoInv = 1.0 / rho;
             double e = eint * rhoInv;
-            temp = eos_T_of_e(P, e);
+            temp = eos_T_of_e(P, e, rX * rhoInv);                            // Castro.cpp:3694
         }
     }
 
@@ -437,10 +444,10 @@ struct RState { double rho, un, ut, utt, p, rhoe, gamc; };   // riemann.H:13-31
 struct RAux { double csmall, cavg, bnd_fac; };              // riemann.H:34-39
 
 // the "cleaning" tail of load_input_states (riemann.H:198-244)
-__device__ __forceinline__ void clean_input_state(RState& q, const DevParams& P)
+__device__ __forceinline__ void clean_input_state(RState& q, double X, const DevParams& P)
 {
     if (q.rhoe <= 0.0 || q.p < P.small_pres) {
-        double e = eos_e_of_T(P, P.small_temp);
+        double e = eos_e_of_T(P, P.small_temp, X);                           // riemann.H:207, :231
         q.rhoe = q.rho * e;
         q.p = (P.gamma - 1.0) * q.rho * e;
         q.gamc = P.gamma;
@@ -1058,8 +1065,8 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
         raux.cavg = 0.5 * (cr + cl);
         raux.bnd_fac = bnd_fac;
 
-        clean_input_state(ql, P);
-        clean_input_state(qr, P);
+        clean_input_state(ql, Xl, P);
+        clean_input_state(qr, Xr, P);
 
         RState qint;
         if (P.riemann_solver == 0) {
@@ -1125,7 +1132,7 @@ __device__ __forceinline__ void reset_edge_state_thermo(double q[NEDGE], const D
 {
     if (P.reset_rhoe == 1) {
         if (q[PRE] < 0.0) {
-            const double e = eos_e_of_T(P, P.small_temp);            // eos(eos_input_rt)
+            const double e = eos_e_of_T(P, P.small_temp, q[PX]);     // eos(eos_input_rt), edge_util.cpp:34
             const double p = (P.gamma - 1.0) * q[PRHO] * e;
             q[PRE] = q[PRHO] * e;
             q[PP] = p;

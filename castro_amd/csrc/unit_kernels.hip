@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) k_flatten_points(long n, const double* pv
 // (rho, mx, my, mz, E, X, Godunov un, Godunov p) at the high (r) and low (l) transverse face
 __global__ void __launch_bounds__(256) k_trans_points(long n, int ntrans, int tdir, const double* q, const double* f1r,
                                                       const double* f1l, const double* f2r, const double* f2l,
-                                                      double cdtdx1, double cdtdx2, DevParams P, double* out)
+                                                      const double* fe, double cdtdx1, double cdtdx2, DevParams P, double* out)
 {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -90,13 +90,15 @@ __global__ void __launch_bounds__(256) k_trans_points(long n, int ntrans, int td
     if (ntrans == 2) {
 #pragma unroll
         for (int m = 0; m < NF1; ++m) { c[m] = f2r[m * n + p]; d[m] = f2l[m * n + p]; }
-        trans_final(qi, a, b, c, d, P.gamma, cdtdx1, cdtdx2, P, qo);
+        // fe: (rho e) fluxes at the faces 1r, 1l, 2r, 2l (rows of n), read with transverse_reset_rhoe = 1
+        trans_final(qi, a, b, c, d, P.gamma, cdtdx1, cdtdx2, P, qo, fe ? fe[p] : 0.0, fe ? fe[n + p] : 0.0,
+                    fe ? fe[2 * n + p] : 0.0, fe ? fe[3 * n + p] : 0.0);
     } else if (tdir == 0) {
-        trans_single<0>(qi, a, b, P.gamma, cdtdx1, P, qo);
+        trans_single<0>(qi, a, b, P.gamma, cdtdx1, P, qo, fe ? fe[p] : 0.0, fe ? fe[n + p] : 0.0);
     } else if (tdir == 1) {
-        trans_single<1>(qi, a, b, P.gamma, cdtdx1, P, qo);
+        trans_single<1>(qi, a, b, P.gamma, cdtdx1, P, qo, fe ? fe[p] : 0.0, fe ? fe[n + p] : 0.0);
     } else {
-        trans_single<2>(qi, a, b, P.gamma, cdtdx1, P, qo);
+        trans_single<2>(qi, a, b, P.gamma, cdtdx1, P, qo, fe ? fe[p] : 0.0, fe ? fe[n + p] : 0.0);
     }
 #pragma unroll
     for (int m = 0; m < NEDGE; ++m) out[m * n + p] = qo[m];
@@ -140,14 +142,14 @@ int castro_amd_flatten_points(long long n, const double* p7, const double* u5, d
 }
 
 int castro_amd_trans_points(long long n, int ntrans, int tdir, const double* q, const double* f1r, const double* f1l,
-                            const double* f2r, const double* f2l, double cdtdx1, double cdtdx2,
+                            const double* f2r, const double* f2l, const double* fe, double cdtdx1, double cdtdx2,
                             const castro_amd_params* params, double* out, void* stream)
 {
     if (n < 0 || (ntrans != 1 && ntrans != 2) || tdir < 0 || tdir > 2 || !q || !f1r || !f1l || !params || !out) return CASTRO_AMD_ERR_ARG;
     if (ntrans == 2 && (!f2r || !f2l)) return CASTRO_AMD_ERR_ARG;
     if (n == 0) return CASTRO_AMD_OK;
     hipLaunchKernelGGL(k_trans_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n, ntrans, tdir,
-                       q, f1r, f1l, f2r, f2l, cdtdx1, cdtdx2, unit_devparams(params), out);
+                       q, f1r, f1l, f2r, f2l, fe, cdtdx1, cdtdx2, unit_devparams(params), out);
     return hipGetLastError() == hipSuccess ? CASTRO_AMD_OK : CASTRO_AMD_ERR_HIP;
 }
 

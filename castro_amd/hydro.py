@@ -96,13 +96,14 @@ class HipHydro:
         L.check(self.lib.castro_amd_flatten_points(n, ptr(p7), ptr(u5), ptr(out), _stream_ptr(None)), "flatten_points")
         return out
 
-    def trans_points(self, q, f1r, f1l, cdtdx1, params, tdir=0, f2r=None, f2l=None, cdtdx2=0.0):
-        """actual_trans_single (f2r is None) / actual_trans_final: q (7, n), flux records (8, n) -> (7, n)."""
+    def trans_points(self, q, f1r, f1l, cdtdx1, params, tdir=0, f2r=None, f2l=None, cdtdx2=0.0, fe=None):
+        """actual_trans_single (f2r is None) / actual_trans_final: q (7, n), flux records (8, n) -> (7, n);
+        fe: (2 or 4, n) (rho e) fluxes for transverse_reset_rhoe = 1."""
         n = q.shape[1]
         out = torch.empty((7, n), dtype=torch.float64, device=self.device)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         L.check(self.lib.castro_amd_trans_points(n, 2 if f2r is not None else 1, int(tdir), ptr(q), ptr(f1r), ptr(f1l), ptr(f2r),
-                                                 ptr(f2l), float(cdtdx1), float(cdtdx2), C.byref(params), ptr(out),
+                                                 ptr(f2l), ptr(fe), float(cdtdx1), float(cdtdx2), C.byref(params), ptr(out),
                                                  _stream_ptr(None)), "trans_points")
         return out
 

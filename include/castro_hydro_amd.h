@@ -422,7 +422,9 @@ void castro_amd_ctx_profile_reset(castro_amd_ctx *ctx);
  *                              p7 = pressure at i-3..i+3, u5 = normal velocity at i-2..i+2
  *   castro_amd_trans_points    actual_trans_single (trans.cpp:66-437, ntrans = 1, tdir = transverse direction) or
  *                              actual_trans_final (:498-862, ntrans = 2): q 7 comps, flux records 8 comps
- *                              (rho, mx, my, mz, E, X fluxes, Godunov un, Godunov p) at the high (r) / low (l) face
+ *                              (rho, mx, my, mz, E, X fluxes, Godunov un, Godunov p) at the high (r) / low (l) face;
+ *                              fe (NULL unless transverse_reset_rhoe = 1): the (rho e) fluxes at the faces 1r, 1l
+ *                              (, 2r, 2l), rows of n
  */
 int castro_amd_cmpflx_points(long long n, int idir, const double *qm, const double *qp, const double *cl, const double *cr,
                              const double *bnd_fac, const int *is_shock, const castro_amd_params *params, double *out,
@@ -431,7 +433,7 @@ int castro_amd_ppm_points(long long n, const double *s, const double *flatn, con
                           double *out, void *stream);
 int castro_amd_flatten_points(long long n, const double *p7, const double *u5, double *out, void *stream);
 int castro_amd_trans_points(long long n, int ntrans, int tdir, const double *q, const double *f1r, const double *f1l,
-                            const double *f2r, const double *f2l, double cdtdx1, double cdtdx2,
+                            const double *f2r, const double *f2l, const double *fe, double cdtdx1, double cdtdx2,
                             const castro_amd_params *params, double *out, void *stream);
 
 #ifdef __cplusplus

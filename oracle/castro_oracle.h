@@ -99,7 +99,9 @@ void ora_finalize_params(ora_params *p);   /* small_pres/small_ener floors, Cast
 ora_a4 ora_make_a4(double *p, const int lo[3], const int hi[3], int nc);
 
 /* ---------------- EOS (Microphysics gamma_law restated) -------- */
-typedef struct { double rho, T, e, p, gam1, cs, dpde, dpdr_e; } ora_eos_t;
+/* xn: mass fraction of the (one) species -- the mean molecular weight of the gamma-law EOS with eos_assume_neutral = 1 is
+ * mu = abar = 1 / sum_k(X_k / A_k), so T(e) and e(T) depend on the composition the caller passes */
+typedef struct { double rho, T, e, p, gam1, cs, dpde, dpdr_e, xn; } ora_eos_t;
 void ora_eos_re(const ora_params *P, ora_eos_t *s);
 /* constant-gravity source terms (Source/gravity/Castro_gravity.cpp:234-614) and Saxpy */
 void ora_old_gravity_source(const int lo[3], const int hi[3], ora_a4 uold, ora_a4 source, const double grav[3],

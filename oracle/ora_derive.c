@@ -17,6 +17,7 @@ static void zone_eos(ora_a4 dat, int i, int j, int k, const ora_params *P, ora_e
     es->rho = A4(dat,i,j,k,URHO);
     es->T = A4(dat,i,j,k,UTEMP);
     es->e = A4(dat,i,j,k,UEINT) * rhoInv;
+    es->xn = A4(dat,i,j,k,UFS) * rhoInv;               /* Derive.cpp:43 */
     ora_eos_re(P, es);
 }
 

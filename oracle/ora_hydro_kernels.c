@@ -65,6 +65,7 @@ void ora_finalize_params(ora_params *p)
     ora_eos_t s;
     s.rho = p->small_dens;
     s.T = p->small_temp;
+    s.xn = 1.0;                 /* Castro_setup.cpp:279: xn = 1 / NumSpec */
     ora_eos_rt(p, &s);
     p->small_pres = amax(p->small_pres, s.p);
     p->small_ener = amax(p->small_ener, s.e);
@@ -89,6 +90,13 @@ ora_a4 ora_make_a4(double *p, const int lo[3], const int hi[3], int nc)
 #define ORA_K_B 1.3806488e-16
 #define ORA_M_U 1.660538921e-24
 
+/* composition(): abar = 1 / sum_k(xn_k / A_k), one species of mass number P->abar; mu = abar (eos_assume_neutral) */
+static inline double eos_mu(const ora_params *P, const ora_eos_t *s)
+{
+    double sum = s->xn * (1.0 / P->abar);
+    return 1.0 / sum;
+}
+
 static inline void eos_finish(const ora_params *P, ora_eos_t *s)
 {
     s->gam1 = P->eos_gamma;
@@ -101,14 +109,14 @@ static inline void eos_finish(const ora_params *P, ora_eos_t *s)
 void ora_eos_re(const ora_params *P, ora_eos_t *s)
 {
     s->p = (P->eos_gamma - 1.0) * s->rho * s->e;
-    s->T = (P->eos_gamma - 1.0) * s->e * (P->abar * ORA_M_U) / ORA_K_B;
+    s->T = (P->eos_gamma - 1.0) * s->e * (eos_mu(P, s) * ORA_M_U) / ORA_K_B;
     eos_finish(P, s);
 }
 
 /* eos_input_rt: rho, T given */
 void ora_eos_rt(const ora_params *P, ora_eos_t *s)
 {
-    s->e = ORA_K_B * s->T / ((P->eos_gamma - 1.0) * (P->abar * ORA_M_U));
+    s->e = ORA_K_B * s->T / ((P->eos_gamma - 1.0) * (eos_mu(P, s) * ORA_M_U));
     s->p = (P->eos_gamma - 1.0) * s->rho * s->e;
     eos_finish(P, s);
 }
@@ -117,7 +125,7 @@ void ora_eos_rt(const ora_params *P, ora_eos_t *s)
 void ora_eos_rp(const ora_params *P, ora_eos_t *s)
 {
     s->e = s->p / ((P->eos_gamma - 1.0) * s->rho);
-    s->T = (P->eos_gamma - 1.0) * s->e * (P->abar * ORA_M_U) / ORA_K_B;
+    s->T = (P->eos_gamma - 1.0) * s->e * (eos_mu(P, s) * ORA_M_U) / ORA_K_B;
     eos_finish(P, s);
 }
 
@@ -163,6 +171,7 @@ int ora_ctoprim(const int lo[3], const int hi[3], ora_a4 uin, ora_a4 q, ora_a4 q
         es.T = A4(q,i,j,k,QTEMP);
         es.rho = A4(q,i,j,k,QRHO);
         es.e = A4(q,i,j,k,QREINT);
+        es.xn = A4(q,i,j,k,QFS);          /* advection_util.cpp:139 */
         ora_eos_re(P, &es);
 
         A4(q,i,j,k,QTEMP) = es.T;
@@ -316,6 +325,7 @@ void ora_src_to_prim(const int lo[3], const int hi[3], ora_a4 q, ora_a4 old_src,
         es.T = A4(q,i,j,k,QTEMP);
         es.rho = A4(q,i,j,k,QRHO);
         es.e = A4(q,i,j,k,QREINT) * rhoinv;
+        es.xn = A4(q,i,j,k,QFS);          /* Castro_ctu.cpp:513 */
         ora_eos_re(P, &es);
 
         A4(srcQ,i,j,k,QRHO) = srcU[URHO];

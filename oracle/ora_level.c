@@ -317,6 +317,7 @@ void ora_sod_init(const int lo[3], const int hi[3], ora_a4 state, const ora_geom
     for (int d = 0; d < 3; ++d) split[d] = frac * (G->problo[d] + G->probhi[d]);
 
     ora_eos_t es;
+    es.xn = 1.0;                                       /* Sod problem_initialize.H:29-30 */
     es.rho = rho_l; es.p = p_l; es.T = 100000.0;
     ora_eos_rp(P, &es);
     const double rhoe_l = rho_l * es.e;

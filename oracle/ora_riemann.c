@@ -49,6 +49,7 @@ static void load_input_states(int i, int j, int k, int idir, ora_a4 qleft, ora_a
         ora_eos_t es;
         es.T = P->small_temp;
         es.rho = ql->rho;
+        es.xn = A4(qleft,i,j,k,QFS);       /* riemann.H:207 */
         ora_eos_rt(P, &es);
         ql->rhoe = ql->rho * es.e;
         ql->p = es.p;
@@ -59,6 +60,7 @@ static void load_input_states(int i, int j, int k, int idir, ora_a4 qleft, ora_a
         ora_eos_t es;
         es.T = P->small_temp;
         es.rho = qr->rho;
+        es.xn = A4(qright,i,j,k,QFS);      /* riemann.H:231 */
         ora_eos_rt(P, &es);
         qr->rhoe = qr->rho * es.e;
         qr->p = es.p;
@@ -761,12 +763,14 @@ void ora_cmpflx_plus_godunov(const int lo[3], const int hi[3], ora_a4 qm, ora_a4
                 es.T = P->T_guess;
                 es.rho = A4(qm,i,j,k,QRHO);
                 es.e = A4(qm,i,j,k,QREINT) / A4(qm,i,j,k,QRHO);
+                es.xn = A4(qm,i,j,k,QFS);
                 ora_eos_re(P, &es);
                 A4(qm,i,j,k,QREINT) = es.e * es.rho;
                 A4(qm,i,j,k,QPRES) = es.p;
 
                 es.rho = A4(qp,i,j,k,QRHO);
                 es.e = A4(qp,i,j,k,QREINT) / A4(qp,i,j,k,QRHO);
+                es.xn = A4(qp,i,j,k,QFS);
                 ora_eos_re(P, &es);
                 A4(qp,i,j,k,QREINT) = es.e * es.rho;
                 A4(qp,i,j,k,QPRES) = es.p;

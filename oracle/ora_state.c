@@ -38,6 +38,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
             ora_eos_t es;
             es.rho = small_dens;
             es.T = P->small_temp;
+            es.xn = A4(u,i,j,k,UFS) / small_dens;      /* advection_util.cpp:1127 */
             ora_eos_rt(P, &es);
 
             A4(u,i,j,k,URHO) = es.rho;
@@ -104,6 +105,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
         ora_eos_t es;
         es.rho = A4(u,i,j,k,URHO);
         es.T = P->small_temp;
+        es.xn = A4(u,i,j,k,UFS) * rhoInv;              /* Castro.cpp:3376 */
         ora_eos_rt(P, &es);
 
         double small_e = es.e;
@@ -128,6 +130,7 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
         es.rho = A4(u,i,j,k,URHO);
         es.T = A4(u,i,j,k,UTEMP);
         es.e = A4(u,i,j,k,UEINT) * rhoInv;
+        es.xn = A4(u,i,j,k,UFS) * rhoInv;              /* Castro.cpp:3694 */
         ora_eos_re(P, &es);
         A4(u,i,j,k,UTEMP) = es.T;
     }
@@ -147,6 +150,7 @@ double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom 
         es.rho = A4(u,i,j,k,URHO);
         es.T = A4(u,i,j,k,UTEMP);
         es.e = A4(u,i,j,k,UEINT) * rhoInv;
+        es.xn = A4(u,i,j,k,UFS) * rhoInv;              /* timestep.cpp:67 */
         ora_eos_re(P, &es);
 
         double ux = A4(u,i,j,k,UMX) * rhoInv;
@@ -243,6 +247,7 @@ void ora_sedov_init(const int lo[3], const int hi[3], ora_a4 state, const ora_ge
     es.rho = dens_ambient;
     es.p = p_ambient;
     es.T = 1.e9;
+    es.xn = 1.0;                                       /* problem_initialize.H:25-29 */
     ora_eos_rp(P, &es);
     const double e_ambient = es.e;
     const double temp_ambient = es.T;

@@ -272,6 +272,7 @@ void ora_reset_edge_state_thermo(const int lo[3], const int hi[3], ora_a4 qedge,
             if (A4(qedge,i,j,k,QREINT) < 0.0) {
                 es.rho = A4(qedge,i,j,k,QRHO);
                 es.T = P->small_temp;
+                es.xn = A4(qedge,i,j,k,QFS);           /* edge_util.cpp:34 */
                 ora_eos_rt(P, &es);
                 A4(qedge,i,j,k,QREINT) = A4(qedge,i,j,k,QRHO) * es.e;
                 A4(qedge,i,j,k,QPRES) = es.p;
@@ -281,6 +282,7 @@ void ora_reset_edge_state_thermo(const int lo[3], const int hi[3], ora_a4 qedge,
             es.rho = A4(qedge,i,j,k,QRHO);
             es.e = A4(qedge,i,j,k,QREINT) / A4(qedge,i,j,k,QRHO);
             es.T = P->small_temp;
+            es.xn = A4(qedge,i,j,k,QFS);               /* edge_util.cpp:54 */
             ora_eos_re(P, &es);
             A4(qedge,i,j,k,QREINT) = es.e * es.rho;
             A4(qedge,i,j,k,QPRES) = amax(es.p, P->small_pres);

@@ -112,6 +112,9 @@ def lib():
         L.ora_divu.argtypes = [I3, I3, A4, A4, C.POINTER(Geom)]
         L.ora_trace_ppm.argtypes = [I3, I3, C.c_int, A4, A4, A4, A4, A4, A4, I3, I3, C.c_double,
                                     C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_trans_single.argtypes = [I3, I3, C.c_int, C.c_int] + [A4] * 7 + [C.c_double, C.c_double, C.POINTER(Params)]
+        L.ora_trans_final.argtypes = [I3, I3, C.c_int, C.c_int, C.c_int] + [A4] * 9 + [C.c_double, C.c_double, C.POINTER(Params)]
+        L.ora_reset_edge_state_thermo.argtypes = [I3, I3, A4, C.POINTER(Params)]
         L.ora_cmpflx_plus_godunov.argtypes = [I3, I3, A4, A4, A4, A4, A4, A4, C.c_int,
                                               C.POINTER(Geom), C.POINTER(Params)]
         L.ora_level_create.restype = C.c_void_p

@@ -1620,6 +1620,67 @@ def test_pointwise_riemann_matches_the_oracle_on_extreme_states(hip, oracle):
             int(np.isnan(ref).sum()))
 
 
+def test_device_functions_reproduce_the_stub_probe_vectors(hip):
+    """tests/golden/stub_probe/vectors.npz (outputs of the reference's own ppm_reconstruct / ppm_int_profile, uflatten,
+    cmpflx_plus_godunov, actual_trans_single / actual_trans_final, compiled unmodified against stand-in headers:
+    STUB-COMPILED, NOT oracle/_ref, tools/stub_probe/) replayed through the device functions of the path
+    (castro_amd_*_points): bit for bit."""
+    import torch
+    import castro_amd
+    V = np.load(os.path.join(os.path.dirname(__file__), "golden", "stub_probe", "vectors.npz"))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(hip.device)
+
+    def params(prefix):
+        P = castro_amd.default_params()
+        for k in ("riemann_solver", "cg_blend", "hybrid_riemann", "transverse_reset_density", "transverse_reset_rhoe",
+                  "transverse_use_eos", "small_dens", "small_pres"):
+            if "in:" + prefix + k in V:
+                v = float(V["in:" + prefix + k][0])
+                setattr(P, k, v if k.startswith("small") else int(v))
+        return P
+
+    def exact(a, b, what):
+        bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+        assert not bad.any(), "%s: %d of %d values differ" % (what, int(bad.sum()), a.size)
+
+    n = V["in:ppm.flat"].size
+    out = hip.ppm_points(dev(V["in:ppm.s"].reshape(5, n)), dev(V["in:ppm.flat"]), dev(V["in:ppm.u"]), dev(V["in:ppm.c"]),
+                         float(V["in:ppm.dtdx"][0])).cpu().numpy()
+    exact(out, V["out:ppm.out"].reshape(8, n), "ppm")
+    n = V["in:flat.p"].size // 7
+    exact(hip.flatten_points(dev(V["in:flat.p"].reshape(7, n)), dev(V["in:flat.u"].reshape(5, n))).cpu().numpy(), V["out:flat.out"], "uflatten")
+    for c in range(12):
+        P = "cmpflx%d." % c
+        qm, qp = V["in:" + P + "qm"].reshape(7, -1), V["in:" + P + "qp"].reshape(7, -1)
+        cz, shk = V["in:" + P + "c"], V["in:" + P + "shk"]
+        n = qm.shape[1]
+        bf = np.ones(n)
+        if int(V["in:" + P + "wall"][0]):
+            bf[0] = 0.0
+        sh = torch.from_numpy(((shk[:-1] + shk[1:]) >= 1).astype(np.int32)).to(hip.device)
+        out = hip.cmpflx_points(int(V["in:" + P + "idir"][0]), dev(qm), dev(qp), dev(cz[:-1]), dev(cz[1:]), params(P), bnd_fac=dev(bf),
+                                is_shock=sh).cpu().numpy()
+        exact(out, V["out:" + P + "out"].reshape(11, n), P)
+    for c in range(9):
+        P = "trans1_%d." % c
+        q = V["in:" + P + "q"].reshape(7, -1)
+        n = q.shape[1]
+        rec = V["in:" + P + "flux"].reshape(9, n + 1)
+        out = hip.trans_points(dev(q), dev(rec[:8, 1:]), dev(rec[:8, :-1]), float(V["in:" + P + "cdtdx"][0]), params(P),
+                               tdir=int(V["in:" + P + "idir_t"][0]), fe=dev(np.stack([rec[8, 1:], rec[8, :-1]]))).cpu().numpy()
+        exact(out, V["out:" + P + "out"].reshape(7, n), P)
+    for c in range(5):
+        P = "trans2_%d." % c
+        q = V["in:" + P + "q"].reshape(7, -1)
+        n = q.shape[1]
+        f1 = V["in:" + P + "flux1"].reshape(9, n + 1)
+        f2l, f2r = V["in:" + P + "flux2l"].reshape(9, n), V["in:" + P + "flux2r"].reshape(9, n)
+        out = hip.trans_points(dev(q), dev(f1[:8, 1:]), dev(f1[:8, :-1]), float(V["in:" + P + "cdtdx1"][0]), params(P),
+                               f2r=dev(f2r[:8]), f2l=dev(f2l[:8]), cdtdx2=float(V["in:" + P + "cdtdx2"][0]),
+                               fe=dev(np.stack([f1[8, 1:], f1[8, :-1], f2r[8], f2l[8]]))).cpu().numpy()
+        exact(out, V["out:" + P + "out"].reshape(7, n), P)
+
+
 def test_randomised_auxiliary_entry_points_match_the_oracle():
     """tools/fuzz_aux.py: clean_state x 1..3 (with small_dens / speed_limit / small_temp variations), estdt, the fused
     clean + reduce, the physical-boundary fill with every boundary type on domains down to one zone wide, all derived

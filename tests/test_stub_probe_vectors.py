@@ -1,0 +1,221 @@
+"""The oracle against tests/golden/stub_probe/vectors.npz: outputs of the reference's own per-zone functions, compiled
+unmodified from /root/reference against stand-in AMReX / Microphysics headers (tools/stub_probe/make_vectors.py).
+
+STUB-COMPILED, NOT oracle/_ref: these vectors do not pin the oracle to a reference binary (parity stays "unpinned",
+DESIGN.md section 6); they show that the oracle's restatement of ppm_reconstruct / ppm_int_profile, uflatten,
+cmpflx_plus_godunov (CGF, CG, HLLC, HLL), actual_trans_single / actual_trans_final, ctoprim and trace_ppm reproduces
+the reference's source text bit for bit on ~200 000 values.  tests/test_gpu_parity.py replays the pointwise sets on the
+device code."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_lib as O
+
+VEC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stub_probe", "vectors.npz")
+
+
+@pytest.fixture(scope="module")
+def V():
+    return np.load(VEC)
+
+
+def cfg_params(V, prefix, **fixed):
+    kw = dict(fixed)
+    for k in ("riemann_solver", "cg_blend", "hybrid_riemann", "ppm_temp_fix", "transverse_reset_density", "transverse_reset_rhoe",
+              "transverse_use_eos", "small_dens", "small_pres", "small_temp", "small_ener"):
+        key = "in:" + prefix + k
+        if key in V:
+            v = float(V[key][0])
+            kw[k] = v if k.startswith("small") else int(v)
+    P = O.default_params()
+    for k, v in kw.items():
+        setattr(P, k, v)                 # the probe sets the parameters as given: no re-derived floors
+    return P
+
+
+def exact(a, b, what):
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    assert not bad.any(), "%s: %d of %d values differ, max abs %.3e" % (what, int(bad.sum()), a.size, float(np.nanmax(np.abs(a - b))))
+
+
+def test_ppm_reconstruct_and_int_profile(V):
+    s, fl, u, c = V["in:ppm.s"].reshape(5, -1), V["in:ppm.flat"], V["in:ppm.u"], V["in:ppm.c"]
+    dtdx = float(V["in:ppm.dtdx"][0])
+    n = fl.size
+    out = np.empty((8, n))
+    L = O.lib()
+    sm, sp = C.c_double(), C.c_double()
+    Ip, Im = (C.c_double * 3)(), (C.c_double * 3)()
+    for p in range(n):
+        st = (C.c_double * 5)(*s[:, p])
+        L.ora_ppm_reconstruct(st, float(fl[p]), C.byref(sm), C.byref(sp))
+        L.ora_ppm_int_profile(sm.value, sp.value, float(s[2, p]), float(u[p]), float(c[p]), dtdx, Ip, Im)
+        out[0, p], out[1, p] = sm.value, sp.value
+        out[2:5, p], out[5:8, p] = list(Ip), list(Im)
+    exact(out, V["out:ppm.out"].reshape(8, n), "ppm")
+
+
+def flatten_lines(V):
+    """the 7 x 7 x 7 arrays of probe.cpp: pressure and x velocity vary along x only"""
+    pv, uv = V["in:flat.p"].reshape(7, -1), V["in:flat.u"].reshape(5, -1)
+    return pv, uv
+
+
+def test_uflatten(V):
+    pv, uv = flatten_lines(V)
+    n = pv.shape[1]
+    out = np.empty(n)
+    lo, hi = (-3, -3, -3), (3, 3, 3)
+    for p in range(n):
+        q = np.zeros((8, 7, 7, 7))
+        q[O.QPRES] = pv[:, p][None, None, :]
+        q[O.QU, :, :, 1:6] = uv[:, p][None, None, :]
+        q[O.QRHO] = 1.0
+        fl = np.zeros((1, 7, 7, 7))
+        O.lib().ora_uflatten(O.i3((0, 0, 0)), O.i3((0, 0, 0)), O.a4(q, lo, hi), O.a4(fl, lo, hi), O.QPRES)
+        out[p] = fl[0, 3, 3, 3]
+    exact(out, V["out:flat.out"], "uflatten")
+
+
+@pytest.mark.parametrize("c", range(12))
+def test_cmpflx_plus_godunov(V, c):
+    P = "cmpflx%d." % c
+    qm, qp = V["in:" + P + "qm"].reshape(7, -1), V["in:" + P + "qp"].reshape(7, -1)
+    cz, shk = V["in:" + P + "c"], V["in:" + P + "shk"]
+    n = qm.shape[1]
+    idir = int(V["in:" + P + "idir"][0])
+    par = cfg_params(V, P)
+    bf = np.ones(n)
+    if int(V["in:" + P + "wall"][0]):
+        bf[0] = 0.0
+    is_shock = ((shk[:-1] + shk[1:]) >= 1).astype(np.int32)
+    out = O.cmpflx_points(idir, qm, qp, cz[:-1], cz[1:], bf, par, is_shock=is_shock)
+    exact(out, V["out:" + P + "out"].reshape(11, n), P)
+
+
+def _flux_arrays(rec, T, N, shape_f, nfaces):
+    """probe.cpp's flux_t (NUM_STATE comps) and q_t (NGDNV comps) arrays from a (9, nfaces) record along direction T
+    (the arrays start at -1 in direction N)"""
+    F = np.zeros((8,) + shape_f)
+    G = np.zeros((4,) + shape_f)
+    sl = [0, 0, 0]
+    sl[2 - T] = slice(0, nfaces)
+    sl[2 - N] = 1
+    sl = tuple(sl)
+    for m, comp in enumerate((O.URHO, O.UMX, O.UMY, O.UMZ, O.UEDEN, O.UFS)):
+        F[(comp,) + sl] = rec[m]
+    F[(O.UEINT,) + sl] = rec[8]
+    G[(T,) + sl] = rec[6]
+    G[(3,) + sl] = rec[7]
+    return F, G
+
+
+@pytest.mark.parametrize("c", range(9))
+def test_actual_trans_single(V, c):
+    P = "trans1_%d." % c
+    T, N = int(V["in:" + P + "idir_t"][0]), int(V["in:" + P + "idir_n"][0])
+    q = V["in:" + P + "q"].reshape(7, -1)
+    n = q.shape[1]
+    rec = V["in:" + P + "flux"].reshape(9, n + 1)
+    par = cfg_params(V, P)
+    lo, hi = [0, 0, 0], [0, 0, 0]
+    hi[T] = n
+    lo[N] = -1                     # the oracle's trans_single also does the minus states: they read zone N-1
+    shp = tuple(hi[2 - a] - lo[2 - a] + 1 for a in range(3))
+    Q, QO = np.ones((8,) + shp), np.zeros((8,) + shp)
+    sl = [0, 0, 0]
+    sl[2 - T] = slice(0, n)
+    sl[2 - N] = 1
+    sl = tuple(sl)
+    for m, comp in enumerate((O.QRHO, O.QU, O.QV, O.QW, O.QPRES, O.QREINT, O.QFS)):
+        Q[(comp,) + sl] = q[m]
+    AUX = np.full((2,) + shp, par.eos_gamma)
+    F, G = _flux_arrays(rec, T, N, shp, n + 1)
+    zlo, zhi = [0, 0, 0], [0, 0, 0]
+    zhi[T] = n - 1
+    L = O.lib()
+    dummy_m, dummy_mo = np.array(Q), np.zeros_like(Q)
+    L.ora_trans_single(O.i3(zlo), O.i3(zhi), T, N, O.a4(dummy_m, lo, hi), O.a4(dummy_mo, lo, hi), O.a4(Q, lo, hi), O.a4(QO, lo, hi),
+                       O.a4(AUX, lo, hi), O.a4(F, lo, hi), O.a4(G, lo, hi), 0.0, float(V["in:" + P + "cdtdx"][0]), C.byref(par))
+    L.ora_reset_edge_state_thermo(O.i3(zlo), O.i3(zhi), O.a4(QO, lo, hi), C.byref(par))
+    out = np.stack([QO[(comp,) + sl] for comp in (O.QRHO, O.QU, O.QV, O.QW, O.QPRES, O.QREINT, O.QFS)])
+    exact(out, V["out:" + P + "out"].reshape(7, n), P)
+
+
+@pytest.mark.parametrize("c", range(5))
+def test_actual_trans_final(V, c):
+    P = "trans2_%d." % c
+    N, T1, T2 = (int(V["in:" + P + k][0]) for k in ("idir_n", "idir_t1", "idir_t2"))
+    q = V["in:" + P + "q"].reshape(7, -1)
+    n = q.shape[1]
+    f1 = V["in:" + P + "flux1"].reshape(9, n + 1)
+    f2l, f2r = V["in:" + P + "flux2l"].reshape(9, n), V["in:" + P + "flux2r"].reshape(9, n)
+    par = cfg_params(V, P)
+    lo, hi = [0, 0, 0], [0, 0, 0]
+    hi[T1], hi[T2] = n, 1
+    lo[N] = -1                     # room for the minus states the oracle's trans_final also computes
+    shp = tuple(hi[2 - a] - lo[2 - a] + 1 for a in range(3))
+
+    def at(a, b):
+        idx = [0, 0, 0]
+        idx[2 - T1], idx[2 - T2], idx[2 - N] = a, b, 1
+        return tuple(idx)
+    Q, QO = np.ones((8,) + shp), np.zeros((8,) + shp)
+    for m, comp in enumerate((O.QRHO, O.QU, O.QV, O.QW, O.QPRES, O.QREINT, O.QFS)):
+        Q[(comp,) + at(slice(0, n), 0)] = q[m]
+    AUX = np.full((2,) + shp, par.eos_gamma)
+    F1, G1, F2, G2 = np.zeros((8,) + shp), np.zeros((4,) + shp), np.zeros((8,) + shp), np.zeros((4,) + shp)
+    for m, comp in enumerate((O.URHO, O.UMX, O.UMY, O.UMZ, O.UEDEN, O.UFS)):
+        F1[(comp,) + at(slice(0, n + 1), 0)] = f1[m]
+        F2[(comp,) + at(slice(0, n), 0)] = f2l[m]
+        F2[(comp,) + at(slice(0, n), 1)] = f2r[m]
+    F1[(O.UEINT,) + at(slice(0, n + 1), 0)] = f1[8]
+    F2[(O.UEINT,) + at(slice(0, n), 0)] = f2l[8]
+    F2[(O.UEINT,) + at(slice(0, n), 1)] = f2r[8]
+    G1[(T1,) + at(slice(0, n + 1), 0)] = f1[6]
+    G1[(3,) + at(slice(0, n + 1), 0)] = f1[7]
+    G2[(T2,) + at(slice(0, n), 0)] = f2l[6]
+    G2[(T2,) + at(slice(0, n), 1)] = f2r[6]
+    G2[(3,) + at(slice(0, n), 0)] = f2l[7]
+    G2[(3,) + at(slice(0, n), 1)] = f2r[7]
+    zlo, zhi = [0, 0, 0], [0, 0, 0]
+    zhi[T1] = n - 1
+    L = O.lib()
+    dm, dmo = np.array(Q), np.zeros_like(Q)
+    L.ora_trans_final(O.i3(zlo), O.i3(zhi), N, T1, T2, O.a4(dm, lo, hi), O.a4(dmo, lo, hi), O.a4(Q, lo, hi), O.a4(QO, lo, hi),
+                      O.a4(AUX, lo, hi), O.a4(F1, lo, hi), O.a4(F2, lo, hi), O.a4(G1, lo, hi), O.a4(G2, lo, hi),
+                      float(V["in:" + P + "cdtdx1"][0]), float(V["in:" + P + "cdtdx2"][0]), C.byref(par))
+    L.ora_reset_edge_state_thermo(O.i3(zlo), O.i3(zhi), O.a4(QO, lo, hi), C.byref(par))
+    out = np.stack([QO[(comp,) + at(slice(0, n), 0)] for comp in (O.QRHO, O.QU, O.QV, O.QW, O.QPRES, O.QREINT, O.QFS)])
+    exact(out, V["out:" + P + "out"].reshape(7, n), P)
+
+
+def test_block_ctoprim_uflatten_trace_ppm(V):
+    nb = int(V["in:block.n"][0])
+    dt = float(V["in:block.dt"][0])
+    dx = V["in:block.dx"]
+    lo, hi = (-4, -4, -4), (nb + 3, nb + 3, nb + 3)
+    m = nb + 8
+    U = np.ascontiguousarray(V["in:block.U"].reshape(8, m, m, m))
+    P = O.default_params()
+    G = O.make_geom((nb, nb, nb), probhi=[nb * dx[d] for d in range(3)])
+    for d in range(3):
+        G.dx[d] = float(dx[d])               # exactly the probe's cell sizes (nb * dx / nb need not round back to dx)
+    q, qaux, fl = np.zeros((8, m, m, m)), np.zeros((2, m, m, m)), np.zeros((1, m, m, m))
+    L = O.lib()
+    assert L.ora_ctoprim(O.i3(lo), O.i3(hi), O.a4(U, lo, hi), O.a4(q, lo, hi), O.a4(qaux, lo, hi), C.byref(P)) == 0
+    l1, h1 = (-1, -1, -1), (nb, nb, nb)
+    L.ora_uflatten(O.i3(l1), O.i3(h1), O.a4(q, lo, hi), O.a4(fl, lo, hi), O.QPRES)
+    exact(q, V["out:block.q"].reshape(q.shape), "ctoprim q")
+    exact(qaux, V["out:block.qaux"].reshape(qaux.shape), "ctoprim qaux")
+    exact(fl, V["out:block.flatn"].reshape(fl.shape), "uflatten")
+    src = np.zeros((7, m, m, m))
+    for idir in range(3):
+        qm, qp = np.zeros_like(q), np.zeros_like(q)
+        L.ora_trace_ppm(O.i3(l1), O.i3(h1), idir, O.a4(q, lo, hi), O.a4(qaux, lo, hi), O.a4(src, lo, hi), O.a4(fl, lo, hi),
+                        O.a4(qm, lo, hi), O.a4(qp, lo, hi), O.i3((0, 0, 0)), O.i3((nb - 1, nb - 1, nb - 1)), dt, C.byref(G), C.byref(P))
+        exact(qm, V["out:block.qm%d" % idir].reshape(q.shape), "trace_ppm qm, direction %d" % idir)
+        exact(qp, V["out:block.qp%d" % idir].reshape(q.shape), "trace_ppm qp, direction %d" % idir)

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/stub_probe/vectors.npz: inputs and outputs of the reference's own per-zone functions.
+
+STUB-COMPILED, NOT oracle/_ref.  The reference cannot be built in this image (AMReX and Microphysics are empty
+submodules, Exec/Make.Castro:24-26,44-46), so this script compiles the reference's hydro sources UNMODIFIED and IN PLACE
+from /root/reference against the stand-in headers in tools/stub_probe/stub/ (about 250 lines: Array4, Box, ParallelFor,
+Geometry, a gamma-law eos(), the castro:: parameters) and runs probe.cpp on seeded inputs.  state_indices.H is produced
+by the reference's own Source/driver/set_variables.py into a temporary directory.  What this shows: whether the
+oracle's C restatement and the device functions of ppm_reconstruct / ppm_int_profile, uflatten, cmpflx_plus_godunov
+(CGF, CG with every cg_blend, HLLC, HLL), actual_trans_single / actual_trans_final, ctoprim and trace_ppm have slipped
+from the source text they follow.  What it does NOT show: anything about a real reference binary (AMReX's Array4 /
+ParallelFor, Microphysics's EOS arithmetic order) -- parity stays "unpinned" (DESIGN.md section 6).
+
+Only runs where /root/reference exists; nothing of the reference's sources is copied into the repository: the committed
+artefacts are this recipe and the vectors (data)."""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CASTRO_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+from tests.util import physical_state   # noqa: E402
+
+
+def write_blob(path, arrays):
+    with open(path, "wb") as f:
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64))).ravel()
+            f.write(name.encode().ljust(48, b"\0"))
+            f.write(struct.pack("<q", a.size))
+            f.write(a.tobytes())
+
+
+def read_blob(path):
+    out = {}
+    with open(path, "rb") as f:
+        while True:
+            h = f.read(48)
+            if len(h) < 48:
+                break
+            n = struct.unpack("<q", f.read(8))[0]
+            out[h.split(b"\0")[0].decode()] = np.frombuffer(f.read(8 * n), dtype=np.float64).copy()
+    return out
+
+
+def build(tmp):
+    src = os.path.join(REF, "Source")
+    subprocess.check_call([sys.executable, "set_variables.py", "--odir", tmp, "--nadv", "0", "--ngroups", "1", "--defines= ",
+                           "_variables"], cwd=os.path.join(src, "driver"), stdout=subprocess.DEVNULL)
+    inc = ["-I" + os.path.join(HERE, "stub"), "-I" + tmp, "-I" + os.path.join(src, "hydro"), "-I" + os.path.join(src, "driver")]
+    flags = ["-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math"]
+    objs = []
+    for f in ("trans", "flatten", "riemann", "riemann_util", "advection_util", "trace_ppm", "trace_plm", "Castro_ctu", "edge_util"):
+        o = os.path.join(tmp, f + ".o")
+        subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(src, "hydro", f + ".cpp"), "-o", o])
+        objs.append(o)
+    for f in ("probe", "probe_params"):
+        o = os.path.join(tmp, f + ".o")
+        subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(HERE, f + ".cpp"), "-o", o])
+        objs.append(o)
+    exe = os.path.join(tmp, "probe")
+    subprocess.check_call(["g++", "-o", exe] + objs)
+    return exe
+
+
+def edge_states(rng, n, gam=1.4, cold=0.15):
+    """(7, n) edge states (rho,u,v,w,p,rhoe,X): jumps of many decades, supersonic flows, some with rho e <= 0 or a tiny
+    pressure (the EOS clean-up of load_input_states)"""
+    rho = 10.0 ** rng.uniform(-3, 2, n)
+    vel = rng.normal(size=(3, n)) * 10.0 ** rng.uniform(-2, 1, n)
+    p = 10.0 ** rng.uniform(-5, 3, n)
+    rhoe = p / (gam - 1.0) * rng.choice([1.0, 1.0, 1.0, 0.6, 2.5], n)
+    bad = rng.uniform(size=n) < cold * 0.2
+    rhoe = np.where(bad, -rhoe, rhoe)
+    X = rng.uniform(size=n)
+    return np.stack([rho, vel[0], vel[1], vel[2], p, rhoe, X])
+
+
+def flux_records(rng, n):
+    """(9, n): rho, mx, my, mz, E, X fluxes, Godunov un, Godunov p, (rho e) flux"""
+    f = rng.normal(size=(9, n)) * 10.0 ** rng.uniform(-2, 1, n)
+    f[7] = 10.0 ** rng.uniform(-4, 2, n)
+    return f
+
+
+def main():
+    rng = np.random.default_rng(20211007)
+    A = {}
+    # ---- ppm ----
+    n = 6000
+    kind = rng.integers(0, 5, n)
+    x = rng.uniform(0, 6.3, n)
+    s = np.empty((5, n))
+    for m in range(5):
+        smooth = np.sin(x + 0.4 * m) + 2.0
+        noisy = rng.normal(size=n)
+        mono = np.cumsum(rng.uniform(0, 1, (5, n)), axis=0)[m]
+        step = np.where(m < 2 + rng.integers(0, 2, n), 1.0, rng.uniform(0.01, 100.0, n))
+        flat = np.full(n, 3.0) + (m == 2) * rng.choice([0.0, 1e-13], n)
+        s[m] = np.choose(kind, [smooth, noisy, mono, step, flat])
+    A["ppm.s"] = s
+    A["ppm.flat"] = rng.choice([0.0, 1.0, 1.0, 0.37], n) * np.where(rng.uniform(size=n) < 0.2, rng.uniform(size=n), 1.0)
+    A["ppm.u"] = rng.normal(scale=2.0, size=n)
+    A["ppm.c"] = 10.0 ** rng.uniform(-2, 1, n)
+    A["ppm.dtdx"] = 0.27
+    # ---- flattening along one direction ----
+    n = 4000
+    base = 10.0 ** rng.uniform(-3, 2, n)
+    p7 = base * (1.0 + 0.05 * rng.normal(size=(7, n)))
+    jump = rng.integers(0, 8, n)
+    for m in range(7):
+        p7[m] = np.where(m >= jump, p7[m] * rng.choice([1.0, 1.5, 4.0, 50.0, 0.02], n), p7[m])
+    A["flat.p"] = np.abs(p7)
+    A["flat.u"] = rng.normal(size=(5, n)) + np.linspace(1.5, -1.5, 5)[:, None] * rng.choice([0.0, 1.0, -1.0], n)
+    # ---- cmpflx_plus_godunov ----
+    cfgs = [dict(idir=0), dict(idir=1), dict(idir=2, wall=1), dict(idir=0, riemann_solver=1, cg_blend=2),
+            dict(idir=1, riemann_solver=1, cg_blend=1), dict(idir=2, riemann_solver=1, cg_blend=1, wall=1),
+            dict(idir=0, riemann_solver=2), dict(idir=2, riemann_solver=2, wall=1), dict(idir=0, hybrid_riemann=1),
+            dict(idir=1, riemann_solver=2, hybrid_riemann=1), dict(idir=1, small_pres=1e-4, small_dens=1e-2),
+            dict(idir=2, riemann_solver=1, cg_blend=2, small_pres=1e-4)]
+    for c, cfg in enumerate(cfgs):
+        n = 450
+        P = "cmpflx%d." % c
+        qm, qp = edge_states(rng, n), edge_states(rng, n)
+        same = rng.uniform(size=n) < 0.15
+        qp[:, same] = qm[:, same] * (1.0 + 1e-3 * rng.normal(size=(7, int(same.sum()))))
+        qp[0] = np.abs(qp[0]); qp[4] = np.abs(qp[4])
+        cz = 10.0 ** rng.uniform(-2, 1.5, n + 1)
+        A[P + "qm"], A[P + "qp"], A[P + "c"] = qm, qp, cz
+        A[P + "shk"] = (rng.uniform(size=n + 1) < 0.3).astype(float) if cfg.get("hybrid_riemann") else np.zeros(n + 1)
+        A[P + "wall"] = float(cfg.get("wall", 0))
+        for k, v in cfg.items():
+            if k != "wall":
+                A[P + k] = float(v)
+    # ---- trans_single ----
+    tcfgs = [dict(idir_t=0, idir_n=1), dict(idir_t=1, idir_n=0), dict(idir_t=2, idir_n=0), dict(idir_t=0, idir_n=2),
+             dict(idir_t=1, idir_n=2), dict(idir_t=2, idir_n=1), dict(idir_t=0, idir_n=1, transverse_reset_density=0),
+             dict(idir_t=1, idir_n=2, transverse_reset_rhoe=1), dict(idir_t=2, idir_n=0, transverse_use_eos=1)]
+    for c, cfg in enumerate(tcfgs):
+        n = 500
+        P = "trans1_%d." % c
+        q = edge_states(rng, n, cold=0.0)
+        q[5] = np.abs(q[5])
+        A[P + "q"] = q
+        A[P + "flux"] = flux_records(rng, n + 1) * rng.choice([1.0, 1.0, 30.0], n + 1)     # some large enough to flip the density
+        A[P + "qt"] = np.zeros(1)
+        A[P + "cdtdx"] = 0.011
+        for k, v in cfg.items():
+            A[P + k] = float(v)
+    # ---- trans_final ----
+    fcfgs = [dict(idir_n=0, idir_t1=1, idir_t2=2), dict(idir_n=1, idir_t1=0, idir_t2=2), dict(idir_n=2, idir_t1=0, idir_t2=1),
+             dict(idir_n=0, idir_t1=1, idir_t2=2, transverse_reset_density=0), dict(idir_n=2, idir_t1=0, idir_t2=1, transverse_reset_rhoe=1)]
+    for c, cfg in enumerate(fcfgs):
+        n = 500
+        P = "trans2_%d." % c
+        q = edge_states(rng, n, cold=0.0)
+        q[5] = np.abs(q[5])
+        A[P + "q"] = q
+        A[P + "flux1"] = flux_records(rng, n + 1) * rng.choice([1.0, 1.0, 20.0], n + 1)
+        A[P + "flux2l"] = flux_records(rng, n)
+        A[P + "flux2r"] = flux_records(rng, n) * rng.choice([1.0, 1.0, 20.0], n)
+        A[P + "cdtdx1"], A[P + "cdtdx2"] = 0.017, 0.013
+        for k, v in cfg.items():
+            A[P + k] = float(v)
+    # ---- a block through ctoprim, uflatten, trace_ppm ----
+    nb = 6
+    U = physical_state(rng, (-4, -4, -4), (nb + 3, nb + 3, nb + 3), smooth=False, vel=1.5, jump=True)
+    A["block.U"], A["block.n"], A["block.dt"], A["block.dx"] = U, float(nb), 7.0e-4, np.array([0.02, 0.025, 0.03])
+
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build(tmp)
+        write_blob(os.path.join(tmp, "in.bin"), A)
+        subprocess.check_call([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
+        O = read_blob(os.path.join(tmp, "out.bin"))
+    dst = os.path.join(ROOT, "tests", "golden", "stub_probe")
+    os.makedirs(dst, exist_ok=True)
+    allv = {"in:" + k: np.atleast_1d(np.asarray(v, dtype=np.float64)) for k, v in A.items()}
+    allv.update({"out:" + k: v for k, v in O.items()})
+    np.savez_compressed(os.path.join(dst, "vectors.npz"), **allv)
+    print("wrote %s: %d input arrays, %d output arrays, %.1f KB" % (
+        os.path.join(dst, "vectors.npz"), len(A), len(O), os.path.getsize(os.path.join(dst, "vectors.npz")) / 1024.0))
+    for k in sorted(O):
+        print("  %-16s %8d values, %d NaN" % (k, O[k].size, int(np.isnan(O[k]).sum())))
+
+
+if __name__ == "__main__":
+    main()
