@@ -1490,6 +1490,104 @@ def test_reference_shock_tube_inputs_with_amr_against_exact_tables(case, tol):
             assert float((S[0] - S[0][:1, :1, :]).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case,tol", [("sod", (0.01, 0.01, 0.01)), ("test2", (0.025, 0.03, 0.03)), ("test3", (0.12, 0.5, 0.025))])
+def test_reference_shock_tube_inputs_along_y_and_z_equal_the_x_run(case, tol):
+    """Exec/hydro_tests/Sod/inputs-{sod,test2,test3}-y and -z: the same tubes along y and along z (8 x 32 x 8 and
+    8 x 8 x 32 base zones, two refined levels).  The profile along the tube must meet the -x run's tolerances and agree
+    with the -x run to round-off (not bit for bit: consup_hydro adds the x, y, z flux differences in that order, so a
+    tube along y rounds (0 + dF) where a tube along x rounds (dF + G) - G, and the box lists of the refined levels are
+    clustered direction by direction)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sod_reference_inputs", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                                       "sod_reference_inputs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rx, _ = mod.run(case, idir=1)
+    for idir in (2, 3):
+        r, a = mod.run(case, idir=idir)
+        assert r["rho"] < tol[0] and r["u"] < tol[1] and r["p"] < tol[2], r
+        assert r["nstep"] == rx["nstep"] and r["time"] == rx["time"]
+        lx, l = rx["line"], r["line"]
+        # density, normal momentum, energies, temperature, species of the line through the origin
+        for comp_x, comp in ((0, 0), (1, idir), (4, 4), (5, 5), (6, 6), (7, 7)):
+            scale = np.abs(lx[comp_x]).max()
+            assert np.abs(lx[comp_x] - l[comp]).max() <= 1e-11 * scale, "direction %d, component %d: %.3e" % (
+                idir, comp, np.abs(lx[comp_x] - l[comp]).max() / scale)
+
+
+def _exact_two_rarefactions_with_vacuum(x_over_t, rho0, u0, p0, gamma):
+    """Exact solution of the symmetric Riemann problem (rho0, -u0, p0 | rho0, +u0, p0) when the two rarefactions leave a
+    vacuum between them (Toro, Riemann Solvers, section 4.6.3): returns rho, u, p at the similarity coordinate x/t."""
+    c0 = np.sqrt(gamma * p0 / rho0)
+    g1, g2 = gamma - 1.0, gamma + 1.0
+    xi = np.abs(x_over_t)                      # by symmetry solve the right half: state (rho0, +u0, p0)
+    head, tail = u0 + c0, u0 - 2.0 * c0 / g1   # head of the fan, vacuum front
+    rho = np.where(xi >= head, rho0, np.where(xi <= tail, 0.0,
+                   rho0 * np.maximum(2.0 / g2 - g1 / (g2 * c0) * (u0 - xi), 0.0) ** (2.0 / g1)))
+    u = np.where(xi >= head, u0, np.where(xi <= tail, 0.0, 2.0 / g2 * (-c0 + g1 / 2.0 * u0 + xi)))
+    p = np.where(xi >= head, p0, np.where(xi <= tail, 0.0,
+                 p0 * np.maximum(2.0 / g2 - g1 / (g2 * c0) * (u0 - xi), 0.0) ** (2.0 * gamma / g1)))
+    return rho, np.sign(x_over_t) * u, p
+
+
+def test_reference_double_rarefaction_input_against_the_exact_vacuum_solution():
+    """Exec/hydro_tests/Sod/inputs-double-rarefaction (400 zones on [0,1], rho = 1, u = -2 | +2, p = 0.1, gamma = 1.4,
+    small_dens = 1e-13, cfl 0.5, init_shrink 0.1, change_max 1.05, stop_time 0.1; a 1-D input, run here as a
+    400 x 4 x 4 slab with slip walls in y and z): the two rarefactions open a vacuum (2 c / (gamma - 1) < |u|), the run
+    must get through it without a rejected step and match the exact similarity solution: volume-weighted L1 of the
+    density within 2 %, momentum within 3 % of rho0 u0, the solution symmetric about the middle and one-dimensional."""
+    import castro_amd
+    n = (400, 4, 4)
+    c = castro_amd.Castro(n, prob_hi=(1.0, 0.01, 0.01), lo_bc=(2, 4, 4), hi_bc=(2, 4, 4),
+                          params=castro_amd.default_params(small_dens=1.e-13, cfl=0.5, init_shrink=0.1, change_max=1.05))
+    c.initData("sod", rho_l=1.0, u_l=-2.0, p_l=0.1, rho_r=1.0, u_r=2.0, p_r=0.1, idir=1, frac=0.5)
+    c.evolve(0.1)
+    S = c.S_new().cpu().numpy()
+    assert c.time == 0.1 and np.isfinite(S).all() and S[0].min() > 0.0
+    assert np.array_equal(S[:, :, :, :], np.broadcast_to(S[:, :1, :1, :], S.shape))          # one-dimensional
+    rho, mx = S[0, 0, 0], S[1, 0, 0]
+    assert np.abs(rho - rho[::-1]).max() < 1e-12 and np.abs(mx + mx[::-1]).max() < 1e-12     # mirror symmetry to round-off
+    x = (np.arange(400) + 0.5) / 400.0 - 0.5
+    er, eu, ep = _exact_two_rarefactions_with_vacuum(x / 0.1, 1.0, 2.0, 0.1, 1.4)
+    l1_rho = np.abs(rho - er).mean() / er.mean()
+    l1_mom = np.abs(mx - er * eu).mean() / 2.0
+    assert l1_rho < 0.02 and l1_mom < 0.03, (l1_rho, l1_mom)
+    assert rho[200] < 1e-3                                                                    # the vacuum region really empties
+
+
+def test_sedov_config_1_64_cubed_against_the_analytic_table_and_the_oracle(oracle):
+    """BASELINE config 1: Exec/hydro_tests/Sedov/inputs.3d.sph at 64^3 (outflow, PPM + CGF, cfl 0.5, init_shrink 0.01,
+    change_max 1.1, r_init 0.01, nsub 10).  (i) the first 25 steps on the device against the oracle's own level driver in C:
+    same dt sequence, same state, bit for bit; (ii) on to stop_time = 0.01: shock radius within one zone of the table's
+    (Exec/hydro_tests/Sedov/Verification/spherical_sedov.dat), radially binned density within 12 %, velocity within 30 % and
+    pressure within 35 % of it in the volume-weighted L1 norm (first-order convergence at the shock: 3.2 / 10 / 13 % at
+    256^3, 4.6 / 19 / 22 % at 128^3), mass and energy conserved to round-off while the shock is inside the box."""
+    import torch
+    import castro_amd
+    n = (64, 64, 64)
+    c = castro_amd.Castro(n)
+    c.initData("sedov")
+    lev = oracle.Level(n, oracle.make_geom(n), oracle.default_params(), nthreads=8)
+    lev.init_sedov()
+    for step in range(25):
+        da, db = c.step(0.01), lev.step(0.01)
+        assert da == db, "dt differs at step %d: %r vs %r" % (step, da, db)
+    torch.cuda.synchronize()
+    assert np.array_equal(c.S_new().cpu().numpy(), lev.state())
+    lev.close()
+    m0, e0 = float(c.S_new()[0].sum()), float(c.S_new()[4].sum())
+    c.evolve(0.01)
+    assert c.time == 0.01
+    assert abs(float(c.S_new()[0].sum()) - m0) < 1e-9 * m0 and abs(float(c.S_new()[4].sum()) - e0) < 1e-9 * e0
+    table = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "reference_verification", "spherical_sedov.dat"))
+    from tests.util import sedov_l1_errors
+    err, rc, prof = sedov_l1_errors(c, table)
+    r_shock_table = table[np.argmax(table[:, 2]), 1]
+    r_peak = rc[np.argmax(prof["density"])]
+    assert abs(r_peak - r_shock_table) <= 1.0 / 64 + 1e-12, (r_peak, r_shock_table)
+    assert err["density"] < 0.12 and err["velocity"] < 0.30 and err["pressure"] < 0.35, err
+
+
 def test_reference_sedov_testsuite_input_four_levels_plm():
     """The reference's regression input Exec/hydro_tests/Sedov/inputs.3d.sph.testsuite as it is: 32^3 base zones,
     amr.max_level = 3 (effective 256^3), ppm_type = 0 (PLM), regrid_int 2, blocking_factor 8, max_grid_size 32 (about 150
