@@ -110,6 +110,8 @@ class _Level:
         self.red = b0.red
         for b in self.boxes:
             b.red = self.red      # one [min dt, min rho] pair for the level: every box reduces into it
+            b.fuse_post_clean = False      # post_timestep's clean_state comes after reflux and avgDown (_time_step)
+        self._pending_cleans, self._post_clean_done, self._whole_step = 2, False, False
         for k in ("use_retry", "retry_subcycle_factor", "max_subcycles", "dt_cutoff", "max_dt", "fixed_dt", "have_sources"):
             setattr(self, k, getattr(b0, k))
         self.fuse_clean = b0.fuse_clean
@@ -369,8 +371,13 @@ class _Level:
 
     def do_advance_ctu(self, time, dt):
         """Castro::do_advance_ctu (Castro_advance_ctu.cpp:15-397) with every stage done for all boxes before the next."""
-        for b in self.boxes:
-            b.clean_state(b.S_old_b, 2)
+        if self.l > 0 and time != self._t0:
+            # a later subcycle of a retried step: the coarse data are interpolated to ITS old time, not the step's
+            self.alpha = self._alpha0 + (time - self._t0) / self._dt_parent
+        if self._pending_cleans > 0:           # see Castro.do_advance_ctu
+            for b in self.boxes:
+                b.clean_state(b.S_old_b, self._pending_cleans)
+        self._pending_cleans = 0
         self.red.fill_(1.e200)
         self.fill("S_old_b")
         if self.have_sources:
@@ -384,7 +391,7 @@ class _Level:
         est, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        new_dt = min(self.max_dt, est * self.params.cfl)
+        new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None
         return True, "", new_dt
@@ -722,9 +729,10 @@ class CastroAmr:
             for lev in self.lev[1:]:
                 for b in lev.boxes:
                     b.initData(problem, **kw)
+        # Castro::post_init (Castro.cpp:2220-2235): average down from the finest level, nothing else -- the averaged zones
+        # are first cleaned by initialize_advance
         for l in range(len(self.lev) - 1, 0, -1):
             self.avgDown(l)
-            self.lev[l - 1].clean_new()
         self.time, self.nstep = 0.0, 0
         self.level_count = [0] * 16
 
@@ -773,6 +781,7 @@ class CastroAmr:
         lev, finest = self.lev[l], len(self.lev) - 1
         h = lev.hydro
         lev.alpha = alpha
+        lev._t0, lev._alpha0, lev._dt_parent = t, alpha, 2.0 * dt
         lev.advance(t, dt)
         self.level_count[l] += 1
         if l > 0:
@@ -818,7 +827,8 @@ class CastroAmr:
                             for p, (lo, hi), csh in b.reflux_to[(d, side)]:
                                 h.reflux(p.S_new_b, _shift(p.gbox, csh), reg, rbox, lo, hi, d, side, NUM_STATE, vol)
             self.avgDown(l + 1)
-            lev.clean_new()
+        # Castro::post_timestep ends with clean_state(S_new) on EVERY level (Castro.cpp:1909-1916), the finest included
+        lev.clean_new()
 
     # ---- Amr::coarseTimeStep ---------------------------------------------------------------------
     def step(self, stop_time=-1.0):

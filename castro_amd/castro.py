@@ -179,6 +179,8 @@ class Castro:
             overlap = self.comm.size > 1 and min(self.n) >= 192
         self.overlap = overlap                                                   # True | "tiles" | False
         self.fuse_clean = bool(fuse_clean)
+        self.fuse_post_clean = True        # post_timestep's clean_state may ride in the fused pass (a level of CastroAmr: no)
+        self._pending_cleans, self._post_clean_done, self._whole_step = 2, False, False
         # one hydro call per step: "zero fluxes, then +=" (Castro_advance.cpp:391-394) is an assignment
         self.flux_assign = bool(flux_assign)
         self._flux_clear = False
@@ -397,14 +399,20 @@ class Castro:
     def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None, stage=None):
         """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
         and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
-        self.red, which the caller has initialised."""
+        self.red, which the caller has initialised.  When the attempt covers the whole step of a single level,
+        the clean_state of Castro::post_timestep (Castro.cpp:1909-1916) is applied in the same pass (a second
+        clean_state changes neither the density check nor the CFL estimate: both are taken from rho, momentum and
+        (rho e), which the first application has already fixed)."""
         h = self.hydro
+        post_clean = fuse_clean and self.fuse_post_clean and getattr(self, "_whole_step", False) and stage != "A"
+        if post_clean:
+            self._post_clean_done = True
         for bx in (tiles or [self.bx]):
             h.construct_ctu_hydro_source(bx, self.S_old_b, self.gbox, self.S_new_b, self.gbox, self.geom,
                                          self.params, time, dt, fluxes=self.fluxes, flux_boxes=self.flux_boxes,
                                          mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=src is None,
                                          src=src, src_box=self.sbox if src is not None else None,
-                                         clean_ntimes=1 if fuse_clean else 0, red=self.red if fuse_clean else None,
+                                         clean_ntimes=(2 if post_clean else 1) if fuse_clean else 0, red=self.red if fuse_clean else None,
                                          flux_assign=self.flux_assign and self._flux_clear, stage=stage)
 
     def _shell_tiles(self):
@@ -435,7 +443,12 @@ class Castro:
         # [Castro_advance.cpp:186] are both zone-local: on the valid zones they compose to
         # "clean twice"; ghost zones are copies (or sign-reflected copies) of twice-cleaned
         # valid zones, so they are filled AFTER the cleaning.  See DESIGN.md "clean_state order".
-        self.clean_state(S, 2)
+        # The first attempt of a step cleans twice (initialize_advance's clean_state(S_old) + this Sborder's); a later
+        # subcycle starts from the previous subcycle's cleaned S_new (Sborder's clean only); a retry on the same old
+        # data finds the valid zones of Sborder already in place.
+        if self._pending_cleans > 0:
+            self.clean_state(S, self._pending_cleans)
+        self._pending_cleans = 0
 
         # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
         # (:221-225) and the estTimeStep validity check (:386-392) are fused into the update pass
@@ -559,8 +572,11 @@ class Castro:
         # initialize_advance: swap_state_time_levels, zero the flux registers, dt_subcycle = 1e200
         self._swap_state_time_levels()
         self._zero_fluxes()
+        self._pending_cleans = 2       # clean_state(S_old) here (Castro_advance.cpp:311) + clean_state(Sborder) (:186)
+        self._post_clean_done = False
         self.nsubcycles, self.nretries = 1, 0
         if not self.use_retry:
+            self._whole_step = True
             ok, reason, new_dt = self.do_advance_ctu(time, dt)
             if not ok:
                 raise AdvanceFailure("Advance was unsuccessful: " + reason)      # amrex::Abort in the reference
@@ -590,12 +606,16 @@ class Castro:
                 raise AdvanceFailure("Error: too many subcycles.")
             if do_swap:
                 self._swap_state_time_levels()
+                self._pending_cleans = 1          # the old data of this subcycle are the cleaned S_new of the last one
             else:
                 do_swap = True
+            # an attempt at the whole step in one go may take post_timestep's clean_state into its fused pass
+            self._whole_step = sub_iteration == 0 and self.nretries == 0
             ok, reason, new_dt = self.do_advance_ctu(subcycle_time, dt_subcycle)
             if not ok:
                 # retry_advance_ctu: halve the subcycle, keep the original old data, clear the fluxes
                 dt_subcycle = min(dt_subcycle, dt_subcycle) * self.retry_subcycle_factor
+                self._post_clean_done = False
                 if prev_old is None:
                     prev_old = self._save_old_state()
                 self._zero_fluxes()
@@ -622,6 +642,8 @@ class Castro:
         else:
             self.dt = self.computeNewDt(self.dt, stop_time, est=self._next_est)
         self._next_est = self.advance(self.time, self.dt)
+        if not self._post_clean_done:
+            self.clean_state(self.S_new_b, 1)       # Castro::post_timestep: clean_state(S_new) on every level
         self.time += self.dt
         self.nstep += 1
         return self.dt

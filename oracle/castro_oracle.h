@@ -219,6 +219,7 @@ double *ora_level_state(ora_level *L);          /* S_new, valid box, FAB layout,
 double *ora_level_flux(ora_level *L, int dir);  /* fluxes[dir], nodal box, NUM_STATE comps */
 double *ora_level_mass_flux(ora_level *L, int dir);
 void ora_level_set_tile(ora_level *L, const int tile[3]);
+void ora_level_post_timestep(ora_level *L);     /* Castro::post_timestep on one level: clean_state(S_new) */
 void ora_level_post_init(ora_level *L);         /* clean_state after initData (Castro.cpp:1100-1160) */
 double ora_level_est_time_step(ora_level *L);
 double ora_level_initial_dt(ora_level *L, double stop_time);
@@ -234,6 +235,20 @@ double *ora_level_old_state(ora_level *L);
 void ora_level_set_gravity(ora_level *L, int do_grav, double const_grav, int grav_source_type);
 void ora_level_set_rotation(ora_level *L, int do_rot, const ora_rotation *R);
 double ora_level_last_hydro_seconds(ora_level *L);
+
+/* ---------------- subcycled AMR driver, one nested box per level (ora_amr_level.c) -------- */
+typedef struct ora_amr ora_amr;
+ora_amr *ora_amr_create(int nlev, const int *boxes /* nlev x (lo[3], hi[3]), each in its own level's index space */,
+                        const ora_geom *G0, const ora_params *P, int nthreads);
+void ora_amr_destroy(ora_amr *A);
+void ora_amr_init_sedov(ora_amr *A, double r_init, double p_ambient, double exp_energy, double dens_ambient, int nsub);
+void ora_amr_init_sod(ora_amr *A, double rho_l, double u_l, double p_l, double rho_r, double u_r, double p_r, int idir, double frac);
+void ora_amr_set_state(ora_amr *A, int level, const double *data);
+void ora_amr_post_init(ora_amr *A, int clean_first);   /* (clean_state on every level,) average down from the finest level */
+double ora_amr_step(ora_amr *A, double stop_time);      /* coarse dt taken, or a negative status */
+double *ora_amr_state(ora_amr *A, int level);            /* new-time state on the level's valid box */
+double ora_amr_time(ora_amr *A);
+int ora_amr_status(ora_amr *A);
 
 #ifdef __cplusplus
 }

@@ -163,8 +163,8 @@ static int level_do_advance(ora_level *L, double time, double dt)
     ora_a4 fl[3], mf[3], qe[3];
     level_fabs(L, fl, mf, qe);
 
-    /* initialize_do_advance: clean_state(S_old); Sborder = FillPatch(S_old, 4 ghosts); clean_state(Sborder, 4) */
-    ora_clean_state(L->lo, L->hi, S_old, P);
+    /* initialize_do_advance: Sborder = FillPatch(S_old, 4 ghosts); clean_state(Sborder, 4)
+     * (clean_state(S_old) is initialize_advance's: once per step, not once per attempt) */
     ora_a4 Sb = ora_make_a4(L->Sborder, L->glo, L->ghi, NUM_STATE);
     ora_fill_interior_copy(Sb, S_old, L->lo, L->hi);
     ora_bc_fill(Sb, &L->G);
@@ -227,10 +227,26 @@ static int level_do_advance(ora_level *L, double time, double dt)
 }
 
 /* Castro::advance without retries: one do_advance_ctu over the whole step */
-int ora_level_advance(ora_level *L, double time, double dt)
+/* initialize_advance (Castro_advance.cpp:232-410): swap the time levels, clean_state(S_old) on the state data, zero
+ * the fluxes */
+static void level_initialize_advance(ora_level *L)
 {
     level_swap(L);
+    ora_set_state_threads(L->nthreads);
+    ora_clean_state(L->lo, L->hi, ora_make_a4(L->S_old, L->lo, L->hi, NUM_STATE), &L->P);
     level_zero_fluxes(L);
+}
+
+/* Castro::post_timestep (Castro.cpp:1871-1916) on a single level: clean_state(S_new) */
+void ora_level_post_timestep(ora_level *L)
+{
+    ora_set_state_threads(L->nthreads);
+    ora_clean_state(L->lo, L->hi, ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE), &L->P);
+}
+
+int ora_level_advance(ora_level *L, double time, double dt)
+{
+    level_initialize_advance(L);
     return level_do_advance(L, time, dt);
 }
 
@@ -241,9 +257,7 @@ int ora_level_advance_retry(ora_level *L, double time, double dt, double retry_s
                             int max_subcycles, double dt_cutoff)
 {
     const size_t nv = (size_t)L->n[0] * L->n[1] * L->n[2] * NUM_STATE;
-    /* initialize_advance */
-    level_swap(L);
-    level_zero_fluxes(L);
+    level_initialize_advance(L);
     double dt_subcycle = 1.e200;
     int have_prev = 0;
 

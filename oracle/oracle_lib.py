@@ -117,6 +117,20 @@ def lib():
         L.ora_reset_edge_state_thermo.argtypes = [I3, I3, A4, C.POINTER(Params)]
         L.ora_cmpflx_plus_godunov.argtypes = [I3, I3, A4, A4, A4, A4, A4, A4, C.c_int,
                                               C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_amr_create.restype = C.c_void_p
+        L.ora_amr_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(Geom), C.POINTER(Params), C.c_int]
+        L.ora_amr_destroy.argtypes = [C.c_void_p]
+        L.ora_amr_init_sedov.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.ora_amr_init_sod.argtypes = [C.c_void_p] + [C.c_double] * 6 + [C.c_int, C.c_double]
+        L.ora_amr_set_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.ora_amr_post_init.argtypes = [C.c_void_p, C.c_int]
+        L.ora_amr_step.restype = C.c_double
+        L.ora_amr_step.argtypes = [C.c_void_p, C.c_double]
+        L.ora_amr_state.restype = C.POINTER(C.c_double)
+        L.ora_amr_state.argtypes = [C.c_void_p, C.c_int]
+        L.ora_amr_time.restype = C.c_double
+        L.ora_amr_time.argtypes = [C.c_void_p]
+        L.ora_amr_status.argtypes = [C.c_void_p]
         L.ora_level_create.restype = C.c_void_p
         L.ora_level_create.argtypes = [I3, C.POINTER(Geom), C.POINTER(Params), C.c_int]
         L.ora_level_destroy.argtypes = [C.c_void_p]
@@ -128,6 +142,7 @@ def lib():
         L.ora_level_mass_flux.argtypes = [C.c_void_p, C.c_int]
         L.ora_level_set_tile.argtypes = [C.c_void_p, I3]
         L.ora_level_post_init.argtypes = [C.c_void_p]
+        L.ora_level_post_timestep.argtypes = [C.c_void_p]
         L.ora_level_est_time_step.restype = C.c_double
         L.ora_level_est_time_step.argtypes = [C.c_void_p]
         L.ora_level_initial_dt.restype = C.c_double
@@ -340,6 +355,7 @@ class Level:
             st = L.ora_level_advance(self.h, self.time, self.dt)
         if st != 0:
             raise RuntimeError("oracle advance failed with status %d" % st)
+        L.ora_level_post_timestep(self.h)
         self.time += self.dt
         self.nstep += 1
         return self.dt
@@ -366,3 +382,48 @@ def cmpflx_points(idir, qm, qp, cl, cr, bnd_fac, P, is_shock=None):
     lib().ora_cmpflx_points(n, int(idir), pd(qm), pd(qp), pd(cl), pd(cr), pd(bf),
                             sh.ctypes.data_as(C.POINTER(C.c_int)) if sh is not None else None, C.byref(P), pd(out))
     return out
+
+
+class Amr:
+    """oracle/ora_amr_level.c: the subcycled AMR step for nested boxes, one per level (ratio 2), restated independently
+    of castro_amd/amr.py.  boxes[l] = (lo, hi) of level l in its own index space; boxes[0] is the domain."""
+
+    def __init__(self, boxes, geom0, params, nthreads=4):
+        self.boxes = [(tuple(lo), tuple(hi)) for lo, hi in boxes]
+        flat = (C.c_int * (6 * len(boxes)))(*[int(x) for lo, hi in boxes for x in tuple(lo) + tuple(hi)])
+        self.h = lib().ora_amr_create(len(boxes), flat, C.byref(geom0), C.byref(params), int(nthreads))
+        if not self.h:
+            raise ValueError("ora_amr_create: bad hierarchy")
+
+    def init_sedov(self, r_init=0.01, p_ambient=1.e-5, exp_energy=1.0, dens_ambient=1.0, nsub=10):
+        lib().ora_amr_init_sedov(self.h, r_init, p_ambient, exp_energy, dens_ambient, nsub)
+
+    def init_sod(self, rho_l, u_l, p_l, rho_r, u_r, p_r, idir=1, frac=0.5):
+        lib().ora_amr_init_sod(self.h, rho_l, u_l, p_l, rho_r, u_r, p_r, idir, frac)
+
+    def set_state(self, l, data):
+        d = np.ascontiguousarray(data, dtype=np.float64)
+        lib().ora_amr_set_state(self.h, l, d.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def post_init(self, clean_first=False):
+        lib().ora_amr_post_init(self.h, 1 if clean_first else 0)
+
+    def step(self, stop_time=-1.0):
+        dt = lib().ora_amr_step(self.h, float(stop_time))
+        if lib().ora_amr_status(self.h) != 0:
+            raise RuntimeError("ora_amr_step: status %d (-1 density, -2 dt validity, -3 nesting)" % lib().ora_amr_status(self.h))
+        return dt
+
+    def state(self, l):
+        lo, hi = self.boxes[l]
+        shp = (8, hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
+        return np.ctypeslib.as_array(lib().ora_amr_state(self.h, l), shape=(int(np.prod(shp)),)).reshape(shp).copy()
+
+    @property
+    def time(self):
+        return lib().ora_amr_time(self.h)
+
+    def close(self):
+        if self.h:
+            lib().ora_amr_destroy(self.h)
+            self.h = None

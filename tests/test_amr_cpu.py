@@ -506,3 +506,74 @@ def test_proper_nesting_domain(oracle):
     want3[:, 1:7, 1:7] = True
     assert np.array_equal(one, want3)
     assert a._nesting_cells(1, 0, (0, 4, 0), (16, 8, 16), 2) is None     # level 0 covers the domain: nothing to respect
+
+
+# ---- the orchestration against an INDEPENDENT restatement of it (oracle/ora_amr_level.c) -----------------------------
+# CastroAmr (castro_amd/amr.py: overlap tables, per-box Castro objects, batched operations) and ora_amr_level.c (whole-level
+# arrays in C, following Castro::advance / finalize_advance / post_timestep / reflux / avgDown / computeNewDt and AMReX's
+# Amr::timeStep recursion) share the per-zone arithmetic here (the oracle's) and nothing of the orchestration.
+def _both(oracle, patches, boxes, n=(16, 16, 16), bc=(2, 2, 2), **pkw):
+    import castro_amd
+    a = castro_amd.CastroAmr(n, patches=patches, params=oracle.default_params(**pkw), make_hydro=OracleBackend, lo_bc=bc, hi_bc=bc)
+    b = oracle.Amr(boxes, oracle.make_geom(n, lo_bc=bc, hi_bc=bc), oracle.default_params(**pkw), nthreads=4)
+    return a, b
+
+
+def _assert_same(a, b, nsteps, stop_time=-1.0):
+    for step in range(nsteps):
+        da, db = a.step(stop_time), b.step(stop_time)
+        assert da == db, "coarse dt differs at step %d: %r vs %r" % (step, da, db)
+        for l, lev in enumerate(a.levels):
+            A, B = lev.S_new().cpu().numpy(), b.state(l)
+            assert np.array_equal(A, B), "level %d differs after step %d: %d values, max %.3e" % (
+                l, step, int((A != B).sum()), float(np.abs(A - B).max()))
+
+
+TWO = ([((4, 4, 4), (11, 11, 11))], [((0, 0, 0), (15, 15, 15)), ((8, 8, 8), (23, 23, 23))])
+THREE = ([((4, 4, 4), (11, 11, 11)), ((12, 12, 12), (19, 19, 19))],
+         [((0, 0, 0), (15, 15, 15)), ((8, 8, 8), (23, 23, 23)), ((24, 24, 24), (39, 39, 39))])
+
+
+@pytest.mark.parametrize("hier", [TWO, THREE], ids=["two-levels", "three-levels"])
+def test_sedov_amr_equals_the_independent_orchestration_oracle(oracle, hier):
+    a, b = _both(oracle, *hier, init_shrink=0.1)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    b.init_sedov(r_init=0.1, nsub=4)
+    for l, lev in enumerate(a.levels):
+        assert np.array_equal(lev.S_new().cpu().numpy(), b.state(l))
+    _assert_same(a, b, 6)
+    b.close()
+
+
+def test_sod_amr_with_walls_and_a_patch_at_the_boundary_equals_the_orchestration_oracle(oracle):
+    """the refined box touches the low-y wall: coarse zones outside the domain come from the coarse level's boundary
+    fill, the register on that face refluxes nothing"""
+    patches = [((6, 0, 4), (11, 5, 11))]
+    boxes = [((0, 0, 0), (15, 15, 15)), ((12, 0, 8), (23, 11, 23))]
+    a, b = _both(oracle, patches, boxes, bc=(2, 4, 4), init_shrink=0.1, cfl=0.8)
+    a.initData("sod", rho_l=1.0, u_l=0.0, p_l=1.0, rho_r=0.125, u_r=0.0, p_r=0.1, idir=1, frac=0.5)
+    b.init_sod(1.0, 0.0, 1.0, 0.125, 0.0, 0.1, idir=1, frac=0.5)
+    _assert_same(a, b, 8)
+    b.close()
+
+
+def test_amr_orchestration_oracle_on_data_where_clean_state_is_not_idempotent(oracle):
+    """random composition and momenta: rho X != rho, so every clean_state application matters (normalize_species moves
+    rho X, the temperature follows the composition) -- the number and the place of the clean_state calls of the two
+    orchestrations must agree exactly: initialize_advance, Sborder, do_advance_ctu, post_timestep on every level."""
+    a, b = _both(oracle, *THREE, init_shrink=0.1)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    b.init_sedov(r_init=0.1, nsub=4)
+    rng = np.random.default_rng(3)
+    for l, lev in enumerate(a.levels):
+        S = lev.S_new().cpu().numpy().copy()
+        S[7] = S[0] * rng.uniform(0.2, 0.999, size=S[0].shape)
+        S[1] = 0.3 * S[0] * rng.uniform(-1, 1, size=S[0].shape)
+        S[4] = S[5] + 0.5 * S[1] ** 2 / S[0]
+        lev.S_new().copy_(torch.from_numpy(S))
+        b.set_state(l, S)
+    for l in range(len(a.lev) - 1, 0, -1):
+        a.avgDown(l)
+    b.post_init(False)
+    _assert_same(a, b, 5)
+    b.close()
