@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; }
+namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; }
 
 using namespace cad;
 
@@ -198,6 +198,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
     if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
+    if (const char* e = std::getenv("CASTRO_AMD_MARCH_PLANES")) { g_march_planes = std::atoi(e); if (g_march_planes < 1) g_march_planes = 1; }
     if (const char* e = std::getenv("CASTRO_AMD_FUSED_TILE_ROWS")) g_fused_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FUSE_CONSUP")) g_fuse_consup = std::atoi(e);   // 0: k_final<x> + k_consup
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_LDS")) g_final_lds = std::atoi(e);   // 0: the plain k_final

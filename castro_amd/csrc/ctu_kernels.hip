@@ -2040,6 +2040,152 @@ __global__ void __launch_bounds__(256) k_finalx_consup(Tile t, XRows b, const do
 }
 
 // ---------------------------------------------------------------------------------------
+// k_final<z>, k_final<x> and consup_hydro in one kernel, marching along z.
+//   The thread of k_finalx_consup (x-faces i, i+1 and zones i, i+1 of one row) walks up a chunk of mz planes: per plane
+//   it solves the z face ABOVE its zones and their two x faces, and updates the zones with the z record of the face
+//   below kept from the plane before.  The two z records (2 x 9 x 2 doubles per thread) are parked in thread-private
+//   LDS slots between their use -- the register file is full with one final_body (230 VGPRs).  A chunk starts by
+//   solving its lowest z face; the face above its last plane belongs to the next chunk, which solves it again (1 / mz
+//   redundant z solves) and stores its outputs.  Saves FL[z] written and read (18 passes), one read of Sborder and
+//   div(u), one launch.  The y records still come from FL[y].
+// ---------------------------------------------------------------------------------------
+struct XZRows { int lo[3]; int hi0, hi2; int nslot, ny, nchunk, mz; int ty; unsigned nb; };
+
+template <bool LIM, bool CLEAN>
+__global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                        DFab U, DFab fluxes0, DFab mass0, DFab qe0, DFab fluxes2, DFab mass2, DFab qe2,
+                                                        DFab Unew, double hdtdx, double hdtdy, double hdtdz, double dt,
+                                                        double area0, double area1, double area2, double vol,
+                                                        int acc_hi0, int acc_hi2, int assign, int from_sborder, DevParams P,
+                                                        int ntimes, double* red)
+{
+    __shared__ double park[2 * 2 * NFIN * 256];        // [buffer][face of the pair][component][thread]
+    unsigned bid = blockIdx.x;
+    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
+    const int lane = threadIdx.x & 63;
+    const unsigned total = (unsigned)b.nslot * (unsigned)b.ny * (unsigned)b.nchunk;
+    unsigned sl = (bid * 4u + (threadIdx.x >> 6)) * 63u + (unsigned)lane;
+    const bool live = sl < total;
+    if (!live) sl = total - 1u;
+    const unsigned row = sl / (unsigned)b.nslot;
+    const int p = (int)(sl - row * (unsigned)b.nslot);
+    int ijk[3];
+    ijk[0] = b.lo[0] + 2 * p;
+    unsigned chunk;
+    if (b.ty > 0) {                                    // rows y-tile by y-tile, chunk by chunk inside a tile
+        const unsigned rpt = (unsigned)b.ty * (unsigned)b.nchunk;
+        const unsigned yt = row / rpt;
+        const unsigned rem = row - yt * rpt;
+        const unsigned left = (unsigned)b.ny - yt * (unsigned)b.ty;
+        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
+        chunk = rem / tyh;
+        ijk[1] = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - chunk * tyh));
+    } else {
+        ijk[1] = b.lo[1] + (int)(row % (unsigned)b.ny);
+        chunk = row / (unsigned)b.ny;
+    }
+    const int k0 = b.lo[2] + (int)chunk * b.mz;
+    const bool owner = live && lane < 63;
+    const bool f0 = ijk[0] <= b.hi0 + 1, f1 = ijk[0] + 1 <= b.hi0 + 1;          // x faces of nodal(bx, x)
+    const bool zA = owner && ijk[0] <= b.hi0, zB = owner && ijk[0] + 1 <= b.hi0; // zones of bx (z-face pairs too)
+    const Str s = gstr(t);
+    double* pk = park + threadIdx.x;
+    double dtmin = 1.e200, rmin_raw = 1.e300;
+
+    {   // the lowest z face of the chunk: this chunk stores its outputs
+        ijk[2] = k0;
+        double Rz[2][NFIN];
+        final_body<2, false, LIM, false>(t, ijk, zA, zB, goff(t, ijk[0], ijk[1], k0), Q, S, g, U, fluxes2, mass2, qe2, hdtdx, hdtdy,
+                                         dt, area2, g.dx[2], acc_hi2, assign, P, Rz);
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int m = 0; m < NFIN; ++m) pk[((0 * 2 + w) * NFIN + m) * 256] = Rz[w][m];
+    }
+
+    for (int mm = 0; mm < b.mz; ++mm) {
+        const bool inz = k0 + mm <= b.hi2;             // false only in the planes a short last chunk does not have
+        const int k = inz ? k0 + mm : b.hi2;           // (they recompute the top plane and store nothing)
+        const int lo_buf = mm & 1, hi_buf = lo_buf ^ 1;
+        {
+            // the z face above.  Faces k0+1 .. k0+mz-1 are stored here; the face above the chunk's last plane belongs to
+            // the next chunk (its lowest face) unless it is the top face of the box
+            ijk[2] = k + 1;
+            const bool store = inz && (k == b.hi2 || mm + 1 < b.mz);
+            double Rz[2][NFIN];
+            final_body<2, false, LIM, false>(t, ijk, zA && store, zB && store, goff(t, ijk[0], ijk[1], k + 1), Q, S, g, U,
+                                             fluxes2, mass2, qe2, hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi2, assign, P, Rz);
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int m = 0; m < NFIN; ++m) pk[((hi_buf * 2 + w) * NFIN + m) * 256] = Rz[w][m];
+        }
+        ijk[2] = k;
+        const unsigned c = goff(t, ijk[0], ijk[1], k);
+        double R[2][NFIN];
+        final_body<0, false, LIM, false>(t, ijk, owner && f0 && inz, owner && f1 && inz, c, Q, S, g, U, fluxes0, mass0, qe0,
+                                         hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi0, assign, P, R);
+        double Rn[NFIN];                               // x face i+2
+#pragma unroll
+        for (int m = 0; m < NFIN; ++m) Rn[m] = __shfl_down(R[0][m], 1, 64);
+
+        if (zA && inz) {
+            const unsigned sy = s.y;
+            const long NC = t.NC;
+            const double volinv = 1.0 / vol;
+            const double* F1 = S.FL[1];
+            const unsigned cn = foff(Unew, ijk[0], ijk[1], k);
+            const unsigned ci = foff(U, ijk[0], ijk[1], k);
+            constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
+#define ZL(w, r) pk[((lo_buf * 2 + (w)) * NFIN + (r)) * 256]
+#define ZH(w, r) pk[((hi_buf * 2 + (w)) * NFIN + (r)) * 256]
+            double un[2][NUM_STATE];
+#pragma unroll
+            for (int m = 0; m < NUM_STATE; ++m) {
+                const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
+                if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }
+                const int r = rec[m];
+                const D2 y0 = ldg2(F1 + (long)r * NC, c), y1 = ldg2(F1 + (long)r * NC, c + sy);
+                un[0][m] = u0.a + dt * (R[0][r] * area0 - R[1][r] * area0 + y0.a * area1 - y1.a * area1 + ZL(0, r) * area2 - ZH(0, r) * area2) * volinv;
+                un[1][m] = u0.b + dt * (R[1][r] * area0 - Rn[r] * area0 + y0.b * area1 - y1.b * area1 + ZL(1, r) * area2 - ZH(1, r) * area2) * volinv;
+                if (m == UEINT) {
+                    const D2 py0 = ldg2(F1 + GPG * NC, c), py1 = ldg2(F1 + GPG * NC, c + sy);
+                    const D2 uy0 = ldg2(F1 + GUG * NC, c), uy1 = ldg2(F1 + GUG * NC, c + sy);
+                    double pdu = (R[1][GPG] + R[0][GPG]) * (R[1][GUG] * area0 - R[0][GUG] * area0);
+                    pdu += (py1.a + py0.a) * (uy1.a * area1 - uy0.a * area1);
+                    pdu += (ZH(0, GPG) + ZL(0, GPG)) * (ZH(0, GUG) * area2 - ZL(0, GUG) * area2);
+                    pdu = 0.5 * pdu * volinv;
+                    un[0][m] = un[0][m] - dt * pdu;
+                    pdu = (Rn[GPG] + R[1][GPG]) * (Rn[GUG] * area0 - R[1][GUG] * area0);
+                    pdu += (py1.b + py0.b) * (uy1.b * area1 - uy0.b * area1);
+                    pdu += (ZH(1, GPG) + ZL(1, GPG)) * (ZH(1, GUG) * area2 - ZL(1, GUG) * area2);
+                    pdu = 0.5 * pdu * volinv;
+                    un[1][m] = un[1][m] - dt * pdu;
+                }
+            }
+#undef ZL
+#undef ZH
+            if (CLEAN) {
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    if (w == 1 && !zB) continue;
+                    rmin_raw = fmin(rmin_raw, nan_guard(un[w][URHO]));
+                    clean_zone(P, ntimes, un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS]);
+                    dtmin = fmin(dtmin, nan_guard(zone_dt_cfl(P, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEINT])));
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NUM_STATE; ++m) {
+                if (m == UTEMP && !CLEAN && !from_sborder) continue;
+                if (zB) stg2(Unew.p + m * Unew.sn, cn, un[0][m], un[1][m]);
+                else stg(Unew.p + m * Unew.sn, cn, un[0][m]);
+            }
+        }
+    }
+    if (CLEAN && red) block_min2_atomic(dtmin, rmin_raw, red);
+}
+
+// ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
@@ -2098,6 +2244,7 @@ int g_brick[3] = { 0, 0, 0 };
 int g_xpad = 0;            // see capi.hip scratch_nx
 int g_final_lds = 0;       // 1: k_final_lds (transverse flux records staged in LDS; measured slower)
 int g_fused_tile_rows = 16; // rows per y-tile of the k_finalx_consup row order (0: plain)
+int g_march_planes = 32;  // planes per chunk of k_finalxz_consup
 int g_fuse_consup = 1;    // 1: k_finalx_consup (the x faces of the final stage and consup_hydro in one kernel)
 int g_brick_lds_budget = 80 * 1024;     // bytes of LDS per workgroup: two workgroups per CU
 static Brick make_brick(const int lo[3], const int hi[3], const int grow[2][3], size_t& lds_bytes)
@@ -2306,12 +2453,39 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     else if (g_fuse_consup) {
         // y and z first (they write FL[1], FL[2]), then the x faces with the conservative update fused in
         KL2("k_trans1", k_trans1<false>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-        if (lim) {
+        if (g_fuse_consup == 2) {
+        } else if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
         } else {
             KL2("k_final_y", (k_final<1, false, false>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2("k_final_z", (k_final<2, false, false>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+        }
+        if (g_fuse_consup == 2) {
+            // k_final<y> (writes FL[y]), then the z and x faces and the conservative update marching along z
+            if (lim) KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
+            else KL2("k_final_y", (k_final<1, false, false>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
+            XZRows xz;
+            for (int d = 0; d < 3; ++d) xz.lo[d] = t.lo[d];
+            xz.hi0 = t.hi[0]; xz.hi2 = t.hi[2];
+            const int nx_ = t.hi[0] - t.lo[0] + 1, nz_ = t.hi[2] - t.lo[2] + 1;
+            xz.nslot = (nx_ + 1) / 2 + 1; xz.ny = t.hi[1] - t.lo[1] + 1;
+            xz.mz = g_march_planes < nz_ ? g_march_planes : nz_;
+            xz.nchunk = (nz_ + xz.mz - 1) / xz.mz;
+            xz.ty = g_fused_tile_rows;
+            const long slots_ = (long)xz.nslot * xz.ny * xz.nchunk;
+            xz.nb = ((unsigned)(((slots_ + 62) / 63 + 3) / 4) + 7u) & ~7u;
+            const double vol2_ = g.dx[0] * g.dx[1] * g.dx[2];
+            prof_begin(prof, "k_finalxz_consup", stream);
+#define FXZ(LIM, CLEAN, nt, rd)                                                                                          \
+            hipLaunchKernelGGL((k_finalxz_consup<LIM, CLEAN>), dim3(xz.nb), dim3(256), 0, stream, t, xz, S.Q, S, g, Sborder, \
+                               fluxes[0], mass[0], qe[0], fluxes[2], mass[2], qe[2], Snew, hdtdx, hdtdy, hdtdz, dt,      \
+                               area0, area1, area2, vol2_, acc_hi[0], acc_hi[2], (flags & 2) ? 1 : 0, (flags & 1) ? 1 : 0, P, nt, rd)
+            if (clean_ntimes > 0) { if (lim) FXZ(true, true, clean_ntimes, red); else FXZ(false, true, clean_ntimes, red); }
+            else { if (lim) FXZ(true, false, 0, (double*)nullptr); else FXZ(false, false, 0, (double*)nullptr); }
+#undef FXZ
+            prof_end(prof, stream);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
         }
         XRows xr;
         for (int d = 0; d < 3; ++d) xr.lo[d] = t.lo[d];

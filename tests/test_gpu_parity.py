@@ -1623,15 +1623,18 @@ def test_randomised_option_combinations_match_the_oracle():
 @pytest.mark.parametrize("env", [{"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "0"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1", "CASTRO_AMD_BRICK": "5,3,2"},
-                                 {"CASTRO_AMD_FUSE_CONSUP": "1", "CASTRO_AMD_XPAD": "12"}],
-                         ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows"])
+                                 {"CASTRO_AMD_FUSE_CONSUP": "1", "CASTRO_AMD_XPAD": "12"},
+                                 {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "32"},
+                                 {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "3"}],
+                         ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows",
+                              "z-marching", "z-marching-short-chunks"])
 def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
     """The final stage has three forms: k_final<x,y,z> + k_consup (round 1), k_final_lds (transverse flux records staged
     in LDS bricks; measured slower, kept as the measured experiment of DESIGN.md section 9) and the default
     k_final<y,z> + k_finalx_consup.  Each must match the oracle bit for bit, odd extents and several tiles included."""
     import castro_amd
     from castro_amd.hydro import HipHydro
-    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD")
+    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD", "CASTRO_AMD_MARCH_PLANES")
     old = {k: os.environ.get(k) for k in keys}
     try:
         os.environ.update(env)
@@ -1664,6 +1667,7 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
         for k, v in (("CASTRO_AMD_FUSE_CONSUP", "1"), ("CASTRO_AMD_FINAL_LDS", "0")):
             os.environ[k] = v
         os.environ["CASTRO_AMD_BRICK"] = "0,0,0"
+        os.environ["CASTRO_AMD_MARCH_PLANES"] = "32"
         HipHydro(0).close()                   # restore the library's defaults for the tests that follow
         for k in keys:
             if old[k] is None:
