@@ -25,7 +25,7 @@ DERIVE_IDS = {"pressure": 0, "kineng": 1, "soundspeed": 2, "Gamma_1": 3, "MachNu
 EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
-    "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status", "castro_amd_ctx_poison_scratch",
+    "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status", "castro_amd_ctx_poison_scratch", "castro_amd_ctx_set_source_corrector",
     "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab",
     "castro_amd_error_tag_fab", "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
@@ -82,7 +82,8 @@ class Params(C.Structure):
             "difmag", "small_dens", "small_temp", "small_pres", "small_ener", "cg_tol",
             "dual_energy_eta1", "dual_energy_eta2", "cfl", "init_shrink", "change_max",
             "eos_gamma", "small_x", "T_guess", "abar", "pslope_cutoff_density")] + \
-        [("limit_fluxes_on_small_dens", C.c_int), ("limit_fluxes_on_large_vel", C.c_int), ("speed_limit", C.c_double)]
+        [("limit_fluxes_on_small_dens", C.c_int), ("limit_fluxes_on_large_vel", C.c_int), ("speed_limit", C.c_double),
+         ("source_term_predictor", C.c_int)]
 
 
 class FabOp(C.Structure):
@@ -118,6 +119,7 @@ def load():
     L.castro_amd_ctx_scratch_bytes.argtypes = [C.c_void_p]
     L.castro_amd_ctx_status.argtypes = [C.c_void_p, C.c_void_p]
     L.castro_amd_ctx_poison_scratch.argtypes = [C.c_void_p, C.c_void_p]
+    L.castro_amd_ctx_set_source_corrector.argtypes = [C.c_void_p, PF]
     L.castro_amd_ctu_hydro_fab.argtypes = [
         C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
         C.c_double, C.c_double, C.c_int, C.c_void_p]

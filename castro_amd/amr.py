@@ -305,6 +305,11 @@ class _Level:
         self.fill_source("new_source_g")
 
     def _advance_with_sources(self, time, dt):
+        if self.params.source_term_predictor == 1:
+            raise NotImplementedError("castro.source_term_predictor = 1 is built for single-level runs (castro_amd.Castro)")
+        return self._advance_with_sources_impl(time, dt)
+
+    def _advance_with_sources_impl(self, time, dt):
         """do_advance_ctu with old- and new-time gravity / rotation sources (Castro_advance_ctu.cpp:94-143, 156-274),
         stage by stage over the boxes of the level; the per-box arithmetic is Castro._do_advance_with_sources'."""
         h = self.hydro

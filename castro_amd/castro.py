@@ -202,6 +202,9 @@ class Castro:
             self.old_source = hydro.alloc(NSRC, *self.sbox)
             self.new_source = hydro.alloc(NSRC, self.lo, self.hi)
             self.src_neighbors = self._build_neighbors(NGS, NSRC)
+            # castro.source_term_predictor = 1: Castro::source_corrector and the bookkeeping of create_source_corrector
+            self.source_corrector = hydro.alloc(NSRC, *self.sbox)
+        self.lastDt, self._in_retry = 1.e200, False
         self._comm_stream = None
         if self.overlap and self.S_new_b.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
@@ -503,6 +506,12 @@ class Castro:
         h = self.hydro
         lo, hi = self.lo, self.hi
         self.expand_state(S)
+        if self.params.source_term_predictor == 1:
+            # create_source_corrector (Castro_advance_ctu.cpp:60-62, Castro.cpp:3780-3818): not on the attempt that follows a
+            # rejected one -- the data it is made from have been overwritten by then
+            if not self._in_retry:
+                self.create_source_corrector()
+            h.set_source_corrector(self.source_corrector, self.sbox)
         # MultiFab::Copy(S_new, Sborder) (:94); do_old_sources (:127-131): construct at t^n, apply with the full dt,
         # clean_state -- the copy, the update and the cleaning in one pass where the backend has it
         fused = hasattr(h, "apply_source")
@@ -549,6 +558,18 @@ class Castro:
             return False, "timestep validity check failed", None
         return True, "", new_dt
 
+    def create_source_corrector(self):
+        """Castro::create_source_corrector (Castro.cpp:3780-3818): the lagged predictor dS/dt ~ 2 x (new-time corrector of
+        the last advance) / lastDt for the momentum sources; the factor dt/2 is applied in src_to_prim.  The "old"
+        Source_Type data after the swap are the corrector `new_source` of the last successful (sub)step."""
+        c = self.source_corrector
+        c.zero_()
+        g = 3                                   # NUM_GROW_SRC
+        n = self.n
+        c[1:4, g:g + n[2], g:g + n[1], g:g + n[0]] = self.new_source[1:4]
+        self.expand_state(c, self.sbox, self.src_neighbors)           # AmrLevel::FillPatch(Source_Type, UMX, 3)
+        c.mul_(2.0 / self.lastDt)
+
     def _swap_state_time_levels(self):
         self.S_old_b, self.S_new_b = self.S_new_b, self.S_old_b
 
@@ -577,9 +598,11 @@ class Castro:
         self.nsubcycles, self.nretries = 1, 0
         if not self.use_retry:
             self._whole_step = True
+            self._in_retry = False
             ok, reason, new_dt = self.do_advance_ctu(time, dt)
             if not ok:
                 raise AdvanceFailure("Advance was unsuccessful: " + reason)      # amrex::Abort in the reference
+            self.lastDt = dt
             return new_dt
         return self.subcycle_advance_ctu(time, dt)
 
@@ -612,6 +635,7 @@ class Castro:
             # an attempt at the whole step in one go may take post_timestep's clean_state into its fused pass
             self._whole_step = sub_iteration == 0 and self.nretries == 0
             ok, reason, new_dt = self.do_advance_ctu(subcycle_time, dt_subcycle)
+            self._in_retry = False                                # Castro_advance_ctu.cpp:651-653
             if not ok:
                 # retry_advance_ctu: halve the subcycle, keep the original old data, clear the fluxes
                 dt_subcycle = min(dt_subcycle, dt_subcycle) * self.retry_subcycle_factor
@@ -622,9 +646,11 @@ class Castro:
                 do_swap = False
                 self.nretries += 1
                 self.last_failure = reason
+                self._in_retry = True
                 continue
             subcycle_time += dt_subcycle
             sub_iteration += 1
+            self.lastDt = dt_subcycle                             # :715
         if sub_iteration > 1 and prev_old is not None:
             self._restore_old_state(prev_old)     # state[k].replaceOldData(*prev_state[k])
         self.nsubcycles = sub_iteration

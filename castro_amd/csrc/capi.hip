@@ -19,6 +19,7 @@ struct castro_amd_ctx {
     size_t arena_doubles = 0;
     int* d_status = nullptr;
     int* h_status = nullptr;   // pinned
+    castro_amd_fab src_corr = { nullptr, { 0, 0, 0 }, { 0, 0, 0 }, 0 };     // Castro::source_corrector
     Profiler prof;
 };
 
@@ -109,6 +110,7 @@ static DevParams to_devparams(const castro_amd_params* p)
     P.pslope_cutoff_density = p->pslope_cutoff_density;
     P.cfl = p->cfl; P.speed_limit = p->speed_limit;
     P.limit_small_dens = p->limit_fluxes_on_small_dens; P.limit_large_vel = p->limit_fluxes_on_large_vel;
+    P.source_term_predictor = p->source_term_predictor;
     return P;
 }
 
@@ -156,6 +158,7 @@ void castro_amd_default_params(castro_amd_params* p)
     p->ppm_temp_fix = 0;
     p->plm_iorder = 2; p->plm_limiter = 2; p->use_pslope = 1; p->pslope_cutoff_density = -1.e20;
     p->limit_fluxes_on_small_dens = 0; p->limit_fluxes_on_large_vel = 0; p->speed_limit = 0.0;
+    p->source_term_predictor = 0;
     p->difmag = 0.1;
     p->small_dens = -1.e200; p->small_temp = -1.e200; p->small_pres = -1.e200; p->small_ener = -1.e200;
     p->cg_tol = 1.0e-5;
@@ -364,8 +367,15 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
         dF[d] = to_dfab(f); dM[d] = to_dfab(m); dQ[d] = to_dfab(q);
     }
 
+    DFab dCorr = to_dfab(nullptr);
+    if (params->source_term_predictor == 1 && c->src_corr.p && src && src->p) {
+        int s3lo[3], s3hi[3];
+        for (int d = 0; d < 3; ++d) { s3lo[d] = bxlo[d] - 3; s3hi[d] = bxhi[d] + 3; }
+        if (!fab_contains(&c->src_corr, s3lo, s3hi)) return CASTRO_AMD_ERR_ARG;
+        dCorr = to_dfab(&c->src_corr);
+    }
     return launch_ctu_hydro(t, S, dS, to_dfab(src), dN, dF, dM, dQ, to_devgeom(geom), to_devparams(params), dt, flags,
-                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof, clean_ntimes, d_out);
+                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof, clean_ntimes, d_out, dCorr);
 }
 
 int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],
@@ -737,6 +747,18 @@ int castro_amd_sod_init_fab(castro_amd_ctx* c, const castro_amd_fab* state, cons
     hipSetDevice(c->device);
     return launch_sod_init(to_dfab(state), lo, hi, geom->dx, geom->problo, split, idir - 1,
                            rho_l, u_l, rho_l * e_l, T_l, rho_r, u_r, rho_r * e_r, T_r, (hipStream_t)stream, &c->prof);
+}
+
+int castro_amd_ctx_set_source_corrector(castro_amd_ctx* c, const castro_amd_fab* corr)
+{
+    if (!c) return CASTRO_AMD_ERR_ARG;
+    if (corr && corr->p) {
+        if (corr->ncomp < 7) return CASTRO_AMD_ERR_ARG;
+        c->src_corr = *corr;
+    } else {
+        c->src_corr.p = nullptr;
+    }
+    return CASTRO_AMD_OK;
 }
 
 int castro_amd_ctx_poison_scratch(castro_amd_ctx* c, void* stream)

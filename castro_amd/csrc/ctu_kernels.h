@@ -65,7 +65,7 @@ void prof_collect(Profiler* p);
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
-                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red);
+                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr);
 
 // auxiliary per-FAB kernels (aux_kernels.hip)
 int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,

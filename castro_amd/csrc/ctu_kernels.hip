@@ -181,8 +181,9 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
 // Castro::src_to_prim (Source/hydro/Castro_ctu.cpp:468-545) on grow(bx,3): conserved old-time
 // sources -> primitive sources (CTU, source_term_predictor = 0: srcU = old_source)
 // ---------------------------------------------------------------------------------------
+// CORR (p != nullptr with source_term_predictor = 1): Castro::source_corrector, dt/2 of it time-centres the momentum sources
 __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const double* __restrict__ Q, DFab SRC,
-                                                     double* __restrict__ SQ, DevParams P)
+                                                     double* __restrict__ SQ, DevParams P, DFab CORR, double dt)
 {
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
@@ -191,9 +192,16 @@ __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const dou
     const long NC = t.NC;
 
     const double s_rho = 0.0 + ldg(SRC.p + URHO * SRC.sn, cs);
-    const double s_mx = 0.0 + ldg(SRC.p + UMX * SRC.sn, cs);
-    const double s_my = 0.0 + ldg(SRC.p + UMY * SRC.sn, cs);
-    const double s_mz = 0.0 + ldg(SRC.p + UMZ * SRC.sn, cs);
+    double s_mx = 0.0, s_my = 0.0, s_mz = 0.0;
+    if (CORR.p) {                                  // Castro_ctu.cpp:493-497
+        const unsigned cc = foff(CORR, i, j, k);
+        s_mx += 0.5 * dt * ldg(CORR.p + UMX * CORR.sn, cc);
+        s_my += 0.5 * dt * ldg(CORR.p + UMY * CORR.sn, cc);
+        s_mz += 0.5 * dt * ldg(CORR.p + UMZ * CORR.sn, cc);
+    }
+    s_mx += ldg(SRC.p + UMX * SRC.sn, cs);
+    s_my += ldg(SRC.p + UMY * SRC.sn, cs);
+    s_mz += ldg(SRC.p + UMZ * SRC.sn, cs);
     const double s_ei = 0.0 + ldg(SRC.p + UEINT * SRC.sn, cs);
 
     const double rho = ldg(Q + PRHO * NC, c);
@@ -2308,7 +2316,7 @@ static int shell_boxes(const int olo[3], const int ohi[3], const int ilo[3], con
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
-                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red)
+                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr)
 {
     // Staged execution (CASTRO_AMD_STAGE_A / _B): A = what needs no ghost zone of Sborder -- ctoprim on the valid
     // zones, PPM tracing on grow(bx, -3) -- so that a caller can run it while the halo exchange is in flight;
@@ -2378,7 +2386,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
-        KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P);
+        KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P, SrcCorr, dt);
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P); }
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {

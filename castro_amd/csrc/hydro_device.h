@@ -44,6 +44,7 @@ struct DevParams {
     double pslope_cutoff_density;
     double cfl, speed_limit;
     int limit_small_dens, limit_large_vel;
+    int source_term_predictor;
 };
 
 // amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument

@@ -66,6 +66,11 @@ class HipHydro:
     def status(self, stream=None):
         return int(self.lib.castro_amd_ctx_status(self.h, _stream_ptr(stream)))
 
+    def set_source_corrector(self, corr, box):
+        """Castro::source_corrector for the hydro calls that follow (params.source_term_predictor = 1); None clears it."""
+        fab = L.fab_of(corr, *box) if corr is not None else L.fab_desc(None, (0, 0, 0), (0, 0, 0), 0)
+        L.check(self.lib.castro_amd_ctx_set_source_corrector(self.h, C.byref(fab)), "ctx_set_source_corrector")
+
     def poison_scratch(self, stream=None):
         """NaN-fill the scratch arena (tests: a call must not read what an earlier call left there)."""
         L.check(self.lib.castro_amd_ctx_poison_scratch(self.h, _stream_ptr(stream)), "ctx_poison_scratch")

@@ -98,6 +98,8 @@ typedef struct castro_amd_params {
     int limit_fluxes_on_small_dens;   /* 0 (default); limit_hydro_fluxes_on_small_dens, advection_util.cpp:657-903 */
     int limit_fluxes_on_large_vel;    /* 0 (default); limit_hydro_fluxes_on_large_vel, :907-1075 (needs speed_limit > 0) */
     double speed_limit;               /* 0 (default: off); also enforce_speed_limit in clean_state, Castro.cpp:3049-3092 */
+    int source_term_predictor;        /* 0 (default); 1: src_to_prim adds dt/2 x source_corrector to the momentum sources
+                                       * (Castro_ctu.cpp:493-497); see castro_amd_ctx_set_source_corrector */
 } castro_amd_params;
 
 typedef struct castro_amd_ctx castro_amd_ctx;
@@ -119,6 +121,11 @@ long long castro_amd_ctx_scratch_bytes(const castro_amd_ctx *ctx);
 /* Synchronises `stream`, returns and clears the latched device status bits:
  * bit0 = rho <= 0 or rho < small_dens met in ctoprim (advection_util.cpp:56-68). */
 int castro_amd_ctx_status(castro_amd_ctx *ctx, void *stream);
+/* Castro::source_corrector (a member MultiFab of the reference, Castro_advance.cpp:292-293, filled by
+ * create_source_corrector, Castro.cpp:3780-3818): NSRC = 7 components on a box containing grow(bx, 3) of the tiles that
+ * follow; the hydro calls on this context read it when params->source_term_predictor == 1.  NULL (or p == NULL)
+ * clears it.  The caller owns the memory. */
+int castro_amd_ctx_set_source_corrector(castro_amd_ctx *ctx, const castro_amd_fab *source_corrector);
 /* Fill the scratch arena with NaNs (asynchronous on `stream`): lets a caller or a test prove that a call reads
  * nothing a previous call left behind. */
 int castro_amd_ctx_poison_scratch(castro_amd_ctx *ctx, void *stream);

@@ -82,6 +82,7 @@ typedef struct {
     int limit_fluxes_on_small_dens;   /* :168 */
     int limit_fluxes_on_large_vel;    /* :171 */
     double speed_limit;               /* :175 */
+    int source_term_predictor;        /* :188  0 (default); 1: lagged predictor of the momentum sources, Castro.cpp:3780-3818 */
 } ora_params;
 
 typedef struct {
@@ -141,7 +142,11 @@ void ora_eos_rp(const ora_params *P, ora_eos_t *s);
 int  ora_ctoprim(const int lo[3], const int hi[3], ora_a4 uin, ora_a4 q, ora_a4 qaux, const ora_params *P);
 void ora_uflatten(const int lo[3], const int hi[3], ora_a4 q, ora_a4 flatn, int pres_comp);
 void ora_shock(const int lo[3], const int hi[3], ora_a4 q, ora_a4 shk, const ora_geom *G);
-void ora_src_to_prim(const int lo[3], const int hi[3], ora_a4 q, ora_a4 old_src, ora_a4 srcQ, const ora_params *P);
+void ora_src_to_prim(const int lo[3], const int hi[3], ora_a4 q, ora_a4 old_src, ora_a4 srcQ, const ora_params *P, double dt);
+/* Castro::source_corrector is a class member, not an argument of construct_ctu_hydro_source: the oracle keeps it the same
+ * way.  NSRC comps on a box containing grow(bx, 3); p == NULL: none.  Read by ora_src_to_prim when
+ * P->source_term_predictor == 1. */
+void ora_set_source_corrector(const ora_a4 *corr);
 void ora_divu(const int lo[3], const int hi[3], ora_a4 q, ora_a4 div, const ora_geom *G);
 void ora_trace_ppm(const int lo[3], const int hi[3], int idir, ora_a4 q, ora_a4 qaux, ora_a4 srcQ,
                    ora_a4 flatn, ora_a4 qm, ora_a4 qp, const int vlo[3], const int vhi[3],

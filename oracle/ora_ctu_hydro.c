@@ -88,7 +88,7 @@ static int ctu_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], cons
 
     /* primitive-variable sources :307-315 */
     fab_resize(&S->src_q, qbx3lo, qbx3hi, NQSRC);
-    ora_src_to_prim(qbx3lo, qbx3hi, S->q.a, old_source, S->src_q.a, P);
+    ora_src_to_prim(qbx3lo, qbx3hi, S->q.a, old_source, S->src_q.a, P, dt);
 
     /* interface states :337-428 */
     fab_resize(&S->qxm, obxlo, obxhi, NQ); fab_resize(&S->qxp, obxlo, obxhi, NQ);

@@ -31,6 +31,7 @@ void ora_default_params(ora_params *p)
     p->limit_fluxes_on_small_dens = 0;
     p->limit_fluxes_on_large_vel = 0;
     p->speed_limit = 0.0;
+    p->source_term_predictor = 0;
     p->ppm_temp_fix = 0;
     p->plm_iorder = 2;
     p->plm_limiter = 2;
@@ -306,8 +307,16 @@ void ora_shock(const int lo[3], const int hi[3], ora_a4 q, ora_a4 shk, const ora
 /* Castro::src_to_prim  (Source/hydro/Castro_ctu.cpp:468-545)          */
 /* CTU with source_term_predictor = 0: srcU = old_src                   */
 /* ------------------------------------------------------------------ */
-void ora_src_to_prim(const int lo[3], const int hi[3], ora_a4 q, ora_a4 old_src, ora_a4 srcQ, const ora_params *P)
+static ora_a4 g_source_corrector;      /* p == NULL: none */
+void ora_set_source_corrector(const ora_a4 *corr)
 {
+    if (corr) g_source_corrector = *corr; else g_source_corrector.p = NULL;
+}
+
+void ora_src_to_prim(const int lo[3], const int hi[3], ora_a4 q, ora_a4 old_src, ora_a4 srcQ, const ora_params *P, double dt)
+{
+    const ora_a4 src_corr = g_source_corrector;
+    const int predict = P->source_term_predictor == 1 && src_corr.p != NULL;
     for (int k = lo[2]; k <= hi[2]; ++k)
     for (int j = lo[1]; j <= hi[1]; ++j)
     for (int i = lo[0]; i <= hi[0]; ++i) {
@@ -316,6 +325,8 @@ void ora_src_to_prim(const int lo[3], const int hi[3], ora_a4 q, ora_a4 old_src,
         double srcU[NSRC];
         for (int n = 0; n < NSRC; ++n) {
             srcU[n] = 0.0;
+            /* Castro_ctu.cpp:493-497: the lagged predictor time-centres the momentum sources */
+            if (predict && (n == UMX || n == UMY || n == UMZ)) srcU[n] += 0.5 * dt * A4(src_corr,i,j,k,n);
             if (old_src.p) srcU[n] += A4(old_src,i,j,k,n);
         }
 

@@ -30,6 +30,9 @@ struct ora_level {
     int do_grav, grav_source_type;   /* castro.do_grav, castro.grav_source_type; gravity.const_grav along z */
     double grav[3];
     double *old_source, *new_source; /* Source_Type old (NUM_GROW_SRC ghosts) / new data */
+    double *source_corrector;        /* Castro::source_corrector (NSRC comps, NUM_GROW_SRC ghosts), source_term_predictor = 1 */
+    double lastDt;                   /* Castro.cpp:906, Castro_advance_ctu.cpp:715 */
+    int in_retry;
     int do_rot;                      /* castro.do_rotation */
     ora_rotation rot;
 };
@@ -49,6 +52,7 @@ ora_level *ora_level_create(const int n[3], const ora_geom *G, const ora_params 
     L->nthreads = nthreads;
     /* hydro_tile_size default on CPU, Source/driver/Castro.cpp:133 */
     L->tile[0] = 1024; L->tile[1] = 16; L->tile[2] = 16;
+    L->lastDt = 1.e200;
     size_t nv = 1, ng = 1;
     for (int d = 0; d < 3; ++d) {
         L->n[d] = n[d];
@@ -74,6 +78,7 @@ void ora_level_destroy(ora_level *L)
 {
     if (!L) return;
     free(L->S_new); free(L->S_old); free(L->Sborder); free(L->prev_old); free(L->old_source); free(L->new_source);
+    free(L->source_corrector);
     for (int d = 0; d < 3; ++d) { free(L->fluxes[d]); free(L->mass_fluxes[d]); }
     free(L);
 }
@@ -186,10 +191,27 @@ static int level_do_advance(ora_level *L, double time, double dt)
             ns *= (size_t)(L->n[d] + 2 * NUM_GROW_SRC); nv1 *= (size_t)L->n[d];
         }
         if (!L->old_source) L->old_source = (double *)malloc(sizeof(double) * ns * NSRC);
-        if (!L->new_source) L->new_source = (double *)malloc(sizeof(double) * nv1 * NSRC);
+        if (!L->new_source) L->new_source = (double *)calloc(nv1 * NSRC, sizeof(double));
         memset(L->old_source, 0, sizeof(double) * ns * NSRC);
         osrc = ora_make_a4(L->old_source, slo, shi, NSRC);
         nsrc = ora_make_a4(L->new_source, L->lo, L->hi, NSRC);
+        if (P->source_term_predictor == 1) {
+            /* create_source_corrector (Castro_advance_ctu.cpp:60-62, Castro.cpp:3780-3818): FillPatch of the old
+             * Source_Type data (the corrector of the last advance after the swap), momentum components, x 2 / lastDt */
+            if (!L->source_corrector) L->source_corrector = (double *)calloc(ns * NSRC, sizeof(double));
+            ora_a4 corr = ora_make_a4(L->source_corrector, slo, shi, NSRC);
+            if (!L->in_retry) {
+                memset(L->source_corrector, 0, sizeof(double) * ns * NSRC);
+                for (int n = UMX; n <= UMZ; ++n)
+                for (int k = L->lo[2]; k <= L->hi[2]; ++k)
+                for (int j = L->lo[1]; j <= L->hi[1]; ++j)
+                for (int i = L->lo[0]; i <= L->hi[0]; ++i) A4(corr,i,j,k,n) = A4(nsrc,i,j,k,n);
+                ora_bc_fill(corr, &L->G);
+                const double f = 2.0 / L->lastDt;
+                for (size_t m = 0; m < ns * NSRC; ++m) L->source_corrector[m] *= f;
+            }
+            ora_set_source_corrector(&corr);
+        }
         if (L->do_grav) ora_old_gravity_source(L->lo, L->hi, Sb, osrc, L->grav, L->grav_source_type, dt);
         if (L->do_rot) ora_old_rotation_source(L->lo, L->hi, Sb, osrc, &L->rot, &L->G, dt);
         ora_saxpy(L->lo, L->hi, S_new, dt, osrc, NSRC);
@@ -204,6 +226,7 @@ static int level_do_advance(ora_level *L, double time, double dt)
                                              time, dt, L->tile, L->nthreads);
     L->hydro_seconds = now_s() - t0;
     (void)bad;
+    ora_set_source_corrector(NULL);
 
     /* small/negative density check (:168-216); retry_small_density_cutoff keeps its default (-1e200) */
     if (ora_min_density(L->lo, L->hi, S_new) < P->small_dens) return 1;
@@ -247,7 +270,10 @@ void ora_level_post_timestep(ora_level *L)
 int ora_level_advance(ora_level *L, double time, double dt)
 {
     level_initialize_advance(L);
-    return level_do_advance(L, time, dt);
+    L->in_retry = 0;
+    const int st = level_do_advance(L, time, dt);
+    if (st == 0) L->lastDt = dt;
+    return st;
 }
 
 /* Castro::advance with castro.use_retry = 1: initialize_advance + subcycle_advance_ctu
@@ -279,6 +305,7 @@ int ora_level_advance_retry(ora_level *L, double time, double dt, double retry_s
         if (do_swap) level_swap(L); else do_swap = 1;
 
         int status = level_do_advance(L, subcycle_time, dt_subcycle);
+        L->in_retry = 0;
 
         if (status != 0) {
             /* retry_advance_ctu */
@@ -291,10 +318,12 @@ int ora_level_advance_retry(ora_level *L, double time, double dt, double retry_s
             level_zero_fluxes(L);
             do_swap = 0;
             L->nretries += 1;
+            L->in_retry = 1;
             continue;
         }
         subcycle_time += dt_subcycle;
         sub_iteration += 1;
+        L->lastDt = dt_subcycle;
     }
     if (sub_iteration > 1 && have_prev) {
         /* state[k].replaceOldData(*prev_state[k]) (:716-726) */

@@ -27,7 +27,8 @@ class Params(C.Structure):
             "difmag", "small_dens", "small_temp", "small_pres", "small_ener", "cg_tol",
             "dual_energy_eta1", "dual_energy_eta2", "cfl", "init_shrink", "change_max",
             "eos_gamma", "small_x", "T_guess", "abar", "pslope_cutoff_density")] + \
-        [("limit_fluxes_on_small_dens", C.c_int), ("limit_fluxes_on_large_vel", C.c_int), ("speed_limit", C.c_double)]
+        [("limit_fluxes_on_small_dens", C.c_int), ("limit_fluxes_on_large_vel", C.c_int), ("speed_limit", C.c_double),
+         ("source_term_predictor", C.c_int)]
 
 
 class Rotation(C.Structure):
@@ -117,6 +118,7 @@ def lib():
         L.ora_reset_edge_state_thermo.argtypes = [I3, I3, A4, C.POINTER(Params)]
         L.ora_cmpflx_plus_godunov.argtypes = [I3, I3, A4, A4, A4, A4, A4, A4, C.c_int,
                                               C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_set_source_corrector.argtypes = [C.POINTER(A4)]
         L.ora_amr_create.restype = C.c_void_p
         L.ora_amr_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(Geom), C.POINTER(Params), C.c_int]
         L.ora_amr_destroy.argtypes = [C.c_void_p]

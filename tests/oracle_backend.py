@@ -139,6 +139,13 @@ class OracleBackend:
         for _ in range(ntimes):
             O.lib().ora_clean_state(O.i3(lo), O.i3(hi), self._a4(state, box), C.byref(params))
 
+    def set_source_corrector(self, corr, box):
+        if corr is None:
+            O.lib().ora_set_source_corrector(None)
+        else:
+            self._corr = self._a4(corr, box)           # kept alive: the library stores the descriptor
+            O.lib().ora_set_source_corrector(C.byref(self._corr))
+
     def clean_state_reduce(self, state, box, lo, hi, geom, params, out, ntimes=1, stream=None):
         a = self._a4(state, box)
         r = O.lib().ora_min_density(O.i3(lo), O.i3(hi), a)

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     # sizes implied by the header (LP64): fab = 8 + 12 + 12 + 4 (+4 pad) = 40
     assert C.sizeof(_lib.Fab) == 40
     assert C.sizeof(_lib.Geom) == 3 * 24 + 4 * 12 + 4 + 4
-    assert C.sizeof(_lib.Params) == 14 * 4 + 16 * 8 + 2 * 4 + 8
+    assert C.sizeof(_lib.Params) == 14 * 4 + 16 * 8 + 2 * 4 + 8 + 4 + 4      # + source_term_predictor (+ tail padding)
     assert C.sizeof(_lib.Rotation) == 6 * 8 + 4 * 4           # castro_amd_rotation
 
 

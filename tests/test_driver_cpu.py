@@ -229,6 +229,42 @@ def test_constant_gravity_sources_match_the_oracle_driver(oracle, pkw, gtype):
     lev.close()
 
 
+@pytest.mark.parametrize("init_shrink", [0.1, 1.0])
+def test_source_term_predictor_matches_the_oracle_driver_and_changes_the_answer(oracle, init_shrink):
+    """castro.source_term_predictor = 1 (Castro_ctu.cpp:493-497, Castro.cpp:3780-3818): the momentum sources traced in the
+    predictor get dt/2 x the lagged dS/dt = 2 x (new-time corrector of the last advance) / lastDt.  Driver == oracle level
+    driver, bitwise, over steps that include retries (init_shrink = 1); and the result differs from the run without it."""
+    import castro_amd
+    n = (4, 4, 32)
+    bc = dict(lo_bc=(4, 4, 3), hi_bc=(4, 4, 3))
+    geo = dict(prob_hi=(0.125, 0.125, 1.0))
+    S0 = _hse_atmosphere(n)
+    rng = np.random.default_rng(5)
+    S0[3] = S0[0] * 0.2 * rng.uniform(-1, 1, size=S0[0].shape)
+    S0[4] += 0.5 * S0[3] ** 2 / S0[0]
+    out = {}
+    for pred in (1, 0):
+        pkw = dict(source_term_predictor=pred, init_shrink=init_shrink, change_max=1.05)
+        c = castro_amd.Castro(n, params=oracle.default_params(**pkw), hydro=OracleBackend(), do_grav=True, const_grav=-20.0, **bc, **geo)
+        c.set_state(S0.copy())
+        lev = oracle.Level(n, oracle.make_geom(n, probhi=geo["prob_hi"], **bc), oracle.default_params(**pkw), nthreads=4)
+        lev.set_gravity(-20.0, 4)
+        lev.state()[...] = S0
+        oracle.lib().ora_level_post_init(lev.h)
+        retries = 0
+        for _ in range(10):
+            c.step(1.0)
+            lev.step(1.0)
+            assert c.dt == lev.dt and c.nretries == lev.nretries
+            retries += c.nretries
+        assert np.array_equal(c.S_new().numpy(), lev.state())
+        out[pred] = (lev.state().copy(), retries)
+        lev.close()
+    assert not np.array_equal(out[1][0], out[0][0])
+    if init_shrink == 1.0:
+        assert out[1][1] > 0                      # the retry path (no new corrector on the attempt after a rejection) ran
+
+
 def _grav_worker(rank, world, port, n, nsteps, out_path):
     import torch.distributed as dist
     import castro_amd

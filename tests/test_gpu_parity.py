@@ -1818,6 +1818,38 @@ def test_device_amr_equals_the_independent_orchestration_oracle(oracle, nlev):
     b.close()
 
 
+def test_source_term_predictor_on_the_device_matches_the_oracle_driver(oracle):
+    """castro.source_term_predictor = 1 through castro_amd_ctx_set_source_corrector and k_src_to_prim: constant gravity,
+    random velocities, PPM and PLM, ten steps with init_shrink = 1 (retries): same dt sequence, same retry counts, same
+    state as the oracle's level driver, bit for bit."""
+    import torch
+    import castro_amd
+    from tests.test_driver_cpu import _hse_atmosphere
+    n = (8, 8, 32)
+    bc = dict(lo_bc=(4, 2, 3), hi_bc=(4, 2, 3))
+    prob_hi = (0.25, 0.25, 1.0)
+    S0 = _hse_atmosphere(n)
+    rng = np.random.default_rng(8)
+    for d in (1, 2, 3):
+        S0[d] = S0[0] * 0.1 * rng.uniform(-1, 1, size=S0[0].shape)
+    S0[4] += 0.5 * (S0[1] ** 2 + S0[2] ** 2 + S0[3] ** 2) / S0[0]
+    for ppm_type in (1, 0):
+        pkw = dict(source_term_predictor=1, init_shrink=1.0, change_max=1.05, ppm_type=ppm_type)
+        c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), do_grav=True, const_grav=-20.0, prob_hi=prob_hi, **bc)
+        c.set_state(S0.copy())
+        lev = oracle.Level(n, oracle.make_geom(n, probhi=prob_hi, **bc), oracle.default_params(**pkw), nthreads=8)
+        lev.set_gravity(-20.0, 4)
+        lev.state()[...] = S0
+        oracle.lib().ora_level_post_init(lev.h)
+        for step in range(10):
+            c.step(1.0)
+            lev.step(1.0)
+            assert c.dt == lev.dt and c.nretries == lev.nretries, (step, c.dt, lev.dt, c.nretries, lev.nretries)
+        torch.cuda.synchronize()
+        _assert_exact({"S_new": (c.S_new().cpu().numpy(), lev.state())}, "source_term_predictor ppm_type %d" % ppm_type)
+        lev.close()
+
+
 def test_randomised_amr_layouts_match_the_oracle_backend():
     """tools/fuzz_amr.py: 40 random hierarchies (random base grid, up to three level-1 boxes anywhere in the domain --
     adjacent, apart, at the physical boundary -- and up to two level-2 boxes, random boundary types, Sedov or Sod, PPM or
