@@ -788,6 +788,42 @@ def test_full_size_256_cubed_properties():
         assert resid.abs().max().item() <= 1e-12 * scale, comp
 
 
+def test_full_size_512_cubed_properties():
+    """BASELINE config 3's global problem (Sedov 512^3) on ONE GPU: 224 GB of the 288 GB (scratch 177 GB + state and
+    fluxes 47 GB), component planes of 1.1 GB addressed with 32-bit byte offsets.  Two steps: conservation to round-off,
+    octahedral symmetry (to the accuracy the reference's arithmetic has at this resolution, see below); and the same two steps as eight 256^3 boxes (the per-rank shape of config 3) are covered by the
+    decomposition tests at smaller sizes (tests/test_driver_cpu.py, bitwise independence of the rank grid)."""
+    import torch
+    import castro_amd
+    free, total = torch.cuda.mem_get_info()
+    if free < 235 * 2 ** 30:
+        pytest.skip("needs ~224 GB of free device memory, %.0f GB available" % (free / 2 ** 30))
+    n = 512
+    c = castro_amd.Castro((n, n, n), flux_assign=True)
+    c.initData("sedov")
+    g = 4
+    v = lambda b: b[:, g:-g, g:-g, g:-g]
+    m0, e0 = v(c.S_new_b)[0].sum().item(), v(c.S_new_b)[4].sum().item()
+    for _ in range(2):
+        c.step(0.01)
+    torch.cuda.synchronize()
+    assert c.hydro.status() == 0
+    S = v(c.S_new_b)
+    assert abs(S[0].sum().item() - m0) <= 1e-12 * m0
+    assert abs(S[4].sum().item() - e0) <= 1e-12 * e0
+    # Mirror symmetry only to 1e-6 here: with r_init = 5.12 zones the energy deposit cuts through zones next to a pressure
+    # contrast of 1e10, and the reference's expression order (the 8-term sums of divu, the x-y-z order of consup_hydro) is
+    # not mirror symmetric in the last bit; the oracle shows the same 2.8e-8 / 7e-8 at 384^3 / 512^3 and the device equals
+    # the oracle bit for bit at 320^3 and 384^3 (tools/big_box_vs_oracle.py).  At 256^3 (r_init = 2.56 zones) it is exact.
+    rho = S[0]
+    for flip in ((0,), (1,), (2,)):
+        assert (rho - rho.flip(flip)).abs().max().item() <= 1e-6
+    assert (rho - rho.permute(2, 1, 0)).abs().max().item() <= 1e-6
+    assert (rho - rho.permute(0, 2, 1)).abs().max().item() <= 1e-6
+    del c
+    torch.cuda.empty_cache()
+
+
 def test_128_cubed_against_oracle(oracle):
     """Largest size at which the oracle finishes in seconds: three Sedov steps at 128^3, bit for bit."""
     import torch
