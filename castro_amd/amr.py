@@ -66,7 +66,7 @@ class _Patch(Castro):
         self.level, self.pbox = level, pbox
         # coarse zones under the grown fine box, grown by one for the slopes
         self.cbox = (tuple(_coarsen(self.glo[d]) - 1 for d in range(3)), tuple(_coarsen(self.ghi[d]) + 1 for d in range(3)))
-        self.ctmp = self.hydro.alloc(NUM_STATE, *self.cbox)
+        self.ctmp = self.hydro.alloc(NUM_STATE, *self.cbox) if self.owned else None
         lo, hi = self.lo, self.hi
         glo, ghi = self.glo, self.ghi
         self.shell = [((glo[0], glo[1], glo[2]), (ghi[0], ghi[1], lo[2] - 1)), ((glo[0], glo[1], hi[2] + 1), (ghi[0], ghi[1], ghi[2])),
@@ -81,7 +81,7 @@ class _Patch(Castro):
             for side in (0, 1):
                 rlo, rhi = list(plo), list(phi)
                 rlo[d] = rhi[d] = (plo[d] if side == 0 else phi[d] + 1)
-                self.regs[(d, side)] = (self.hydro.alloc(NUM_STATE, rlo, rhi), (tuple(rlo), tuple(rhi)))
+                self.regs[(d, side)] = (self.hydro.alloc(NUM_STATE, rlo, rhi) if self.owned else None, (tuple(rlo), tuple(rhi)))
 
     def _bind_sources(self):
         """Source_Type data (NUM_GROW_SRC ghost zones): the coarse zones under the grown box, and the ghost shell."""
@@ -104,11 +104,12 @@ class _Level:
 
     def __init__(self, amr, l, boxes):
         self.amr, self.l, self.boxes = amr, l, list(boxes)
+        self.mine = [b for b in self.boxes if b.owned]        # the boxes this rank advances (all of them on one rank)
         self.alpha = 0.0          # (t_level - t_parent_old) / dt_parent of the FillPatch being prepared
         b0 = self.boxes[0]
         self.hydro, self.params, self.geom = b0.hydro, b0.params, b0.geom
-        self.red = b0.red
-        for b in self.boxes:
+        self.red = self.mine[0].red if self.mine else self.hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)
+        for b in self.mine:
             b.red = self.red      # one [min dt, min rho] pair for the level: every box reduces into it
             b.fuse_post_clean = False      # post_timestep's clean_state comes after reflux and avgDown (_time_step)
         self._pending_cleans, self._post_clean_done, self._whole_step = 2, False, False
@@ -121,7 +122,7 @@ class _Level:
     def __getattr__(self, name):
         # a level of one box answers for its box (S_new(), lo, hi, n, gbox, S_new_b, ...)
         boxes = self.__dict__.get("boxes", ())
-        if len(boxes) == 1:
+        if len(boxes) == 1 and boxes[0].owned:
             return getattr(boxes[0], name)
         raise AttributeError("%s (level %d has %d boxes)" % (name, self.__dict__.get("l", -1), len(boxes)))
 
@@ -188,7 +189,7 @@ class _Level:
             # ghost zones outside the problem domain (only then the physical-BC fill has anything to do)
             b.at_domain_edge = any(b.glo[d] < b.geom.domlo[d] or b.ghi[d] > b.geom.domhi[d] for d in range(3))
         self._op_cache = {}
-        self.batched = hasattr(self.hydro, "make_ops")
+        self.batched = hasattr(self.hydro, "make_ops") and self.amr.nranks == 1
         if self.batched:
             # flux-register operations never change between regrids (registers and flux FABs keep their storage)
             mk = self.hydro.make_ops
@@ -234,9 +235,11 @@ class _Level:
     def fill(self, which):
         """Ghost zones of S_old_b / S_new_b (`which`) of every box of the level."""
         if self.l == 0:
-            for b in self.boxes:
+            for b in self.mine:
                 b.expand_state(getattr(b, which))
             return
+        if self.amr.nranks > 1:
+            return self._fill_ranks(which)
         if not self.batched:
             for b in self.boxes:
                 self._interp_ghosts(b, getattr(b, which))
@@ -270,6 +273,25 @@ class _Level:
         for b in self.boxes:
             if b.at_domain_edge:
                 h.bc_fill(getattr(b, which), b.gbox, b.geom)
+
+    def _fill_ranks(self, which):
+        """fill() with the boxes of this level and of the parent level spread over ranks: the same four passes, every
+        box-to-box transfer through CastroAmr._xrun (local where both boxes are here, one message otherwise)."""
+        h, a, X = self.hydro, self.alpha, self.amr._xrun
+        X([("lincomb", b, p, lo, hi, a) for b in self.boxes for p, (lo, hi) in b.csrc])           # ghost zones of the parents first,
+        X([("lincomb", b, p, lo, hi, a) for b in self.boxes for p, (lo, hi) in b.csrc_valid])     # valid zones last
+        for b in self.mine:
+            h.fillpatch_shell(b.ctmp, b.cbox, getattr(b, which), b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1) \
+                if hasattr(h, "fillpatch_shell") else self._interp_shell(b, getattr(b, which))
+        X([("copy", b, sb, lo, hi, (which, sh)) for b in self.boxes for sb, (lo, hi), sh in b.sib])
+        for b in self.mine:
+            h.bc_fill(getattr(b, which), b.gbox, b.geom)
+
+    def _interp_shell(self, b, S):
+        for lo, hi in b.shell:
+            self.hydro.cc_interp(b.ctmp, b.cbox, S, b.gbox, lo, hi, NUM_STATE)
+        for lo, hi in b.shell:
+            self.hydro.clean_state(S, b.gbox, lo, hi, b.params, ntimes=1)
 
     def fill_box(self, b, S):
         which = "S_new_b" if S is b.S_new_b else "S_old_b"
@@ -357,18 +379,18 @@ class _Level:
 
     # ---- Castro::advance over the boxes of the level (Castro_advance.cpp:19-121) ----------------------
     def _swap_state_time_levels(self):
-        for b in self.boxes:
+        for b in self.mine:
             b._swap_state_time_levels()
 
     def _zero_fluxes(self):
-        for b in self.boxes:
+        for b in self.mine:
             b._zero_fluxes()
 
     def _save_old_state(self):
-        return [b.S_old_b.clone() for b in self.boxes]
+        return [b.S_old_b.clone() for b in self.mine]
 
     def _restore_old_state(self, prev):
-        for b, p in zip(self.boxes, prev):
+        for b, p in zip(self.mine, prev):
             b.S_old_b.copy_(p)
 
     advance = Castro.advance
@@ -380,19 +402,22 @@ class _Level:
             # a later subcycle of a retried step: the coarse data are interpolated to ITS old time, not the step's
             self.alpha = self._alpha0 + (time - self._t0) / self._dt_parent
         if self._pending_cleans > 0:           # see Castro.do_advance_ctu
-            for b in self.boxes:
+            for b in self.mine:
                 b.clean_state(b.S_old_b, self._pending_cleans)
         self._pending_cleans = 0
         self.red.fill_(1.e200)
         self.fill("S_old_b")
         if self.have_sources:
+            if self.amr.nranks > 1:
+                raise NotImplementedError("gravity / rotation sources with the boxes of a level on several ranks")
             return self._advance_with_sources(time, dt)
-        for b in self.boxes:
+        for b in self.mine:
             b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
             b._flux_clear = False
         if not self.fuse_clean:
-            for b in self.boxes:
+            for b in self.mine:
                 self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
+        self.amr.comm.allreduce_min(self.red)                 # the level's minima over the ranks that hold its boxes
         est, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
@@ -403,12 +428,13 @@ class _Level:
 
     def estTimeStep(self):
         self.red.fill_(1.e200)
-        for b in self.boxes:
+        for b in self.mine:
             self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
+        self.amr.comm.allreduce_min(self.red)
         return min(self.max_dt, self.red.tolist()[0] * self.params.cfl)
 
     def clean_new(self):
-        for b in self.boxes:
+        for b in self.mine:
             b.clean_state(b.S_new_b, 1)
 
 
@@ -420,8 +446,13 @@ class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
                  blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None):
-        """patch_crse = (lo, hi): the coarse zones covered by a FIXED refined box;
+                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None, comm=None):
+        """comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of a level on rank
+        i mod size, level 0 on rank 0; fixed hierarchies, no sources): every rank builds the same hierarchy, holds the
+        memory of its own boxes only and moves box-to-box data (coarse data under fine ghost shells, sibling ghost zones,
+        coarse fluxes for the registers, registers for the reflux, averaged-down zones) with one grouped RCCL
+        point-to-point exchange per pass.
+        patch_crse = (lo, hi): the coarse zones covered by a FIXED refined box;
         patches = [entry, ...]: one entry per refined level, a box (lo, hi) or a list of boxes in the zones of the
         level below it (amr.max_level = len(patches)); or
         refine = [(field, kind, value), ...] like amr.refinement_indicators (field: a state name or a pointwise
@@ -433,6 +464,11 @@ class CastroAmr:
             assert patches is None
             patches = [patch_crse]
         assert (patches is None) != (refine is None), "give either fixed patches or refinement indicators"
+        from .castro import SingleComm
+        self.comm = comm if comm is not None else SingleComm()
+        self.rank, self.nranks = self.comm.rank, self.comm.size
+        if self.nranks > 1:
+            assert refine is None, "tag-driven regridding with the boxes on several ranks is not built: fixed `patches` only"
         self._mk = (lambda: None) if make_hydro is None else make_hydro
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
         self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False,
@@ -440,8 +476,9 @@ class CastroAmr:
         self.n_cell = tuple(n_cell)
         self.periodic = tuple(lo_bc[d] == 0 and hi_bc[d] == 0 for d in range(3))
         self._hydros = []
-        base = Castro(n_cell, hydro=self._hydro_for(0), **self._kw)
-        if base.have_sources:
+        base = Castro(n_cell, hydro=self._hydro_for(0), alloc=(self.rank == 0), **self._kw)
+        base.owner = 0
+        if base.have_sources and base.owned:
             base.new_source_g = base.hydro.alloc(NSRC, *base.sbox)
         self.lev = [_Level(self, 0, [base])]                          # lev[0] covers the domain
         self.refine = refine
@@ -479,15 +516,106 @@ class CastroAmr:
     def _make_level(self, l, pboxes):
         """Level l >= 1 covering the boxes `pboxes` (zones of level l-1), with its flux registers."""
         boxes = []
-        for plo, phi in pboxes:
+        for i, (plo, phi) in enumerate(pboxes):
             flo = tuple(2 * x for x in plo)
             fhi = tuple(2 * x + 1 for x in phi)
-            b = _Patch(tuple((2 ** l) * x for x in self.n_cell), hydro=self._hydro_for(l), box=(flo, fhi), **self._kw)
+            owner = i % self.nranks
+            b = _Patch(tuple((2 ** l) * x for x in self.n_cell), hydro=self._hydro_for(l), box=(flo, fhi),
+                       alloc=(owner == self.rank), **self._kw)
+            b.owner = owner
             boxes.append(b)
         lev = _Level(self, l, boxes)
         for b, pb in zip(boxes, pboxes):
             b.bind(lev, pb)
         return lev
+
+    # ---- box-to-box operations with the boxes spread over ranks ----------------------------------------------
+    def _xrun(self, ops):
+        """ops = [(kind, D, S, lo, hi, extra)]: region [lo, hi] of box D from box S.  Both here: the operation itself.
+        S here and D elsewhere: the source's contribution is staged in a buffer of the region's shape and sent; D here
+        and S elsewhere: it is received and applied, in list order together with the local ones (later entries overwrite
+        earlier ones exactly like on one rank).  Every rank walks the same list, so the messages pair up by position."""
+        me = self.rank
+        sends, recvs, bufs = [], [], {}
+        for n, (kind, D, S, lo, hi, extra) in enumerate(ops):
+            if D.owner == S.owner:
+                continue
+            if S.owner == me:
+                t = self._xstage(kind, D, S, lo, hi, extra)
+                sends.append((D.owner, n, t))
+            elif D.owner == me:
+                h = D.hydro
+                t = h.alloc(NUM_STATE, lo, hi)
+                bufs[n] = t
+                recvs.append((S.owner, n, t))
+        self.comm.exchange(sends, recvs)
+        for n, (kind, D, S, lo, hi, extra) in enumerate(ops):
+            if D.owner != me:
+                continue
+            self._xapply(kind, D, S, lo, hi, extra, bufs.get(n))
+
+    def _xstage(self, kind, D, S, lo, hi, extra):
+        h = S.hydro
+        t = h.alloc(NUM_STATE, lo, hi)
+        box = (tuple(lo), tuple(hi))
+        if kind == "lincomb":
+            h.lincomb(t, box, 1.0 - extra, S.S_old_b, S.gbox, extra, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
+        elif kind == "copy":
+            which, sh = extra
+            h.copy(t, box, getattr(S, which), _shift(S.gbox, sh), lo, hi)
+        elif kind == "crse_init":
+            d, side = extra
+            h.copy(t, box, S.fluxes[d], S.flux_boxes[d], lo, hi)
+        elif kind == "reflux":
+            d, side, vol, csh = extra
+            reg, rbox = S.regs[(d, side)]
+            h.copy(t, box, reg, rbox, lo, hi)
+        elif kind == "avgdown":
+            h.avgdown(S.S_new_b, S.gbox, t, box, lo, hi, NUM_STATE)
+        else:
+            raise ValueError(kind)
+        return t
+
+    def _xapply(self, kind, D, S, lo, hi, extra, buf):
+        """the operation on this rank's box D; `buf` holds the staged source when S lives elsewhere"""
+        h = D.hydro
+        box = (tuple(lo), tuple(hi))
+        if kind == "lincomb":
+            if buf is None:
+                h.lincomb(D.ctmp, D.cbox, 1.0 - extra, S.S_old_b, S.gbox, extra, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
+            else:
+                h.copy(D.ctmp, D.cbox, buf, box, lo, hi)
+        elif kind == "copy":
+            which, sh = extra
+            if buf is None:
+                h.copy(getattr(D, which), D.gbox, getattr(S, which), _shift(S.gbox, sh), lo, hi)
+            else:
+                h.copy(getattr(D, which), D.gbox, buf, box, lo, hi)
+        elif kind == "crse_init":
+            d, side = extra
+            reg, rbox = D.regs[(d, side)]
+            src, sbox = (S.fluxes[d], S.flux_boxes[d]) if buf is None else (buf, box)
+            h.fluxreg_crse_init(reg, rbox, src, sbox, lo, hi, NUM_STATE, -1.0)
+        elif kind == "reflux":
+            d, side, vol, csh = extra
+            reg, rbox = S.regs[(d, side)] if buf is None else (buf, box)
+            h.reflux(D.S_new_b, _shift(D.gbox, csh), reg, rbox, lo, hi, d, side, NUM_STATE, vol)
+        elif kind == "avgdown":
+            if buf is None:
+                h.avgdown(S.S_new_b, S.gbox, D.S_new_b, D.gbox, lo, hi, NUM_STATE)
+            else:
+                h.copy(D.S_new_b, D.gbox, buf, box, lo, hi)
+        else:
+            raise ValueError(kind)
+
+    def gather_level(self, l):
+        """[(box, new-time state as a numpy array)] of level l on rank 0 (None elsewhere): for tests and plotfiles"""
+        mine = [(b.bx, b.S_new().cpu().numpy()) for b in self.lev[l].mine]
+        allv = self.comm.gather_objects(mine)
+        if self.rank != 0:
+            return None
+        got = {bx: a for part in allv for bx, a in part}
+        return [(b.bx, got[b.bx]) for b in self.lev[l].boxes]
 
     def _push_level(self, pboxes):
         lev = self._make_level(len(self.lev), pboxes)
@@ -704,7 +832,8 @@ class CastroAmr:
 
     # ---- Amr::init (bldFineLevels: one new level per pass) / Castro::post_init ---------------------------
     def initData(self, problem="sedov", **kw):
-        self.crse.boxes[0].initData(problem, **kw)
+        for b in self.lev[0].mine:
+            b.initData(problem, **kw)
         if self.refine is not None:
             self._drop_fine()
             while len(self.lev) - 1 < self.max_level:
@@ -732,7 +861,7 @@ class CastroAmr:
                         b.initData(problem, **kw)
         else:
             for lev in self.lev[1:]:
-                for b in lev.boxes:
+                for b in lev.mine:
                     b.initData(problem, **kw)
         # Castro::post_init (Castro.cpp:2220-2235): average down from the finest level, nothing else -- the averaged zones
         # are first cleaned by initialize_advance
@@ -743,6 +872,8 @@ class CastroAmr:
 
     # ---- Castro::avgDown (Castro.cpp:3096-3113): level l onto level l-1 ------------------------------
     def avgDown(self, l=1):
+        if self.nranks > 1:
+            return self._xrun([("avgdown", p, b, lo, hi, None) for b in self.lev[l].boxes for p, (lo, hi) in b.avg_to])
         h = self.lev[l].hydro
         for b in self.lev[l].boxes:
             for p, (lo, hi) in b.avg_to:
@@ -794,7 +925,7 @@ class CastroAmr:
             if lev.batched:
                 h.fab_ops(lev.ops_fine_add)
             else:
-                for b in lev.boxes:
+                for b in lev.mine:
                     for (d, side), (reg, rbox) in b.regs.items():
                         h.fluxreg_fine_add(reg, rbox, b.fluxes[d], b.flux_boxes[d], rbox[0], rbox[1], d, NUM_STATE, 1.0)
         if l < finest:
@@ -805,7 +936,10 @@ class CastroAmr:
             if lev.have_sources:
                 lev.fill_new_source()
             # FluxRegCrseInit: -1 x this level's fluxes through the faces of the finer boxes
-            if fine.batched:
+            if self.nranks > 1:
+                self._xrun([("crse_init", b, p, lo, hi, (d, side)) for b in fine.boxes for (d, side) in b.regs
+                            for p, (lo, hi) in b.crse_init[(d, side)]])
+            elif fine.batched:
                 h.fab_ops(fine.ops_crse_init)
             else:
                 for b in fine.boxes:
@@ -819,7 +953,10 @@ class CastroAmr:
             # face orientation by face orientation, like FluxRegister::Reflux's OrientationIter [3P]: the registers of one
             # orientation touch disjoint coarse zones (two boxes with a common outside neighbour on the same side would
             # overlap), so they can share launches; a zone next to several boxes gets its contributions in this order
-            for d in range(3):
+            if self.nranks > 1:
+                self._xrun([("reflux", p, b, lo, hi, (d, side, vol, csh)) for d in range(3) for side in (0, 1)
+                            for b in fine.boxes for p, (lo, hi), csh in b.reflux_to[(d, side)]])
+            for d in (range(3) if self.nranks == 1 else ()):
                 for side in (0, 1):
                     if fine.batched:
                         pp = tuple(p.S_new_b.data_ptr() for p in lev.boxes)

@@ -116,8 +116,11 @@ class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0, max_dt=1.e200):
+                 do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0, max_dt=1.e200,
+                 alloc=True):
+        """alloc=False: the geometry and bookkeeping of a box another rank owns (castro_amd/amr.py), no device memory."""
         self.n_cell = tuple(int(x) for x in n_cell)
+        self.owned = bool(alloc)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
             from .hydro import HipHydro
@@ -155,16 +158,20 @@ class Castro:
         self.bx = (self.lo, self.hi)
 
         # --- state: two bordered buffers (Sborder / S_new share storage layout; swap per step) ---
-        self.S_old_b = hydro.alloc(NUM_STATE, self.glo, self.ghi)
-        self.S_new_b = hydro.alloc(NUM_STATE, self.glo, self.ghi)
+        if not alloc:
+            hydro_alloc = lambda *a, **k: None
+        else:
+            hydro_alloc = hydro.alloc
+        self.S_old_b = hydro_alloc(NUM_STATE, self.glo, self.ghi)
+        self.S_new_b = hydro_alloc(NUM_STATE, self.glo, self.ghi)
         self.flux_boxes, self.fluxes, self.mass_fluxes = [], [], []
         for d in range(3):
             fhi = list(self.hi)
             fhi[d] += 1
             self.flux_boxes.append((self.lo, tuple(fhi)))
-            self.fluxes.append(hydro.alloc(NUM_STATE, self.lo, fhi))
-            self.mass_fluxes.append(hydro.alloc(1, self.lo, fhi))
-        self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)   # [min dt, min rho]
+            self.fluxes.append(hydro_alloc(NUM_STATE, self.lo, fhi))
+            self.mass_fluxes.append(hydro_alloc(1, self.lo, fhi))
+        self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2) if alloc else None   # [min dt, min rho]
 
         self._plans = {}
         self.neighbors = self._build_neighbors() if box is None else []
@@ -199,14 +206,14 @@ class Castro:
         if self.have_sources:
             NSRC, NGS = 7, 3            # NSRC, NUM_GROW_SRC (Castro_setup.cpp:317-327)
             self.sbox = (tuple(x - NGS for x in self.lo), tuple(x + NGS for x in self.hi))
-            self.old_source = hydro.alloc(NSRC, *self.sbox)
-            self.new_source = hydro.alloc(NSRC, self.lo, self.hi)
-            self.src_neighbors = self._build_neighbors(NGS, NSRC)
+            self.old_source = hydro_alloc(NSRC, *self.sbox)
+            self.new_source = hydro_alloc(NSRC, self.lo, self.hi)
+            self.src_neighbors = self._build_neighbors(NGS, NSRC) if alloc else []
             # castro.source_term_predictor = 1: Castro::source_corrector and the bookkeeping of create_source_corrector
-            self.source_corrector = hydro.alloc(NSRC, *self.sbox)
+            self.source_corrector = hydro_alloc(NSRC, *self.sbox)
         self.lastDt, self._in_retry = 1.e200, False
         self._comm_stream = None
-        if self.overlap and self.S_new_b.is_cuda:
+        if self.overlap and alloc and self.S_new_b.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self.S_new_b.device)
 
         self.time = 0.0

@@ -577,3 +577,67 @@ def test_amr_orchestration_oracle_on_data_where_clean_state_is_not_idempotent(or
     b.post_init(False)
     _assert_same(a, b, 5)
     b.close()
+
+
+# ---- the boxes of the refined levels spread over ranks (gloo, oracle backend) -----------------------------------------
+import os
+import socket
+
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+# level 1: four boxes (two ranks -> boxes 0, 2 here, 1, 3 there), level 2: three boxes over two of them, one at the edge
+# of its parent so that its ghost shell and its flux registers reach into boxes of the other rank
+_MR_PATCHES = [[((2, 2, 2), (7, 7, 13)), ((8, 2, 2), (13, 7, 13)), ((2, 8, 2), (7, 13, 13)), ((8, 8, 2), (13, 13, 13))],
+               [((8, 8, 8), (15, 15, 23)), ((16, 8, 8), (23, 15, 23)), ((8, 16, 8), (23, 19, 19))]]
+
+
+def _mr_run(comm, nsteps, bc):
+    import castro_amd
+    from oracle import oracle_lib as O
+    a = castro_amd.CastroAmr((16, 16, 16), patches=_MR_PATCHES, params=O.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+                             lo_bc=bc[0], hi_bc=bc[1], comm=comm)
+    a.initData("sedov", r_init=0.1, nsub=4)
+    dts = [a.step() for _ in range(nsteps)]
+    return a, dts
+
+
+def _mr_worker(rank, world, port, nsteps, bc, out_path):
+    import torch.distributed as dist
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, dts = _mr_run(castro_amd.DistComm(), nsteps, bc)
+        owned = [[b.owned for b in lev.boxes] for lev in a.lev]
+        assert all(any(o) for o in owned[1:]) and not all(all(o) for o in owned[1:])     # every rank holds a part only
+        levels = [a.gather_level(l) for l in range(len(a.lev))]
+        if rank == 0:
+            np.savez(out_path, dts=np.array(dts), **{"L%d_%d" % (l, i): arr for l, lv in enumerate(levels) for i, (bx, arr) in enumerate(lv)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bc", [(2, ((2, 2, 2), (2, 2, 2))), (3, ((2, 4, 2), (2, 4, 3)))])
+def test_amr_with_boxes_spread_over_ranks_is_bitwise_identical_gloo(tmp_path, oracle, world, bc):
+    """CastroAmr(comm=DistComm()): three levels, four and three boxes on the refined ones, dealt round-robin to 2 and to
+    3 ranks.  Coarse data under fine ghost shells, sibling ghost zones, coarse fluxes into registers, registers into
+    the reflux and averaged-down zones all cross ranks; dt sequence and every box of every level equal the one-rank
+    run bit for bit."""
+    nsteps = 4
+    out = str(tmp_path / "amr_ranks.npz")
+    mp.spawn(_mr_worker, args=(world, _free_port(), nsteps, bc, out), nprocs=world, join=True)
+    got = np.load(out)
+    a, dts = _mr_run(None, nsteps, bc)
+    assert np.array_equal(got["dts"], np.array(dts))
+    for l, lev in enumerate(a.lev):
+        for i, b in enumerate(lev.boxes):
+            assert np.array_equal(got["L%d_%d" % (l, i)], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)

@@ -1086,6 +1086,54 @@ def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, world, overlap, bc):
     assert np.array_equal(got["S"], c.S_new().cpu().numpy())
 
 
+def _amr_rank_gpu_worker(rank, world, port, nsteps, out_path):
+    import torch.distributed as dist
+    import torch
+    import castro_amd
+    from tests.test_amr_cpu import _MR_PATCHES
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = castro_amd.CastroAmr((16, 16, 16), patches=_MR_PATCHES, params=castro_amd.default_params(init_shrink=0.1),
+                                 comm=castro_amd.DistComm())
+        a.initData("sedov", r_init=0.1, nsub=4)
+        dts = [a.step() for _ in range(nsteps)]
+        torch.cuda.synchronize()
+        levels = [a.gather_level(l) for l in range(len(a.lev))]
+        if rank == 0:
+            np.savez(out_path, dts=np.array(dts), **{"L%d_%d" % (l, i): arr for l, lv in enumerate(levels) for i, (bx, arr) in enumerate(lv)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_amr_boxes_over_ranks_on_the_device_equal_one_rank(tmp_path, world):
+    """CastroAmr(comm=DistComm()) on the device: three levels (1 + 4 + 3 boxes) dealt to 2 and to 4 processes sharing the
+    one GPU of the test box (gloo transport; RCCL needs a device per rank): device staging of every cross-rank transfer
+    (time-interpolated coarse data, sibling ghost zones, coarse fluxes, flux registers, averaged-down zones), grouped
+    point-to-point exchange, 2-double all-reduce per level -- dt sequence and every box equal the one-process run bit for
+    bit."""
+    import torch
+    import torch.multiprocessing as mp
+    import castro_amd
+    from tests.test_driver_cpu import _free_port
+    from tests.test_amr_cpu import _MR_PATCHES
+    nsteps = 4
+    out = str(tmp_path / "amr_ranks_gpu.npz")
+    mp.spawn(_amr_rank_gpu_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
+    got = np.load(out)
+    a = castro_amd.CastroAmr((16, 16, 16), patches=_MR_PATCHES, params=castro_amd.default_params(init_shrink=0.1))
+    a.initData("sedov", r_init=0.1, nsub=4)
+    dts = [a.step() for _ in range(nsteps)]
+    torch.cuda.synchronize()
+    assert np.array_equal(got["dts"], np.array(dts))
+    for l, lev in enumerate(a.lev):
+        for i, b in enumerate(lev.boxes):
+            assert np.array_equal(got["L%d_%d" % (l, i)], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
+
+
 def test_tag_driven_amr_on_the_device_matches_oracle_backend(oracle):
     """Error tagging + single-box regridding + the AMR step on the device against the oracle-backed orchestration:
     same patch boxes at every step, same data bit for bit."""
