@@ -1316,8 +1316,12 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 //   F2 slot (N|T): flux in direction N from states corrected with the T-direction flux.
 // (Castro_ctu_hydro.cpp:724-945 for the corrections, :949-1135 for the six solves)
 // ---------------------------------------------------------------------------------------
-template <bool XRIEM>
-__global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+#ifndef TRACE_SPLIT_WAVES
+#define TRACE_SPLIT_WAVES 2
+#endif
+template <bool XRIEM, int DMASK = 7>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : 2)))
+k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P, SkipBox skip)
 {
     int i, j, k;
@@ -1370,11 +1374,13 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
     dp[0] = valid && i >= t.lo[0]; dp[1] = v1 && i + 1 >= t.lo[0];
     dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
     double sa[2][5], sb[2][5];
-    load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1]);
-    load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1]);
-    trace_pair_dir<0, 1>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+    if (DMASK & 1) {
+        load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1]);
+        load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1]);
+        trace_pair_dir<0, (DMASK & 2) ? 1 : -1>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+    }
 
-    if (XRIEM)
+    if (XRIEM && (DMASK & 1))
     // ---- first Riemann solve in x (Castro_ctu_hydro.cpp:719) on the two faces of this thread:
     //      face i+1 lies between its two zones; face i needs the minus state of the zone to the left, which
     //      the neighbouring lane (or, across a wavefront boundary, LDS) hands over.  The first thread of a
@@ -1414,10 +1420,22 @@ __global__ void __launch_bounds__(256) k_trace_pair(Tile t, LinBox b, const doub
         }
     }
 
-    { const bool a = j >= t.lo[1], z = j <= t.hi[1]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z; }
-    trace_pair_dir<1, 2>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sb[0], sb[1], sa[0], sa[1]);
-    { const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z; }
-    trace_pair_dir<2, -1>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+    if (DMASK & 2) {
+        if (!(DMASK & 1)) {
+            load_stencil_2<1>(Q + (long)PV * NC, c, s.y, sb[0], sb[1]);
+            load_stencil_2<1>(Q + (long)PRHO * NC, c, s.y, sa[0], sa[1]);
+        }
+        const bool a = j >= t.lo[1], z = j <= t.hi[1]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
+        trace_pair_dir<1, (DMASK & 4) ? 2 : -1>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sb[0], sb[1], sa[0], sa[1]);
+    }
+    if (DMASK & 4) {
+        if (!(DMASK & 2)) {
+            load_stencil_2<2>(Q + (long)PW * NC, c, s.z, sa[0], sa[1]);
+            load_stencil_2<2>(Q + (long)PRHO * NC, c, s.z, sb[0], sb[1]);
+        }
+        const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
+        trace_pair_dir<2, -1>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+    }
 }
 
 // the x-faces k_trace_pair leaves out: face i of the first thread of every workgroup of that launch
@@ -2253,6 +2271,7 @@ int g_xpad = 0;            // see capi.hip scratch_nx
 int g_final_lds = 0;       // 1: k_final_lds (transverse flux records staged in LDS; measured slower)
 int g_fused_tile_rows = 16; // rows per y-tile of the k_finalx_consup row order (0: plain)
 int g_march_planes = 32;  // planes per chunk of k_finalxz_consup
+int g_trace_split = 0;    // experiment: 1 = one trace launch per direction, 2 = x and y+z
 int g_fuse_consup = 1;    // 1: k_finalx_consup (the x faces of the final stage and consup_hydro in one kernel)
 int g_brick_lds_budget = 80 * 1024;     // bytes of LDS per workgroup: two workgroups per CU
 static Brick make_brick(const int lo[3], const int hi[3], const int grow[2][3], size_t& lds_bytes)
@@ -2345,7 +2364,17 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // launch covers; the faces at the workgroup starts follow in a one-thread-per-workgroup launch, those on the
     // x faces of the launch box (lo[0] and hi[0] + 1) are left to the caller.
     auto trace_with_xriemann = [&](const int lo[3], const int hi[3]) {
-        KL2("k_trace", k_trace_pair<true>, lo, hi, S.Q, S, g, dt, P, none);
+#ifdef EXPERIMENT_TRACE_SPLIT       // tools/build_variant.sh split "-DEXPERIMENT_TRACE_SPLIT"; measured slower, DESIGN.md section 9
+        if (g_trace_split == 1) {
+            KL2("k_trace_x", (k_trace_pair<true, 1>), lo, hi, S.Q, S, g, dt, P, none);
+            KL2("k_trace_y", (k_trace_pair<false, 2>), lo, hi, S.Q, S, g, dt, P, none);
+            KL2("k_trace_z", (k_trace_pair<false, 4>), lo, hi, S.Q, S, g, dt, P, none);
+        } else if (g_trace_split == 2) {
+            KL2("k_trace_x", (k_trace_pair<true, 1>), lo, hi, S.Q, S, g, dt, P, none);
+            KL2("k_trace_yz", (k_trace_pair<false, 6>), lo, hi, S.Q, S, g, dt, P, none);
+        } else
+#endif
+        { KL2("k_trace", k_trace_pair<true>, lo, hi, S.Q, S, g, dt, P, none); }
         long n_;
         LinBox b_ = linbox2(lo, hi, n_);
         if (n_ > 0) {
