@@ -1477,8 +1477,15 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 #pragma unroll
         for (int n = 0; n < NF1; ++n) fr[w][n] = fl[w][n] * 1.01;
 #else
+#ifdef DIAG_T1_NOLOAD     // timing diagnostic (wrong results): inputs made up from the index instead of loaded
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int n = 0; n < NF1; ++n) { fr[w][n] = 1e-3 * (double)((c + n + w) & 255u); fl[w][n] = 1e-3 * (double)((c + st + n) & 255u); }
+#else
     load_f1_2(S.F1[T], t.NC, c - sn + st, fr);
     load_f1_2(S.F1[T], t.NC, c - sn, fl);
+#endif
 #endif
     if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
         const D2 er = ldg2(S.F1E[T], c - sn + st), el = ldg2(S.F1E[T], c - sn);
@@ -1490,7 +1497,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     }
 
     // plus states live in zones c
-#ifndef DIAG_F1_REUSE
+#if !defined(DIAG_F1_REUSE) && !defined(DIAG_T1_NOLOAD)
     load_f1_2(S.F1[T], t.NC, c + st, fr);
     load_f1_2(S.F1[T], t.NC, c, fl);
 #endif
@@ -1510,13 +1517,23 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
     IFlux f[2];
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
+#ifdef DIAG_T1_NOSOLVE    // timing diagnostic (wrong results): the Riemann solve replaced by sums of its inputs
+        f[w].rho = qmo[w][PRHO] + qpo[w][PRHO]; f[w].mn = qmo[w][PU] + qpo[w][PU]; f[w].mt = qmo[w][PV] + qpo[w][PV];
+        f[w].mtt = qmo[w][PW] + qpo[w][PW]; f[w].E = qmo[w][PP] + qpo[w][PP]; f[w].eint = qmo[w][PRE] + qpo[w][PRE];
+        f[w].X = qmo[w][PX] + qpo[w][PX]; f[w].ugd = (w ? cl.b : cl.a) + bnd_fac[w]; f[w].pgd = (w ? cr.b : cr.a);
+        f[w].ut = 0.0; f[w].utt = 0.0;
+#else
         RState ql, qr;
         double Xl, Xr;
         rstate_from_edge<N>(qmo[w], P.gamma, ql, Xl);
         rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
         interface_flux<N>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
+#endif
     }
+#ifdef DIAG_T1_NOSTORE    // timing diagnostic: the stores behind a condition that never holds
+    if (f[0].rho == 1.2345e300)
+#endif
     store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, RE ? S.F2E[f2_slot(N, T)] : nullptr);
 }
 
@@ -1546,10 +1563,21 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
     if (!any1 && !any2) return;
 
     double qm[2][NEDGE], qp[2][NEDGE];
+#ifdef DIAG_T1_NOLOAD
+    D2 cl, cr;
+    cl.a = cl.b = cr.a = cr.b = 1.3;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const double e = 1e-6 * (double)((c + w) & 255u);
+        qm[w][PRHO] = 1.0 + e; qm[w][PU] = 0.1; qm[w][PV] = 0.2 + e; qm[w][PW] = 0.3; qm[w][PP] = 1.0 + e; qm[w][PRE] = 2.5; qm[w][PX] = 1.0;
+        qp[w][PRHO] = 1.1 + e; qp[w][PU] = 0.2; qp[w][PV] = 0.1 + e; qp[w][PW] = 0.2; qp[w][PP] = 1.1 + e; qp[w][PRE] = 2.75; qp[w][PX] = 1.0;
+    }
+#else
     load_edge_2(S.QM[N], t.NC, c, qm);
     load_edge_2(S.QP[N], t.NC, c, qp);
     const D2 cl = ldg2(Q + PC * t.NC, c - sn);
     const D2 cr = ldg2(Q + PC * t.NC, c);
+#endif
     double bnd_fac[2];
     bnd_fac[0] = wall_fac<N>(g, ijk[N]);
     bnd_fac[1] = wall_fac<N>(g, ijk[N] + (N == 0 ? 1 : 0));
