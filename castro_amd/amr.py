@@ -447,8 +447,8 @@ class CastroAmr:
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
                  blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128,
                  do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None, comm=None):
-        """comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of a level on rank
-        i mod size, level 0 on rank 0; fixed hierarchies, no sources): every rank builds the same hierarchy, holds the
+        """comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of level l on rank
+        (i + l) mod size, level 0 on rank 0; no sources): every rank builds the same hierarchy, holds the
         memory of its own boxes only and moves box-to-box data (coarse data under fine ghost shells, sibling ghost zones,
         coarse fluxes for the registers, registers for the reflux, averaged-down zones) with one grouped RCCL
         point-to-point exchange per pass.
@@ -467,8 +467,6 @@ class CastroAmr:
         from .castro import SingleComm
         self.comm = comm if comm is not None else SingleComm()
         self.rank, self.nranks = self.comm.rank, self.comm.size
-        if self.nranks > 1:
-            assert refine is None, "tag-driven regridding with the boxes on several ranks is not built: fixed `patches` only"
         self._mk = (lambda: None) if make_hydro is None else make_hydro
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
         self._kw = dict(prob_lo=prob_lo, prob_hi=prob_hi, lo_bc=lo_bc, hi_bc=hi_bc, params=self.params, overlap=False,
@@ -519,7 +517,7 @@ class CastroAmr:
         for i, (plo, phi) in enumerate(pboxes):
             flo = tuple(2 * x for x in plo)
             fhi = tuple(2 * x + 1 for x in phi)
-            owner = i % self.nranks
+            owner = (i + l) % self.nranks             # level 0 is box 0 of rank 0; one-box levels go round the ranks
             b = _Patch(tuple((2 ** l) * x for x in self.n_cell), hydro=self._hydro_for(l), box=(flo, fhi),
                        alloc=(owner == self.rank), **self._kw)
             b.owner = owner
@@ -560,6 +558,8 @@ class CastroAmr:
         box = (tuple(lo), tuple(hi))
         if kind == "lincomb":
             h.lincomb(t, box, 1.0 - extra, S.S_old_b, S.gbox, extra, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
+        elif kind == "crse_new":
+            h.lincomb(t, box, 0.0, S.S_new_b, S.gbox, 1.0, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
         elif kind == "copy":
             which, sh = extra
             h.copy(t, box, getattr(S, which), _shift(S.gbox, sh), lo, hi)
@@ -583,6 +583,11 @@ class CastroAmr:
         if kind == "lincomb":
             if buf is None:
                 h.lincomb(D.ctmp, D.cbox, 1.0 - extra, S.S_old_b, S.gbox, extra, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
+            else:
+                h.copy(D.ctmp, D.cbox, buf, box, lo, hi)
+        elif kind == "crse_new":                                # FillCoarsePatch of a regrid: the parents' new-time data
+            if buf is None:
+                h.lincomb(D.ctmp, D.cbox, 0.0, S.S_new_b, S.gbox, 1.0, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
             else:
                 h.copy(D.ctmp, D.cbox, buf, box, lo, hi)
         elif kind == "copy":
@@ -643,6 +648,10 @@ class CastroAmr:
         h = lev.hydro
         tags, mask = h.alloc(1, olo, ohi)[0], h.alloc(1, olo, ohi)[0]
         for b in lev.boxes:
+            sl = tuple(slice(b.lo[d] - olo[d], b.hi[d] - olo[d] + 1) for d in (2, 1, 0))
+            mask[sl] = 1.0
+            if not b.owned:                                     # its owner tags it; tag_boxes() combines the ranks' tags
+                continue
             t = h.alloc(1, b.lo, b.hi)
             for field, kind, value in self.refine:
                 if field in _FIELDS:
@@ -655,9 +664,7 @@ class CastroAmr:
                     center = [0.5 * (b.geom.problo[dd] + b.geom.probhi[dd]) for dd in range(3)]
                     h.derive(field, b.S_new_b, b.gbox, d, g1, 0, g1[0], g1[1], b.geom, b.params, center)
                     h.error_tag(d, g1, 0, t, (b.lo, b.hi), b.lo, b.hi, _TAG_KINDS[kind], value)
-            sl = tuple(slice(b.lo[d] - olo[d], b.hi[d] - olo[d] + 1) for d in (2, 1, 0))
             tags[sl] = (t[0] > 0.5).to(tags.dtype)
-            mask[sl] = 1.0
         return tags, mask, olo
 
     def _cell_images(self, l, a):
@@ -742,6 +749,10 @@ class CastroAmr:
         else:
             ct, cm = tags, mask
         ct = (ct > 0.5).cpu().numpy()
+        if self.nranks > 1:
+            # buffering and pooling are maxima, so the maximum over the ranks' partial tags commutes with them: only the
+            # reduced arrays travel
+            ct = np.logical_or.reduce(self.comm.gather_objects(ct))
         oc = tuple(x // a for x in o)
         for lo, hi in nest:                                     # one cell around the footprint of level l+2
             for sh in self._cell_images(l, a):
@@ -816,6 +827,20 @@ class CastroAmr:
             self._push_level(new[l - 1])
             lev = self.lev[l]
             h = lev.hydro
+            if self.nranks > 1:
+                self._xrun([("crse_new", b, p, lo, hi, None) for b in lev.boxes for p, (lo, hi) in b.csrc + b.csrc_valid])
+                for b in lev.mine:
+                    h.cc_interp(b.ctmp, b.cbox, b.S_new_b, b.gbox, b.lo, b.hi, NUM_STATE)
+                if l < len(old_lev):
+                    ops = []
+                    for b in lev.boxes:
+                        for ob in old_lev[l].boxes:
+                            it = CL.intersect(ob.bx, b.bx)
+                            if it:
+                                ops.append(("copy", b, ob, it[0], it[1], ("S_new_b", (0, 0, 0))))
+                    self._xrun(ops)
+                lev.time, lev.nstep = self.time, self.nstep
+                continue
             for b in lev.boxes:
                 # FillCoarsePatch: cell-conservative interpolation of the (ghost-filled) coarse data over the whole new box
                 for p, (lo, hi) in b.csrc + b.csrc_valid:
@@ -841,7 +866,7 @@ class CastroAmr:
                 if not bl:
                     break
                 self._push_level(bl)
-                for b in self.lev[-1].boxes:
+                for b in self.lev[-1].mine:
                     b.initData(problem, **kw)                   # fine levels start from the problem initialiser
             # Amr::bldFineLevels' closing loop [3P]: each level above was placed inside the one before it; regrid from
             # level 0 (initial data from the initialiser again) until the coarser levels have grown around the finer
@@ -857,7 +882,7 @@ class CastroAmr:
                 self._drop_fine()
                 for bl in new:
                     self._push_level(bl)
-                    for b in self.lev[-1].boxes:
+                    for b in self.lev[-1].mine:
                         b.initData(problem, **kw)
         else:
             for lev in self.lev[1:]:

@@ -641,3 +641,59 @@ def test_amr_with_boxes_spread_over_ranks_is_bitwise_identical_gloo(tmp_path, or
     for l, lev in enumerate(a.lev):
         for i, b in enumerate(lev.boxes):
             assert np.array_equal(got["L%d_%d" % (l, i)], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
+
+
+def _mr_tag_run(comm, nsteps):
+    import castro_amd
+    from oracle import oracle_lib as O
+    a = castro_amd.CastroAmr((16, 16, 16), params=O.default_params(init_shrink=0.3), make_hydro=OracleBackend,
+                             refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2,
+                             n_error_buf=1, blocking_factor=4, max_level=2, cluster=True, grid_eff=0.7, max_grid_size=16, comm=comm)
+    a.initData("sedov", r_init=0.08, nsub=4)
+    dts, boxes = [], [a.boxes[1:]]
+    for _ in range(nsteps):
+        dts.append(a.step())
+        boxes.append(a.boxes[1:])
+    return a, dts, boxes
+
+
+def _mr_tag_worker(rank, world, port, nsteps, out_path):
+    import pickle
+    import torch.distributed as dist
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, dts, boxes = _mr_tag_run(castro_amd.DistComm(), nsteps)
+        owned = [[b.owned for b in lev.boxes] for lev in a.lev]
+        levels = [a.gather_level(l) for l in range(len(a.lev))]
+        if rank == 0:
+            pickle.dump(dict(dts=dts, boxes=boxes, nregrid=a.nregrid, owned=owned,
+                             data=[[arr for bx, arr in lv] for lv in levels]), open(out_path, "wb"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tag_driven_amr_regrids_with_boxes_spread_over_ranks_gloo(tmp_path, oracle, world):
+    """Regridding with the boxes of every level dealt over ranks: each rank tags its own boxes, the buffered tags reduced
+    to blocking cells are combined over the ranks (a maximum, like the buffering and the pooling), every rank clusters
+    the same array into the same box lists, and the data of a new level come from the parents' and the old boxes'
+    owners through the staged transfers.  Box lists after every step, dt sequence and every box equal the one-rank
+    run bit for bit, with Berger-Rigoutsos boxes on two refined levels and regrids in between."""
+    import pickle
+    nsteps = 6
+    out = str(tmp_path / "amr_tag_ranks.pkl")
+    mp.spawn(_mr_tag_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
+    got = pickle.load(open(out, "rb"))
+    a, dts, boxes = _mr_tag_run(None, nsteps)
+    assert a.nregrid >= 2 and got["nregrid"] == a.nregrid and len(a.lev) == 3
+    assert got["boxes"] == boxes and boxes[0] != boxes[-1]
+    assert got["dts"] == dts
+    assert sum(len(o) for o in got["owned"]) > world and not all(all(o) for o in got["owned"][1:])
+    for l, lev in enumerate(a.lev):
+        assert len(got["data"][l]) == len(lev.boxes)
+        for i, b in enumerate(lev.boxes):
+            assert np.array_equal(got["data"][l][i], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)

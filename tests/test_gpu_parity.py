@@ -1134,6 +1134,61 @@ def test_amr_boxes_over_ranks_on_the_device_equal_one_rank(tmp_path, world):
             assert np.array_equal(got["L%d_%d" % (l, i)], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
 
 
+def _amr_tag_rank_gpu_run(comm, nsteps):
+    import castro_amd
+    a = castro_amd.CastroAmr((32, 32, 32), params=castro_amd.default_params(init_shrink=0.3),
+                             refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2,
+                             n_error_buf=1, blocking_factor=8, max_level=2, cluster=True, grid_eff=0.7, max_grid_size=32, comm=comm)
+    a.initData("sedov", r_init=0.08, nsub=4)
+    dts, boxes = [], [a.boxes[1:]]
+    for _ in range(nsteps):
+        dts.append(a.step())
+        boxes.append(a.boxes[1:])
+    return a, dts, boxes
+
+
+def _amr_tag_rank_gpu_worker(rank, world, port, nsteps, out_path):
+    import pickle
+    import torch.distributed as dist
+    import torch
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, dts, boxes = _amr_tag_rank_gpu_run(castro_amd.DistComm(), nsteps)
+        torch.cuda.synchronize()
+        levels = [a.gather_level(l) for l in range(len(a.lev))]
+        if rank == 0:
+            pickle.dump(dict(dts=dts, boxes=boxes, nregrid=a.nregrid, data=[[arr for bx, arr in lv] for lv in levels]), open(out_path, "wb"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tag_driven_amr_over_ranks_on_the_device_equals_one_rank(tmp_path):
+    """Tag-driven regridding (Berger-Rigoutsos boxes, two refined levels, regrid every two steps) with the boxes dealt over
+    three processes sharing the test GPU: box lists after every step, dt sequence and every box equal the one-process
+    run bit for bit."""
+    import pickle
+    import torch
+    import torch.multiprocessing as mp
+    from tests.test_driver_cpu import _free_port
+    nsteps, world = 6, 3
+    out = str(tmp_path / "amr_tag_ranks_gpu.pkl")
+    mp.spawn(_amr_tag_rank_gpu_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
+    got = pickle.load(open(out, "rb"))
+    a, dts, boxes = _amr_tag_rank_gpu_run(None, nsteps)
+    torch.cuda.synchronize()
+    assert a.nregrid >= 2 and got["nregrid"] == a.nregrid and len(a.lev) == 3
+    assert got["boxes"] == boxes and boxes[0] != boxes[-1]
+    assert got["dts"] == dts
+    for l, lev in enumerate(a.lev):
+        assert len(got["data"][l]) == len(lev.boxes)
+        for i, b in enumerate(lev.boxes):
+            assert np.array_equal(got["data"][l][i], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
+
+
 def test_tag_driven_amr_on_the_device_matches_oracle_backend(oracle):
     """Error tagging + single-box regridding + the AMR step on the device against the oracle-backed orchestration:
     same patch boxes at every step, same data bit for bit."""
