@@ -1861,6 +1861,59 @@ def test_pointwise_riemann_matches_the_oracle_on_extreme_states(hip, oracle):
             int(np.isnan(ref).sum()))
 
 
+@pytest.mark.parametrize("c", range(14))
+def test_whole_tile_on_the_device_matches_the_reference_functions_driven_by_the_probe(hip, c):
+    """castro_amd_ctu_hydro_fab against tests/golden/stub_probe/vectors.npz `hydro<c>.*`: one whole tile of
+    Castro::construct_ctu_hydro_source computed by the reference's OWN member functions (compiled unmodified against
+    stand-in AMReX / Microphysics headers -- STUB-COMPILED, NOT oracle/_ref), called by tools/stub_probe/probe.cpp in the
+    order and on the boxes of Castro_ctu_hydro.cpp:130-1480.  14 configurations: CGF / CG / HLLC / hybrid HLL, PPM and
+    PLM (iorder 1, both limiters), ppm_temp_fix = 2, the transverse_* options, both flux limiters with a speed limit, slip
+    walls, old-time sources with and without source_term_predictor, first_order_hydro, no flattening.  S_new, the three
+    flux arrays, the mass fluxes and the Godunov states: bit for bit."""
+    import torch
+    import castro_amd
+    from tests import test_stub_probe_vectors as T
+    V = np.load(T.VEC)
+    nb, dt, U, src, corr, Go, Po = T.hydro_case(V, c)
+    glo, ghi, lo, hi = (-4, -4, -4), (nb + 3, nb + 3, nb + 3), (0, 0, 0), (nb - 1, nb - 1, nb - 1)
+    Ph = castro_amd.default_params()
+    for k in T.HYDRO_KEYS + T.HYDRO_REAL_KEYS:
+        setattr(Ph, k, getattr(Po, k))
+    wall = Go.lo_bc[0] == 4
+    Gh = castro_amd.make_geom((2001, 2001, 2001), lo_bc=(4, 4, 4) if wall else (2, 2, 2), domlo=(0, 0, 0) if wall else (-1000, -1000, -1000))
+    for d in range(3):
+        Gh.dx[d] = Go.dx[d]
+        Gh.domhi[d] = 1000
+    Ud = _to_dev(hip, U)
+    Snew = _to_dev(hip, U[:, 4:4 + nb, 4:4 + nb, 4:4 + nb])
+    fl, mf, qe, fboxes = [], [], [], []
+    for d in range(3):
+        fhi = list(hi)
+        fhi[d] += 1
+        fboxes.append((lo, tuple(fhi)))
+        fl.append(hip.alloc(8, lo, fhi))
+        mf.append(hip.alloc(1, lo, fhi))
+        qe.append(hip.alloc(4, lo, fhi))
+    corr_d = _to_dev(hip, corr) if corr is not None else None
+    if corr_d is not None:
+        hip.set_source_corrector(corr_d, (glo, ghi))
+    try:
+        hip.construct_ctu_hydro_source((lo, hi), Ud, (glo, ghi), Snew, (lo, hi), Gh, Ph, 0.0, dt, fluxes=fl, flux_boxes=fboxes,
+                                       mass_fluxes=mf, qe=qe, vbx=(lo, hi), update_from_sborder=False,
+                                       src=_to_dev(hip, src) if src is not None else None, src_box=(glo, ghi) if src is not None else None)
+        torch.cuda.synchronize()
+    finally:
+        hip.set_source_corrector(None, None)
+    assert hip.status() == 0
+    Pn = "out:hydro%d." % c
+    T.exact(Snew.cpu().numpy(), V[Pn + "unew"].reshape(8, nb, nb, nb), "S_new")
+    for d in range(3):
+        ref = V[Pn + "flux%d" % d].reshape(tuple(fl[d].shape))
+        T.exact(fl[d].cpu().numpy(), ref, "flux %d" % d)
+        T.exact(mf[d].cpu().numpy()[0], ref[0], "mass flux %d" % d)
+        T.exact(qe[d].cpu().numpy(), V[Pn + "qe%d" % d].reshape(tuple(qe[d].shape)), "Godunov state %d" % d)
+
+
 def test_device_functions_reproduce_the_stub_probe_vectors(hip):
     """tests/golden/stub_probe/vectors.npz (outputs of the reference's own ppm_reconstruct / ppm_int_profile, uflatten,
     cmpflx_plus_godunov, actual_trans_single / actual_trans_final, compiled unmodified against stand-in headers:

@@ -4,7 +4,8 @@ unmodified from /root/reference against stand-in AMReX / Microphysics headers (t
 STUB-COMPILED, NOT oracle/_ref: these vectors do not pin the oracle to a reference binary (parity stays "unpinned",
 DESIGN.md section 6); they show that the oracle's restatement of ppm_reconstruct / ppm_int_profile, uflatten,
 cmpflx_plus_godunov (CGF, CG, HLLC, HLL), actual_trans_single / actual_trans_final, ctoprim and trace_ppm reproduces
-the reference's source text bit for bit on ~200 000 values.  tests/test_gpu_parity.py replays the pointwise sets on the
+the reference's source text bit for bit on ~200 000 values, and that whole tiles of construct_ctu_hydro_source driven
+through the reference's own member functions (14 option sets, `hydro<c>.*`) equal ora_construct_ctu_hydro_source.  tests/test_gpu_parity.py replays the pointwise sets on the
 device code."""
 import ctypes as C
 import os
@@ -219,3 +220,62 @@ def test_block_ctoprim_uflatten_trace_ppm(V):
                         O.a4(qm, lo, hi), O.a4(qp, lo, hi), O.i3((0, 0, 0)), O.i3((nb - 1, nb - 1, nb - 1)), dt, C.byref(G), C.byref(P))
         exact(qm, V["out:block.qm%d" % idir].reshape(q.shape), "trace_ppm qm, direction %d" % idir)
         exact(qp, V["out:block.qp%d" % idir].reshape(q.shape), "trace_ppm qp, direction %d" % idir)
+
+
+# ---- whole tiles of Castro::construct_ctu_hydro_source: the reference's own functions driven by probe.cpp in the order and
+#      on the boxes of Castro_ctu_hydro.cpp:130-1480 (ctoprim, uflatten, shock, src_to_prim, ctu_ppm_states /
+#      ctu_plm_states, divu, 12 x cmpflx_plus_godunov, 6 x trans_single, 3 x trans_final, reset_edge_state_thermo,
+#      apply_av, the flux limiters, normalize_species_fluxes, consup_hydro, scale_flux) ----
+HYDRO_KEYS = ("riemann_solver", "cg_blend", "hybrid_riemann", "ppm_temp_fix", "transverse_reset_density", "transverse_reset_rhoe",
+              "transverse_use_eos", "ppm_type", "use_flattening", "first_order_hydro", "limit_fluxes_on_small_dens",
+              "limit_fluxes_on_large_vel", "plm_iorder", "plm_limiter", "use_pslope", "source_term_predictor")
+HYDRO_REAL_KEYS = ("small_dens", "small_pres", "small_temp", "small_ener", "difmag", "cfl", "speed_limit")
+
+
+def hydro_case(V, c):
+    """inputs of whole-tile configuration c: (nb, dt, U, src, corr, geometry, parameters)"""
+    P = "in:hydro%d." % c
+    nb, dt, dx = int(V[P + "n"][0]), float(V[P + "dt"][0]), V[P + "dx"]
+    m = nb + 8
+    U = np.ascontiguousarray(V[P + "U"].reshape(8, m, m, m))
+    src = np.ascontiguousarray(V[P + "src"].reshape(7, m, m, m)) if P + "src" in V else None
+    corr = np.ascontiguousarray(V[P + "corr"].reshape(7, m, m, m)) if P + "corr" in V else None
+    wall = P + "wall_lo" in V and V[P + "wall_lo"][0] != 0.0
+    G = O.make_geom((2001, 2001, 2001), lo_bc=(4, 4, 4) if wall else (2, 2, 2), domlo=(0, 0, 0) if wall else (-1000, -1000, -1000))
+    for d in range(3):
+        G.dx[d] = float(dx[d])
+        G.domhi[d] = 1000
+    par = O.default_params()
+    for k in HYDRO_KEYS + HYDRO_REAL_KEYS:
+        if P + k in V:
+            v = float(V[P + k][0])
+            setattr(par, k, v if k in HYDRO_REAL_KEYS else int(v))
+    return nb, dt, U, src, corr, G, par
+
+
+def n_hydro_cases():
+    with np.load(VEC) as v:
+        return sum(1 for k in v.files if k.startswith("in:hydro") and k.endswith(".U"))
+
+
+@pytest.mark.parametrize("c", range(14))
+def test_whole_tile_matches_the_reference_functions_driven_by_the_probe(V, c):
+    assert n_hydro_cases() == 14
+    nb, dt, U, src, corr, G, par = hydro_case(V, c)
+    glo, ghi, lo, hi = (-4, -4, -4), (nb + 3, nb + 3, nb + 3), (0, 0, 0), (nb - 1, nb - 1, nb - 1)
+    S_new = np.ascontiguousarray(U[:, 4:4 + nb, 4:4 + nb, 4:4 + nb])
+    keep = None
+    if corr is not None:
+        keep = O.a4(corr, glo, ghi)
+        O.lib().ora_set_source_corrector(C.byref(keep))
+    try:
+        st, fl, mf, qe = O.ctu_hydro(lo, hi, U, glo, ghi, S_new, G, par, dt, src=src, src_lo=glo, src_hi=ghi, want_qe=True)
+    finally:
+        O.lib().ora_set_source_corrector(None)
+    assert st == 0
+    Pn = "out:hydro%d." % c
+    exact(S_new, V[Pn + "unew"].reshape(S_new.shape), "S_new")
+    for d in range(3):
+        exact(fl[d], V[Pn + "flux%d" % d].reshape(fl[d].shape), "flux %d" % d)
+        exact(mf[d][0], V[Pn + "flux%d" % d].reshape(fl[d].shape)[0], "mass flux %d" % d)
+        exact(qe[d], V[Pn + "qe%d" % d].reshape(qe[d].shape), "Godunov state %d" % d)

@@ -173,11 +173,57 @@ def main():
     U = physical_state(rng, (-4, -4, -4), (nb + 3, nb + 3, nb + 3), smooth=False, vel=1.5, jump=True)
     A["block.U"], A["block.n"], A["block.dt"], A["block.dx"] = U, float(nb), 7.0e-4, np.array([0.02, 0.025, 0.03])
 
+    # ---- whole tiles of construct_ctu_hydro_source (probe.cpp drives the reference's own functions) ----
+    nb = 6
+    glo, ghi = (-4, -4, -4), (nb + 3, nb + 3, nb + 3)
+    floors = dict(small_dens=1e-8, small_pres=1e-10, small_temp=1e-10, small_ener=1e-12)
+    hcfgs = [dict(), dict(riemann_solver=1, cg_blend=2), dict(riemann_solver=2, ppm_type=0), dict(hybrid_riemann=1),
+             dict(ppm_temp_fix=2), dict(transverse_reset_rhoe=1, transverse_use_eos=1, transverse_reset_density=0),
+             dict(limit_fluxes_on_small_dens=1, limit_fluxes_on_large_vel=1, speed_limit=2.0, small_dens=0.1, cfl=0.5),
+             dict(wall_lo=1), dict(src=1), dict(src=1, ppm_type=0, source_term_predictor=1, corr=1, use_pslope=1),
+             dict(first_order_hydro=1), dict(use_flattening=0, difmag=0.0, riemann_solver=1, cg_blend=1),
+             dict(ppm_type=0, plm_iorder=1), dict(ppm_type=0, plm_limiter=1, hybrid_riemann=1, riemann_solver=2)]
+    for c, cfg in enumerate(hcfgs):
+        P = "hydro%d." % c
+        U = physical_state(rng, glo, ghi, smooth=(c % 3 == 0), vel=1.5 if c % 2 else 0.7, jump=True)
+        if cfg.get("wall_lo"):                      # reflect the ghost zones below index 0 like a SlipWall fill would
+            for d, ax in enumerate((3, 2, 1)):
+                idx = [slice(None)] * 4
+                for g in range(4):
+                    src_i, dst_i = list(idx), list(idx)
+                    src_i[ax], dst_i[ax] = 4 + g, 3 - g
+                    U[tuple(dst_i)] = U[tuple(src_i)]
+                    U[(1 + d,) + tuple(dst_i[1:])] *= -1.0
+        A[P + "U"], A[P + "n"], A[P + "dt"], A[P + "dx"] = U, float(nb), 6.0e-3, np.array([0.05, 0.055, 0.045])
+        if cfg.get("src"):
+            S = np.zeros((7,) + U.shape[1:])
+            g = np.array([0.3, -9.0, 1.5])
+            for d in range(3):
+                S[1 + d] = U[0] * g[d]
+                S[4] += U[1 + d] * g[d]
+            A[P + "src"] = S
+        if cfg.get("corr"):
+            A[P + "corr"] = 0.4 * A[P + "src"] * rng.uniform(0.5, 1.5, size=A[P + "src"].shape)
+        for k, v in dict(floors, **cfg).items():
+            if k not in ("src", "corr"):
+                A[P + k] = float(v)
+
     with tempfile.TemporaryDirectory() as tmp:
         exe = build(tmp)
         write_blob(os.path.join(tmp, "in.bin"), A)
         subprocess.check_call([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
         O = read_blob(os.path.join(tmp, "out.bin"))
+    # whole-tile outputs: keep the zones and faces the call defines (everything lives on the box grown by 4 in the probe)
+    m = nb + 8
+    for c in range(len(hcfgs)):
+        P = "hydro%d." % c
+        O[P + "unew"] = O[P + "unew"].reshape(8, m, m, m)[:, 4:4 + nb, 4:4 + nb, 4:4 + nb].copy()
+        for d in range(3):
+            sl = [slice(4, 4 + nb + (1 if ax == d else 0)) for ax in (2, 1, 0)]
+            O[P + "flux%d" % d] = O[P + "flux%d" % d].reshape(8, m, m, m)[(slice(None),) + tuple(sl)].copy()
+            O[P + "qe%d" % d] = O[P + "qe%d" % d].reshape(4, m, m, m)[(slice(None),) + tuple(sl)].copy()
+        for k in ("div", "shk", "srcq"):
+            O.pop(P + k)
     dst = os.path.join(ROOT, "tests", "golden", "stub_probe")
     os.makedirs(dst, exist_ok=True)
     allv = {"in:" + k: np.atleast_1d(np.asarray(v, dtype=np.float64)) for k, v in A.items()}

@@ -57,6 +57,33 @@ static void set_params(const std::string& p)
     castro::small_pres = g("small_pres", 1.e-100);
     castro::small_temp = g("small_temp", 1.e-100);
     castro::small_ener = g("small_ener", 1.e-100);
+    castro::ppm_type = (int)g("ppm_type", 1);
+    castro::use_flattening = (int)g("use_flattening", 1);
+    castro::first_order_hydro = (int)g("first_order_hydro", 0);
+    castro::difmag = g("difmag", 0.1);
+    castro::cfl = g("cfl", 0.5);
+    castro::limit_fluxes_on_small_dens = (int)g("limit_fluxes_on_small_dens", 0);
+    castro::limit_fluxes_on_large_vel = (int)g("limit_fluxes_on_large_vel", 0);
+    castro::speed_limit = g("speed_limit", 0.0);
+    castro::plm_iorder = (int)g("plm_iorder", 2);
+    castro::plm_limiter = (int)g("plm_limiter", 2);
+    castro::use_pslope = (int)g("use_pslope", 1);
+    castro::source_term_predictor = (int)g("source_term_predictor", 0);
+    castro::dual_energy_eta1 = g("dual_energy_eta1", 1.0);
+    castro::dual_energy_eta2 = g("dual_energy_eta2", 1.0e-4);
+}
+
+// the box algebra of one tile of the reference's hydro driver, with the stand-in Box
+static Box grown(const Box& b, int gx, int gy, int gz)
+{
+    const int lo[3] = {b.lo_[0] - gx, b.lo_[1] - gy, b.lo_[2] - gz}, hi[3] = {b.hi_[0] + gx, b.hi_[1] + gy, b.hi_[2] + gz};
+    return Box(lo, hi);
+}
+static Box nodal(const Box& b, int d)
+{
+    int hi[3] = {b.hi_[0], b.hi_[1], b.hi_[2]};
+    hi[d] += 1;
+    return Box(b.lo_, hi);
 }
 
 int main(int argc, char** argv)
@@ -249,6 +276,125 @@ int main(int argc, char** argv)
             out["block.qm" + std::to_string(idir)] = QM;
             out["block.qp" + std::to_string(idir)] = QP;
         }
+    }
+
+    // ---- one whole tile of Castro::construct_ctu_hydro_source: the reference's own member functions called in the order
+    //      and on the boxes of the MFIter body (Castro_ctu_hydro.cpp:130-1480, 3-D, no radiation); the driver below is a
+    //      restatement of that orchestration, every function it calls is the reference's ----
+    for (int cfg = 0; cfg < 32; ++cfg) {
+        const std::string P = "hydro" + std::to_string(cfg) + ".";
+        if (!in.count(P + "U")) continue;
+        set_params(P);
+        const int nb = (int)scalar(P + "n");
+        const double dt = scalar(P + "dt");
+        for (int d = 0; d < 3; ++d) {
+            Castro::geom.d.dx[d] = in[P + "dx"][d];
+            const bool wall = in.count(P + "wall_lo") && scalar(P + "wall_lo") != 0.0;
+            Castro::phys_bc.l[d] = wall ? SlipWall : Outflow;
+            Castro::geom.d.domain.lo_[d] = wall ? 0 : -1000;
+        }
+        const double* dx = Castro::geom.d.dx;
+        const int vlo[3] = {0, 0, 0}, vhi[3] = {nb - 1, nb - 1, nb - 1};
+        const Box bx(vlo, vhi), obx = grown(bx, 1, 1, 1), qbx = grown(bx, 4, 4, 4), qbx3 = grown(bx, 3, 3, 3);
+        const int* lo = qbx.lo_; const int* hi = qbx.hi_;                 // every array lives on grow(bx, 4)
+        const long nt = (long)(nb + 8) * (nb + 8) * (nb + 8);
+        auto A = [&](Arr& a, int nc) { return Array4<Real>(a.data(), lo, hi, nc); };
+        auto CA = [&](Arr& a, int nc) { return Array4<Real const>(a.data(), lo, hi, nc); };
+        Arr U = in[P + "U"], Unew = U, Q((size_t)NQ * nt, 0.0), AUX((size_t)NQAUX * nt, 0.0), FLT(nt, 0.0), SHK(nt, 0.0), DIV(nt, 0.0);
+        Arr SRC((size_t)NSRC * nt, 0.0), CORR((size_t)NSRC * nt, 0.0), SRCQ((size_t)NQSRC * nt, 0.0);
+        if (in.count(P + "src")) SRC = in[P + "src"];
+        if (in.count(P + "corr")) CORR = in[P + "corr"];
+        Arr E[3][2];                                                      // traced states: [dir][minus, plus]
+        for (auto& d : E) for (auto& a : d) a.assign((size_t)NQ * nt, 0.0);
+        Arr T[3][3][2];                                                   // [normal][transverse] after trans_single
+        for (int n = 0; n < 3; ++n) for (int t = 0; t < 3; ++t) if (n != t) for (auto& a : T[n][t]) a.assign((size_t)NQ * nt, 0.0);
+        Arr QL((size_t)NQ * nt, 0.0), QR((size_t)NQ * nt, 0.0), F1((size_t)NUM_STATE * nt, 0.0), F2((size_t)NUM_STATE * nt, 0.0),
+            G1((size_t)NGDNV * nt, 0.0), G2((size_t)NGDNV * nt, 0.0);
+        Arr FX[3], QE[3], AREA[3], VOL(nt, dx[0] * dx[1] * dx[2]);
+        for (int d = 0; d < 3; ++d) {
+            FX[d].assign((size_t)NUM_STATE * nt, 0.0); QE[d].assign((size_t)NGDNV * nt, 0.0);
+            AREA[d].assign(nt, d == 0 ? dx[1] * dx[2] : d == 1 ? dx[0] * dx[2] : dx[0] * dx[1]);
+        }
+
+        castro_obj.ctoprim(qbx, 0.0, CA(U, NUM_STATE), A(Q, NQ), A(AUX, NQAUX));
+        if (castro::first_order_hydro == 1) { /* FLT stays 0 */ }
+        else if (castro::use_flattening == 1) castro_obj.uflatten(obx, CA(Q, NQ), A(FLT, 1), QPRES);
+        else FLT.assign(nt, 1.0);
+        if (castro::hybrid_riemann == 1) castro_obj.shock(obx, CA(Q, NQ), A(SHK, 1));
+        castro_obj.src_to_prim(qbx3, dt, CA(Q, NQ), CA(SRC, NSRC), CA(CORR, NSRC), A(SRCQ, NQSRC));
+        if (castro::ppm_type == 0)
+            castro_obj.ctu_plm_states(obx, bx, CA(Q, NQ), CA(FLT, 1), CA(AUX, NQAUX), CA(SRCQ, NQSRC), A(E[0][0], NQ), A(E[0][1], NQ),
+                                      A(E[1][0], NQ), A(E[1][1], NQ), A(E[2][0], NQ), A(E[2][1], NQ), dt);
+        else
+            castro_obj.ctu_ppm_states(obx, bx, CA(Q, NQ), CA(FLT, 1), CA(AUX, NQAUX), CA(SRCQ, NQSRC), A(E[0][0], NQ), A(E[0][1], NQ),
+                                      A(E[1][0], NQ), A(E[1][1], NQ), A(E[2][0], NQ), A(E[2][1], NQ), dt);
+        castro_obj.divu(obx, CA(Q, NQ), A(DIV, 1));
+
+        const Box fb[3] = {nodal(bx, 0), nodal(bx, 1), nodal(bx, 2)};
+        const double hdt = 0.5 * dt, cdt[3] = {dt / dx[0] / 3.0, dt / dx[1] / 3.0, dt / dx[2] / 3.0};
+        const double hdtd[3] = {0.5 * dt / dx[0], 0.5 * dt / dx[1], 0.5 * dt / dx[2]};
+        auto riemann = [&](const Box& b, Arr& qm, Arr& qp, Arr& f, Arr& g, int idir) {
+            castro_obj.cmpflx_plus_godunov(b, A(qm, NQ), A(qp, NQ), A(f, NUM_STATE), A(g, NGDNV), CA(AUX, NQAUX), CA(SHK, 1), idir, false);
+        };
+        // first solves, each followed by the two transverse corrections that use its flux (x, y, z)
+        for (int t = 0; t < 3; ++t) {
+            int gr[3] = {1, 1, 1};
+            gr[t] = 0;
+            riemann(grown(fb[t], gr[0], gr[1], gr[2]), E[t][0], E[t][1], F1, G1, t);
+            for (int n = 0; n < 3; ++n) {
+                if (n == t) continue;
+                int g2[3] = {1, 1, 1};                      // faces of n, not grown along n nor along t
+                g2[n] = 0; g2[t] = 0;
+                const Box tb = grown(fb[n], g2[0], g2[1], g2[2]);
+                castro_obj.trans_single(tb, t, n, CA(E[n][0], NQ), A(T[n][t][0], NQ), CA(E[n][1], NQ), A(T[n][t][1], NQ), CA(AUX, NQAUX),
+                                        CA(F1, NUM_STATE), CA(G1, NGDNV), hdt, cdt[t]);
+                castro_obj.reset_edge_state_thermo(tb, A(T[n][t][0], NQ));
+                castro_obj.reset_edge_state_thermo(tb, A(T[n][t][1], NQ));
+            }
+        }
+        // final stage per normal direction: the two solves on the singly corrected transverse states, trans_final, solve
+        for (int n = 0; n < 3; ++n) {
+            const int t1 = (n == 0) ? 1 : 0, t2 = (n == 2) ? 1 : 2;
+            int g1[3] = {0, 0, 0}, g2[3] = {0, 0, 0};
+            g1[n] = 1; g2[n] = 1;                           // faces of t1 (t2) grown along n only
+            if (n == 0) {
+                riemann(grown(fb[1], g1[0], g1[1], g1[2]), T[1][2][0], T[1][2][1], F1, G1, 1);      // F^{y|z}
+                riemann(grown(fb[2], g2[0], g2[1], g2[2]), T[2][1][0], T[2][1][1], F2, G2, 2);      // F^{z|y}
+                castro_obj.trans_final(fb[0], 0, 1, 2, CA(E[0][0], NQ), A(QL, NQ), CA(E[0][1], NQ), A(QR, NQ), CA(AUX, NQAUX),
+                                       CA(F1, NUM_STATE), CA(F2, NUM_STATE), CA(G1, NGDNV), CA(G2, NGDNV), hdtd[1], hdtd[2]);
+            } else if (n == 1) {
+                riemann(grown(fb[2], g2[0], g2[1], g2[2]), T[2][0][0], T[2][0][1], F1, G1, 2);      // F^{z|x}
+                riemann(grown(fb[0], g1[0], g1[1], g1[2]), T[0][2][0], T[0][2][1], F2, G2, 0);      // F^{x|z}
+                castro_obj.trans_final(fb[1], 1, 0, 2, CA(E[1][0], NQ), A(QL, NQ), CA(E[1][1], NQ), A(QR, NQ), CA(AUX, NQAUX),
+                                       CA(F2, NUM_STATE), CA(F1, NUM_STATE), CA(G2, NGDNV), CA(G1, NGDNV), hdtd[0], hdtd[2]);
+            } else {
+                riemann(grown(fb[0], g1[0], g1[1], g1[2]), T[0][1][0], T[0][1][1], F1, G1, 0);      // F^{x|y}
+                riemann(grown(fb[1], g2[0], g2[1], g2[2]), T[1][0][0], T[1][0][1], F2, G2, 1);      // F^{y|x}
+                castro_obj.trans_final(fb[2], 2, 0, 1, CA(E[2][0], NQ), A(QL, NQ), CA(E[2][1], NQ), A(QR, NQ), CA(AUX, NQAUX),
+                                       CA(F1, NUM_STATE), CA(F2, NUM_STATE), CA(G1, NGDNV), CA(G2, NGDNV), hdtd[0], hdtd[1]);
+            }
+            castro_obj.reset_edge_state_thermo(fb[n], A(QL, NQ));
+            castro_obj.reset_edge_state_thermo(fb[n], A(QR, NQ));
+            riemann(fb[n], QL, QR, FX[n], QE[n], n);
+        }
+        for (int d = 0; d < 3; ++d) {
+            Array4<Real> f = A(FX[d], NUM_STATE);
+            for (int k = fb[d].lo_[2]; k <= fb[d].hi_[2]; ++k) for (int j = fb[d].lo_[1]; j <= fb[d].hi_[1]; ++j)
+                for (int i = fb[d].lo_[0]; i <= fb[d].hi_[0]; ++i) f(i, j, k, UTEMP) = 0.0;
+            castro_obj.apply_av(fb[d], d, CA(DIV, 1), CA(U, NUM_STATE), f);
+            if (castro::limit_fluxes_on_small_dens == 1)
+                castro_obj.limit_hydro_fluxes_on_small_dens(fb[d], d, CA(U, NUM_STATE), CA(Q, NQ), CA(VOL, 1), f, CA(AREA[d], 1), dt);
+            if (castro::limit_fluxes_on_large_vel == 1)
+                castro_obj.limit_hydro_fluxes_on_large_vel(fb[d], d, CA(U, NUM_STATE), CA(Q, NQ), CA(VOL, 1), f, CA(AREA[d], 1), dt);
+            castro_obj.normalize_species_fluxes(fb[d], f);
+        }
+        castro_obj.consup_hydro(bx, A(Unew, NUM_STATE), A(FX[0], NUM_STATE), CA(QE[0], NGDNV), A(FX[1], NUM_STATE), CA(QE[1], NGDNV),
+                                A(FX[2], NUM_STATE), CA(QE[2], NGDNV), dt);
+        for (int d = 0; d < 3; ++d) castro_obj.scale_flux(fb[d], A(FX[d], NUM_STATE), CA(AREA[d], 1), dt);
+        out[P + "unew"] = Unew;
+        for (int d = 0; d < 3; ++d) { out[P + "flux" + std::to_string(d)] = FX[d]; out[P + "qe" + std::to_string(d)] = QE[d]; }
+        out[P + "div"] = DIV; out[P + "shk"] = SHK; out[P + "srcq"] = SRCQ;
+        for (int d = 0; d < 3; ++d) { Castro::phys_bc.l[d] = Outflow; Castro::geom.d.domain.lo_[d] = -1000; }
     }
 
     write_blob(argv[2]);
