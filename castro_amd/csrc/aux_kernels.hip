@@ -371,11 +371,13 @@ __device__ __forceinline__ void rotational_acceleration(const RotDev& R, const d
     }
 }
 
+// Castro::fill_rotational_potential (Rotation.cpp:6-39) evaluates the potential at problo + dx * (i + 1/2) - center, not at
+// position()'s (problo + dx / 2) + i * dx - center: the two differ in the last bit
 __device__ __forceinline__ double rot_phi_at(const RotDev& R, int i, int j, int k)
 {
+    const int idx[3] = { i, j, k };
     double loc[3];
-    rot_position(R, i, j, k, loc);
-    for (int d = 0; d < 3; ++d) loc[d] -= R.center[d];
+    for (int d = 0; d < 3; ++d) loc[d] = R.problo[d] + R.dx[d] * ((double)idx[d] + 0.5) - R.center[d];
     double phi = 0.0;
     if (R.include_centrifugal == 1) {
         double omega_cross_r[3];

@@ -186,12 +186,14 @@ static double rotational_potential(const ora_rotation *R, const double r[3])
     return phi;
 }
 
+/* Castro::fill_rotational_potential, Rotation.cpp:6-39: the PhiRot data corrrsrc reads.  Its zone centre is
+ * problo + dx * (i + 1/2) - center, NOT position()'s (problo + dx / 2) + i * dx - center (found by the stub probe) */
 static double phi_at(const ora_rotation *R, const ora_geom *G, int i, int j, int k)
 {
-    double loc[3];
-    position(i, j, k, G, loc);
-    for (int d = 0; d < 3; ++d) loc[d] -= R->center[d];
-    return rotational_potential(R, loc);
+    const int idx[3] = { i, j, k };
+    double r[3];
+    for (int d = 0; d < 3; ++d) r[d] = G->problo[d] + G->dx[d] * ((double)idx[d] + 0.5) - R->center[d];
+    return rotational_potential(R, r);
 }
 
 /* Castro::rsrc, rotation_sources.cpp:9-137 */

@@ -279,3 +279,117 @@ def test_whole_tile_matches_the_reference_functions_driven_by_the_probe(V, c):
         exact(fl[d], V[Pn + "flux%d" % d].reshape(fl[d].shape), "flux %d" % d)
         exact(mf[d][0], V[Pn + "flux%d" % d].reshape(fl[d].shape)[0], "mass flux %d" % d)
         exact(qe[d], V[Pn + "qe%d" % d].reshape(qe[d].shape), "Godunov state %d" % d)
+
+
+# ---- the problem initialisers: Exec/hydro_tests/{Sedov,Sod}/problem_initialize.H + problem_initialize_state_data.H,
+#      included unmodified by tools/stub_probe/probe_init.cpp ----
+def init_case(V, name, c):
+    P = "in:%s%d." % (name, c)
+    n = tuple(int(x) for x in V[P + "n"])
+    problo, probhi = tuple(V[P + "problo"]), tuple(V[P + "probhi"])
+    G = O.make_geom(n, problo=problo, probhi=probhi)
+    for d in range(3):
+        G.dx[d] = (probhi[d] - problo[d]) / n[d]
+    return P, n, G
+
+
+@pytest.mark.parametrize("c", range(3))
+def test_sedov_initial_state_matches_the_reference_initialiser(V, c):
+    P, n, G = init_case(V, "sedov", c)
+    lo, hi = (0, 0, 0), tuple(x - 1 for x in n)
+    S = np.zeros((8, n[2], n[1], n[0]))
+    O.lib().ora_sedov_init(O.i3(lo), O.i3(hi), O.a4(S, lo, hi), C.byref(G), C.byref(O.default_params()), float(V[P + "r_init"][0]),
+                           float(V[P + "p_ambient"][0]), float(V[P + "exp_energy"][0]), float(V[P + "dens_ambient"][0]), int(V[P + "nsub"][0]))
+    ref = V["out:sedov%d.state" % c].reshape(S.shape)
+    exact(S, ref, "Sedov initial state")
+    assert len(np.unique(ref[4])) >= (2 if c == 0 else 3)    # zones outside, inside and (coarse sphere) across the initial sphere
+
+
+@pytest.mark.parametrize("c", range(3))
+def test_sod_initial_state_matches_the_reference_initialiser(V, c):
+    P, n, G = init_case(V, "sod", c)
+    lo, hi = (0, 0, 0), tuple(x - 1 for x in n)
+    S = np.zeros((8, n[2], n[1], n[0]))
+    l, r = V[P + "left"], V[P + "right"]
+    O.lib().ora_sod_init(O.i3(lo), O.i3(hi), O.a4(S, lo, hi), C.byref(G), C.byref(O.default_params()), float(l[0]), float(l[1]), float(l[2]),
+                         float(r[0]), float(r[1]), float(r[2]), int(V[P + "idir"][0]), float(V[P + "frac"][0]))
+    exact(S, V["out:sod%d.state" % c].reshape(S.shape), "Sod initial state")
+
+
+# ---- the derived fields: Source/driver/Derive.cpp compiled unmodified (tools/stub_probe/probe_derive.cpp) ----
+DERIVED = ("pressure", "kineng", "soundspeed", "Gamma_1", "MachNumber", "magvort", "divu", "eint_E", "eint_e", "logden", "X(X)",
+           "abar", "x_velocity", "y_velocity", "z_velocity", "magvel", "radvel", "magmom", "circvel", "angular_momentum_x",
+           "angular_momentum_y", "angular_momentum_z")
+
+
+def derive_case(V):
+    n = tuple(int(x) for x in V["in:derive.n"])
+    dx, problo, center = V["in:derive.dx"], V["in:derive.problo"], V["in:derive.center"]
+    G = O.make_geom(n, problo=tuple(problo), probhi=tuple(problo[d] + n[d] * dx[d] for d in range(3)))
+    for d in range(3):
+        G.dx[d] = float(dx[d])
+    U = np.ascontiguousarray(V["in:derive.U"].reshape(8, n[2] + 2, n[1] + 2, n[0] + 2))
+    return n, G, U, tuple(float(x) for x in center)
+
+
+def derive_reference(V, name):
+    """(field, StateErr component or None) -> recorded array (nz, ny, nx)"""
+    if name.startswith("StateErr_"):
+        return V["out:derive.StateErr"][int(name[-1])]
+    return V["out:derive." + name][0]
+
+
+@pytest.mark.parametrize("name", DERIVED + ("StateErr_0", "StateErr_1", "StateErr_2"))
+def test_derived_field_matches_the_reference_function(V, name):
+    from castro_amd._lib import DERIVE_IDS
+    n, G, U, center = derive_case(V)
+    glo, ghi, lo, hi = (-1, -1, -1), n, (0, 0, 0), tuple(x - 1 for x in n)
+    out = np.zeros((1, n[2], n[1], n[0]))
+    ctr = (C.c_double * 3)(*center)
+    rc = O.lib().ora_derive(DERIVE_IDS[name], O.i3(lo), O.i3(hi), O.a4(U, glo, ghi), O.a4(out, lo, hi), C.byref(G),
+                            C.byref(O.default_params()), C.byref(ctr))
+    assert rc == 0
+    exact(out[0], derive_reference(V, name), name)
+
+
+# ---- rotation sources: Source/rotation/rotation_sources.cpp + Rotation.cpp/.H compiled unmodified (probe_rotation.cpp) ----
+def rotation_case(V, c, mod=O):
+    P = "in:rot%d." % c
+    n = tuple(int(x) for x in V[P + "n"])
+    dx, problo = V[P + "dx"], V[P + "problo"]
+    ext = dict(zip(("problo", "probhi") if mod is O else ("prob_lo", "prob_hi"),
+                   (tuple(problo), tuple(problo[d] + n[d] * dx[d] for d in range(3)))))
+    G = mod.make_geom(n, **ext)
+    for d in range(3):
+        G.dx[d] = float(dx[d])
+    R = mod.make_rotation(float(V[P + "period"][0]), rot_axis=int(V[P + "axis"][0]), center=tuple(V[P + "center"]),
+                          include_centrifugal=int(V[P + "centrifugal"][0]), include_coriolis=int(V[P + "coriolis"][0]),
+                          rot_source_type=int(V[P + "rot_source_type"][0]), implicit_rotation_update=int(V[P + "implicit"][0]))
+    shape = (8, n[2], n[1], n[0])
+    uold = np.ascontiguousarray(V[P + "uold"].reshape(shape))
+    unew = np.ascontiguousarray(V[P + "unew"].reshape(shape))
+    mf = []
+    for d in range(3):
+        s = [n[2], n[1], n[0]]
+        s[2 - d] += 1
+        mf.append(np.ascontiguousarray(V[P + "mflux%d" % d].reshape([1] + s)))
+    return n, G, R, uold, unew, mf, float(V[P + "dt"][0])
+
+
+@pytest.mark.parametrize("c", range(6))
+def test_rotation_sources_match_the_reference_functions(V, c):
+    n, G, R, uold, unew, mf, dt = rotation_case(V, c)
+    lo, hi = (0, 0, 0), tuple(x - 1 for x in n)
+    L = O.lib()
+    s1 = np.zeros((7, n[2], n[1], n[0]))
+    L.ora_old_rotation_source(O.i3(lo), O.i3(hi), O.a4(uold, lo, hi), O.a4(s1, lo, hi), C.byref(R), C.byref(G), dt)
+    exact(s1, V["out:rot%d.old" % c].reshape(s1.shape), "rsrc")
+    s2 = np.zeros_like(s1)
+    ma = (O.A4 * 3)()
+    for d in range(3):
+        fhi = list(hi)
+        fhi[d] += 1
+        ma[d] = O.a4(mf[d], lo, fhi)
+    L.ora_new_rotation_source(O.i3(lo), O.i3(hi), O.a4(uold, lo, hi), O.a4(unew, lo, hi), O.a4(s2, lo, hi), ma, C.byref(R), C.byref(G), dt)
+    exact(s2, V["out:rot%d.new" % c].reshape(s2.shape), "corrrsrc")
+    assert np.abs(s1[1:5]).max() > 0 and np.abs(s2[1:5]).max() > 0

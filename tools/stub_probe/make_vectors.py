@@ -53,7 +53,8 @@ def build(tmp):
     src = os.path.join(REF, "Source")
     subprocess.check_call([sys.executable, "set_variables.py", "--odir", tmp, "--nadv", "0", "--ngroups", "1", "--defines= ",
                            "_variables"], cwd=os.path.join(src, "driver"), stdout=subprocess.DEVNULL)
-    inc = ["-I" + os.path.join(HERE, "stub"), "-I" + tmp, "-I" + os.path.join(src, "hydro"), "-I" + os.path.join(src, "driver")]
+    inc = ["-I" + os.path.join(HERE, "stub"), "-I" + tmp, "-I" + os.path.join(src, "hydro"), "-I" + os.path.join(src, "driver"),
+           "-I" + os.path.join(src, "problems"), "-I" + os.path.join(src, "rotation")]
     flags = ["-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math"]
     objs = []
     for f in ("trans", "flatten", "riemann", "riemann_util", "advection_util", "trace_ppm", "trace_plm", "Castro_ctu", "edge_util"):
@@ -66,6 +67,24 @@ def build(tmp):
         objs.append(o)
     exe = os.path.join(tmp, "probe")
     subprocess.check_call(["g++", "-o", exe] + objs)
+    # the problem initialisers (Exec/hydro_tests/{Sedov,Sod}) in their own executable
+    o = os.path.join(tmp, "probe_init.o")
+    subprocess.check_call(["g++"] + flags + inc + ["-DREFERENCE_EXEC=" + os.path.join(REF, "Exec", "hydro_tests"), "-c",
+                                                   os.path.join(HERE, "probe_init.cpp"), "-o", o])
+    subprocess.check_call(["g++", "-o", exe + "_init", o, os.path.join(tmp, "probe_params.o")])
+    # the derived fields (Source/driver/Derive.cpp, unmodified)
+    od = [os.path.join(tmp, "Derive.o"), os.path.join(tmp, "probe_derive.o")]
+    subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(src, "driver", "Derive.cpp"), "-o", od[0]])
+    subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(HERE, "probe_derive.cpp"), "-o", od[1]])
+    subprocess.check_call(["g++", "-o", exe + "_derive"] + od + [os.path.join(tmp, "probe_params.o")])
+    # the rotation sources (Source/rotation/rotation_sources.cpp, Rotation.cpp, unmodified)
+    orot = []
+    for path in (os.path.join(src, "rotation", "rotation_sources.cpp"), os.path.join(src, "rotation", "Rotation.cpp"),
+                 os.path.join(HERE, "probe_rotation.cpp")):
+        o = os.path.join(tmp, "rot_" + os.path.basename(path)[:-4] + ".o")
+        subprocess.check_call(["g++"] + flags + inc + ["-c", path, "-o", o])
+        orot.append(o)
+    subprocess.check_call(["g++", "-o", exe + "_rotation"] + orot + [os.path.join(tmp, "probe_params.o")])
     return exe
 
 
@@ -208,11 +227,64 @@ def main():
             if k not in ("src", "corr"):
                 A[P + k] = float(v)
 
+    # ---- problem initialisers: Exec/hydro_tests/Sedov and Sod (problem_initialize + problem_initialize_state_data) ----
+    B = {}
+    sed = [dict(n=(16, 16, 16), problo=(0., 0., 0.), probhi=(1., 1., 1.), r_init=0.01, p_ambient=1.e-5, exp_energy=1.0, dens_ambient=1.0, nsub=10),
+           dict(n=(12, 10, 14), problo=(-0.5, 0., 0.25), probhi=(0.7, 1.1, 1.3), r_init=0.2, p_ambient=1.e-3, exp_energy=2.5, dens_ambient=0.7, nsub=4),
+           dict(n=(8, 8, 8), problo=(0., 0., 0.), probhi=(1., 1., 1.), r_init=0.3, p_ambient=1.e-5, exp_energy=1.0, dens_ambient=1.0, nsub=5)]
+    for c, cfg in enumerate(sed):
+        for k, v in cfg.items():
+            B["sedov%d.%s" % (c, k)] = np.atleast_1d(np.asarray(v, dtype=np.float64))
+    sod = [dict(n=(32, 4, 4), problo=(0., 0., 0.), probhi=(1., 0.125, 0.125), idir=1, frac=0.5, left=(1.0, 0.0, 1.0), right=(0.125, 0.0, 0.1)),
+           dict(n=(4, 24, 4), problo=(0.1, -0.2, 0.), probhi=(0.35, 1.3, 0.25), idir=2, frac=0.3, left=(1.0, 0.75, 1.0), right=(0.125, -2.0, 0.4)),
+           dict(n=(4, 6, 20), problo=(0., 0., 0.), probhi=(0.2, 0.3, 1.0), idir=3, frac=0.5, left=(5.99924, 19.5975, 460.894), right=(5.99242, -6.19633, 46.0950))]
+    for c, cfg in enumerate(sod):
+        for k, v in cfg.items():
+            B["sod%d.%s" % (c, k)] = np.atleast_1d(np.asarray(v, dtype=np.float64))
+
     with tempfile.TemporaryDirectory() as tmp:
         exe = build(tmp)
         write_blob(os.path.join(tmp, "in.bin"), A)
         subprocess.check_call([exe, os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")])
         O = read_blob(os.path.join(tmp, "out.bin"))
+        write_blob(os.path.join(tmp, "in2.bin"), B)
+        subprocess.check_call([exe + "_init", os.path.join(tmp, "in2.bin"), os.path.join(tmp, "out2.bin")])
+        O.update(read_blob(os.path.join(tmp, "out2.bin")))
+        # ---- derived fields on one box (state with one ghost zone for the vorticity and the divergence) ----
+        dn = (10, 9, 8)
+        D = {"derive.n": np.array(dn, dtype=np.float64), "derive.dx": np.array([0.05, 0.04, 0.0625]), "derive.problo": np.array([-0.2, 0.1, 0.0]),
+             "derive.center": np.array([0.05, 0.28, 0.25]),
+             "derive.U": physical_state(rng, (-1, -1, -1), dn, smooth=False, vel=1.5, jump=True)}
+        write_blob(os.path.join(tmp, "in3.bin"), D)
+        subprocess.check_call([exe + "_derive", os.path.join(tmp, "in3.bin"), os.path.join(tmp, "out3.bin")])
+        for k, v in read_blob(os.path.join(tmp, "out3.bin")).items():
+            nc = v.size // ((dn[0] + 2) * (dn[1] + 2) * (dn[2] + 2))
+            O[k] = v.reshape(nc, dn[2] + 2, dn[1] + 2, dn[0] + 2)[:, 1:-1, 1:-1, 1:-1].copy()
+        B.update(D)
+        # ---- rotation sources: rsrc on the old state, corrrsrc with old and new state and the mass fluxes ----
+        R = {}
+        rn = (7, 6, 5)
+        rcfg = [dict(axis=3, rot_source_type=4, implicit=1, centrifugal=1, coriolis=1), dict(axis=1, rot_source_type=1, implicit=0, centrifugal=1, coriolis=1),
+                dict(axis=2, rot_source_type=2, implicit=1, centrifugal=0, coriolis=1), dict(axis=3, rot_source_type=3, implicit=1, centrifugal=1, coriolis=0),
+                dict(axis=3, rot_source_type=4, implicit=0, centrifugal=1, coriolis=1), dict(axis=1, rot_source_type=3, implicit=0, centrifugal=1, coriolis=1)]
+        for c, cfg in enumerate(rcfg):
+            P = "rot%d." % c
+            R[P + "n"], R[P + "dx"], R[P + "problo"] = np.array(rn, dtype=np.float64), np.array([0.1, 0.12, 0.15]), np.array([-0.3, 0.0, 0.2])
+            R[P + "center"], R[P + "period"], R[P + "dt"] = np.array([0.05, 0.36, 0.55]), np.array([2.5]), np.array([0.02])
+            hi = tuple(x - 1 for x in rn)
+            R[P + "uold"] = physical_state(rng, (0, 0, 0), hi, smooth=False, vel=1.5, jump=True)
+            R[P + "unew"] = R[P + "uold"] * rng.uniform(0.9, 1.1, size=R[P + "uold"].shape)
+            for d in range(3):
+                shp = [rn[2], rn[1], rn[0]]
+                shp[2 - d] += 1
+                R[P + "mflux%d" % d] = rng.normal(scale=1e-4, size=shp)
+            for k, v in cfg.items():
+                R[P + k] = np.array([float(v)])
+        write_blob(os.path.join(tmp, "in4.bin"), R)
+        subprocess.check_call([exe + "_rotation", os.path.join(tmp, "in4.bin"), os.path.join(tmp, "out4.bin")])
+        O.update(read_blob(os.path.join(tmp, "out4.bin")))
+        B.update(R)
+    A.update(B)
     # whole-tile outputs: keep the zones and faces the call defines (everything lives on the box grown by 4 in the probe)
     m = nb + 8
     for c in range(len(hcfgs)):
