@@ -47,7 +47,12 @@ __device__ __forceinline__ double ldg(const double* base, unsigned boff)
 }
 __device__ __forceinline__ void stg(double* base, unsigned boff, double v)
 {
+#ifndef PLAIN_STORES            // non-temporal stores: what a kernel writes is not read again before it has left every cache,
+                                // so it should not evict the stencil neighbours from L2 (step -4 %, k_trace -12 %)
+    __builtin_nontemporal_store(v, reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff));
+#else
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + boff) = v;
+#endif
 }
 
 // Two x-adjacent zones per thread.  The stencil kernels issue ~100 vector-memory instructions per
@@ -58,13 +63,21 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 struct D2 { double a, b; };
 __device__ __forceinline__ D2 ldg2(const double* base, unsigned boff)
 {
+#ifdef EXPERIMENT_NT_LOADS
+    const d2u v = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(reinterpret_cast<const char*>(base) + boff));
+#else
     const d2u v = *reinterpret_cast<const d2u*>(reinterpret_cast<const char*>(base) + boff);
+#endif
     return D2{ v.x, v.y };
 }
 __device__ __forceinline__ void stg2(double* base, unsigned boff, double a, double b)
 {
     d2u v; v.x = a; v.y = b;
+#ifndef PLAIN_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<d2u*>(reinterpret_cast<char*>(base) + boff));
+#else
     *reinterpret_cast<d2u*>(reinterpret_cast<char*>(base) + boff) = v;
+#endif
 }
 
 // byte offset of zone (i,j,k) in the scratch index space / in a caller FAB
@@ -1111,7 +1124,14 @@ __device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC,
 __device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long NC, unsigned c, double q[2][NEDGE])
 {
 #pragma unroll
-    for (int n = 0; n < NEDGE; ++n) { const D2 v = ldg2(E + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b; }
+    for (int n = 0; n < NEDGE; ++n) {
+#ifdef EXPERIMENT_NT_EDGE_LOADS     // an edge state is read by one thread of a kernel only
+        const d2u w = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(reinterpret_cast<const char*>(E + (long)n * NC) + c));
+        q[0][n] = w.x; q[1][n] = w.y;
+#else
+        const D2 v = ldg2(E + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b;
+#endif
+    }
 }
 
 template <int D>
