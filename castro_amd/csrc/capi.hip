@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; }
+namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; extern int g_trace_tile_rows; }
 
 using namespace cad;
 
@@ -205,6 +205,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (const char* e = std::getenv("CASTRO_AMD_FUSED_TILE_ROWS")) g_fused_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FUSE_CONSUP")) g_fuse_consup = std::atoi(e);   // 0: k_final<x> + k_consup
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_LDS")) g_final_lds = std::atoi(e);   // 0: the plain k_final
+    if (const char* e = std::getenv("CASTRO_AMD_TRACE_TILE_ROWS")) g_trace_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_TRACE_SPLIT")) g_trace_split = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_XPAD")) g_xpad = std::atoi(e);             // unused columns in front of every scratch row
     if (const char* e = std::getenv("CASTRO_AMD_BRICK_LDS")) g_brick_lds_budget = std::atoi(e);   // bytes per workgroup
