@@ -1625,7 +1625,7 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
 
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one
 // kernel instead of two (F1[T] serves the two N != T), the other reads hit in L2.
-template <bool RE>
+template <bool RE, int NMASK = 7>
 __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                 double cdtdx, double cdtdy, double cdtdz, DevParams P)
 {
@@ -1633,9 +1633,9 @@ __global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* 
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second zone of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    trans1_body<0, RE>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
-    trans1_body<1, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdz, P);
-    trans1_body<2, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdy, P);
+    if (NMASK & 1) trans1_body<0, RE>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
+    if (NMASK & 2) trans1_body<1, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdz, P);
+    if (NMASK & 4) trans1_body<2, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdy, P);
 }
 
 // one normal direction of the final stage for the faces (ijk) and (ijk + x); v0 / v1: the faces belong to
@@ -2543,7 +2543,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     if (P.reset_rhoe == 1 || tfix) { if (lim) TRANSVERSE_STAGES(true, true); else TRANSVERSE_STAGES(true, false); }
     else if (g_fuse_consup) {
         // y and z first (they write FL[1], FL[2]), then the x faces with the conservative update fused in
+#ifdef EXPERIMENT_TRANS1_SPLIT     // one launch per normal direction (46 instead of 114 concurrent planes): DESIGN.md section 9
+        KL2("k_trans1_x", (k_trans1<false, 1>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+        KL2("k_trans1_y", (k_trans1<false, 2>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+        KL2("k_trans1_z", (k_trans1<false, 4>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+#else
         KL2("k_trans1", k_trans1<false>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+#endif
         if (g_fuse_consup == 2) {
         } else if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
