@@ -64,6 +64,11 @@ class _Patch(Castro):
 
     def bind(self, level, pbox):
         self.level, self.pbox = level, pbox
+        if pbox is None:                       # a box of a level-0 that is cut into several boxes: nothing coarser
+            self.cbox, self.ctmp, self.shell, self.regs = None, None, [], {}
+            if self.have_sources:
+                self.new_source_g = self.hydro.alloc(NSRC, *self.sbox) if self.owned else None
+            return
         # coarse zones under the grown fine box, grown by one for the slopes
         self.cbox = (tuple(_coarsen(self.glo[d]) - 1 for d in range(3)), tuple(_coarsen(self.ghi[d]) + 1 for d in range(3)))
         self.ctmp = self.hydro.alloc(NUM_STATE, *self.cbox) if self.owned else None
@@ -131,9 +136,10 @@ class _Level:
 
     # ---- static overlap tables (rebuilt at every regrid) -----------------------------------------
     def bind(self):
-        if self.l == 0:
+        self.plain_base = self.l == 0 and len(self.boxes) == 1 and not isinstance(self.boxes[0], _Patch)
+        if self.plain_base:                    # the whole domain in one Castro box: it fills its own ghost zones
             return
-        parents = self.amr.lev[self.l - 1].boxes
+        parents = self.amr.lev[self.l - 1].boxes if self.l > 0 else []
         # periodic images: shifts by the domain extent (in zones of this level / of the parent level)
         per = self.amr.periodic
         ext = [(2 ** self.l) * self.amr.n_cell[d] for d in range(3)]
@@ -142,6 +148,14 @@ class _Level:
         for b in self.boxes:
             b.sib = [(s, it, sh) for s in self.boxes for sh in shifts if not (s is b and sh == (0, 0, 0))
                      for it in [CL.intersect(b.gbox, _shift(s.bx, sh))] if it]
+            b.at_domain_edge = any(b.glo[d] < b.geom.domlo[d] or b.ghi[d] > b.geom.domhi[d] for d in range(3))
+            if self.l == 0:                    # no coarser level: no coarse data, no flux registers, nothing to average onto
+                b.csrc, b.csrc_valid, b.crse_init, b.reflux_to, b.avg_to = [], [], {}, {}, []
+                if self.have_sources:
+                    b.ssib = [(sb, it, sh) for sb in self.boxes for sh in shifts if not (sb is b and sh == (0, 0, 0))
+                              for it in [CL.intersect(b.sbox, _shift(sb.bx, sh))] if it]
+                    b.ssrc, b.ssrc_valid, b.sshell = [], [], []
+                continue
             b.csrc = [(p, it) for p in parents for it in [CL.intersect(b.cbox, p.gbox)] if it]
             if len(b.csrc) == 1:
                 assert b.csrc[0][1] == b.cbox, "box not properly nested: its ghost zones need parent data beyond the parent's own ghost zones"
@@ -186,11 +200,9 @@ class _Level:
                           for it in [CL.intersect(b.sbox, _shift(sb.bx, sh))] if it]
                 b.ssrc = [(p, it) for p in parents for it in [CL.intersect(b.scbox, p.sbox)] if it]
                 b.ssrc_valid = [(p, it) for p in parents for it in [CL.intersect(b.scbox, p.bx)] if it]
-            # ghost zones outside the problem domain (only then the physical-BC fill has anything to do)
-            b.at_domain_edge = any(b.glo[d] < b.geom.domlo[d] or b.ghi[d] > b.geom.domhi[d] for d in range(3))
         self._op_cache = {}
         self.batched = hasattr(self.hydro, "make_ops") and self.amr.nranks == 1
-        if self.batched:
+        if self.batched and self.l > 0:
             # flux-register operations never change between regrids (registers and flux FABs keep their storage)
             mk = self.hydro.make_ops
             self.ops_fine_add = mk([(L.OP_FLUXREG_FINE_ADD, d, NUM_STATE, rbox[0], rbox[1], 1.0, 0.0, (reg, rbox),
@@ -234,7 +246,7 @@ class _Level:
 
     def fill(self, which):
         """Ghost zones of S_old_b / S_new_b (`which`) of every box of the level."""
-        if self.l == 0:
+        if self.plain_base:
             for b in self.mine:
                 b.expand_state(getattr(b, which))
             return
@@ -242,18 +254,19 @@ class _Level:
             return self._fill_ranks(which)
         if not self.batched:
             for b in self.boxes:
-                self._interp_ghosts(b, getattr(b, which))
+                if self.l > 0:
+                    self._interp_ghosts(b, getattr(b, which))
             for b in self.boxes:                               # valid zones are final only after every box's clean pass
                 self._copy_siblings(b, getattr(b, which), which)
             return
         h, a = self.hydro, self.alpha
-        parents = self.amr.lev[self.l - 1].boxes
+        parents = self.amr.lev[self.l - 1].boxes if self.l > 0 else []
         # 1. time-interpolated coarse data under every box, all boxes in a few launches.  Where a box has several parents
         #    their grown boxes overlap: the ghost-zone pass goes first (overlapping entries carry identical values: a
         #    ghost zone of one parent is a copy of the valid zone of another or the same interpolation), the valid-zone
         #    pass second, as separate launches
         pp = tuple(t.data_ptr() for p in parents for t in (p.S_old_b, p.S_new_b))
-        for key, attr in (("lincomb_ghost", "csrc"), ("lincomb_valid", "csrc_valid")):
+        for key, attr in ((("lincomb_ghost", "csrc"), ("lincomb_valid", "csrc_valid")) if self.l > 0 else ()):
             ops = self._cached_ops((key,), pp, lambda attr=attr: h.make_ops(
                 [(L.OP_LINCOMB, 0, NUM_STATE, lo, hi, 0.0, 0.0, (b.ctmp, b.cbox), (p.S_old_b, p.gbox), (p.S_new_b, p.gbox))
                  for b in self.boxes for p, (lo, hi) in getattr(b, attr)]))
@@ -262,7 +275,7 @@ class _Level:
                 arr[i].a, arr[i].b = 1.0 - a, a
             h.fab_ops(ops)
         # 2. interpolation + clean_state of the ghost shell, one launch per box
-        for b in self.boxes:
+        for b in (self.boxes if self.l > 0 else ()):
             h.fillpatch_shell(b.ctmp, b.cbox, getattr(b, which), b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1)
         # 3. valid zones of the siblings (final only after every box's clean pass), all boxes in a few launches
         sp = tuple(getattr(b, which).data_ptr() for b in self.boxes)
@@ -280,7 +293,7 @@ class _Level:
         h, a, X = self.hydro, self.alpha, self.amr._xrun
         X([("lincomb", b, p, lo, hi, a) for b in self.boxes for p, (lo, hi) in b.csrc])           # ghost zones of the parents first,
         X([("lincomb", b, p, lo, hi, a) for b in self.boxes for p, (lo, hi) in b.csrc_valid])     # valid zones last
-        for b in self.mine:
+        for b in (self.mine if self.l > 0 else ()):
             h.fillpatch_shell(b.ctmp, b.cbox, getattr(b, which), b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1) \
                 if hasattr(h, "fillpatch_shell") else self._interp_shell(b, getattr(b, which))
         X([("copy", b, sb, lo, hi, (which, sh)) for b in self.boxes for sb, (lo, hi), sh in b.sib])
@@ -296,7 +309,8 @@ class _Level:
     def fill_box(self, b, S):
         which = "S_new_b" if S is b.S_new_b else "S_old_b"
         assert S is getattr(b, which)
-        self._interp_ghosts(b, S)
+        if self.l > 0:
+            self._interp_ghosts(b, S)
         self._copy_siblings(b, S, which)
 
     # ---- AmrLevel::FillPatch of Source_Type (Castro_advance_ctu.cpp:138-140) ------------------------------
@@ -304,7 +318,7 @@ class _Level:
         """Ghost zones of the Source_Type data `name` (old_source / new_source_g) of every box: coarse Source_Type data
         interpolated in time ((1 - alpha) old + alpha new, StateData's rule) and space (cell_cons_interp,
         Castro_setup.cpp:317-327), valid data of the other boxes of the level, physical boundaries."""
-        if self.l == 0:
+        if self.plain_base:
             for b in self.boxes:
                 b.expand_state(getattr(b, name), b.sbox, b.src_neighbors)
             return
@@ -446,8 +460,10 @@ class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
                  blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None, comm=None):
-        """comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of level l on rank
+                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None, comm=None, base_grid=None):
+        """base_grid = (gx, gy, gz): level 0 as gx x gy x gz equal boxes instead of one (amr.max_grid_size on the base level);
+        with `comm` they are dealt over the ranks like the boxes of the refined levels.
+        comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of level l on rank
         (i + l) mod size, level 0 on rank 0; no sources): every rank builds the same hierarchy, holds the
         memory of its own boxes only and moves box-to-box data (coarse data under fine ghost shells, sibling ghost zones,
         coarse fluxes for the registers, registers for the reflux, averaged-down zones) with one grouped RCCL
@@ -474,11 +490,32 @@ class CastroAmr:
         self.n_cell = tuple(n_cell)
         self.periodic = tuple(lo_bc[d] == 0 and hi_bc[d] == 0 for d in range(3))
         self._hydros = []
-        base = Castro(n_cell, hydro=self._hydro_for(0), alloc=(self.rank == 0), **self._kw)
-        base.owner = 0
-        if base.have_sources and base.owned:
-            base.new_source_g = base.hydro.alloc(NSRC, *base.sbox)
-        self.lev = [_Level(self, 0, [base])]                          # lev[0] covers the domain
+        if base_grid is None or tuple(base_grid) == (1, 1, 1):
+            base = Castro(n_cell, hydro=self._hydro_for(0), alloc=(self.rank == 0), **self._kw)
+            base.owner = 0
+            if base.have_sources and base.owned:
+                base.new_source_g = base.hydro.alloc(NSRC, *base.sbox)
+            self.lev = [_Level(self, 0, [base])]                      # lev[0] covers the domain
+            self.lev[0].bind()
+        else:
+            gx = tuple(int(x) for x in base_grid)
+            assert all(self.n_cell[d] % gx[d] == 0 and self.n_cell[d] // gx[d] >= 2 * NUM_GROW for d in range(3)), \
+                "base_grid must divide the domain into boxes of at least %d zones a side" % (2 * NUM_GROW)
+            nb = tuple(self.n_cell[d] // gx[d] for d in range(3))
+            self.lev = []
+            boxes = []
+            for i, (kz, jy, ix) in enumerate(itertools.product(range(gx[2]), range(gx[1]), range(gx[0]))):
+                lo = (ix * nb[0], jy * nb[1], kz * nb[2])
+                hi = tuple(lo[d] + nb[d] - 1 for d in range(3))
+                owner = i % self.nranks
+                b = _Patch(self.n_cell, hydro=self._hydro_for(0), box=(lo, hi), alloc=(owner == self.rank), **self._kw)
+                b.owner = owner
+                boxes.append(b)
+            lev0 = _Level(self, 0, boxes)
+            for b in boxes:
+                b.bind(lev0, None)
+            self.lev.append(lev0)
+            lev0.bind()
         self.refine = refine
         self.regrid_int, self.n_error_buf, self.blocking_factor = int(regrid_int), int(n_error_buf), int(blocking_factor)
         self.cluster = bool(cluster)

@@ -2413,6 +2413,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // launch covers; the faces at the workgroup starts follow in a one-thread-per-workgroup launch, those on the
     // x faces of the launch box (lo[0] and hi[0] + 1) are left to the caller.
     auto trace_with_xriemann = [&](const int lo[3], const int hi[3]) {
+        // the trace launch and the block-start fix-up share one workgroup order: both see the trace's rows per y-tile
+        struct RowsGuard { int keep; RowsGuard() : keep(g_tile_rows) { if (g_trace_tile_rows >= 0) g_tile_rows = g_trace_tile_rows; }
+                           ~RowsGuard() { g_tile_rows = keep; } } rows_guard;
 #ifdef EXPERIMENT_TRACE_SPLIT       // tools/build_variant.sh split "-DEXPERIMENT_TRACE_SPLIT"; measured slower, DESIGN.md section 9
         if (g_trace_split == 1) {
             KL2("k_trace_x", (k_trace_pair<true, 1>), lo, hi, S.Q, S, g, dt, P, none);
@@ -2423,12 +2426,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             KL2("k_trace_yz", (k_trace_pair<false, 6>), lo, hi, S.Q, S, g, dt, P, none);
         } else
 #endif
-        {
-            const int keep_rows = g_tile_rows;
-            if (g_trace_tile_rows >= 0) g_tile_rows = g_trace_tile_rows;
-            KL2("k_trace", k_trace_pair<true>, lo, hi, S.Q, S, g, dt, P, none);
-            g_tile_rows = keep_rows;
-        }
+        { KL2("k_trace", k_trace_pair<true>, lo, hi, S.Q, S, g, dt, P, none); }
         long n_;
         LinBox b_ = linbox2(lo, hi, n_);
         if (n_ > 0) {

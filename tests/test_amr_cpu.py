@@ -580,6 +580,7 @@ def test_amr_orchestration_oracle_on_data_where_clean_state_is_not_idempotent(or
 
 
 # ---- the boxes of the refined levels spread over ranks (gloo, oracle backend) -----------------------------------------
+import itertools
 import os
 import socket
 
@@ -643,10 +644,10 @@ def test_amr_with_boxes_spread_over_ranks_is_bitwise_identical_gloo(tmp_path, or
             assert np.array_equal(got["L%d_%d" % (l, i)], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
 
 
-def _mr_tag_run(comm, nsteps):
+def _mr_tag_run(comm, nsteps, base_grid=None):
     import castro_amd
     from oracle import oracle_lib as O
-    a = castro_amd.CastroAmr((16, 16, 16), params=O.default_params(init_shrink=0.3), make_hydro=OracleBackend,
+    a = castro_amd.CastroAmr((16, 16, 16), params=O.default_params(init_shrink=0.3), make_hydro=OracleBackend, base_grid=base_grid,
                              refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2,
                              n_error_buf=1, blocking_factor=4, max_level=2, cluster=True, grid_eff=0.7, max_grid_size=16, comm=comm)
     a.initData("sedov", r_init=0.08, nsub=4)
@@ -657,7 +658,7 @@ def _mr_tag_run(comm, nsteps):
     return a, dts, boxes
 
 
-def _mr_tag_worker(rank, world, port, nsteps, out_path):
+def _mr_tag_worker(rank, world, port, nsteps, out_path, base_grid=None):
     import pickle
     import torch.distributed as dist
     import castro_amd
@@ -666,7 +667,7 @@ def _mr_tag_worker(rank, world, port, nsteps, out_path):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        a, dts, boxes = _mr_tag_run(castro_amd.DistComm(), nsteps)
+        a, dts, boxes = _mr_tag_run(castro_amd.DistComm(), nsteps, base_grid)
         owned = [[b.owned for b in lev.boxes] for lev in a.lev]
         levels = [a.gather_level(l) for l in range(len(a.lev))]
         if rank == 0:
@@ -676,8 +677,8 @@ def _mr_tag_worker(rank, world, port, nsteps, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_tag_driven_amr_regrids_with_boxes_spread_over_ranks_gloo(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,base_grid", [(2, None), (3, None), (3, (2, 2, 2))])
+def test_tag_driven_amr_regrids_with_boxes_spread_over_ranks_gloo(tmp_path, oracle, world, base_grid):
     """Regridding with the boxes of every level dealt over ranks: each rank tags its own boxes, the buffered tags reduced
     to blocking cells are combined over the ranks (a maximum, like the buffering and the pooling), every rank clusters
     the same array into the same box lists, and the data of a new level come from the parents' and the old boxes'
@@ -686,9 +687,15 @@ def test_tag_driven_amr_regrids_with_boxes_spread_over_ranks_gloo(tmp_path, orac
     import pickle
     nsteps = 6
     out = str(tmp_path / "amr_tag_ranks.pkl")
-    mp.spawn(_mr_tag_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
+    mp.spawn(_mr_tag_worker, args=(world, _free_port(), nsteps, out, base_grid), nprocs=world, join=True)
     got = pickle.load(open(out, "rb"))
-    a, dts, boxes = _mr_tag_run(None, nsteps)
+    a, dts, boxes = _mr_tag_run(None, nsteps)           # the reference run keeps level 0 in one box
+    if base_grid is not None:                           # level 0 came back as 8 boxes: paste them together
+        full = np.empty_like(a.lev[0].boxes[0].S_new().cpu().numpy())
+        assert len(got["data"][0]) == 8 and not all(got["owned"][0])
+        for i, (kz, jy, ix) in enumerate(itertools.product(range(2), range(2), range(2))):
+            full[:, 8 * kz:8 * kz + 8, 8 * jy:8 * jy + 8, 8 * ix:8 * ix + 8] = got["data"][0][i]
+        got["data"][0] = [full]
     assert a.nregrid >= 2 and got["nregrid"] == a.nregrid and len(a.lev) == 3
     assert got["boxes"] == boxes and boxes[0] != boxes[-1]
     assert got["dts"] == dts
@@ -697,3 +704,38 @@ def test_tag_driven_amr_regrids_with_boxes_spread_over_ranks_gloo(tmp_path, orac
         assert len(got["data"][l]) == len(lev.boxes)
         for i, b in enumerate(lev.boxes):
             assert np.array_equal(got["data"][l][i], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
+
+
+@pytest.mark.parametrize("case", ["patches", "periodic_tags", "gravity"])
+def test_base_level_cut_into_boxes_is_bitwise_identical(oracle, case):
+    """CastroAmr(base_grid=(2, 2, 2)): level 0 as eight boxes (same-level copies incl. periodic images + physical boundaries,
+    no coarse data, no flux registers) instead of one box that fills its own ghost zones; the refined levels take their
+    coarse data, coarse fluxes and reflux targets from several level-0 boxes.  Fixed patches, tag-driven regridding in a
+    periodic domain, constant gravity with sources on every level: dt sequence and every zone equal the one-box run."""
+    import castro_amd
+    kw = dict(params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend)
+    if case == "patches":
+        kw.update(patches=_MR_PATCHES)
+    elif case == "periodic_tags":
+        kw.update(refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2, n_error_buf=1, blocking_factor=4,
+                  max_level=2, cluster=True, grid_eff=0.7, max_grid_size=16, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0),
+                  params=oracle.default_params(init_shrink=0.3))
+    else:
+        kw.update(patches=[((4, 4, 4), (11, 11, 11))], do_grav=True, const_grav=-2.0, lo_bc=(2, 2, 4), hi_bc=(2, 2, 4))
+    runs = []
+    for bg in (None, (2, 2, 2)):
+        a = castro_amd.CastroAmr((16, 16, 16), base_grid=bg, **kw)
+        a.initData("sedov", r_init=0.1 if case != "periodic_tags" else 0.08, nsub=4)
+        dts = [a.step() for _ in range(5)]
+        runs.append((a, dts))
+    (a1, d1), (a2, d2) = runs
+    assert d1 == d2 and a1.boxes == a2.boxes and len(a2.lev[0].boxes) == 8
+    if case == "periodic_tags":
+        assert a1.nregrid >= 1 and a1.nregrid == a2.nregrid
+    full = a1.lev[0].boxes[0].S_new().numpy()
+    for b in a2.lev[0].boxes:
+        sl = (slice(None),) + tuple(slice(b.lo[d], b.hi[d] + 1) for d in (2, 1, 0))
+        assert np.array_equal(full[sl], b.S_new().numpy()), b.bx
+    for l in range(1, len(a1.lev)):
+        for x, y in zip(a1.lev[l].boxes, a2.lev[l].boxes):
+            assert np.array_equal(x.S_new().numpy(), y.S_new().numpy()), (l, x.bx)

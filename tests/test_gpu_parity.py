@@ -91,7 +91,10 @@ def _assert_exact(out, what=""):
     assert not bad, what + " not bit-exact:\n" + "\n".join(bad)
 
 
-@pytest.mark.parametrize("shape,seed", [((16, 12, 10), 1), ((9, 17, 8), 2), ((8, 8, 8), 3), ((33, 9, 11), 4)])
+# the last two shapes have more rows than a y-tile of the XCD-tiled workgroup order (32 rows; 64 for the trace launch), so
+# the launches whose thread-to-zone maps must agree (the trace and its block-start fix-up) are exercised across tiles
+@pytest.mark.parametrize("shape,seed", [((16, 12, 10), 1), ((9, 17, 8), 2), ((8, 8, 8), 3), ((33, 9, 11), 4), ((24, 72, 5), 5),
+                                        ((10, 140, 3), 6)])
 def test_ctu_hydro_fab_bit_exact(hip, oracle, shape, seed):
     rng = np.random.default_rng(seed)
     bxlo = (3, -2, 5)
@@ -1134,9 +1137,9 @@ def test_amr_boxes_over_ranks_on_the_device_equal_one_rank(tmp_path, world):
             assert np.array_equal(got["L%d_%d" % (l, i)], b.S_new().cpu().numpy()), "level %d box %d" % (l, i)
 
 
-def _amr_tag_rank_gpu_run(comm, nsteps):
+def _amr_tag_rank_gpu_run(comm, nsteps, base_grid=None):
     import castro_amd
-    a = castro_amd.CastroAmr((32, 32, 32), params=castro_amd.default_params(init_shrink=0.3),
+    a = castro_amd.CastroAmr((32, 32, 32), params=castro_amd.default_params(init_shrink=0.3), base_grid=base_grid,
                              refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)], regrid_int=2,
                              n_error_buf=1, blocking_factor=8, max_level=2, cluster=True, grid_eff=0.7, max_grid_size=32, comm=comm)
     a.initData("sedov", r_init=0.08, nsub=4)
@@ -1147,7 +1150,7 @@ def _amr_tag_rank_gpu_run(comm, nsteps):
     return a, dts, boxes
 
 
-def _amr_tag_rank_gpu_worker(rank, world, port, nsteps, out_path):
+def _amr_tag_rank_gpu_worker(rank, world, port, nsteps, out_path, base_grid=None):
     import pickle
     import torch.distributed as dist
     import torch
@@ -1157,7 +1160,7 @@ def _amr_tag_rank_gpu_worker(rank, world, port, nsteps, out_path):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        a, dts, boxes = _amr_tag_rank_gpu_run(castro_amd.DistComm(), nsteps)
+        a, dts, boxes = _amr_tag_rank_gpu_run(castro_amd.DistComm(), nsteps, base_grid)
         torch.cuda.synchronize()
         levels = [a.gather_level(l) for l in range(len(a.lev))]
         if rank == 0:
@@ -1166,20 +1169,28 @@ def _amr_tag_rank_gpu_worker(rank, world, port, nsteps, out_path):
         dist.destroy_process_group()
 
 
-def test_tag_driven_amr_over_ranks_on_the_device_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("base_grid", [None, (2, 2, 2)])
+def test_tag_driven_amr_over_ranks_on_the_device_equals_one_rank(tmp_path, base_grid):
     """Tag-driven regridding (Berger-Rigoutsos boxes, two refined levels, regrid every two steps) with the boxes dealt over
-    three processes sharing the test GPU: box lists after every step, dt sequence and every box equal the one-process
-    run bit for bit."""
+    three processes sharing the test GPU -- also with level 0 cut into eight boxes (base_grid) and dealt like the others:
+    box lists after every step, dt sequence and every box equal the one-process, one-base-box run bit for bit."""
     import pickle
     import torch
     import torch.multiprocessing as mp
     from tests.test_driver_cpu import _free_port
     nsteps, world = 6, 3
     out = str(tmp_path / "amr_tag_ranks_gpu.pkl")
-    mp.spawn(_amr_tag_rank_gpu_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
+    mp.spawn(_amr_tag_rank_gpu_worker, args=(world, _free_port(), nsteps, out, base_grid), nprocs=world, join=True)
     got = pickle.load(open(out, "rb"))
     a, dts, boxes = _amr_tag_rank_gpu_run(None, nsteps)
     torch.cuda.synchronize()
+    if base_grid is not None:
+        import itertools
+        full = np.empty_like(a.lev[0].boxes[0].S_new().cpu().numpy())
+        assert len(got["data"][0]) == 8
+        for i, (kz, jy, ix) in enumerate(itertools.product(range(2), range(2), range(2))):
+            full[:, 16 * kz:16 * kz + 16, 16 * jy:16 * jy + 16, 16 * ix:16 * ix + 16] = got["data"][0][i]
+        got["data"][0] = [full]
     assert a.nregrid >= 2 and got["nregrid"] == a.nregrid and len(a.lev) == 3
     assert got["boxes"] == boxes and boxes[0] != boxes[-1]
     assert got["dts"] == dts
