@@ -92,8 +92,8 @@ class _Patch(Castro):
         """Source_Type data (NUM_GROW_SRC ghost zones): the coarse zones under the grown box, and the ghost shell."""
         slo, shi = self.sbox
         self.scbox = (tuple(_coarsen(slo[d]) - 1 for d in range(3)), tuple(_coarsen(shi[d]) + 1 for d in range(3)))
-        self.stmp = self.hydro.alloc(NSRC, *self.scbox)
-        self.new_source_g = self.hydro.alloc(NSRC, *self.sbox)
+        self.stmp = self.hydro.alloc(NSRC, *self.scbox) if self.owned else None
+        self.new_source_g = self.hydro.alloc(NSRC, *self.sbox) if self.owned else None
         lo, hi = self.lo, self.hi
         self.sshell = [((slo[0], slo[1], slo[2]), (shi[0], shi[1], lo[2] - 1)), ((slo[0], slo[1], hi[2] + 1), (shi[0], shi[1], shi[2])),
                        ((slo[0], slo[1], lo[2]), (shi[0], lo[1] - 1, hi[2])), ((slo[0], hi[1] + 1, lo[2]), (shi[0], shi[1], hi[2])),
@@ -319,10 +319,20 @@ class _Level:
         interpolated in time ((1 - alpha) old + alpha new, StateData's rule) and space (cell_cons_interp,
         Castro_setup.cpp:317-327), valid data of the other boxes of the level, physical boundaries."""
         if self.plain_base:
-            for b in self.boxes:
+            for b in self.mine:
                 b.expand_state(getattr(b, name), b.sbox, b.src_neighbors)
             return
         h, a = self.hydro, self.alpha
+        if self.amr.nranks > 1:
+            X = self.amr._xrun
+            X([("src_lincomb", b, p, lo, hi, a) for b in self.boxes for p, (lo, hi) in b.ssrc + b.ssrc_valid], NSRC)
+            for b in self.mine:
+                for lo, hi in b.sshell:
+                    h.cc_interp(b.stmp, b.scbox, getattr(b, name), b.sbox, lo, hi, NSRC)
+            X([("src_copy", b, sb, lo, hi, (name, sh)) for b in self.boxes for sb, (lo, hi), sh in b.ssib], NSRC)
+            for b in self.mine:
+                h.bc_fill(getattr(b, name), b.sbox, b.geom)
+            return
         for b in self.boxes:
             for p, (lo, hi) in b.ssrc + b.ssrc_valid:           # ghost zones of the parents first, valid zones last
                 h.lincomb(b.stmp, b.scbox, 1.0 - a, p.old_source, p.sbox, a, p.new_source_g, p.sbox, NSRC, lo, hi)
@@ -336,7 +346,7 @@ class _Level:
     def fill_new_source(self):
         """The new-time Source_Type data with ghost zones, for the FillPatch of the next finer level."""
         h = self.hydro
-        for b in self.boxes:
+        for b in self.mine:
             h.copy(b.new_source_g, b.sbox, b.new_source, b.bx, b.lo, b.hi)
         self.fill_source("new_source_g")
 
@@ -350,7 +360,7 @@ class _Level:
         stage by stage over the boxes of the level; the per-box arithmetic is Castro._do_advance_with_sources'."""
         h = self.hydro
         fused = hasattr(h, "apply_source")
-        for b in self.boxes:
+        for b in self.mine:
             S, lo, hi = b.S_old_b, b.lo, b.hi
             b.old_source.zero_()
             if b.do_grav:
@@ -364,15 +374,16 @@ class _Level:
                 h.saxpy(b.S_new_b, b.gbox, dt, b.old_source, b.sbox, NSRC, lo, hi)
                 h.clean_state(b.S_new_b, b.gbox, lo, hi, b.params, ntimes=1)
         self.fill_source("old_source")
-        for b in self.boxes:
+        for b in self.mine:
             b.construct_ctu_hydro_source(time, dt, src=b.old_source)
             b._flux_clear = False
-        for b in self.boxes:
+        for b in self.mine:
             h.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
+        self.amr.comm.allreduce_min(self.red)
         _, rho_min = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        for b in self.boxes:
+        for b in self.mine:
             S, lo, hi = b.S_old_b, b.lo, b.hi
             b.new_source.zero_()
             if b.do_grav:
@@ -422,8 +433,6 @@ class _Level:
         self.red.fill_(1.e200)
         self.fill("S_old_b")
         if self.have_sources:
-            if self.amr.nranks > 1:
-                raise NotImplementedError("gravity / rotation sources with the boxes of a level on several ranks")
             return self._advance_with_sources(time, dt)
         for b in self.mine:
             b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
@@ -464,7 +473,7 @@ class CastroAmr:
         """base_grid = (gx, gy, gz): level 0 as gx x gy x gz equal boxes instead of one (amr.max_grid_size on the base level);
         with `comm` they are dealt over the ranks like the boxes of the refined levels.
         comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of level l on rank
-        (i + l) mod size, level 0 on rank 0; no sources): every rank builds the same hierarchy, holds the
+        (i + l) mod size, level 0 on rank 0 unless base_grid cuts it up): every rank builds the same hierarchy, holds the
         memory of its own boxes only and moves box-to-box data (coarse data under fine ghost shells, sibling ghost zones,
         coarse fluxes for the registers, registers for the reflux, averaged-down zones) with one grouped RCCL
         point-to-point exchange per pass.
@@ -565,7 +574,7 @@ class CastroAmr:
         return lev
 
     # ---- box-to-box operations with the boxes spread over ranks ----------------------------------------------
-    def _xrun(self, ops):
+    def _xrun(self, ops, ncomp=NUM_STATE):
         """ops = [(kind, D, S, lo, hi, extra)]: region [lo, hi] of box D from box S.  Both here: the operation itself.
         S here and D elsewhere: the source's contribution is staged in a buffer of the region's shape and sent; D here
         and S elsewhere: it is received and applied, in list order together with the local ones (later entries overwrite
@@ -580,7 +589,7 @@ class CastroAmr:
                 sends.append((D.owner, n, t))
             elif D.owner == me:
                 h = D.hydro
-                t = h.alloc(NUM_STATE, lo, hi)
+                t = h.alloc(ncomp, lo, hi)
                 bufs[n] = t
                 recvs.append((S.owner, n, t))
         self.comm.exchange(sends, recvs)
@@ -591,8 +600,15 @@ class CastroAmr:
 
     def _xstage(self, kind, D, S, lo, hi, extra):
         h = S.hydro
-        t = h.alloc(NUM_STATE, lo, hi)
+        t = h.alloc(NSRC if kind.startswith("src_") else NUM_STATE, lo, hi)
         box = (tuple(lo), tuple(hi))
+        if kind == "src_lincomb":              # Source_Type data of a parent, interpolated in time
+            h.lincomb(t, box, 1.0 - extra, S.old_source, S.sbox, extra, S.new_source_g, S.sbox, NSRC, lo, hi)
+            return t
+        if kind == "src_copy":
+            name, sh = extra
+            h.copy(t, box, getattr(S, name), _shift(S.sbox, sh), lo, hi)
+            return t
         if kind == "lincomb":
             h.lincomb(t, box, 1.0 - extra, S.S_old_b, S.gbox, extra, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
         elif kind == "crse_new":
@@ -617,7 +633,18 @@ class CastroAmr:
         """the operation on this rank's box D; `buf` holds the staged source when S lives elsewhere"""
         h = D.hydro
         box = (tuple(lo), tuple(hi))
-        if kind == "lincomb":
+        if kind == "src_lincomb":
+            if buf is None:
+                h.lincomb(D.stmp, D.scbox, 1.0 - extra, S.old_source, S.sbox, extra, S.new_source_g, S.sbox, NSRC, lo, hi)
+            else:
+                h.copy(D.stmp, D.scbox, buf, box, lo, hi)
+        elif kind == "src_copy":
+            name, sh = extra
+            if buf is None:
+                h.copy(getattr(D, name), D.sbox, getattr(S, name), _shift(S.sbox, sh), lo, hi)
+            else:
+                h.copy(getattr(D, name), D.sbox, buf, box, lo, hi)
+        elif kind == "lincomb":
             if buf is None:
                 h.lincomb(D.ctmp, D.cbox, 1.0 - extra, S.S_old_b, S.gbox, extra, S.S_new_b, S.gbox, NUM_STATE, lo, hi)
             else:

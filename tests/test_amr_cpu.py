@@ -739,3 +739,49 @@ def test_base_level_cut_into_boxes_is_bitwise_identical(oracle, case):
     for l in range(1, len(a1.lev)):
         for x, y in zip(a1.lev[l].boxes, a2.lev[l].boxes):
             assert np.array_equal(x.S_new().numpy(), y.S_new().numpy()), (l, x.bx)
+
+
+def _mr_grav_run(comm, nsteps, base_grid):
+    import castro_amd
+    from oracle import oracle_lib as O
+    a = castro_amd.CastroAmr((16, 16, 16), patches=_MR_PATCHES, params=O.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+                             do_grav=True, const_grav=-2.0, lo_bc=(2, 2, 4), hi_bc=(2, 2, 4), comm=comm, base_grid=base_grid,
+                             rotation=castro_amd.make_rotation(3.0, rot_axis=3, center=(0.5, 0.5, 0.5)))
+    a.initData("sedov", r_init=0.1, nsub=4)
+    dts = [a.step() for _ in range(nsteps)]
+    return a, dts
+
+
+def _mr_grav_worker(rank, world, port, nsteps, base_grid, out_path):
+    import pickle
+    import torch.distributed as dist
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, dts = _mr_grav_run(castro_amd.DistComm(), nsteps, base_grid)
+        levels = [a.gather_level(l) for l in range(len(a.lev))]
+        if rank == 0:
+            pickle.dump(dict(dts=dts, data=[[(bx, arr) for bx, arr in lv] for lv in levels]), open(out_path, "wb"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,base_grid", [(2, None), (3, (2, 2, 2))])
+def test_amr_with_sources_and_boxes_spread_over_ranks_gloo(tmp_path, oracle, world, base_grid):
+    """Constant gravity and rotation on three levels with the boxes (and, with base_grid, level 0 too) dealt over ranks:
+    the Source_Type FillPatch of a refined level -- coarse sources interpolated in time and space, the siblings' sources --
+    goes through the staged transfers like the state.  dt sequence and every box equal the one-rank run bit for bit."""
+    import pickle
+    nsteps = 4
+    out = str(tmp_path / "amr_grav_ranks.pkl")
+    mp.spawn(_mr_grav_worker, args=(world, _free_port(), nsteps, base_grid, out), nprocs=world, join=True)
+    got = pickle.load(open(out, "rb"))
+    a, dts = _mr_grav_run(None, nsteps, base_grid)
+    assert got["dts"] == dts
+    for l, lev in enumerate(a.lev):
+        assert [bx for bx, _ in got["data"][l]] == [b.bx for b in lev.boxes]
+        for (bx, arr), b in zip(got["data"][l], lev.boxes):
+            assert np.array_equal(arr, b.S_new().cpu().numpy()), "level %d box %s" % (l, bx)
