@@ -34,6 +34,7 @@ flux-register and clustering arithmetic is AMReX's, restated from its published 
 (include/castro_hydro_amd.h, castro_amd/cluster.py): parity with an AMReX build is unpinned.
 """
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -374,9 +375,10 @@ class _Level:
                 h.saxpy(b.S_new_b, b.gbox, dt, b.old_source, b.sbox, NSRC, lo, hi)
                 h.clean_state(b.S_new_b, b.gbox, lo, hi, b.params, ntimes=1)
         self.fill_source("old_source")
-        for b in self.mine:
+        def hydro(b):
             b.construct_ctu_hydro_source(time, dt, src=b.old_source)
             b._flux_clear = False
+        self._hydro_calls(hydro)
         for b in self.mine:
             h.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
         self.amr.comm.allreduce_min(self.red)
@@ -421,6 +423,33 @@ class _Level:
     advance = Castro.advance
     subcycle_advance_ctu = Castro.subcycle_advance_ctu
 
+    def _hydro_calls(self, fn):
+        """fn(b) -- the hydro update of one box -- for every box of this rank.  The boxes of a level are independent
+        there, and one small box fills a fraction of the chip (a 32^3 box is 64 workgroups of 256 CUs' worth), so with
+        the device backend up to `box_streams` boxes are in flight at once, each on its own stream with its own scratch
+        context; the level's reductions are atomic minima into one pair, the streams are joined before anything else runs."""
+        pool = self.amr._stream_pool(self.l) if len(self.mine) > 1 else None
+        if not pool:
+            for b in self.mine:
+                fn(b)
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        used = pool[:min(len(pool), len(self.mine))]
+        for _, st in used:
+            st.wait_event(ev)
+        for i, b in enumerate(self.mine):
+            ctx, st = pool[i % len(pool)]
+            keep, b.hydro = b.hydro, ctx
+            try:
+                with torch.cuda.stream(st):
+                    fn(b)
+            finally:
+                b.hydro = keep
+        for _, st in used:
+            main.wait_stream(st)
+
     def do_advance_ctu(self, time, dt):
         """Castro::do_advance_ctu (Castro_advance_ctu.cpp:15-397) with every stage done for all boxes before the next."""
         if self.l > 0 and time != self._t0:
@@ -434,9 +463,10 @@ class _Level:
         self.fill("S_old_b")
         if self.have_sources:
             return self._advance_with_sources(time, dt)
-        for b in self.mine:
+        def hydro(b):
             b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
             b._flux_clear = False
+        self._hydro_calls(hydro)
         if not self.fuse_clean:
             for b in self.mine:
                 self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
@@ -469,7 +499,7 @@ class CastroAmr:
     def __init__(self, n_cell, patch_crse=None, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, make_hydro=None, make_params=None, refine=None, regrid_int=2, n_error_buf=1,
                  blocking_factor=8, patches=None, max_level=1, cluster=False, grid_eff=0.7, max_grid_size=128,
-                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None, comm=None, base_grid=None):
+                 do_grav=False, const_grav=0.0, grav_source_type=4, rotation=None, comm=None, base_grid=None, box_streams=4):
         """base_grid = (gx, gy, gz): level 0 as gx x gy x gz equal boxes instead of one (amr.max_grid_size on the base level);
         with `comm` they are dealt over the ranks like the boxes of the refined levels.
         comm: a castro_amd.DistComm to spread the boxes of every refined level over its ranks (box i of level l on rank
@@ -498,6 +528,8 @@ class CastroAmr:
                         do_grav=do_grav, const_grav=const_grav, grav_source_type=grav_source_type, rotation=rotation)
         self.n_cell = tuple(n_cell)
         self.periodic = tuple(lo_bc[d] == 0 and hi_bc[d] == 0 for d in range(3))
+        # boxes of a level whose hydro updates may be in flight at once (device backend); CASTRO_AMD_BOX_STREAMS overrides
+        self.box_streams = int(os.environ.get("CASTRO_AMD_BOX_STREAMS", box_streams))
         self._hydros = []
         if base_grid is None or tuple(base_grid) == (1, 1, 1):
             base = Castro(n_cell, hydro=self._hydro_for(0), alloc=(self.rank == 0), **self._kw)
@@ -547,6 +579,19 @@ class CastroAmr:
     pbox = property(lambda self: [None] + [bl[0] if len(bl) == 1 else bl for bl in self.boxes[1:]])
     plo = property(lambda self: self.pbox[1][0] if len(self.lev) > 1 else None)
     phi = property(lambda self: self.pbox[1][1] if len(self.lev) > 1 else None)
+
+    def _stream_pool(self, l):
+        """[(scratch context, stream)] for the concurrent hydro calls of the boxes of level l, or None (one stream)"""
+        if self.box_streams <= 1 or not torch.cuda.is_available() or not hasattr(self._hydro_for(l), "device") \
+                or not hasattr(self._hydro_for(l), "lib"):
+            return None
+        pools = self.__dict__.setdefault("_pools", {})
+        if l not in pools:
+            from .hydro import HipHydro
+            dev = self._hydro_for(l).device
+            pools[l] = [(self._hydro_for(l) if k == 0 else HipHydro(dev.index), torch.cuda.Stream(device=dev))
+                        for k in range(self.box_streams)]
+        return pools[l]
 
     def _hydro_for(self, l):
         while len(self._hydros) <= l:
