@@ -2004,6 +2004,11 @@ def test_derived_fields_on_the_device_match_the_reference_functions(hip):
             assert np.allclose(got, ref, rtol=1e-14, atol=0.0)
         else:
             T.exact(got, ref, name)
+    # Castro::estdt_cfl of the same state (timestep.cpp compiled unmodified)
+    red = torch.full((2,), 1.e200, dtype=torch.float64, device=hip.device)
+    hip.estdt_cfl(Ud, (glo, ghi), lo, hi, G, par, red)
+    torch.cuda.synchronize()
+    assert red[0].item() == float(V["out:derive.estdt"][0])
 
 
 def test_device_functions_reproduce_the_stub_probe_vectors(hip):

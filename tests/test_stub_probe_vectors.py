@@ -393,3 +393,13 @@ def test_rotation_sources_match_the_reference_functions(V, c):
     L.ora_new_rotation_source(O.i3(lo), O.i3(hi), O.a4(uold, lo, hi), O.a4(unew, lo, hi), O.a4(s2, lo, hi), ma, C.byref(R), C.byref(G), dt)
     exact(s2, V["out:rot%d.new" % c].reshape(s2.shape), "corrrsrc")
     assert np.abs(s1[1:5]).max() > 0 and np.abs(s2[1:5]).max() > 0
+
+
+def test_estdt_cfl_matches_the_reference_function(V):
+    """Castro::estdt_cfl (Source/driver/timestep.cpp, compiled unmodified behind a one-box MultiFab / ReduceOps stand-in)"""
+    n, G, U, _ = derive_case(V)
+    lo, hi = (0, 0, 0), tuple(x - 1 for x in n)
+    L = O.lib()
+    L.ora_estdt_cfl.restype = C.c_double
+    got = L.ora_estdt_cfl(O.i3(lo), O.i3(hi), O.a4(U, (-1, -1, -1), n), C.byref(G), C.byref(O.default_params()))
+    assert got == float(V["out:derive.estdt"][0]), (got, float(V["out:derive.estdt"][0]))

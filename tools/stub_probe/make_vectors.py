@@ -73,8 +73,9 @@ def build(tmp):
                                                    os.path.join(HERE, "probe_init.cpp"), "-o", o])
     subprocess.check_call(["g++", "-o", exe + "_init", o, os.path.join(tmp, "probe_params.o")])
     # the derived fields (Source/driver/Derive.cpp, unmodified)
-    od = [os.path.join(tmp, "Derive.o"), os.path.join(tmp, "probe_derive.o")]
+    od = [os.path.join(tmp, "Derive.o"), os.path.join(tmp, "probe_derive.o"), os.path.join(tmp, "timestep.o")]
     subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(src, "driver", "Derive.cpp"), "-o", od[0]])
+    subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(src, "driver", "timestep.cpp"), "-o", od[2]])
     subprocess.check_call(["g++"] + flags + inc + ["-c", os.path.join(HERE, "probe_derive.cpp"), "-o", od[1]])
     subprocess.check_call(["g++", "-o", exe + "_derive"] + od + [os.path.join(tmp, "probe_params.o")])
     # the rotation sources (Source/rotation/rotation_sources.cpp, Rotation.cpp, unmodified)
@@ -258,6 +259,9 @@ def main():
         write_blob(os.path.join(tmp, "in3.bin"), D)
         subprocess.check_call([exe + "_derive", os.path.join(tmp, "in3.bin"), os.path.join(tmp, "out3.bin")])
         for k, v in read_blob(os.path.join(tmp, "out3.bin")).items():
+            if k == "derive.estdt":
+                O[k] = v
+                continue
             nc = v.size // ((dn[0] + 2) * (dn[1] + 2) * (dn[2] + 2))
             O[k] = v.reshape(nc, dn[2] + 2, dn[1] + 2, dn[0] + 2)[:, 1:-1, 1:-1, 1:-1].copy()
         B.update(D)

@@ -1,5 +1,6 @@
 // probe_derive.cpp -- the reference's derived-field functions (Source/driver/Derive.cpp, compiled UNMODIFIED and IN PLACE
-// from /root/reference against the stand-in headers) on one box of seeded state data.  STUB-COMPILED, NOT oracle/_ref.
+// from /root/reference against the stand-in headers) on one box of seeded state data, and Castro::estdt_cfl
+// (Source/driver/timestep.cpp) on the same state.  STUB-COMPILED, NOT oracle/_ref.
 // Every function gets the state components its registration in Castro_setup.cpp hands it (the whole State_Type, or
 // (rho, momenta), (rho, one momentum), (momenta), (rho, rho X), (rho, Temp, rho X)).
 #include <Castro.H>
@@ -84,6 +85,18 @@ int main(int argc, char** argv)
         FArrayBox datfab(dat.data(), gbx, (int)it.comps.size()), derfab(der.data(), gbx, it.nout);
         it.fn(bx, derfab, 0, it.nout, datfab, Castro::geom, 0.0, nullptr, 0);
         out[std::string("derive.") + it.name] = der;
+    }
+    // ---- Castro::estdt_cfl (Source/driver/timestep.cpp:22-137, compiled unmodified) over the valid zones ----
+    {
+        const long nv = (long)n[0] * n[1] * n[2];
+        Arr V((size_t)NUM_STATE * nv);
+        Array4<Real> g(U.data(), glo, ghi, NUM_STATE), v(V.data(), lo, hi, NUM_STATE);
+        for (int c = 0; c < NUM_STATE; ++c)
+            for (int k = 0; k < n[2]; ++k) for (int j = 0; j < n[1]; ++j) for (int i = 0; i < n[0]; ++i) v(i, j, k, c) = g(i, j, k, c);
+        MultiFab mf(V.data(), bx, NUM_STATE);
+        Castro castro_obj;
+        castro_obj.state_mf = &mf;
+        out["derive.estdt"] = {castro_obj.estdt_cfl(0.0)};
     }
     write_blob(argv[2]);
     return 0;
