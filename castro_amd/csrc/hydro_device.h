@@ -554,6 +554,62 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
 }
 
 // riemann.H:248-282
+// ---------------------------------------------------------------------------------------
+// XD: a double whose NaNs carry the sign the reference's x86-64 CPU build gives them.  IEEE 754 leaves the sign of a NaN
+// open and nothing in the physics depends on it -- but `sgnm = copysign(1.0, ustar)` in the Colella-Glaz solver does, and
+// with it whether a face whose iteration ended in NaNs returns the finite upwind state or a NaN.  SSE2: an invalid operation
+// (0/0, inf - inf, 0 * inf, sqrt of a negative) yields the NEGATIVE default NaN; an operation with a NaN operand returns that
+// operand (the first one if both are), sign included; fabs clears the sign.  gfx950 generates the positive NaN.  The
+// iteration of riemanncg up to `ustar` runs on XD (non-default solver: the cost is beside the point), so that the sign of a
+// NaN `ustar` is the host's in the cases met so far: born in the fall-back formula (negative), or born in the iteration
+// behind an fabs (positive: found by the round-2 campaign, tools/fuzz_case_faces.py).
+// ---------------------------------------------------------------------------------------
+struct XD {
+    double v;
+    __device__ __forceinline__ XD() : v(0.0) {}
+    __device__ __forceinline__ XD(double x) : v(x) {}
+};
+__device__ __forceinline__ double x86_nan(double a, double b)
+{
+    return (a != a) ? a : ((b != b) ? b : __longlong_as_double((long long)0xFFF8000000000000ULL));
+}
+__device__ __forceinline__ XD operator+(XD a, XD b) { const double r = a.v + b.v; return XD((r != r) ? x86_nan(a.v, b.v) : r); }
+__device__ __forceinline__ XD operator-(XD a, XD b) { const double r = a.v - b.v; return XD((r != r) ? x86_nan(a.v, b.v) : r); }
+__device__ __forceinline__ XD operator*(XD a, XD b) { const double r = a.v * b.v; return XD((r != r) ? x86_nan(a.v, b.v) : r); }
+__device__ __forceinline__ XD operator/(XD a, XD b) { const double r = a.v / b.v; return XD((r != r) ? x86_nan(a.v, b.v) : r); }
+__device__ __forceinline__ bool operator<(XD a, XD b) { return a.v < b.v; }
+__device__ __forceinline__ bool operator<=(XD a, XD b) { return a.v <= b.v; }
+__device__ __forceinline__ bool operator==(XD a, XD b) { return a.v == b.v; }
+__device__ __forceinline__ XD amin(XD a, XD b) { return (b < a) ? b : a; }
+__device__ __forceinline__ XD amax(XD a, XD b) { return (a < b) ? b : a; }
+__device__ __forceinline__ XD xabs(XD a) { return XD(fabs(a.v)); }                 // andpd: the sign bit goes, NaN or not
+__device__ __forceinline__ XD xsqrt(XD a) { const double r = sqrt(a.v); return XD((r != r) ? x86_nan(a.v, a.v) : r); }
+__device__ __forceinline__ double xabs(double a) { return fabs(a); }
+__device__ __forceinline__ double xsqrt(double a) { return sqrt(a); }
+
+// riemann_solvers.H:125-160 on T = double or XD
+template <class T>
+__device__ __forceinline__ void wsqge_t(T p, T v, T gam, T gdot, T& gstar, T gmin, T gmax, T csq, T pstar, T& wsq)
+{
+    const T smlp1(1.e-10), one(1.0), half(0.5), zero(0.0);
+    gstar = (pstar - p) * gdot / (pstar + p) + gam;
+    gstar = amax(gmin, amin(gmax, gstar));
+
+    T alpha = pstar - (gstar - one) * p / (gam - one);
+    if (alpha == zero) {
+        alpha = smlp1 * (pstar + p);
+    }
+
+    T beta = pstar + half * (gstar - one) * (pstar + p);
+
+    wsq = (pstar - p) * beta / (v * alpha);
+
+    if (xabs(pstar - p) < smlp1 * (pstar + p)) {
+        wsq = csq;
+    }
+    wsq = amax(wsq, (half * (gam - one) / gam) * csq);
+}
+
 __device__ __forceinline__ void wsqge(double p, double v, double gam, double gdot, double& gstar,
                                       double gmin, double gmax, double csq, double pstar, double& wsq)
 {
@@ -643,111 +699,122 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     constexpr double smallu = 1.e-12;
     constexpr double small = 1.e-8;
 
-    double taul = 1.0 / ql.rho;
-    double taur = 1.0 / qr.rho;
+    // ---- up to `ustar` on XD: NaNs with the reference's (x86-64) signs, see XD above ----
+    const XD qlp(ql.p), qrp(qr.p), qlun(ql.un), qrun(qr.un), one(1.0), half(0.5), two(2.0);
+    const XD small_pres(P.small_pres), cavg(raux.cavg);
+    XD taul = one / XD(ql.rho);
+    XD taur = one / XD(qr.rho);
 
-    double clsql = ql.gamc * ql.p * ql.rho;
-    double clsqr = qr.gamc * qr.p * qr.rho;
+    XD clsql = XD(ql.gamc) * qlp * XD(ql.rho);
+    XD clsqr = XD(qr.gamc) * qrp * XD(qr.rho);
 
-    double gamel = ql.p / ql.rhoe + 1.0;
-    double gamer = qr.p / qr.rhoe + 1.0;
+    XD gamel = qlp / XD(ql.rhoe) + one;
+    XD gamer = qrp / XD(qr.rhoe) + one;
 
-    double gmin = amin(amin(gamel, gamer), 1.0);
-    double gmax = amax(amax(gamel, gamer), 2.0);
+    XD gmin = amin(amin(gamel, gamer), one);
+    XD gmax = amax(amax(gamel, gamer), two);
 
-    double game_bar = 0.5 * (gamel + gamer);
-    double gamc_bar = 0.5 * (ql.gamc + qr.gamc);
+    XD game_bar = half * (gamel + gamer);
+    XD gamc_bar = half * (XD(ql.gamc) + XD(qr.gamc));
 
-    double gdot = 2.0 * (1.0 - game_bar / gamc_bar) * (game_bar - 1.0);
+    XD gdot = two * (one - game_bar / gamc_bar) * (game_bar - one);
 
-    double wsmall = P.small_dens * raux.csmall;
-    double wl = amax(wsmall, sqrt(fabs(clsql)));
-    double wr = amax(wsmall, sqrt(fabs(clsqr)));
+    XD wsmall = XD(P.small_dens) * XD(raux.csmall);
+    XD wl = amax(wsmall, xsqrt(xabs(clsql)));
+    XD wr = amax(wsmall, xsqrt(xabs(clsqr)));
 
-    double pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
-    pstar = amax(pstar, P.small_pres);
+    XD pstar = qlp + ((qrp - qlp) - wr * (qrun - qlun)) * wl / (wl + wr);
+    pstar = amax(pstar, small_pres);
 
-    double gamstar = 0.0;
-    double wlsq = 0.0;
-    wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
-    double wrsq = 0.0;
-    wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
+    XD gamstar(0.0);
+    XD wlsq(0.0);
+    wsqge_t(qlp, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
+    XD wrsq(0.0);
+    wsqge_t(qrp, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
 
-    double pstar_old = pstar;
+    XD pstar_old = pstar;
 
-    wl = sqrt(wlsq);
-    wr = sqrt(wrsq);
+    wl = xsqrt(wlsq);
+    wr = xsqrt(wrsq);
 
-    double ustar_l = ql.un - (pstar - ql.p) / wl;
-    double ustar_r = qr.un + (pstar - qr.p) / wr;
+    XD ustar_l = qlun - (pstar - qlp) / wl;
+    XD ustar_r = qrun + (pstar - qrp) / wr;
 
-    pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
-    pstar = amax(pstar, P.small_pres);
+    pstar = qlp + ((qrp - qlp) - wr * (qrun - qlun)) * wl / (wl + wr);
+    pstar = amax(pstar, small_pres);
 
     bool converged = false;
     int iter = 0;
-    double hist_lo = 1.e200, hist_hi = -1.e200;          // over pstar_hist[cg_maxiter-6 .. cg_maxiter-1]
+    XD hist_lo(1.e200), hist_hi(-1.e200);          // over pstar_hist[cg_maxiter-6 .. cg_maxiter-1]
     while ((iter < P.cg_maxiter && !converged) || iter < 2) {
-        wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
-        wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
+        wsqge_t(qlp, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
+        wsqge_t(qrp, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
 
-        wl = 1.0 / sqrt(wlsq);
-        wr = 1.0 / sqrt(wrsq);
+        wl = one / xsqrt(wlsq);
+        wr = one / xsqrt(wrsq);
 
-        double ustar_r_old = ustar_r;
-        double ustar_l_old = ustar_l;
+        XD ustar_r_old = ustar_r;
+        XD ustar_l_old = ustar_l;
 
-        ustar_r = qr.un - (qr.p - pstar) * wr;
-        ustar_l = ql.un + (ql.p - pstar) * wl;
+        ustar_r = qrun - (qrp - pstar) * wr;
+        ustar_l = qlun + (qlp - pstar) * wl;
 
-        double dpditer = fabs(pstar_old - pstar);
+        XD dpditer = xabs(pstar_old - pstar);
 
-        double zp = fabs(ustar_l - ustar_l_old);
-        if (zp - weakwv * raux.cavg <= 0.0) zp = dpditer * wl;
+        XD zp = xabs(ustar_l - ustar_l_old);
+        if (zp - XD(weakwv) * cavg <= XD(0.0)) zp = dpditer * wl;
 
-        double zm = fabs(ustar_r - ustar_r_old);
-        if (zm - weakwv * raux.cavg <= 0.0) zm = dpditer * wr;
+        XD zm = xabs(ustar_r - ustar_r_old);
+        if (zm - XD(weakwv) * cavg <= XD(0.0)) zm = dpditer * wr;
 
-        double denom = dpditer / amax(zp + zm, small * raux.cavg);
+        XD denom = dpditer / amax(zp + zm, XD(small) * cavg);
         pstar_old = pstar;
         pstar = pstar - denom * (ustar_r - ustar_l);
-        pstar = amax(pstar, P.small_pres);
+        pstar = amax(pstar, small_pres);
 
-        double err = fabs(pstar - pstar_old);
-        if (err < P.cg_tol * pstar) converged = true;
+        XD err = xabs(pstar - pstar_old);
+        if (err < XD(P.cg_tol) * pstar) converged = true;
 
         if (iter >= P.cg_maxiter - 6) { hist_lo = amin(hist_lo, pstar); hist_hi = amax(hist_hi, pstar); }
         iter++;
     }
 
     if (!converged && P.cg_blend == 1) {
-        pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+        pstar = qlp + ((qrp - qlp) - wr * (qrun - qlun)) * wl / (wl + wr);
     } else if (!converged && P.cg_blend == 2) {
-        double pstarl = amax(hist_lo, P.small_pres);
-        double pstaru = amax(hist_hi, P.small_pres);
-        pstar_bisection(pstarl, pstaru, ql.un, ql.p, taul, gamel, clsql, qr.un, qr.p, taur, gamer, clsqr,
-                        gdot, gmin, gmax, P.cg_maxiter, P.cg_tol, pstar, gamstar, converged);
+        double pstarl = amax(hist_lo, small_pres).v;
+        double pstaru = amax(hist_hi, small_pres).v;
+        double pb = pstar.v, gb = gamstar.v;
+        pstar_bisection(pstarl, pstaru, ql.un, ql.p, taul.v, gamel.v, clsql.v, qr.un, qr.p, taur.v, gamer.v, clsqr.v,
+                        gdot.v, gmin.v, gmax.v, P.cg_maxiter, P.cg_tol, pb, gb, converged);
+        pstar = XD(pb);
+        gamstar = XD(gb);
     }
 
-    ustar_r = qr.un - (qr.p - pstar) * wr;
-    ustar_l = ql.un + (ql.p - pstar) * wl;
+    ustar_r = qrun - (qrp - pstar) * wr;
+    ustar_l = qlun + (qlp - pstar) * wl;
 
-    double ustar = 0.5 * (ustar_l + ustar_r);
+    // ---- from here on plain doubles: nothing below looks at the sign of a NaN except sgnm ----
+    double ustar = (half * (ustar_l + ustar_r)).v;
+    const double pstar_d = pstar.v;
+    double gamstar_d = gamstar.v;
+    const double taul_d = taul.v, taur_d = taur.v, gamel_d = gamel.v, gamer_d = gamer.v;
+    const double gdot_d = gdot.v, gmin_d = gmin.v, gmax_d = gmax.v;
 
     if (fabs(ustar) < smallu * 0.5 * (fabs(ql.un) + fabs(qr.un))) ustar = 0.0;
 
     double ro, uo, po, tauo, gamco, gameo;
     if (ustar > 0.0) {
-        ro = ql.rho; uo = ql.un; po = ql.p; tauo = taul; gamco = ql.gamc; gameo = gamel;
+        ro = ql.rho; uo = ql.un; po = ql.p; tauo = taul_d; gamco = ql.gamc; gameo = gamel_d;
     } else if (ustar < 0.0) {
-        ro = qr.rho; uo = qr.un; po = qr.p; tauo = taur; gamco = qr.gamc; gameo = gamer;
+        ro = qr.rho; uo = qr.un; po = qr.p; tauo = taur_d; gamco = qr.gamc; gameo = gamer_d;
     } else {
         ro = 0.5 * (ql.rho + qr.rho);
         uo = 0.5 * (ql.un + qr.un);
         po = 0.5 * (ql.p + qr.p);
-        tauo = 0.5 * (taul + taur);
+        tauo = 0.5 * (taul_d + taur_d);
         gamco = 0.5 * (ql.gamc + qr.gamc);
-        gameo = 0.5 * (gamel + gamer);
+        gameo = 0.5 * (gamel_d + gamer_d);
     }
 
     ro = amax(P.small_dens, 1.0 / tauo);
@@ -758,18 +825,18 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     double clsq = (co * ro) * (co * ro);
 
     double wosq = 0.0;
-    wsqge(po, tauo, gameo, gdot, gamstar, gmin, gmax, clsq, pstar, wosq);
+    wsqge(po, tauo, gameo, gdot_d, gamstar_d, gmin_d, gmax_d, clsq, pstar_d, wosq);
 
-    double sgnm = sign_of(ustar);
+    double sgnm = copysign(1.0, ustar);
 
     double wo = sqrt(wosq);
-    double dpjmp = pstar - po;
+    double dpjmp = pstar_d - po;
 
     double rstar = 1.0 - ro * dpjmp / wosq;
     rstar = ro / rstar;
     rstar = amax(P.small_dens, rstar);
 
-    double cstar = sqrt(fabs(gamco * pstar / rstar));
+    double cstar = sqrt(fabs(gamco * pstar_d / rstar));
     cstar = amax(cstar, raux.csmall);
 
     double spout = co - sgnm * uo;
@@ -777,7 +844,7 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
 
     double ushock = wo * tauo - sgnm * uo;
 
-    if (pstar - po >= 0.0) {
+    if (pstar_d - po >= 0.0) {
         spin = ushock;
         spout = ushock;
     }
@@ -795,14 +862,14 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
 
     qint.rho = frac * rstar + (1.0 - frac) * ro;
     qint.un = frac * ustar + (1.0 - frac) * uo;
-    qint.p = frac * pstar + (1.0 - frac) * po;
-    double game_int = frac * gamstar + (1.0 - frac) * gameo;
+    qint.p = frac * pstar_d + (1.0 - frac) * po;
+    double game_int = frac * gamstar_d + (1.0 - frac) * gameo;
 
     if (spout < 0.0) {
         qint.rho = ro; qint.un = uo; qint.p = po; game_int = gameo;
     }
     if (spin >= 0.0) {
-        qint.rho = rstar; qint.un = ustar; qint.p = pstar; game_int = gamstar;
+        qint.rho = rstar; qint.un = ustar; qint.p = pstar_d; game_int = gamstar_d;
     }
 
     qint.p = amax(qint.p, P.small_pres);

@@ -12,6 +12,8 @@
 #endif
 #include "ora_internal.h"
 
+
+
 static void box_grow(const int lo[3], const int hi[3], int gx, int gy, int gz, int olo[3], int ohi[3])
 {
     olo[0] = lo[0] - gx; olo[1] = lo[1] - gy; olo[2] = lo[2] - gz;

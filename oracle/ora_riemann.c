@@ -734,10 +734,17 @@ static void HLL(const double *ql, const double *qr, double cl, double cr, int id
 
 /* Castro::cmpflx_plus_godunov (riemann.cpp:15-206) with riemann_state
  * (riemann_solvers.H:1262-1388) inlined; store_full_state = false */
+/* debugging aid for the parity campaigns (tools/fuzz_case_faces.py): called at the start of every box-level Riemann solve with
+ * its input states, so that the solve can be repeated face by face on another implementation */
+typedef void (*ora_riemann_hook_t)(int idir, const int lo[3], const int hi[3], ora_a4 qm, ora_a4 qp, ora_a4 qaux, ora_a4 shk);
+static ora_riemann_hook_t ora_riemann_hook = 0;
+void ora_set_debug_riemann_hook(ora_riemann_hook_t f) { ora_riemann_hook = f; }
+
 void ora_cmpflx_plus_godunov(const int lo[3], const int hi[3], ora_a4 qm, ora_a4 qp, ora_a4 flx,
                              ora_a4 qgdnv, ora_a4 qaux, ora_a4 shk, int idir,
                              const ora_geom *G, const ora_params *P)
 {
+    if (ora_riemann_hook) ora_riemann_hook(idir, lo, hi, qm, qp, qaux, shk);
     const int special_bnd_lo = (G->lo_bc[idir] == BC_SYMMETRY || G->lo_bc[idir] == BC_SLIPWALL ||
                                 G->lo_bc[idir] == BC_NOSLIPWALL);
     const int special_bnd_hi = (G->hi_bc[idir] == BC_SYMMETRY || G->hi_bc[idir] == BC_SLIPWALL ||

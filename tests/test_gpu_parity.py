@@ -2011,6 +2011,28 @@ def test_derived_fields_on_the_device_match_the_reference_functions(hip):
     assert red[0].item() == float(V["out:derive.estdt"][0])
 
 
+def test_cg_nan_born_behind_an_fabs_takes_the_host_branch(hip, oracle):
+    """fuzz_parity.py 16000 411, case 15219 (round 2): a z face whose right state has p / (rho e) below one ulp, so
+    gamma_e - 1 == 0 there, the Colella-Glaz iteration runs into inf - inf BEHIND an fabs and ends in a NaN with the sign bit
+    CLEAR on x86-64 (a NaN straight out of an invalid operation has it set).  copysign(1.0, ustar) is then +1, spout < 0, and
+    the reference's CPU build returns the finite averaged state.  The device runs the iteration on a double that keeps the
+    host's NaN signs (hydro_device.h: XD) and must return the same finite state, bit for bit."""
+    import torch
+    import castro_amd
+    h = float.fromhex
+    qm = np.array([[h(x)] for x in ("0x1.f09c77c418f95p-1", "0x1.689b9f771c1b2p+0", "0x1.ba0613b4802a8p-7", "0x1.dbdb38f508301p-1",
+                                    "0x1.87d691c7a1f54p-9", "0x1.f2342b25270d0p-8", "0x1.ffc681ffb11d7p-1")])
+    qp = np.array([[h(x)] for x in ("0x1.f291ce84edb45p-1", "0x1.753fc8bafb077p+0", "0x1.af26675d6cf08p-4", "0x1.ca46848c45296p-1",
+                                    "0x1.a36e2eb1c432dp-75", "0x1.f2a1eb46e88ecp-8", "0x1.fff4c9ffbd5f7p-1")])
+    cl, cr = np.array([h("0x1.10eceb8f88a52p-4")]), np.array([h("0x1.0eed7bcc4ade7p-4")])
+    pkw = dict(riemann_solver=1, cg_blend=1, small_dens=0.05)
+    want = oracle.cmpflx_points(2, qm, qp, cl, cr, None, oracle.default_params(**pkw))
+    got = hip.cmpflx_points(2, _to_dev(hip, qm), _to_dev(hip, qp), _to_dev(hip, cl), _to_dev(hip, cr),
+                            castro_amd.default_params(**pkw)).cpu().numpy()
+    assert np.isfinite(want).all() and want[10, 0] == 0.5 * (qm[4, 0] + qp[4, 0])        # the averaged state's pressure
+    assert np.array_equal(got, want)
+
+
 def test_device_functions_reproduce_the_stub_probe_vectors(hip):
     """tests/golden/stub_probe/vectors.npz (outputs of the reference's own ppm_reconstruct / ppm_int_profile, uflatten,
     cmpflx_plus_godunov, actual_trans_single / actual_trans_final, compiled unmodified against stand-in headers:
