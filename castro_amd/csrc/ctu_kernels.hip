@@ -36,6 +36,14 @@
 #include "hydro_device.h"
 #include "ctu_kernels.h"
 
+// the Colella-Glaz instantiations (GEN == 2) carry the out-of-line NaN-sign fall-back (hydro_device.h: XD), whose call
+// frame would push them past 256 VGPRs to one wave per SIMD; held at two waves the overflow is spilled around the call only
+// (Sedov 256^3, riemann_solver = 1: k_trans1 18.6 -> see DESIGN.md section 9)
+#ifndef CG_ONE_WAVE
+#define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : 1, GEN == 2 ? 2 : 8)))
+#else
+#define CG_TWO_WAVES
+#endif
 namespace cad {
 
 // ---------------------------------------------------------------------------------------
@@ -1166,7 +1174,7 @@ __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsi
 // TFIX: castro.ppm_temp_fix = 2 -- the EOS fix of riemann_state on the two input states (the reference changes them
 // in place; here the stored states stay as traced and every later reader applies the fix where the reference's
 // order of operations has it: see trans1_body / final_body)
-template <int D, bool TFIX = false>
+template <int D, bool TFIX = false, int GEN = 2>
 __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
                                                   DevGeom g, DevParams P)
 {
@@ -1194,7 +1202,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
         rstate_from_edge<D>(qm[w], P.gamma, ql, Xl);
         rstate_from_edge<D>(qp[w], P.gamma, qr, Xr);
         const int idx = (D == 0) ? i + w : (D == 1) ? j : k;
-        interface_flux<D>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<D>(g, idx),
+        interface_flux<D, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<D>(g, idx),
                           face_shock(S, P, c + 8u * w, sd), P, f[w]);
     }
     store_f1_2<D>(S.F1[D], t.NC, c, f, true, v1, S.F1E[D]);
@@ -1339,7 +1347,7 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 #ifndef TRACE_SPLIT_WAVES
 #define TRACE_SPLIT_WAVES 2
 #endif
-template <bool XRIEM, int DMASK = 7>
+template <bool XRIEM, int DMASK = 7, int GEN = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : 2)))
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P, SkipBox skip)
@@ -1432,10 +1440,10 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             double Xl, Xr;
             rstate_from_edge<0>(qmL, P.gamma, ql, Xl);
             rstate_from_edge<0>(qp[0], P.gamma, qr, Xr);
-            interface_flux<0>(ql, qr, Xl, Xr, cm1, cc01.a, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f[0]);
+            interface_flux<0, GEN>(ql, qr, Xl, Xr, cm1, cc01.a, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f[0]);
             rstate_from_edge<0>(qm[0], P.gamma, ql, Xl);
             rstate_from_edge<0>(qp[1], P.gamma, qr, Xr);
-            interface_flux<0>(ql, qr, Xl, Xr, cc01.a, cc01.b, wall_fac<0>(g, i + 1), face_shock(S, P, c + 8u, 8u), P, f[1]);
+            interface_flux<0, GEN>(ql, qr, Xl, Xr, cc01.a, cc01.b, wall_fac<0>(g, i + 1), face_shock(S, P, c + 8u, 8u), P, f[1]);
             store_f1_2<0>(S.F1[0], NC, c, f, mA, mB, S.F1E[0]);
         }
     }
@@ -1459,6 +1467,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
 }
 
 // the x-faces k_trace_pair leaves out: face i of the first thread of every workgroup of that launch
+template <int GEN = 2>
 __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
                                                              DevGeom g, DevParams P)
 {
@@ -1475,13 +1484,13 @@ __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, c
     const double cl = ldg(Q + PC * t.NC, c - 8u);
     const double cr = ldg(Q + PC * t.NC, c);
     IFlux f;
-    interface_flux<0>(ql, qr, Xl, Xr, cl, cr, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f);
+    interface_flux<0, GEN>(ql, qr, Xl, Xr, cl, cr, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f);
     store_f1<0>(S.F1[0], t.NC, c, f, S.F1E[0]);
 }
 
 
 
-template <int N, int T, bool RE>
+template <int N, int T, bool RE, int GEN = 2>
 __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, unsigned c, unsigned sn, unsigned st,
                                             const double qm[2][NEDGE], const double qp[2][NEDGE],
                                             const D2& cl, const D2& cr, const double bnd_fac[2], double cdtdx,
@@ -1547,7 +1556,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
         double Xl, Xr;
         rstate_from_edge<N>(qmo[w], P.gamma, ql, Xl);
         rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
-        interface_flux<N>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
+        interface_flux<N, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
 #endif
     }
@@ -1558,7 +1567,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 }
 
 // one normal direction of the transverse stage for the faces (ijk) and (ijk + x) -- `v1`: the second face exists
-template <int N, bool RE>
+template <int N, bool RE, int GEN = 2>
 __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], bool v1, unsigned c,
                                             const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                             double cdtdx_t1, double cdtdx_t2, const DevParams& P)
@@ -1613,36 +1622,36 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
             for (int n = 0; n < NEDGE; ++n) { qmf[w][n] = qm[w][n]; qpf[w][n] = qp[w][n]; }
             temp_fix_edge(qmf[w], P); temp_fix_edge(qpf[w], P);
         }
-        if (any1) trans1_pair<N, T1, RE>(t, S, c, sn, dstr(s, T1), (N < T1) ? qmf : qm, (N < T1) ? qpf : qp, cl, cr, bnd_fac,
+        if (any1) trans1_pair<N, T1, RE, GEN>(t, S, c, sn, dstr(s, T1), (N < T1) ? qmf : qm, (N < T1) ? qpf : qp, cl, cr, bnd_fac,
                                          cdtdx_t1, in_t1[0], in_t1[1], P);
-        if (any2) trans1_pair<N, T2, RE>(t, S, c, sn, dstr(s, T2), (N < T2) ? qmf : qm, (N < T2) ? qpf : qp, cl, cr, bnd_fac,
+        if (any2) trans1_pair<N, T2, RE, GEN>(t, S, c, sn, dstr(s, T2), (N < T2) ? qmf : qm, (N < T2) ? qpf : qp, cl, cr, bnd_fac,
                                          cdtdx_t2, in_t2[0], in_t2[1], P);
         return;
     }
-    if (any1) trans1_pair<N, T1, RE>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, in_t1[0], in_t1[1], P);
-    if (any2) trans1_pair<N, T2, RE>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
+    if (any1) trans1_pair<N, T1, RE, GEN>(t, S, c, sn, dstr(s, T1), qm, qp, cl, cr, bnd_fac, cdtdx_t1, in_t1[0], in_t1[1], P);
+    if (any2) trans1_pair<N, T2, RE, GEN>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
 }
 
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one
 // kernel instead of two (F1[T] serves the two N != T), the other reads hit in L2.
-template <bool RE, int NMASK = 7>
-__global__ void __launch_bounds__(256) k_trans1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+template <bool RE, int NMASK = 7, int GEN = 2>
+__global__ void __launch_bounds__(256) CG_TWO_WAVES k_trans1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                 double cdtdx, double cdtdy, double cdtdz, DevParams P)
 {
     int ijk[3];
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second zone of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    if (NMASK & 1) trans1_body<0, RE>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
-    if (NMASK & 2) trans1_body<1, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdz, P);
-    if (NMASK & 4) trans1_body<2, RE>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdy, P);
+    if (NMASK & 1) trans1_body<0, RE, GEN>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
+    if (NMASK & 2) trans1_body<1, RE, GEN>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdz, P);
+    if (NMASK & 4) trans1_body<2, RE, GEN>(t, ijk, v1, c, Q, S, g, cdtdx, cdtdy, P);
 }
 
 // one normal direction of the final stage for the faces (ijk) and (ijk + x); v0 / v1: the faces belong to
 // nodal(bx, N)
 // c0 / c1: compute face 0 / 1 of the pair; v0 / v1: store its outputs (fluxes, mass_fluxes, qe and, with STORE_FL, the
 // record for consup).  R returns the records of both faces.
-template <int N, bool RE, bool LIM, bool STORE_FL = true>
+template <int N, bool RE, bool LIM, bool STORE_FL = true, int GEN = 2>
 __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool v0, bool v1, unsigned c,
                                            const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                            const DFab& U, const DFab& fluxes, const DFab& mass, const DFab& qe,
@@ -1724,7 +1733,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
         rstate_from_edge<N>(ql[w], P.gamma, rl, Xl);
         rstate_from_edge<N>(qr[w], P.gamma, rr, Xr);
         const int idxN = (N == 0) ? ijk[0] + w : ijk[N];
-        interface_flux<N>(rl, rr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
+        interface_flux<N, GEN>(rl, rr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
     }
     final_flux_tail<N, LIM>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
@@ -1745,8 +1754,8 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 
 // One launch per normal direction.  (All three in one launch, which fetches Sborder and div(u) once instead of
 // three times, measured slower: 5.0 vs 4.6 ms at 256^3 -- ~150 concurrent streams per workgroup.)
-template <int N, bool RE, bool LIM>
-__global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+template <int N, bool RE, bool LIM, int GEN = 2>
+__global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
                                                int acc_hi, int assign, DevParams P)
@@ -1756,7 +1765,7 @@ __global__ void __launch_bounds__(256) k_final(Tile t, LinBox b, const double* _
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     double R[2][NFIN];
-    final_body<N, RE, LIM>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R);
+    final_body<N, RE, LIM, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2009,8 +2018,8 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 // ---------------------------------------------------------------------------------------
 struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; };
 
-template <bool LIM, bool CLEAN>
-__global__ void __launch_bounds__(256) k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+template <bool LIM, bool CLEAN, int GEN = 2>
+__global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                        DFab U, DFab fluxes, DFab mass, DFab qe, DFab Unew,
                                                        double hdtdy, double hdtdz, double dt,
                                                        double area0, double area1, double area2, double vol,
@@ -2049,7 +2058,7 @@ __global__ void __launch_bounds__(256) k_finalx_consup(Tile t, XRows b, const do
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
 
     double R[2][NFIN];
-    final_body<0, false, LIM, false>(t, ijk, owner && f0, owner && f1, c, Q, S, g, U, fluxes, mass, qe, hdtdy, hdtdz, dt,
+    final_body<0, false, LIM, false, GEN>(t, ijk, owner && f0, owner && f1, c, Q, S, g, U, fluxes, mass, qe, hdtdy, hdtdz, dt,
                                      area0, g.dx[0], acc_hi, assign, P, R);
     double Rn[NFIN];                                   // face i+2
 #pragma unroll
@@ -2301,6 +2310,20 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         }                                                                                    \
     } while (0)
 
+#define K_R1_0(V) (k_riemann1<0, false, V>)
+#define K_R1_1(V) (k_riemann1<1, false, V>)
+#define K_R1_2(V) (k_riemann1<2, false, V>)
+#define K_T1(V) (k_trans1<false, 7, V>)
+#define K_FY(V) (k_final<1, false, false, V>)
+#define K_FZ(V) (k_final<2, false, false, V>)
+// the instantiation of a kernel template for `solv` (see interface_flux): KERN(2), KERN(1) or KERN(0)
+#define KL2_SOLV(name, KERN, lo, hi, ...)                                                    \
+    do {                                                                                     \
+        if (solv == 2) KL2(name, KERN(2), lo, hi, __VA_ARGS__);                              \
+        else if (solv == 1) KL2(name, KERN(1), lo, hi, __VA_ARGS__);                         \
+        else KL2(name, KERN(0), lo, hi, __VA_ARGS__);                                        \
+    } while (0)
+
 #define KL(name, kern, lo, hi, ...)                                                          \
     do {                                                                                     \
         long n_;                                                                             \
@@ -2394,6 +2417,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     const bool tfix = P.ppm_temp_fix == 2 && P.riemann_solver != 2;
     // hybrid_riemann = 1: the fused x solve of stage A would read the shock flags, which k_divu writes in stage B
     const bool splittable = !Src.p && P.ppm_type == 1 && !tfix && P.hybrid_riemann != 1;
+    // which solvers the kernels of the default-option path contain (interface_flux<D, SOLV>): 0 default only, 1 all but CG, 2 all
+    const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1) ? 1 : 0);
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
     const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
     SkipBox valid_box, inner_box;
@@ -2426,12 +2451,17 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             KL2("k_trace_yz", (k_trace_pair<false, 6>), lo, hi, S.Q, S, g, dt, P, none);
         } else
 #endif
-        { KL2("k_trace", k_trace_pair<true>, lo, hi, S.Q, S, g, dt, P, none); }
+        {
+#define K_(V) (k_trace_pair<true, 7, V>)
+            KL2_SOLV("k_trace", K_, lo, hi, S.Q, S, g, dt, P, none);
+#undef K_
+        }
         long n_;
         LinBox b_ = linbox2(lo, hi, n_);
         if (n_ > 0) {
             prof_begin(prof, "k_riemann1_blockstart", stream);
-            hipLaunchKernelGGL(k_riemann1_blockstart, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
+            auto kbs = solv == 2 ? k_riemann1_blockstart<2> : solv == 1 ? k_riemann1_blockstart<1> : k_riemann1_blockstart<0>;
+            hipLaunchKernelGGL(kbs, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
             prof_end(prof, stream);
         }
     };
@@ -2481,7 +2511,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                 for (int side = 0; side < 2; ++side) {
                     const int xf = side ? inner_box.hi[0] + 1 : inner_box.lo[0];
                     const int plo[3] = { xf, inner_box.lo[1], inner_box.lo[2] }, phi[3] = { xf, inner_box.hi[1], inner_box.hi[2] };
-                    KL2("k_riemann1", k_riemann1<0>, plo, phi, S.Q, S, g, P);
+                    KL2_SOLV("k_riemann1", K_R1_0, plo, phi, S.Q, S, g, P);
                 }
             } else {
                 trace_with_xriemann(olo, ohi);
@@ -2498,9 +2528,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         KL2("k_riemann1", (k_riemann1<1, true>), flo[1], fhi[1], S.Q, S, g, P);
         KL2("k_riemann1", (k_riemann1<2, true>), flo[2], fhi[2], S.Q, S, g, P);
     } else {
-        if (!x_done) KL2("k_riemann1", k_riemann1<0>, flo[0], fhi[0], S.Q, S, g, P);
-        KL2("k_riemann1", k_riemann1<1>, flo[1], fhi[1], S.Q, S, g, P);
-        KL2("k_riemann1", k_riemann1<2>, flo[2], fhi[2], S.Q, S, g, P);
+        if (!x_done) KL2_SOLV("k_riemann1", K_R1_0, flo[0], fhi[0], S.Q, S, g, P);
+        KL2_SOLV("k_riemann1", K_R1_1, flo[1], fhi[1], S.Q, S, g, P);
+        KL2_SOLV("k_riemann1", K_R1_2, flo[2], fhi[2], S.Q, S, g, P);
     }
 
     // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690); hdtdx = 0.5*dt/dx (:684-686)
@@ -2546,15 +2576,15 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         KL2("k_trans1_y", (k_trans1<false, 2>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
         KL2("k_trans1_z", (k_trans1<false, 4>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
 #else
-        KL2("k_trans1", k_trans1<false>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+        KL2_SOLV("k_trans1", K_T1, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
 #endif
         if (g_fuse_consup == 2) {
         } else if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
         } else {
-            KL2("k_final_y", (k_final<1, false, false>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
-            KL2("k_final_z", (k_final<2, false, false>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+            KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
+            KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
         }
         if (g_fuse_consup == 2) {
             // k_final<y> (writes FL[y]), then the z and x faces and the conservative update marching along z
@@ -2593,12 +2623,21 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         xr.nb = ((unsigned)((waves + 3) / 4) + 7u) & ~7u;
         const double vol_ = g.dx[0] * g.dx[1] * g.dx[2];
         prof_begin(prof, "k_finalx_consup", stream);
-#define FXC(LIM, CLEAN, nt, rd)                                                                                         \
-        hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN>), dim3(xr.nb), dim3(256), 0, stream, t, xr, S.Q, S, g, Sborder,      \
+#define FXC(LIM, CLEAN, GENF, nt, rd)                                                                                        \
+        hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN, GENF>), dim3(xr.nb), dim3(256), 0, stream, t, xr, S.Q, S, g, Sborder,      \
                            fluxes[0], mass[0], qe[0], Snew, hdtdy, hdtdz, dt, area0, area1, area2, vol_, acc_hi[0],      \
                            (flags & 2) ? 1 : 0, (flags & 1) ? 1 : 0, P, nt, rd)
-        if (clean_ntimes > 0) { if (lim) FXC(true, true, clean_ntimes, red); else FXC(false, true, clean_ntimes, red); }
-        else { if (lim) FXC(true, false, 0, (double*)nullptr); else FXC(false, false, 0, (double*)nullptr); }
+        if (clean_ntimes > 0) {
+            if (lim) FXC(true, true, 2, clean_ntimes, red);
+            else if (solv == 2) FXC(false, true, 2, clean_ntimes, red);
+            else if (solv == 1) FXC(false, true, 1, clean_ntimes, red);
+            else FXC(false, true, 0, clean_ntimes, red);
+        } else {
+            if (lim) FXC(true, false, 2, 0, (double*)nullptr);
+            else if (solv == 2) FXC(false, false, 2, 0, (double*)nullptr);
+            else if (solv == 1) FXC(false, false, 1, 0, (double*)nullptr);
+            else FXC(false, false, 0, 0, (double*)nullptr);
+        }
 #undef FXC
         prof_end(prof, stream);
         return hipGetLastError() == hipSuccess ? 0 : -4;

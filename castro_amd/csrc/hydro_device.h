@@ -692,34 +692,48 @@ __device__ __forceinline__ void pstar_bisection(double pstar_lo, double pstar_hi
 // riemann_solvers.H:225-581 -- Colella & Glaz (riemann_solver = 1) with the CPU path's handling of non-convergence:
 // cg_blend = 1 falls back to the two-shock guess, cg_blend = 2 bisects between the extremes of the last six iterates
 // (only their minimum and maximum are kept, not the whole pstar history)
-__device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, const RAux& raux,
-                                          RState& qint, const DevParams& P)
+// The sign x86-64 gives a NaN `ustar` of riemanncg: the iteration repeated on XD.  Out of line and called only for a NaN
+// ustar, so the Colella-Glaz kernels keep the register footprint of the plain iteration; scalars by value: a reference
+// argument would pin the caller's states in scratch memory for the whole solve.
+#ifdef CG_NAN_SIGN_INLINE
+__device__ __forceinline__
+#elif defined(CG_NAN_SIGN_COLD)
+__device__ __noinline__ __attribute__((cold))
+#else
+__device__ __noinline__
+#endif
+double riemanncg_nan_sign_x86(double ql_rho, double ql_un, double ql_p, double ql_rhoe, double ql_gamc,
+                              double qr_rho, double qr_un, double qr_p, double qr_rhoe, double qr_gamc,
+                              double csmall, double cavg_, double small_dens, double small_pres_, double cg_tol,
+                              int cg_maxiter, int cg_blend)
 {
+#ifdef CG_NAN_SIGN_STUB     // timing diagnostic
+    return -1.0;
+#endif
     constexpr double weakwv = 1.e-3;
-    constexpr double smallu = 1.e-12;
     constexpr double small = 1.e-8;
 
     // ---- up to `ustar` on XD: NaNs with the reference's (x86-64) signs, see XD above ----
-    const XD qlp(ql.p), qrp(qr.p), qlun(ql.un), qrun(qr.un), one(1.0), half(0.5), two(2.0);
-    const XD small_pres(P.small_pres), cavg(raux.cavg);
-    XD taul = one / XD(ql.rho);
-    XD taur = one / XD(qr.rho);
+    const XD qlp(ql_p), qrp(qr_p), qlun(ql_un), qrun(qr_un), one(1.0), half(0.5), two(2.0);
+    const XD small_pres(small_pres_), cavg(cavg_);
+    XD taul = one / XD(ql_rho);
+    XD taur = one / XD(qr_rho);
 
-    XD clsql = XD(ql.gamc) * qlp * XD(ql.rho);
-    XD clsqr = XD(qr.gamc) * qrp * XD(qr.rho);
+    XD clsql = XD(ql_gamc) * qlp * XD(ql_rho);
+    XD clsqr = XD(qr_gamc) * qrp * XD(qr_rho);
 
-    XD gamel = qlp / XD(ql.rhoe) + one;
-    XD gamer = qrp / XD(qr.rhoe) + one;
+    XD gamel = qlp / XD(ql_rhoe) + one;
+    XD gamer = qrp / XD(qr_rhoe) + one;
 
     XD gmin = amin(amin(gamel, gamer), one);
     XD gmax = amax(amax(gamel, gamer), two);
 
     XD game_bar = half * (gamel + gamer);
-    XD gamc_bar = half * (XD(ql.gamc) + XD(qr.gamc));
+    XD gamc_bar = half * (XD(ql_gamc) + XD(qr_gamc));
 
     XD gdot = two * (one - game_bar / gamc_bar) * (game_bar - one);
 
-    XD wsmall = XD(P.small_dens) * XD(raux.csmall);
+    XD wsmall = XD(small_dens) * XD(csmall);
     XD wl = amax(wsmall, xsqrt(xabs(clsql)));
     XD wr = amax(wsmall, xsqrt(xabs(clsqr)));
 
@@ -746,7 +760,7 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     bool converged = false;
     int iter = 0;
     XD hist_lo(1.e200), hist_hi(-1.e200);          // over pstar_hist[cg_maxiter-6 .. cg_maxiter-1]
-    while ((iter < P.cg_maxiter && !converged) || iter < 2) {
+    while ((iter < cg_maxiter && !converged) || iter < 2) {
         wsqge_t(qlp, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
         wsqge_t(qrp, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
 
@@ -773,20 +787,20 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
         pstar = amax(pstar, small_pres);
 
         XD err = xabs(pstar - pstar_old);
-        if (err < XD(P.cg_tol) * pstar) converged = true;
+        if (err < XD(cg_tol) * pstar) converged = true;
 
-        if (iter >= P.cg_maxiter - 6) { hist_lo = amin(hist_lo, pstar); hist_hi = amax(hist_hi, pstar); }
+        if (iter >= cg_maxiter - 6) { hist_lo = amin(hist_lo, pstar); hist_hi = amax(hist_hi, pstar); }
         iter++;
     }
 
-    if (!converged && P.cg_blend == 1) {
+    if (!converged && cg_blend == 1) {
         pstar = qlp + ((qrp - qlp) - wr * (qrun - qlun)) * wl / (wl + wr);
-    } else if (!converged && P.cg_blend == 2) {
+    } else if (!converged && cg_blend == 2) {
         double pstarl = amax(hist_lo, small_pres).v;
         double pstaru = amax(hist_hi, small_pres).v;
         double pb = pstar.v, gb = gamstar.v;
-        pstar_bisection(pstarl, pstaru, ql.un, ql.p, taul.v, gamel.v, clsql.v, qr.un, qr.p, taur.v, gamer.v, clsqr.v,
-                        gdot.v, gmin.v, gmax.v, P.cg_maxiter, P.cg_tol, pb, gb, converged);
+        pstar_bisection(pstarl, pstaru, ql_un, ql_p, taul.v, gamel.v, clsql.v, qr_un, qr_p, taur.v, gamer.v, clsqr.v,
+                        gdot.v, gmin.v, gmax.v, cg_maxiter, cg_tol, pb, gb, converged);
         pstar = XD(pb);
         gamstar = XD(gb);
     }
@@ -794,27 +808,121 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     ustar_r = qrun - (qrp - pstar) * wr;
     ustar_l = qlun + (qlp - pstar) * wl;
 
-    // ---- from here on plain doubles: nothing below looks at the sign of a NaN except sgnm ----
-    double ustar = (half * (ustar_l + ustar_r)).v;
-    const double pstar_d = pstar.v;
-    double gamstar_d = gamstar.v;
-    const double taul_d = taul.v, taur_d = taur.v, gamel_d = gamel.v, gamer_d = gamer.v;
-    const double gdot_d = gdot.v, gmin_d = gmin.v, gmax_d = gmax.v;
+    return copysign(1.0, (half * (ustar_l + ustar_r)).v);
+}
+
+__device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, const RAux& raux,
+                                          RState& qint, const DevParams& P)
+{
+    constexpr double weakwv = 1.e-3;
+    constexpr double smallu = 1.e-12;
+    constexpr double small = 1.e-8;
+
+    double taul = 1.0 / ql.rho;
+    double taur = 1.0 / qr.rho;
+
+    double clsql = ql.gamc * ql.p * ql.rho;
+    double clsqr = qr.gamc * qr.p * qr.rho;
+
+    double gamel = ql.p / ql.rhoe + 1.0;
+    double gamer = qr.p / qr.rhoe + 1.0;
+
+    double gmin = amin(amin(gamel, gamer), 1.0);
+    double gmax = amax(amax(gamel, gamer), 2.0);
+
+    double game_bar = 0.5 * (gamel + gamer);
+    double gamc_bar = 0.5 * (ql.gamc + qr.gamc);
+
+    double gdot = 2.0 * (1.0 - game_bar / gamc_bar) * (game_bar - 1.0);
+
+    double wsmall = P.small_dens * raux.csmall;
+    double wl = amax(wsmall, sqrt(fabs(clsql)));
+    double wr = amax(wsmall, sqrt(fabs(clsqr)));
+
+    double pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    pstar = amax(pstar, P.small_pres);
+
+    double gamstar = 0.0;
+    double wlsq = 0.0;
+    wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
+    double wrsq = 0.0;
+    wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
+
+    double pstar_old = pstar;
+
+    wl = sqrt(wlsq);
+    wr = sqrt(wrsq);
+
+    double ustar_l = ql.un - (pstar - ql.p) / wl;
+    double ustar_r = qr.un + (pstar - qr.p) / wr;
+
+    pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    pstar = amax(pstar, P.small_pres);
+
+    bool converged = false;
+    int iter = 0;
+    double hist_lo = 1.e200, hist_hi = -1.e200;          // over pstar_hist[cg_maxiter-6 .. cg_maxiter-1]
+    while ((iter < P.cg_maxiter && !converged) || iter < 2) {
+        wsqge(ql.p, taul, gamel, gdot, gamstar, gmin, gmax, clsql, pstar, wlsq);
+        wsqge(qr.p, taur, gamer, gdot, gamstar, gmin, gmax, clsqr, pstar, wrsq);
+
+        wl = 1.0 / sqrt(wlsq);
+        wr = 1.0 / sqrt(wrsq);
+
+        double ustar_r_old = ustar_r;
+        double ustar_l_old = ustar_l;
+
+        ustar_r = qr.un - (qr.p - pstar) * wr;
+        ustar_l = ql.un + (ql.p - pstar) * wl;
+
+        double dpditer = fabs(pstar_old - pstar);
+
+        double zp = fabs(ustar_l - ustar_l_old);
+        if (zp - weakwv * raux.cavg <= 0.0) zp = dpditer * wl;
+
+        double zm = fabs(ustar_r - ustar_r_old);
+        if (zm - weakwv * raux.cavg <= 0.0) zm = dpditer * wr;
+
+        double denom = dpditer / amax(zp + zm, small * raux.cavg);
+        pstar_old = pstar;
+        pstar = pstar - denom * (ustar_r - ustar_l);
+        pstar = amax(pstar, P.small_pres);
+
+        double err = fabs(pstar - pstar_old);
+        if (err < P.cg_tol * pstar) converged = true;
+
+        if (iter >= P.cg_maxiter - 6) { hist_lo = amin(hist_lo, pstar); hist_hi = amax(hist_hi, pstar); }
+        iter++;
+    }
+
+    if (!converged && P.cg_blend == 1) {
+        pstar = ql.p + ((qr.p - ql.p) - wr * (qr.un - ql.un)) * wl / (wl + wr);
+    } else if (!converged && P.cg_blend == 2) {
+        double pstarl = amax(hist_lo, P.small_pres);
+        double pstaru = amax(hist_hi, P.small_pres);
+        pstar_bisection(pstarl, pstaru, ql.un, ql.p, taul, gamel, clsql, qr.un, qr.p, taur, gamer, clsqr,
+                        gdot, gmin, gmax, P.cg_maxiter, P.cg_tol, pstar, gamstar, converged);
+    }
+
+    ustar_r = qr.un - (qr.p - pstar) * wr;
+    ustar_l = ql.un + (ql.p - pstar) * wl;
+
+    double ustar = 0.5 * (ustar_l + ustar_r);
 
     if (fabs(ustar) < smallu * 0.5 * (fabs(ql.un) + fabs(qr.un))) ustar = 0.0;
 
     double ro, uo, po, tauo, gamco, gameo;
     if (ustar > 0.0) {
-        ro = ql.rho; uo = ql.un; po = ql.p; tauo = taul_d; gamco = ql.gamc; gameo = gamel_d;
+        ro = ql.rho; uo = ql.un; po = ql.p; tauo = taul; gamco = ql.gamc; gameo = gamel;
     } else if (ustar < 0.0) {
-        ro = qr.rho; uo = qr.un; po = qr.p; tauo = taur_d; gamco = qr.gamc; gameo = gamer_d;
+        ro = qr.rho; uo = qr.un; po = qr.p; tauo = taur; gamco = qr.gamc; gameo = gamer;
     } else {
         ro = 0.5 * (ql.rho + qr.rho);
         uo = 0.5 * (ql.un + qr.un);
         po = 0.5 * (ql.p + qr.p);
-        tauo = 0.5 * (taul_d + taur_d);
+        tauo = 0.5 * (taul + taur);
         gamco = 0.5 * (ql.gamc + qr.gamc);
-        gameo = 0.5 * (gamel_d + gamer_d);
+        gameo = 0.5 * (gamel + gamer);
     }
 
     ro = amax(P.small_dens, 1.0 / tauo);
@@ -825,18 +933,28 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
     double clsq = (co * ro) * (co * ro);
 
     double wosq = 0.0;
-    wsqge(po, tauo, gameo, gdot_d, gamstar_d, gmin_d, gmax_d, clsq, pstar_d, wosq);
+    wsqge(po, tauo, gameo, gdot, gamstar, gmin, gmax, clsq, pstar, wosq);
 
+    // a NaN ustar: the sign the reference's x86-64 build would see (XD above), else the plain sign
+    // a NaN ustar: the sign the reference's x86-64 build would see (XD above), else the plain sign.  With a NaN among
+    // the inputs every output is a NaN whatever the sign: no need to ask.
     double sgnm = copysign(1.0, ustar);
+    if (ustar != ustar) {
+        const double chk = ((ql.rho + ql.un) + (ql.p + ql.rhoe)) + ((qr.rho + qr.un) + (qr.p + qr.rhoe));
+        sgnm = -1.0;
+        if (chk - chk == 0.0)        // all inputs finite
+            sgnm = riemanncg_nan_sign_x86(ql.rho, ql.un, ql.p, ql.rhoe, ql.gamc, qr.rho, qr.un, qr.p, qr.rhoe, qr.gamc, raux.csmall, raux.cavg,
+                                          P.small_dens, P.small_pres, P.cg_tol, P.cg_maxiter, P.cg_blend);
+    }
 
     double wo = sqrt(wosq);
-    double dpjmp = pstar_d - po;
+    double dpjmp = pstar - po;
 
     double rstar = 1.0 - ro * dpjmp / wosq;
     rstar = ro / rstar;
     rstar = amax(P.small_dens, rstar);
 
-    double cstar = sqrt(fabs(gamco * pstar_d / rstar));
+    double cstar = sqrt(fabs(gamco * pstar / rstar));
     cstar = amax(cstar, raux.csmall);
 
     double spout = co - sgnm * uo;
@@ -844,7 +962,7 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
 
     double ushock = wo * tauo - sgnm * uo;
 
-    if (pstar_d - po >= 0.0) {
+    if (pstar - po >= 0.0) {
         spin = ushock;
         spout = ushock;
     }
@@ -862,14 +980,14 @@ __device__ __forceinline__ void riemanncg(const RState& ql, const RState& qr, co
 
     qint.rho = frac * rstar + (1.0 - frac) * ro;
     qint.un = frac * ustar + (1.0 - frac) * uo;
-    qint.p = frac * pstar_d + (1.0 - frac) * po;
-    double game_int = frac * gamstar_d + (1.0 - frac) * gameo;
+    qint.p = frac * pstar + (1.0 - frac) * po;
+    double game_int = frac * gamstar + (1.0 - frac) * gameo;
 
     if (spout < 0.0) {
         qint.rho = ro; qint.un = uo; qint.p = po; game_int = gameo;
     }
     if (spin >= 0.0) {
-        qint.rho = rstar; qint.un = ustar; qint.p = pstar_d; game_int = gamstar_d;
+        qint.rho = rstar; qint.un = ustar; qint.p = pstar; game_int = gamstar;
     }
 
     qint.p = amax(qint.p, P.small_pres);
@@ -1114,13 +1232,16 @@ __device__ __forceinline__ void hll_flux(const RState& ql, const RState& qr, dou
 //   ql/qr carry gamc already (= qaux(QGAMC) of the zones either side); cl, cr = qaux(QC)
 //   Xl, Xr = passive edge values; is_shock = shk(left zone) + shk(right zone) >= 1.
 //   Outputs: F = (rho, m_n, m_t, m_tt, E, eint, X) fluxes, Godunov (un, ut, utt, p).
-template <int D>
+// SOLV selects the solvers compiled into the caller: 0 = the default only (riemann_solver = 0, no hybrid HLL), 1 = everything but
+// Colella-Glaz (HLLC, hybrid HLL), 2 = everything.  A kernel is sized for the registers of the largest solver it contains, so
+// the launcher picks the instantiation that matches the run-time parameters (ctu_kernels.hip: `solv`).
+template <int D, int SOLV = 2>
 __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RState& qr_raw, double Xl, double Xr,
                                                double cl, double cr, double bnd_fac, bool is_shock,
                                                const DevParams& P, IFlux& F)
 {
     constexpr double small = 1.e-8;
-    if (P.riemann_solver == 2) {
+    if (SOLV >= 1 && P.riemann_solver == 2) {
         hllc_flux<D>(ql_raw, qr_raw, Xl, Xr, cl, cr, bnd_fac, P, F);
     } else {
         RState ql = ql_raw, qr = qr_raw;
@@ -1137,7 +1258,7 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
         clean_input_state(qr, Xr, P);
 
         RState qint;
-        if (P.riemann_solver == 0) {
+        if (SOLV < 2 || P.riemann_solver == 0) {
             riemannus(ql, qr, raux, qint, P);
         } else {
             riemanncg(ql, qr, raux, qint, P);
@@ -1169,7 +1290,7 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
         F.X = F.rho * X_int;
     }
 
-    if (P.hybrid_riemann == 1 && is_shock) {
+    if (SOLV >= 1 && P.hybrid_riemann == 1 && is_shock) {
         hll_flux(ql_raw, qr_raw, Xl, Xr, cl, cr, F);
     }
 }

@@ -251,6 +251,11 @@ static void pstar_bisection(double *pstar_lo, double *pstar_hi,
 }
 
 /* riemann_solvers.H:225-581 -- Colella & Glaz (1985), CPU path (history kept) */
+/* faces on which the reference would have called amrex::Error since ora_cg_aborts_reset() (cg_blend = 0, no convergence) */
+static long ora_cg_aborts = 0;
+long ora_cg_aborts_count(void) { return ora_cg_aborts; }
+void ora_cg_aborts_reset(void) { ora_cg_aborts = 0; }
+
 void ora_riemanncg(const RiemannState *ql, const RiemannState *qr, const RiemannAux *raux,
                    RiemannState *qint, const ora_params *P)
 {
@@ -344,7 +349,9 @@ void ora_riemanncg(const RiemannState *ql, const RiemannState *qr, const Riemann
 
     if (!converged) {
         if (P->cg_blend == 0) {
-            fprintf(stderr, "oracle: non-convergence in the Riemann solver (cg_blend=0)\n");
+            /* riemann_solvers.H:392-394: the reference aborts here (amrex::Error) -- the input has no defined result */
+            ora_cg_aborts++;
+            if (ora_cg_aborts == 1) fprintf(stderr, "oracle: non-convergence in the Riemann solver (cg_blend=0): the reference aborts\n");
         } else if (P->cg_blend == 1) {
             pstar = ql->p + ((qr->p - ql->p) - wr * (qr->un - ql->un)) * wl / (wl + wr);
         } else if (P->cg_blend == 2) {

@@ -64,11 +64,16 @@ for case in range(ncases):
     flux_assign = bool(rng.integers(0, 2))
     if only is not None and case not in only:
         continue
+    oracle.lib().ora_cg_aborts_reset()
     try:
         out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, dt, dx=dx, pkw=pkw, src=src, src_box=src_box,
                         geom_kw=dict(lo_bc=tuple(bcs[:3]), hi_bc=tuple(bcs[3:])), flux_assign=flux_assign, hip_tiles=tiles)
     except AssertionError as e:                              # a state the reference would abort on (rho <= 0 in ctoprim)
         stats["skipped"] = stats.get("skipped", 0) + 1
+        continue
+    oracle.lib().ora_cg_aborts_count.restype = __import__("ctypes").c_long
+    if oracle.lib().ora_cg_aborts_count() > 0 and only is None:  # cg_blend = 0 and no convergence: the reference calls amrex::Error
+        stats["reference aborts"] = stats.get("reference aborts", 0) + 1
         continue
     if any(np.isnan(b).any() for _, b in out.values()) and only is None:   # the algorithm itself breaks down on this input
         stats["oracle NaN"] = stats.get("oracle NaN", 0) + 1   # (sqrt of a negative pressure in the HLL wave speeds, ...): not a
