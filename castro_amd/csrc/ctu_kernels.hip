@@ -39,7 +39,9 @@
 // the Colella-Glaz instantiations (GEN == 2) carry the out-of-line NaN-sign fall-back (hydro_device.h: XD), whose call
 // frame would push them past 256 VGPRs to one wave per SIMD; held at two waves the overflow is spilled around the call only
 // (Sedov 256^3, riemann_solver = 1: k_trans1 18.6 -> see DESIGN.md section 9)
-#ifndef CG_ONE_WAVE
+#ifdef EXPERIMENT_DEFAULT_THREE_WAVES      // A/B: the default-solver instantiations of k_trans1 / k_final / k_finalx_consup at 3 waves per SIMD
+#define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : (GEN == 0 ? 3 : 1), GEN == 2 ? 2 : (GEN == 0 ? 3 : 8))))
+#elif !defined(CG_ONE_WAVE)
 #define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : 1, GEN == 2 ? 2 : 8)))
 #else
 #define CG_TWO_WAVES
