@@ -222,16 +222,28 @@ def fab_desc(ptr, lo, hi, ncomp):
     return Fab(ptr, _I3(int(lo[0]), int(lo[1]), int(lo[2])), _I3(int(hi[0]), int(hi[1]), int(hi[2])), int(ncomp))
 
 
+_FAB_MEMO = {}
+
+
 def fab_of(tensor, lo, hi):
     """Descriptor for a contiguous torch tensor shaped (ncomp, nz, ny, nx) covering box [lo, hi]
-    (C order of that shape == AMReX FAB layout: i fastest, component slowest)."""
+    (C order of that shape == AMReX FAB layout: i fastest, component slowest).  A descriptor is a function of
+    (pointer, shape, box) only, so it is memoised: a level of small AMR boxes builds thousands per coarse step."""
     if tensor is None:
         return fab_desc(None, lo, hi, 0)
     shp = tensor.shape
+    key = (tensor.data_ptr(), shp, lo if type(lo) is tuple else tuple(lo), hi if type(hi) is tuple else tuple(hi))
+    f = _FAB_MEMO.get(key)
+    if f is not None and tensor.is_contiguous():
+        return f
     if not (tensor.is_contiguous() and shp[-1] == hi[0] - lo[0] + 1 and shp[-2] == hi[1] - lo[1] + 1 and shp[-3] == hi[2] - lo[2] + 1):
         raise AssertionError("FAB tensors must be contiguous and shaped (ncomp, nz, ny, nx) of their box: %s for %s"
                              % (tuple(shp), (lo, hi)))
-    return fab_desc(tensor.data_ptr(), lo, hi, shp[0] if len(shp) == 4 else 1)
+    f = fab_desc(key[0], lo, hi, shp[0] if len(shp) == 4 else 1)
+    if len(_FAB_MEMO) > 4096:
+        _FAB_MEMO.clear()
+    _FAB_MEMO[key] = f
+    return f
 
 
 def check(rc, what):
