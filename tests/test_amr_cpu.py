@@ -785,3 +785,53 @@ def test_amr_with_sources_and_boxes_spread_over_ranks_gloo(tmp_path, oracle, wor
         assert [bx for bx, _ in got["data"][l]] == [b.bx for b in lev.boxes]
         for (bx, arr), b in zip(got["data"][l], lev.boxes):
             assert np.array_equal(arr, b.S_new().cpu().numpy()), "level %d box %s" % (l, bx)
+
+
+# two refined boxes that touch through the periodic x boundary and one in the middle; level 0 in eight boxes
+_PER_PATCHES = [[((0, 4, 4), (3, 11, 11)), ((6, 4, 4), (9, 11, 11)), ((12, 4, 4), (15, 11, 11))]]
+
+
+def _mr_periodic_run(comm, nsteps):
+    import castro_amd
+    from oracle import oracle_lib as O
+    a = castro_amd.CastroAmr((16, 16, 16), patches=_PER_PATCHES, params=O.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+                             lo_bc=(0, 0, 2), hi_bc=(0, 0, 2), comm=comm, base_grid=(2, 2, 2))
+    a.initData("sod", rho_l=1.0, u_l=0.3, p_l=1.0, rho_r=0.125, u_r=-0.2, p_r=0.1, idir=1, frac=0.8)
+    dts = [a.step() for _ in range(nsteps)]
+    return a, dts
+
+
+def _mr_periodic_worker(rank, world, port, nsteps, out_path):
+    import pickle
+    import torch.distributed as dist
+    import castro_amd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, dts = _mr_periodic_run(castro_amd.DistComm(), nsteps)
+        levels = [a.gather_level(l) for l in range(len(a.lev))]
+        if rank == 0:
+            pickle.dump(dict(dts=dts, data=[[(bx, arr) for bx, arr in lv] for lv in levels]), open(out_path, "wb"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_periodic_amr_with_boxes_spread_over_ranks_gloo(tmp_path, oracle, world):
+    """A periodic domain (x and y) with the boxes on several ranks: the periodic images of the level-0 boxes and of two
+    refined boxes that touch through the x boundary are read from other ranks (a staged transfer of a box shifted by the
+    domain extent), the reflux of a fine face on the boundary lands in the coarse zone at the other end of the domain.
+    A Sod discontinuity at 0.8 of the x extent with moving gas on both sides crosses the boundary within the run.  Bitwise
+    equal to one rank."""
+    import pickle
+    nsteps = 5
+    out = str(tmp_path / "amr_periodic_ranks.pkl")
+    mp.spawn(_mr_periodic_worker, args=(world, _free_port(), nsteps, out), nprocs=world, join=True)
+    got = pickle.load(open(out, "rb"))
+    a, dts = _mr_periodic_run(None, nsteps)
+    assert got["dts"] == dts
+    for l, lev in enumerate(a.lev):
+        for (bx, arr), b in zip(got["data"][l], lev.boxes):
+            assert bx == b.bx and np.array_equal(arr, b.S_new().cpu().numpy()), "level %d box %s" % (l, bx)
