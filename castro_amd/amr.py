@@ -41,7 +41,7 @@ import torch
 
 from . import _lib as L
 from . import cluster as CL
-from .castro import Castro, NUM_GROW, NUM_STATE
+from .castro import Castro, NUM_GROW, NUM_STATE, checked_estimate
 
 NSRC = 7                     # components of Source_Type (Castro_setup.cpp:317-327)
 
@@ -484,7 +484,7 @@ class _Level:
         for b in self.mine:
             self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
         self.amr.comm.allreduce_min(self.red)
-        return min(self.max_dt, self.red.tolist()[0] * self.params.cfl)
+        return min(self.max_dt, checked_estimate(self.red.tolist()[0], empty_ok=not self.boxes) * self.params.cfl)
 
     def clean_new(self):
         for b in self.mine:
@@ -592,6 +592,24 @@ class CastroAmr:
             pools[l] = [(self._hydro_for(l) if k == 0 else HipHydro(dev.index), torch.cuda.Stream(device=dev))
                         for k in range(self.box_streams)]
         return pools[l]
+
+    def all_hydros(self):
+        """Every scratch context this hierarchy launches kernels through: the per-level ones and those of the box-stream
+        pools (their latched device status and their kernel profilers are otherwise invisible to the caller)."""
+        seen, out = set(), []
+        for h in list(self._hydros) + [h for pool in self.__dict__.get("_pools", {}).values() for h, _ in pool]:
+            if id(h) not in seen:
+                seen.add(id(h))
+                out.append(h)
+        return out
+
+    def status(self):
+        """OR of the latched device status words (rho <= 0 met in ctoprim) of all contexts; clears them."""
+        st = 0
+        for h in self.all_hydros():
+            if hasattr(h, "status"):
+                st |= int(h.status())
+        return st
 
     def _hydro_for(self, l):
         while len(self._hydros) <= l:

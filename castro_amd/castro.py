@@ -107,6 +107,17 @@ def default_grid(size):
     return tuple(g)
 
 
+def checked_estimate(est, empty_ok=False):
+    """The CFL estimate of estTimeStep has no retry path behind it (Castro.cpp:1507-1626): a NaN zone is dropped by the
+    minimum like in the reference, but an estimate that is not a positive finite number (every zone NaN, a negative sound
+    speed sum, an empty level) must not become a time step."""
+    if empty_ok and est == 1.e200:          # no zone contributed: the initial value of the reduction
+        return est
+    if not (est > 0.0) or est == float("inf") or est >= 1.e199:
+        raise AdvanceFailure("estTimeStep: the CFL estimate is not a positive finite number (%r)" % (est,))
+    return est
+
+
 class AdvanceFailure(RuntimeError):
     pass
 
@@ -386,7 +397,7 @@ class Castro:
         if self.fixed_dt > 0.0:                                 # Castro.cpp:1511-1513
             return self.fixed_dt
         est, _ = self._reduce()
-        return min(self.max_dt, est * self.params.cfl)
+        return min(self.max_dt, checked_estimate(est) * self.params.cfl)
 
     def computeInitialDt(self, stop_time=-1.0):
         # Castro::initialTimeStep (Castro.cpp:1490-1504)
@@ -537,7 +548,11 @@ class Castro:
         # FillPatch of the source for the tracing
         self.expand_state(self.old_source, self.sbox, self.src_neighbors)
         # hydro with the old source traced in the predictor; S_new += (it already holds the old source)
-        self.construct_ctu_hydro_source(time, dt, src=self.old_source)
+        try:
+            self.construct_ctu_hydro_source(time, dt, src=self.old_source)
+        finally:
+            if self.params.source_term_predictor == 1:
+                h.set_source_corrector(None, None)        # the context must not keep a pointer into this object's tensor
         self._flux_clear = False
         # S_new.min(URHO) (:168-216), clean_state(S_new) (:221-225)
         h.clean_state_reduce(self.S_new_b, self.gbox, lo, hi, self.geom, self.params, self.red, ntimes=1)

@@ -140,8 +140,11 @@ __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, doubl
         double dt2 = dx1 / (cs + fabs(uy));
         double dt3 = dx2 / (cs + fabs(uz));
 
-        dtmin = fmin(dtmin, nan_guard(amin(amin(dt1, dt2), dt3)));
-        rmin = fmin(rmin, nan_guard(rho));
+        // NaNs are dropped here, like the reference's std::min fold (timestep.cpp:131-137): the consumers of this
+        // estimate (estTimeStep, computeInitialDt, computeNewDt) have no retry path; they reject a non-positive or
+        // non-finite result instead (castro.py / amr.py: _checked_estimate).  The guarded minima are those of the advance.
+        dtmin = fmin(dtmin, amin(amin(dt1, dt2), dt3));
+        rmin = fmin(rmin, rho);
     }
     block_min2_atomic(dtmin, rmin, out);
 }

@@ -370,6 +370,9 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
     }
 
     DFab dCorr = to_dfab(nullptr);
+    // the reference always has source_corrector defined when the predictor is on (Castro_advance_ctu.cpp:60-62):
+    // running without it would silently drop the predictor
+    if (params->source_term_predictor == 1 && src && src->p && !c->src_corr.p) return CASTRO_AMD_ERR_ARG;
     if (params->source_term_predictor == 1 && c->src_corr.p && src && src->p) {
         int s3lo[3], s3hi[3];
         for (int d = 0; d < 3; ++d) { s3lo[d] = bxlo[d] - 3; s3hi[d] = bxhi[d] + 3; }

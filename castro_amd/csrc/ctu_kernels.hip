@@ -2276,12 +2276,17 @@ __global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const 
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
 int g_trace_tile_rows = 64;   // rows per y-tile of the trace launch (its L2 holds only Q now that the stores are non-temporal: 2.72 -> 2.60 ms; -1: g_tile_rows)
 
+// rows per y-tile of the launches the calling thread is building right now, if it differs from g_tile_rows (the trace launch
+// and its block-start fix-up must agree on one workgroup order); thread-local, so that host threads driving their own
+// contexts never see each other's choice.  The g_* knobs themselves are written by castro_amd_ctx_create only.
+static thread_local int tl_tile_rows = -1;
+
 static LinBox linbox(const int lo[3], const int hi[3], long& n)
 {
     LinBox b;
     n = 1;
     for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.n[d] = hi[d] - lo[d] + 1; n *= b.n[d]; }
-    b.ty = g_tile_rows;
+    b.ty = tl_tile_rows >= 0 ? tl_tile_rows : g_tile_rows;
     b.w = 1;
     b.hi0 = hi[0];
     b.nb = (unsigned)((n + 255) / 256);
@@ -2441,8 +2446,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // x faces of the launch box (lo[0] and hi[0] + 1) are left to the caller.
     auto trace_with_xriemann = [&](const int lo[3], const int hi[3]) {
         // the trace launch and the block-start fix-up share one workgroup order: both see the trace's rows per y-tile
-        struct RowsGuard { int keep; RowsGuard() : keep(g_tile_rows) { if (g_trace_tile_rows >= 0) g_tile_rows = g_trace_tile_rows; }
-                           ~RowsGuard() { g_tile_rows = keep; } } rows_guard;
+        struct RowsGuard { int keep; RowsGuard() : keep(tl_tile_rows) { if (g_trace_tile_rows >= 0) tl_tile_rows = g_trace_tile_rows; }
+                           ~RowsGuard() { tl_tile_rows = keep; } } rows_guard;
 #ifdef EXPERIMENT_TRACE_SPLIT       // tools/build_variant.sh split "-DEXPERIMENT_TRACE_SPLIT"; measured slower, DESIGN.md section 9
         if (g_trace_split == 1) {
             KL2("k_trace_x", (k_trace_pair<true, 1>), lo, hi, S.Q, S, g, dt, P, none);

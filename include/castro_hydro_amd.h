@@ -31,6 +31,13 @@
  *    flag readable with castro_amd_ctx_status().
  *  - A context is bound to one device and must be used from one stream at a
  *    time (re-entrant per (device, stream): create one context per stream).
+ *  - Thread safety: different host threads may drive different contexts
+ *    concurrently (the reference calls the path from inside `#pragma omp
+ *    parallel`, Castro_ctu_hydro.cpp:66-72); ONE context must not be entered
+ *    by two threads at once.  The CASTRO_AMD_* environment knobs are read by
+ *    castro_amd_ctx_create() into process-wide settings: create the contexts
+ *    before the threads start using them, not while another thread is
+ *    inside a call.
  */
 #ifndef CASTRO_HYDRO_AMD_H
 #define CASTRO_HYDRO_AMD_H

@@ -44,7 +44,7 @@ print("ms per coarse step: total %.2f, regrid %.2f (grid_places %.2f of which ta
 print("boxes per level", [len(lev.boxes) for lev in a.levels], "zones per level", [sum(b.n[0] * b.n[1] * b.n[2] for b in lev.boxes) for lev in a.levels])
 
 # per-kernel device time of one coarse step (hipEvent-timed inside the library), all levels together
-for h in a._hydros:
+for h in a.all_hydros():
     h.profile(True)
     h.profile_reset()
 torch.cuda.synchronize()
@@ -54,7 +54,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 tot = {}
-for h in a._hydros:
+for h in a.all_hydros():
     for k, (ms, n_) in h.profile_report().items():
         e = tot.setdefault(k, [0.0, 0])
         e[0] += ms; e[1] += n_
