@@ -38,6 +38,7 @@ KERNEL_BYTES_PER_UNIT = {
     "k_trace": 8 * (8 + 42 + 8),                          # + F1[x]: the first x Riemann solve is fused in
     "k_riemann1": 8 * (14 + 1 + 8),
     "k_trans1": 8 * (42 + 24 + 1 + 48),                   # all three normal directions in one launch
+    "k_trans1_fold": 8 * (42 + 8 + 1 + 48),               # + the first y / z solves: F1[y], F1[z] are neither written nor read
     "k_final_rmw": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),    # fluxes read-modify-write (8 read + 8 write + mass)
     "k_final_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 9),  # fluxes written only
     "k_finalx_consup_rmw": 8 * (14 + 16 + 1 + 1 + 8 + 17 + 18 + 8),   # x faces + consup: + FL[y], FL[z] read, S_new written
@@ -65,6 +66,7 @@ def kernel_units(name, n):
         "k_trace": (nx + 2) * (ny + 2) * (nz + 2),
         "k_riemann1": ((nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 2.0,     # y and z launches
         "k_trans1": (nx + 2) * (ny + 2) * (nz + 2),
+        "k_trans1_fold": (nx + 2) * (ny + 2) * (nz + 2),
         "k_final_x": (nx + 1) * ny * nz,
         "k_final_y": nx * (ny + 1) * nz,
         "k_final_z": nx * ny * (nz + 1),
@@ -163,6 +165,8 @@ def main():
                     "exchange runs on the communication stream), as every rank of a multi-GPU run does")
     ap.add_argument("--overlap-tiles", action="store_true", help="the older interior tile + 6 boundary slabs form of the overlap")
     ap.add_argument("--no-contract-leg", action="store_true", help="skip the 600-B contract leg of the default run")
+    ap.add_argument("--stepwise", action="store_true", help="one host round trip per step (Castro.step) instead of the "
+                    "host-free batch (Castro.run_steps)")
     ap.add_argument("--reference-contract", action="store_true",
                     help="zero-fill + accumulate fluxes and run clean_state/estdt as separate passes (600 B/cell form)")
     args = ap.parse_args()
@@ -214,12 +218,24 @@ def main():
         c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc, overlap=overlap,
                               fuse_clean=not contract_mode, flux_assign=not contract_mode)
         c.initData("sedov")                      # synthetic input, generated on the device
-        for _ in range(warmup):
-            c.step()
+        # host-free stepping (Castro.run_steps): dt, time and the step checks stay on the device, one host
+        # synchronisation per batch; on one rank a captured pair of steps is replayed as a hipGraph.  --stepwise keeps
+        # the round-1/2 form (one allreduce + host read per step).  Same kernels, same dt, bit-identical states.
+        host_free = (not args.stepwise) and c.host_free_ok()
+        if host_free:
+            c.run_steps(warmup)
+            if world == 1 and warmup >= 2:
+                c.capture_step_graph()           # untimed: the graph for the roles the state buffers have now
+        else:
+            for _ in range(warmup):
+                c.step()
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            c.step()
+        if host_free:
+            c.run_steps(steps)
+        else:
+            for _ in range(steps):
+                c.step()
         sync()
         wall = time.perf_counter() - t0
         if comm is not None:
@@ -238,7 +254,8 @@ def main():
             c.hydro.profile(False)
         info = {"zones_per_gpu": c.n[0] * c.n[1] * c.n[2], "sim_time": c.time, "nstep": c.nstep, "n": c.n,
                 "overlap_halo": ("tiles" if c.overlap == "tiles" else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
-                "halo": c.halo_stats() if hasattr(c, "halo_stats") else None}
+                "halo": c.halo_stats() if hasattr(c, "halo_stats") else None, "host_free": host_free,
+                "step_graph": bool(host_free and getattr(c, "_graphs", None))}
         del c
         torch.cuda.empty_cache()
         return wall, prof, ksteps, info
@@ -289,7 +306,8 @@ def main():
                    "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": info["zones_per_gpu"],
                    "overlap_halo": info["overlap_halo"], "sim_time": info["sim_time"], "nstep": info["nstep"],
                    "flux_mode": "accumulate (600 B/cell contract)" if contract else "assign (344 B/cell, declared)",
-                   "fused_clean_state": not contract, "halo": info["halo"]},
+                   "fused_clean_state": not contract, "halo": info["halo"],
+                   "host_free_steps": info["host_free"], "step_graph": info["step_graph"]},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
     "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status", "castro_amd_ctx_poison_scratch", "castro_amd_ctx_set_source_corrector",
-    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_derive_fab",
+    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_ctu_hydro_fab_ex", "castro_amd_step_control", "castro_amd_derive_fab",
     "castro_amd_error_tag_fab", "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
     "castro_amd_old_rotation_source_fab", "castro_amd_new_rotation_source_fab",
@@ -44,6 +44,16 @@ EXPORTED_SYMBOLS = (
 class Fab(C.Structure):
     """castro_amd_fab: FArrayBox descriptor (pointer, lo, hi, ncomp)."""
     _fields_ = [("p", C.c_void_p), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("ncomp", C.c_int)]
+
+
+# castro_amd_step_control's ctl vector (include/castro_hydro_amd.h)
+CTL_DT, CTL_TIME, CTL_NSTEP, CTL_STATUS, CTL_RHOMIN, CTL_EST, CTL_DTHYDRO, CTL_HIST, CTL_NHIST, CTL_SIZE = 0, 1, 2, 3, 4, 5, 6, 8, 56, 64
+
+
+class HydroOpts(C.Structure):
+    """castro_amd_hydro_opts"""
+    _fields_ = [("flags", C.c_int), ("clean_ntimes", C.c_int), ("d_out", C.c_void_p), ("sborder_clean_ntimes", C.c_int),
+                ("d_dt", C.c_void_p)]
 
 
 class Rotation(C.Structure):
@@ -126,6 +136,11 @@ def load():
     L.castro_amd_ctu_hydro_clean_fab.argtypes = [
         C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
         C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.castro_amd_ctu_hydro_fab_ex.argtypes = [
+        C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
+        C.c_double, C.c_double, C.POINTER(HydroOpts), C.c_void_p]
+    L.castro_amd_step_control.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_double, C.c_double,
+                                          C.c_double, C.c_int, C.c_void_p]
     L.castro_amd_clean_state_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]
     L.castro_amd_clean_state_reduce_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params),
                                                     C.c_int, C.c_void_p, C.c_void_p]

@@ -114,7 +114,7 @@ class _Level:
         self.alpha = 0.0          # (t_level - t_parent_old) / dt_parent of the FillPatch being prepared
         b0 = self.boxes[0]
         self.hydro, self.params, self.geom = b0.hydro, b0.params, b0.geom
-        self.red = self.mine[0].red if self.mine else self.hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2)
+        self.red = self.mine[0].red if self.mine else self.hydro.alloc(1, (0, 0, 0), (2, 0, 0)).reshape(3)
         for b in self.mine:
             b.red = self.red      # one [min dt, min rho] pair for the level: every box reduces into it
             b.fuse_post_clean = False      # post_timestep's clean_state comes after reflux and avgDown (_time_step)
@@ -382,7 +382,7 @@ class _Level:
         for b in self.mine:
             h.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
         self.amr.comm.allreduce_min(self.red)
-        _, rho_min = self.red.tolist()
+        _, rho_min, _ = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         for b in self.mine:
@@ -471,7 +471,7 @@ class _Level:
             for b in self.mine:
                 self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
         self.amr.comm.allreduce_min(self.red)                 # the level's minima over the ranks that hold its boxes
-        est, rho_min = self.red.tolist()
+        _, rho_min, est = self.red.tolist()           # [2]: the estimate after the first clean_state (the only one here)
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)

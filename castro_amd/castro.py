@@ -16,6 +16,7 @@ xGMI link) on a communication stream, overlapped with the hydro update of the in
 sub-box, which needs no remote data, on the compute stream.
 """
 import itertools
+import os
 
 import time
 
@@ -31,6 +32,7 @@ NUM_STATE, NUM_GROW = L.NUM_STATE, L.NUM_GROW
 # --------------------------------------------------------------------------------------------
 class SingleComm:
     rank, size = 0, 1
+    device_side = True          # no collective ever touches the host
 
     def exchange(self, sends, recvs):
         assert not sends and not recvs
@@ -54,6 +56,8 @@ class DistComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
+        # RCCL collectives are enqueued on the device (the host does not wait for them); gloo moves host memory
+        self.device_side = dist.get_backend(group) == "nccl"
 
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer_rank, tag, tensor).  Grouped point-to-point."""
@@ -182,7 +186,8 @@ class Castro:
             self.flux_boxes.append((self.lo, tuple(fhi)))
             self.fluxes.append(hydro_alloc(NUM_STATE, self.lo, fhi))
             self.mass_fluxes.append(hydro_alloc(1, self.lo, fhi))
-        self.red = hydro.alloc(1, (0, 0, 0), (1, 0, 0)).reshape(2) if alloc else None   # [min dt, min rho]
+        # [CFL estimate after the last clean_state, min rho, CFL estimate after the first clean_state]
+        self.red = hydro.alloc(1, (0, 0, 0), (2, 0, 0)).reshape(3) if alloc else None
 
         self._plans = {}
         self.neighbors = self._build_neighbors() if box is None else []
@@ -198,6 +203,10 @@ class Castro:
         self.overlap = overlap                                                   # True | "tiles" | False
         self.fuse_clean = bool(fuse_clean)
         self.fuse_post_clean = True        # post_timestep's clean_state may ride in the fused pass (a level of CastroAmr: no)
+        # the clean_state sweeps in front of the hydro update ride inside k_ctoprim (castro_amd_ctu_hydro_fab_ex) when the
+        # rank's box is updated by one un-staged call; CASTRO_AMD_FUSE_SBORDER_CLEAN=0 keeps the separate sweep
+        self.fuse_sborder_clean = (self.fuse_clean and hasattr(self.hydro, "lib") and box is None
+                                   and os.environ.get("CASTRO_AMD_FUSE_SBORDER_CLEAN", "1") != "0")
         self._pending_cleans, self._post_clean_done, self._whole_step = 2, False, False
         # one hydro call per step: "zero fluxes, then +=" (Castro_advance.cpp:391-394) is an assignment
         self.flux_assign = bool(flux_assign)
@@ -417,7 +426,8 @@ class Castro:
         return dt_0
 
     # ---- Castro::construct_ctu_hydro_source over this rank's box ------------------------------
-    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None, stage=None):
+    def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None, stage=None, sborder_clean=0,
+                                   d_dt=None):
         """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
         and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
         self.red, which the caller has initialised.  When the attempt covers the whole step of a single level,
@@ -434,7 +444,9 @@ class Castro:
                                          mass_fluxes=self.mass_fluxes, vbx=self.bx, update_from_sborder=src is None,
                                          src=src, src_box=self.sbox if src is not None else None,
                                          clean_ntimes=(2 if post_clean else 1) if fuse_clean else 0, red=self.red if fuse_clean else None,
-                                         flux_assign=self.flux_assign and self._flux_clear, stage=stage)
+                                         flux_assign=self.flux_assign and self._flux_clear, stage=stage,
+                                         **({"sborder_clean": sborder_clean} if sborder_clean else {}),
+                                         **({"d_dt": d_dt} if d_dt is not None else {}))
 
     def _shell_tiles(self):
         """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
@@ -467,8 +479,16 @@ class Castro:
         # The first attempt of a step cleans twice (initialize_advance's clean_state(S_old) + this Sborder's); a later
         # subcycle starts from the previous subcycle's cleaned S_new (Sborder's clean only); a retry on the same old
         # data finds the valid zones of Sborder already in place.
+        # With one box per rank, no sources and no staged overlap the pending cleans ride inside k_ctoprim instead of a
+        # sweep of their own (castro_amd_hydro_opts.sborder_clean_ntimes): FillPatch copies the uncleaned zones and the
+        # hydro call cleans valid and ghost zones alike -- the same zone-local function of the same values.
+        use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
+        sb_clean = 0
         if self._pending_cleans > 0:
-            self.clean_state(S, self._pending_cleans)
+            if self.fuse_sborder_clean and not self.have_sources and not use_overlap:
+                sb_clean = self._pending_cleans
+            else:
+                self.clean_state(S, self._pending_cleans)
         self._pending_cleans = 0
 
         # S_new.min(URHO) check (Castro_advance_ctu.cpp:168-216) on the un-cleaned update, clean_state(S_new)
@@ -479,7 +499,6 @@ class Castro:
         if self.have_sources:
             return self._do_advance_with_sources(time, dt, S)
 
-        use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
         if use_overlap and self.overlap == "tiles":
             # interior tile + six boundary slabs (measured slower than the staged form, kept for comparison)
             interior, shells = self._shell_tiles()
@@ -503,19 +522,23 @@ class Castro:
             self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, stage="B")
         else:
             self.expand_state(S)
-            self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse)
+            self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, sborder_clean=sb_clean)
         self._flux_clear = False
 
         if not fuse:
             h.clean_state_reduce(self.S_new_b, self.gbox, self.lo, self.hi, self.geom, self.params, self.red, ntimes=1)
         self.comm.allreduce_min(self.red)
-        est, rho_min = self.red.tolist()
+        est, rho_min, est1 = self.red.tolist()
         if rho_min < self.params.small_dens:
             # retry_small_density_cutoff keeps its default (-1e200): every such step is rejected
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)
-        if self.params.change_max * new_dt < dt:
+        # the validity check sees S_new cleaned once (Castro_advance_ctu.cpp:221-225, 386-392); what is handed on as the
+        # next step's estimate is the one of the state as the step leaves it (post_timestep's clean_state included when
+        # it rode along), which is what estTimeStep would return at the start of the next coarse step
+        chk_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est1 * self.params.cfl)
+        if self.params.change_max * chk_dt < dt:
             return False, "timestep validity check failed", None
+        new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)
         return True, "", new_dt
 
     def _do_advance_with_sources(self, time, dt, S):
@@ -557,7 +580,7 @@ class Castro:
         # S_new.min(URHO) (:168-216), clean_state(S_new) (:221-225)
         h.clean_state_reduce(self.S_new_b, self.gbox, lo, hi, self.geom, self.params, self.red, ntimes=1)
         self.comm.allreduce_min(self.red)
-        _, rho_min = self.red.tolist()
+        _, rho_min, _ = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         # do_new_sources (:262-268): corrector from the new state, apply, clean_state
@@ -692,9 +715,140 @@ class Castro:
         self._next_est = self.advance(self.time, self.dt)
         if not self._post_clean_done:
             self.clean_state(self.S_new_b, 1)       # Castro::post_timestep: clean_state(S_new) on every level
+            self._next_est = None                   # computeNewDt estimates from the state post_timestep leaves
         self.time += self.dt
         self.nstep += 1
         return self.dt
+
+    # ---- host-free stepping: dt, time and the step checks stay on the device -----------------------------------
+    def host_free_ok(self):
+        """The device-resident form of step() covers the plain single-level advance: fused clean_state / CFL reduction, no
+        source terms, device-side collectives.  A rejected step is latched on the device; with castro.use_retry the host
+        then redoes that step with the reference's retry logic, without it the batch raises like step() does."""
+        use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
+        # with castro.use_retry a rejected step is redone by the host from its old state (run_steps): every write to the
+        # caller's arrays must then sit in a kernel that checks the latched status, i.e. the cleans ride in k_ctoprim
+        retry_ok = (not self.use_retry) or (self.fuse_sborder_clean and not use_overlap)
+        return (self.fuse_clean and self.fuse_post_clean and not self.have_sources and retry_ok
+                and hasattr(self.hydro, "step_control") and getattr(self.comm, "device_side", False)
+                and self.overlap != "tiles")
+
+    def _step_device(self, stop_time):
+        """One coarse step with every decision left on the device: advance (Castro_advance.cpp:19-121) with dt read from
+        self._ctl, then castro_amd_step_control (checks of do_advance_ctu, time += dt, computeNewDt)."""
+        self._swap_state_time_levels()
+        self._zero_fluxes()
+        self._post_clean_done, self._whole_step, self._in_retry = True, True, False
+        S = self.S_old_b
+        use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
+        sb_clean = 2 if (self.fuse_sborder_clean and not use_overlap) else 0
+        if not sb_clean:
+            self.clean_state(S, 2)                  # clean_state(S_old) + clean_state(Sborder), see do_advance_ctu
+        if use_overlap:
+            cur = torch.cuda.current_stream()
+            self._comm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._comm_stream):
+                self.expand_state(S)
+            self.construct_ctu_hydro_source(0.0, 0.0, stage="A", d_dt=self._ctl)
+            cur.wait_stream(self._comm_stream)
+            self.construct_ctu_hydro_source(0.0, 0.0, fuse_clean=True, stage="B", d_dt=self._ctl)
+        else:
+            self.expand_state(S)
+            self.construct_ctu_hydro_source(0.0, 0.0, fuse_clean=True, sborder_clean=sb_clean, d_dt=self._ctl)
+        self._flux_clear = False
+        self.comm.allreduce_min(self.red)
+        self.hydro.step_control(self.red, self._ctl, self.params, self.max_dt, self.fixed_dt, stop_time, use_retry=self.use_retry)
+        if not torch.cuda.is_current_stream_capturing():
+            self._eager_done = True
+
+    def _ensure_ctl(self):
+        if getattr(self, "_ctl", None) is None:
+            self._ctl = torch.zeros(L.CTL_SIZE, dtype=torch.float64, device=self.red.device)
+            self._graphs, self._eager_done = {}, False
+
+    def capture_step_graph(self, stop_time=-1.0):
+        """The hipGraph of a PAIR of host-free steps (the state buffers swap roles every step) for the buffers' current
+        roles; captured once per (stop_time, roles) and cached.  Capturing executes nothing and leaves this object as it was."""
+        self._ensure_ctl()
+        assert self._eager_done, "capture_step_graph: run at least one host-free step first (scratch is reserved lazily)"
+        key = (float(stop_time), self.S_old_b.data_ptr(), self.S_new_b.data_ptr())
+        if key not in self._graphs:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_device(stop_time)
+                self._step_device(stop_time)
+            self._graphs[key] = g
+        return self._graphs[key]
+
+    def run_steps(self, nsteps, stop_time=-1.0, graph=None):
+        """`nsteps` coarse steps with ONE host synchronisation at the end instead of one per step: the time step lives in a
+        device vector (castro_amd_step_control), the kernels read it from there, a rejected step latches a status that
+        is raised here.  With graph (default: a single rank and at least 6 steps) a pair of steps -- the two roles of the
+        ping-pong state buffers -- is captured in a hipGraph once and replayed.  Falls back to step() when host_free_ok()
+        is false.  Bit-identical to step(): the same kernels with the same dt, computed by the same expressions."""
+        if nsteps <= 0:
+            return
+        if not self.host_free_ok():
+            for _ in range(nsteps):
+                self.step(stop_time)
+            return
+        dt0 = self.computeInitialDt(stop_time) if self.nstep == 0 else self.computeNewDt(self.dt, stop_time, est=self._next_est)
+        self._ensure_ctl()
+        head = torch.zeros(L.CTL_HIST, dtype=torch.float64)
+        head[L.CTL_DT], head[L.CTL_TIME], head[L.CTL_NSTEP] = dt0, self.time, float(self.nstep)
+        # with castro.use_retry the advance is subcycle_advance_ctu's single subcycle, (time + dt) - time
+        head[L.CTL_DTHYDRO] = ((self.time + dt0) - self.time) if self.use_retry else dt0
+        self._ctl[:L.CTL_HIST].copy_(head)
+        self.red.fill_(1.e200)
+        n0 = self.nstep
+        if graph is None:
+            graph = self.comm.size == 1 and nsteps >= 4 and os.environ.get("CASTRO_AMD_STEP_GRAPH", "1") != "0"
+        left = nsteps
+        if graph:
+            if not self._eager_done:
+                self._step_device(stop_time)            # two eager steps first: every lazy allocation happens outside a capture
+                self._step_device(stop_time)
+                left -= 2
+            g = self.capture_step_graph(stop_time)
+            while left >= 2:
+                g.replay()
+                left -= 2
+        for _ in range(left):
+            self._step_device(stop_time)
+        v = self._ctl.tolist()                      # the one synchronisation
+        status, done = int(v[L.CTL_STATUS]), int(v[L.CTL_NSTEP]) - n0
+        self.time, self.nstep = v[L.CTL_TIME], int(v[L.CTL_NSTEP])
+        if done > 0:
+            self.dt = v[L.CTL_HIST + (self.nstep - 1) % L.CTL_NHIST]
+            self.lastDt = self.dt
+            k = min(done, L.CTL_NHIST)
+            self.dt_history = [v[L.CTL_HIST + (self.nstep - k + m) % L.CTL_NHIST] for m in range(k)]
+        self._next_est, self._device_next_dt = None, v[L.CTL_DT]
+        if status:
+            # The launches after the rejected step wrote nothing (they check the latched status): its old state is intact
+            # in whichever buffer held it.  `nsteps - done` steps were issued from the rejected one on, each swapping roles.
+            if (nsteps - done) % 2 == 0:
+                self._swap_state_time_levels()
+            dt_failed = v[L.CTL_DT]                 # not advanced on a rejected step
+            rho_min = v[L.CTL_RHOMIN]
+            why = ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min if status & 1 \
+                else "timestep validity check failed"
+            if not self.use_retry:
+                raise AdvanceFailure("Advance was unsuccessful: %s (step %d of a host-free batch)" % (why, self.nstep + 1))
+            # Castro::retry_advance_ctu on the host: the step again from its (already cleaned) old state; the first
+            # attempt repeats the rejected one, then the reference's subcycling takes over
+            self.dt = dt_failed
+            self._zero_fluxes()
+            self._pending_cleans, self._post_clean_done = 0, False
+            self.nsubcycles, self.nretries = 1, 0
+            self._next_est = self.subcycle_advance_ctu(self.time, self.dt)
+            if not self._post_clean_done:
+                self.clean_state(self.S_new_b, 1)
+                self._next_est = None
+            self.time += self.dt
+            self.nstep += 1
+            self.run_steps(nsteps - done - 1, stop_time, graph=graph)
 
     def evolve(self, stop_time, max_step=10 ** 9):
         eps = 2.220446049250313e-16

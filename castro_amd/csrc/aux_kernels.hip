@@ -47,7 +47,7 @@ template <bool REDUCE>
 __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P, int ntimes,
                                                      double dx0, double dx1, double dx2, double* red)
 {
-    double dtmin = 1.e200, rmin_raw = 1.e300;
+    double dtmin = 1.e200, rmin_raw = 1.e300, dtmin1 = 1.e200;
     const long total = (long)b.n[0] * b.n[1] * b.n[2];
     for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
     const int i = b.lo[0] + (int)(tid % b.n[0]);
@@ -65,7 +65,14 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     double rX = U.p[c + U.sn * UFS];
     if (REDUCE) rmin_raw = fmin(rmin_raw, nan_guard(rho));
 
-    clean_zone(P, ntimes, rho, mx, my, mz, eden, eint, temp, rX);
+    if (REDUCE) {
+        double d1, d2;
+        clean_zone_dt(P, ntimes, dx0, dx1, dx2, rho, mx, my, mz, eden, eint, temp, rX, d1, d2);
+        dtmin1 = fmin(dtmin1, d1);
+        dtmin = fmin(dtmin, d2);
+    } else {
+        clean_zone(P, ntimes, rho, mx, my, mz, eden, eint, temp, rX);
+    }
 
     U.p[c + U.sn * URHO] = rho;
     U.p[c + U.sn * UMX] = mx;
@@ -76,9 +83,8 @@ __global__ void __launch_bounds__(256) k_clean_state(DFab U, Box3 b, DevParams P
     U.p[c + U.sn * UTEMP] = temp;
     U.p[c + U.sn * UFS] = rX;
 
-    if (REDUCE) dtmin = fmin(dtmin, nan_guard(zone_dt_cfl(P, dx0, dx1, dx2, rho, mx, my, mz, eint)));
     }
-    if (REDUCE) block_min2_atomic(dtmin, rmin_raw, red);
+    if (REDUCE) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
 }
 
 int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,
@@ -147,6 +153,49 @@ __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, doubl
         rmin = fmin(rmin, rho);
     }
     block_min2_atomic(dtmin, rmin, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// castro_amd_step_control: the host's work between two hydro updates of a single level, by one thread
+//   do_advance_ctu's checks (Castro_advance_ctu.cpp:168-216, 386-392), time += dt, Castro::computeNewDt (Castro.cpp:1629-1819)
+// The expressions are those of castro.py (Castro.do_advance_ctu / computeNewDt), in the same order.
+// ---------------------------------------------------------------------------------------
+__global__ void k_step_control(double* red, double* ctl, double cfl, double change_max, double small_dens, double max_dt,
+                               double fixed_dt, double stop_time, int retry_form)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double est = red[0], rho_min = red[1], est1 = red[2];
+    red[0] = 1.e200; red[1] = 1.e200; red[2] = 1.e200;
+    if (ctl[3] != 0.0) return;                               // a rejected step: the host finds time / nstep / dt of the failure
+    const double dt = ctl[0], dt_hydro = ctl[6];
+    ctl[4] = rho_min; ctl[5] = est;
+    int status = 0;
+    if (rho_min < small_dens) status |= 1;
+    const double chk = fixed_dt > 0.0 ? fixed_dt : amin(max_dt, est1 * cfl);
+    if (change_max * chk < dt_hydro) status |= 2;
+    if (status) { ctl[3] = (double)status; return; }
+    const long n = (long)ctl[2];
+    ctl[8 + (int)(n % 56)] = dt;
+    const double time = ctl[1] + dt;
+    ctl[1] = time;
+    ctl[2] = (double)(n + 1);
+    double dt_0 = fixed_dt > 0.0 ? fixed_dt : amin(max_dt, est * cfl);
+    if (fixed_dt <= 0.0) dt_0 = amin(dt_0, change_max * dt);
+    const double eps = 2.220446049250313e-16;
+    if (stop_time >= 0.0 && (time + dt_0) >= (stop_time - eps)) dt_0 = stop_time - time;
+    ctl[0] = dt_0;
+    // castro.use_retry: the advance goes through subcycle_advance_ctu, whose single subcycle is (time + dt) - time
+    // (Castro_advance_ctu.cpp:463-471) -- not always dt in the last bit
+    ctl[6] = retry_form ? (time + dt_0) - time : dt_0;
+}
+
+int launch_step_control(double* red, double* ctl, double cfl, double change_max, double small_dens, double max_dt,
+                        double fixed_dt, double stop_time, int retry_form, hipStream_t stream, Profiler* prof)
+{
+    prof_begin(prof, "k_step_control", stream);
+    hipLaunchKernelGGL(k_step_control, dim3(1), dim3(64), 0, stream, red, ctl, cfl, change_max, small_dens, max_dt, fixed_dt, stop_time, retry_form);
+    prof_end(prof, stream);
+    return launch_status();
 }
 
 int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; extern int g_trace_tile_rows; }
+namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile_rows; }
 
 using namespace cad;
 
@@ -21,6 +21,10 @@ struct castro_amd_ctx {
     int* h_status = nullptr;   // pinned
     castro_amd_fab src_corr = { nullptr, { 0, 0, 0 }, { 0, 0, 0 }, 0 };     // Castro::source_corrector
     Profiler prof;
+    // a second stream for launches that depend on nothing the main stream is about to produce (k_divu beside the trace
+    // kernel), forked from and joined to the caller's stream with events inside one call: CASTRO_AMD_SIDE_STREAM=0 turns it off
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace cad {
@@ -111,6 +115,7 @@ static DevParams to_devparams(const castro_amd_params* p)
     P.cfl = p->cfl; P.speed_limit = p->speed_limit;
     P.limit_small_dens = p->limit_fluxes_on_small_dens; P.limit_large_vel = p->limit_fluxes_on_large_vel;
     P.source_term_predictor = p->source_term_predictor;
+    P.dtp = nullptr;
     return P;
 }
 
@@ -215,6 +220,17 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
             g_brick[0] = a; g_brick[1] = b; g_brick[2] = c2;          // 0,0,0: chosen per launch
         }
     }
+    if (const char* e = std::getenv("CASTRO_AMD_SIDE_STREAM")) g_side_stream = std::atoi(e);
+    if (const char* e = std::getenv("CASTRO_AMD_FOLD_R1")) g_fold_r1 = std::atoi(e);
+    if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE_ROWS")) g_fold_tile_rows = std::atoi(e);
+    if (g_side_stream) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            castro_amd_ctx_destroy(c);
+            return CASTRO_AMD_ERR_HIP;
+        }
+    }
     *out = c;
     return CASTRO_AMD_OK;
 }
@@ -223,6 +239,9 @@ void castro_amd_ctx_destroy(castro_amd_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     prof_collect(&c->prof);
     for (auto e : c->prof.pool) hipEventDestroy(e);
     if (c->arena) hipFree(c->arena);
@@ -283,8 +302,31 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
                                    const castro_amd_geom* geom, const castro_amd_params* params,
                                    double time, double dt, int flags, int clean_ntimes, double* d_out, void* stream)
 {
+    castro_amd_hydro_opts o;
+    o.flags = flags; o.clean_ntimes = clean_ntimes; o.d_out = d_out; o.sborder_clean_ntimes = 0; o.d_dt = nullptr;
+    return castro_amd_ctu_hydro_fab_ex(c, bxlo, bxhi, vbxlo, vbxhi, Sborder, src, S_new, flux_out, mass_flux_out, qe_out,
+                                       geom, params, time, dt, &o, stream);
+}
+
+int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3],
+                                const int vbxlo[3], const int vbxhi[3],
+                                const castro_amd_fab* Sborder, const castro_amd_fab* src,
+                                const castro_amd_fab* S_new, const castro_amd_fab flux_out[3],
+                                const castro_amd_fab mass_flux_out[3], const castro_amd_fab qe_out[3],
+                                const castro_amd_geom* geom, const castro_amd_params* params,
+                                double time, double dt, const castro_amd_hydro_opts* opts, void* stream)
+{
     (void)time;
-    if (clean_ntimes < 0) return CASTRO_AMD_ERR_ARG;
+    if (!opts) return CASTRO_AMD_ERR_ARG;
+    const int flags = opts->flags, clean_ntimes = opts->clean_ntimes, sb_clean = opts->sborder_clean_ntimes;
+    double* d_out = opts->d_out;
+    if (clean_ntimes < 0 || sb_clean < 0) return CASTRO_AMD_ERR_ARG;
+    if (sb_clean > 0) {
+        // in-place cleaning of Sborder: whole-box calls only, never staged (see the header)
+        if (flags & (CASTRO_AMD_STAGE_A | CASTRO_AMD_STAGE_B)) return CASTRO_AMD_ERR_ARG;
+        if (vbxlo && vbxhi)
+            for (int d = 0; d < 3; ++d) if (vbxlo[d] != bxlo[d] || vbxhi[d] != bxhi[d]) return CASTRO_AMD_ERR_ARG;
+    }
     if (!c || !bxlo || !bxhi || !Sborder || !Sborder->p || !S_new || !S_new->p || !geom || !params)
         return CASTRO_AMD_ERR_ARG;
     if (Sborder->ncomp != NUM_STATE || S_new->ncomp != NUM_STATE) return CASTRO_AMD_ERR_ARG;
@@ -379,8 +421,22 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
         if (!fab_contains(&c->src_corr, s3lo, s3hi)) return CASTRO_AMD_ERR_ARG;
         dCorr = to_dfab(&c->src_corr);
     }
-    return launch_ctu_hydro(t, S, dS, to_dfab(src), dN, dF, dM, dQ, to_devgeom(geom), to_devparams(params), dt, flags,
-                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof, clean_ntimes, d_out, dCorr);
+    LaunchAux aux;
+    aux.sb_clean = sb_clean;
+    aux.side = c->side; aux.ev_fork = c->ev_fork; aux.ev_join = c->ev_join;
+    DevParams devP = to_devparams(params);
+    devP.dtp = opts->d_dt;
+    return launch_ctu_hydro(t, S, dS, to_dfab(src), dN, dF, dM, dQ, to_devgeom(geom), devP, dt, flags,
+                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof, clean_ntimes, d_out, dCorr, aux);
+}
+
+int castro_amd_step_control(castro_amd_ctx* c, double* d_red, double* d_ctl, const castro_amd_params* params,
+                            double max_dt, double fixed_dt, double stop_time, int use_retry, void* stream)
+{
+    if (!c || !d_red || !d_ctl || !params) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    return launch_step_control(d_red, d_ctl, params->cfl, params->change_max, params->small_dens, max_dt, fixed_dt, stop_time,
+                               use_retry ? 1 : 0, (hipStream_t)stream, &c->prof);
 }
 
 int castro_amd_clean_state_fab(castro_amd_ctx* c, const castro_amd_fab* state, const int lo[3], const int hi[3],

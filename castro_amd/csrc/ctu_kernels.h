@@ -62,16 +62,26 @@ void prof_begin(Profiler* p, const char* name, hipStream_t s);
 void prof_end(Profiler* p, hipStream_t s);
 void prof_collect(Profiler* p);
 
+// what a call carries besides its arrays: in-place cleaning of Sborder inside k_ctoprim, the context's side stream
+struct LaunchAux {
+    int sb_clean = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
-                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr);
+                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr,
+                     const LaunchAux& aux);
 
 // auxiliary per-FAB kernels (aux_kernels.hip)
 int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,
                        hipStream_t stream, Profiler* prof);
 int launch_clean_state_reduce(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
                               int ntimes, double* d_out, hipStream_t stream, Profiler* prof);
+int launch_step_control(double* red, double* ctl, double cfl, double change_max, double small_dens, double max_dt,
+                        double fixed_dt, double stop_time, int retry_form, hipStream_t stream, Profiler* prof);
 int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom& g, const DevParams& P,
                  double* d_out, hipStream_t stream, Profiler* prof);
 int launch_old_grav_source(const DFab& U, const DFab& SRC, const int lo[3], const int hi[3], const double grav[3],

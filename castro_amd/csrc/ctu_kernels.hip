@@ -48,6 +48,11 @@
 #endif
 namespace cad {
 
+// Host-free stepping: DevParams::dtp points at castro_amd_step_control's vector; once a step has been rejected
+// (ctl[CASTRO_AMD_CTL_STATUS] != 0) the launches that follow in the same batch must leave the caller's arrays alone --
+// the host retries from the old state of the rejected step.
+#define RETURN_IF_BATCH_FAILED() if (P.dtp && P.dtp[3] != 0.0) return
+
 // ---------------------------------------------------------------------------------------
 // addressing helpers
 // ---------------------------------------------------------------------------------------
@@ -156,9 +161,14 @@ __device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
     return i >= s.lo[0] && i <= s.hi[0] && j >= s.lo[1] && j <= s.hi[1] && k >= s.lo[2] && k <= s.hi[2];
 }
 
+// CLEAN: Castro::clean_state applied `clean_n` times to the zone first, in place (castro_amd_hydro_opts.sborder_clean_ntimes):
+// the clean_state(S_old) of initialize_advance and the clean_state(Sborder) after FillPatch inside the pass that reads the
+// state anyway.  Plain stores: k_final / k_finalx_consup read the cleaned zones again.
+template <bool CLEAN>
 __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                 SkipBox skip)
+                                                 SkipBox skip, int clean_n)
 {
+    RETURN_IF_BATCH_FAILED();
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
     if (in_skip(skip, i, j, k)) return;
@@ -166,25 +176,42 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     const unsigned cu = foff(U, i, j, k);
     const long NC = t.NC;
 
-    const double rho = ldg(U.p + URHO * U.sn, cu);
+    double rho = ldg(U.p + URHO * U.sn, cu);
+    double mx = ldg(U.p + UMX * U.sn, cu), my = ldg(U.p + UMY * U.sn, cu), mz = ldg(U.p + UMZ * U.sn, cu);
+    double eden = ldg(U.p + UEDEN * U.sn, cu);
+    double rX = ldg(U.p + UFS * U.sn, cu);
+    double eint = 0.0;
+    if (CLEAN) {
+        eint = ldg(U.p + UEINT * U.sn, cu);
+        double temp = ldg(U.p + UTEMP * U.sn, cu);
+        clean_zone(P, clean_n, rho, mx, my, mz, eden, eint, temp, rX);
+        double* up = U.p;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + URHO * U.sn) + cu) = rho;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UMX * U.sn) + cu) = mx;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UMY * U.sn) + cu) = my;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UMZ * U.sn) + cu) = mz;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UEDEN * U.sn) + cu) = eden;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UEINT * U.sn) + cu) = eint;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UTEMP * U.sn) + cu) = temp;
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UFS * U.sn) + cu) = rX;
+    }
     if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
 
     const double rhoinv = 1.0 / rho;
-    const double u = ldg(U.p + UMX * U.sn, cu) * rhoinv;
-    const double v = ldg(U.p + UMY * U.sn, cu) * rhoinv;
-    const double w = ldg(U.p + UMZ * U.sn, cu) * rhoinv;
+    const double u = mx * rhoinv;
+    const double v = my * rhoinv;
+    const double w = mz * rhoinv;
 
     const double kineng = 0.5 * rho * (u * u + v * v + w * w);
-    const double eden = ldg(U.p + UEDEN * U.sn, cu);
 
     double e;
     if ((eden - kineng) > P.eta1 * eden) {
         e = (eden - kineng) * rhoinv;
     } else {
-        e = ldg(U.p + UEINT * U.sn, cu) * rhoinv;
+        e = (CLEAN ? eint : ldg(U.p + UEINT * U.sn, cu)) * rhoinv;
     }
 
-    const double X = ldg(U.p + UFS * U.sn, cu) * rhoinv;
+    const double X = rX * rhoinv;
 
     // eos(eos_input_re): p = (gamma-1) rho e ; cs = sqrt(gamma p / rho)
     const double p = (P.gamma - 1.0) * rho * e;
@@ -210,6 +237,7 @@ __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const dou
 {
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
+    if (P.dtp) dt = P.dtp[6];
     const unsigned c = goff(t, i, j, k);
     const unsigned cs = foff(SRC, i, j, k);
     const long NC = t.NC;
@@ -1000,6 +1028,7 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
 {
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
+    if (P.dtp) dt = P.dtp[6];
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
 
@@ -1349,11 +1378,15 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 #ifndef TRACE_SPLIT_WAVES
 #define TRACE_SPLIT_WAVES 2
 #endif
+// device-resident time step (DevParams::dtp): cdtdx = dt/dx/3 as launch_ctu_hydro computes it on the host
+#define DT_THIRDS_FROM_DEVICE()                                                                          \
+    if (P.dtp) { const double dt_ = P.dtp[6]; cdtdx = dt_ / g.dx[0] / 3.0; cdtdy = dt_ / g.dx[1] / 3.0; cdtdz = dt_ / g.dx[2] / 3.0; }
 template <bool XRIEM, int DMASK = 7, int GEN = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : 2)))
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P, SkipBox skip)
 {
+    if (P.dtp) dt = P.dtp[6];
     int i, j, k;
     bool valid = box_thread(b, i, j, k);           // no early exit when XRIEM: the block synchronises below
     if (!valid) { i = b.lo[0]; j = b.lo[1]; k = b.lo[2]; }
@@ -1560,6 +1593,17 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
         rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
         interface_flux<N, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
+#ifdef DIAG_T1_EXTRA_SOLVES   // timing diagnostic (wrong results): DIAG_T1_EXTRA_SOLVES more Riemann solves per face and (N,T), on
+                              // perturbed states so that they are not merged: what "recompute instead of store" costs this kernel
+#pragma unroll
+        for (int x = 0; x < DIAG_T1_EXTRA_SOLVES; ++x) {
+            IFlux fx;
+            ql.rho = ql.rho * 1.0000001 + 1e-12 * f[w].rho; qr.p = qr.p * 0.9999999 + 1e-12 * f[w].pgd;
+            interface_flux<N, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w],
+                              face_shock(S, P, c + 8u * w, sn), P, fx);
+            f[w].rho += 1e-30 * fx.rho; f[w].mn += 1e-30 * fx.mn; f[w].E += 1e-30 * fx.E; f[w].ugd += 1e-30 * fx.ugd; f[w].pgd += 1e-30 * fx.pgd;
+        }
+#endif
 #endif
     }
 #ifdef DIAG_T1_NOSTORE    // timing diagnostic: the stores behind a condition that never holds
@@ -1634,6 +1678,379 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
     if (any2) trans1_pair<N, T2, RE, GEN>(t, S, c, sn, dstr(s, T2), qm, qp, cl, cr, bnd_fac, cdtdx_t2, in_t2[0], in_t2[1], P);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_trans1 with the first y and z Riemann solves folded in (default solver, no transverse_reset_rhoe / ppm_temp_fix):
+// F1[y] and F1[z] are never written.  The transverse stage reads QM/QP[y], QM/QP[z] anyway; a thread solves the four
+// y-faces and the four z-faces of its two zones itself (records A), takes those of the zone to its left from the
+// neighbouring lane (one wave shuffle per component; consecutive waves overlap by one slot, so lane 0 of a wave only
+// gives), and re-solves those of the zones below in the other transverse direction (records B).  8 first solves per
+// zone instead of 2 -- k_trans1's arithmetic hides under its memory traffic (profiles/r03b_ab_trans1_extra_solves.txt:
+// +6 solves per zone cost 0.5 ms) -- against two k_riemann1 launches (1.36 ms, 46 plane passes) and 16 planes less
+// to read here.  The arithmetic per face is that of k_riemann1: bit-identical F2.
+// ---------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void flux_to_rec(const IFlux& f, double r[NF1])
+{
+    r[FRHO] = f.rho;
+    r[FMX + RDir<D>::n] = f.mn;
+    r[FMX + RDir<D>::t] = f.mt;
+    r[FMX + RDir<D>::tt] = f.mtt;
+    r[FE] = f.E;
+    r[FX] = f.X;
+    r[FUG] = f.ugd;
+    r[FPG] = f.pgd;
+}
+
+// first Riemann solve on the D-faces of the two zones of a pair from their edge states (cmpflx_plus_godunov, riemann.cpp:15-206)
+template <int D, int GEN>
+__device__ __forceinline__ void f1_solve_2(const double qm[2][NEDGE], const double qp[2][NEDGE], const D2& cl, const D2& cr,
+                                           double bnd, const DevParams& P, double r[2][NF1])
+{
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState ql, qr;
+        double Xl, Xr;
+        rstate_from_edge<D>(qm[w], P.gamma, ql, Xl);
+        rstate_from_edge<D>(qp[w], P.gamma, qr, Xr);
+        IFlux f;
+        interface_flux<D, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd, false, P, f);
+        flux_to_rec<D>(f, r[w]);
+#ifndef FOLD_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);        // one zone's solve at a time: the two interleaved cost ~50 more registers
+#endif
+    }
+}
+
+// ... with the edge states and sound speeds of the faces at offset cf loaded here; idx: index of those faces along D
+template <int D, int GEN>
+__device__ __forceinline__ void f1_at_2(const Tile& t, const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
+                                        const DevParams& P, unsigned cf, int idx, double r[2][NF1])
+{
+    double qm[2][NEDGE], qp[2][NEDGE];
+    load_edge_2(S.QM[D], t.NC, cf, qm);
+    load_edge_2(S.QP[D], t.NC, cf, qp);
+    const unsigned sd = dstr(gstr(t), D);
+    const D2 cl = ldg2(Q + PC * t.NC, cf - sd), cr = ldg2(Q + PC * t.NC, cf);
+    f1_solve_2<D, GEN>(qm, qp, cl, cr, wall_fac<D>(g, idx), P, r);
+}
+
+// second-stage Riemann solve of trans1_pair on already corrected states
+template <int N, int T, int GEN>
+__device__ __forceinline__ void trans1_solve_store(const Tile& t, const DevScratch& S, unsigned c,
+                                                   const double qmo[2][NEDGE], const double qpo[2][NEDGE],
+                                                   const D2& cl, const D2& cr, const double bnd_fac[2],
+                                                   bool m0, bool m1, const DevParams& P)
+{
+    IFlux f[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState ql, qr;
+        double Xl, Xr;
+        rstate_from_edge<N>(qmo[w], P.gamma, ql, Xl);
+        rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
+        interface_flux<N, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w], false, P, f[w]);
+    }
+    store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, nullptr);
+}
+
+// slot -> zone pair for the launches whose waves overlap by one slot: lane 0 of a wave repeats the last slot of the wave
+// before it (it only hands its records to lane 1), lanes 1..63 own 63 new slots.  Same XCD-tiled row order as LinBox.
+__device__ __forceinline__ void fold_thread(const LinBox& b, int& i, int& j, int& k, bool& owner)
+{
+    unsigned bid = blockIdx.x;
+    if (b.ty > 0) {
+        const unsigned per = b.nb >> 3;
+        bid = (bid & 7u) * per + (bid >> 3);
+    }
+    const int lane = threadIdx.x & 63;
+    const long total = (long)b.n[0] * b.n[1] * b.n[2];
+    long sl = (long)(bid * 4u + (threadIdx.x >> 6)) * 63 + lane - 1;
+    owner = lane >= 1 && sl < total;
+    if (sl < 0) sl = 0;
+    if (sl >= total) sl = total - 1;
+    const unsigned tid = (unsigned)sl;
+    const unsigned ii = tid % (unsigned)b.n[0];
+    const unsigned r = tid / (unsigned)b.n[0];
+    i = b.lo[0] + b.w * (int)ii;
+    if (b.ty > 0) {
+        const unsigned rpt = (unsigned)b.ty * (unsigned)b.n[2];
+        const unsigned yt = r / rpt;
+        const unsigned rem = r - yt * rpt;
+        const unsigned left = (unsigned)b.n[1] - yt * (unsigned)b.ty;
+        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
+        const unsigned kk = rem / tyh;
+        j = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - kk * tyh));
+        k = b.lo[2] + (int)kk;
+    } else {
+        j = b.lo[1] + (int)(r % (unsigned)b.n[1]);
+        k = b.lo[2] + (int)(r / (unsigned)b.n[1]);
+    }
+}
+
+// the two (N, T) combinations of one transverse direction T = y or z whose first solves are folded in:
+// N = x (minus zones: the left neighbour, by shuffle) and N = O, the other transverse direction (minus zones: re-solved)
+template <int T, int GEN>
+__device__ __forceinline__ void trans1_fold_dir(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
+                                                const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
+                                                double cdtdt, const DevParams& P)
+{
+    constexpr int O = (T == 1) ? 2 : 1;            // the other transverse direction of N = x
+    const Str s = gstr(t);
+    const unsigned st = dstr(s, T), so = dstr(s, O);
+    const long NC = t.NC;
+    const double* Cp = Q + PC * NC;
+
+    // records A: the T-faces (low, high) of this thread's own two zones.  Every lane computes them: the neighbour may need them.
+    double A0[2][NF1], A1[2][NF1];
+    {
+        double qm[2][NEDGE], qp[2][NEDGE];
+        load_edge_2(S.QM[T], NC, c, qm);
+        load_edge_2(S.QP[T], NC, c, qp);
+        const D2 cl = ldg2(Cp, c - st), cr = ldg2(Cp, c);
+        f1_solve_2<T, GEN>(qm, qp, cl, cr, wall_fac<T>(g, ijk[T]), P, A0);
+    }
+    f1_at_2<T, GEN>(t, Q, S, g, P, c + st, ijk[T] + 1, A1);
+    double L0[NF1], L1[NF1];                       // the same for zone i - 1: the second zone of the lane to the left
+#pragma unroll
+    for (int n = 0; n < NF1; ++n) { L0[n] = __shfl_up(A0[1][n], 1, 64); L1[n] = __shfl_up(A1[1][n], 1, 64); }
+
+    const bool tin = owner && ijk[T] >= t.lo[T] && ijk[T] <= t.hi[T];      // T index inside bx: the (N|T) states exist
+    // ---- N = x: minus states live in the zones (i - 1, i), plus states in (i, i + 1)
+    {
+        const bool m0 = tin && ijk[0] >= t.lo[0], m1 = tin && v1 && ijk[0] + 1 >= t.lo[0];
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            load_edge_2(S.QM[0], NC, c, q);
+            trans_single<T>(q[0], L1, L0, P.gamma, cdtdt, P, qmo[0]);
+            trans_single<T>(q[1], A1[0], A0[0], P.gamma, cdtdt, P, qmo[1]);
+            load_edge_2(S.QP[0], NC, c, q);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) trans_single<T>(q[w], A1[w], A0[w], P.gamma, cdtdt, P, qpo[w]);
+            const D2 cl = ldg2(Cp, c - 8u), cr = ldg2(Cp, c);
+            double bnd[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
+            trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
+        }
+    }
+    // ---- N = O: faces between the zones c - so and c; the T-faces of the zones c - so are solved here (records B)
+    {
+        const bool m0 = tin && ijk[O] >= t.lo[O], m1 = m0 && v1;
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            {
+                double B0[2][NF1], B1[2][NF1];
+                f1_at_2<T, GEN>(t, Q, S, g, P, c - so, ijk[T], B0);
+                f1_at_2<T, GEN>(t, Q, S, g, P, c - so + st, ijk[T] + 1, B1);
+                load_edge_2(S.QM[O], NC, c, q);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) trans_single<T>(q[w], B1[w], B0[w], P.gamma, cdtdt, P, qmo[w]);
+            }
+            load_edge_2(S.QP[O], NC, c, q);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) trans_single<T>(q[w], A1[w], A0[w], P.gamma, cdtdt, P, qpo[w]);
+            const D2 cl = ldg2(Cp, c - so), cr = ldg2(Cp, c);
+            double bnd[2];
+            bnd[0] = bnd[1] = wall_fac<O>(g, ijk[O]);
+            trans1_solve_store<O, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
+        }
+    }
+}
+
+// ---- the same with the A records parked in LDS (64 KB per workgroup, thread-private slots [face][zone][component][thread]):
+// they are needed three times over the life of a direction and cost 64 VGPRs held in registers (28 spilled at two waves
+// per SIMD).  The left neighbour's records are then an LDS read of slot tid - 1, so only thread 0 of a WORKGROUP repeats
+// the slot before it (255 new slots per workgroup).
+__device__ __forceinline__ void fold_thread_wg(const LinBox& b, int& i, int& j, int& k, bool& owner)
+{
+    unsigned bid = blockIdx.x;
+    if (b.ty > 0) {
+        const unsigned per = b.nb >> 3;
+        bid = (bid & 7u) * per + (bid >> 3);
+    }
+    const long total = (long)b.n[0] * b.n[1] * b.n[2];
+    long sl = (long)bid * 255 + (long)threadIdx.x - 1;
+    owner = threadIdx.x >= 1 && sl < total;
+    if (sl < 0) sl = 0;
+    if (sl >= total) sl = total - 1;
+    const unsigned tid = (unsigned)sl;
+    const unsigned ii = tid % (unsigned)b.n[0];
+    const unsigned r = tid / (unsigned)b.n[0];
+    i = b.lo[0] + b.w * (int)ii;
+    if (b.ty > 0) {
+        const unsigned rpt = (unsigned)b.ty * (unsigned)b.n[2];
+        const unsigned yt = r / rpt;
+        const unsigned rem = r - yt * rpt;
+        const unsigned left = (unsigned)b.n[1] - yt * (unsigned)b.ty;
+        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
+        const unsigned kk = rem / tyh;
+        j = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - kk * tyh));
+        k = b.lo[2] + (int)kk;
+    } else {
+        j = b.lo[1] + (int)(r % (unsigned)b.n[1]);
+        k = b.lo[2] + (int)(r / (unsigned)b.n[1]);
+    }
+}
+
+// record (face f, zone w) of thread `th`
+__device__ __forceinline__ void park_get(const double* __restrict__ park, int f, int w, int th, double r[NF1])
+{
+#pragma unroll
+    for (int n = 0; n < NF1; ++n) r[n] = park[((f * 2 + w) * NF1 + n) * 256 + th];
+}
+
+template <int T, int GEN>
+__device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
+                                                    const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
+                                                    double cdtdt, const DevParams& P, double* __restrict__ park)
+{
+    constexpr int O = (T == 1) ? 2 : 1;
+    const Str s = gstr(t);
+    const unsigned st = dstr(s, T), so = dstr(s, O);
+    const long NC = t.NC;
+    const double* Cp = Q + PC * NC;
+    const int th = threadIdx.x;
+
+    __syncthreads();                               // the readers of the previous direction's records are done
+    {
+        double A[2][NF1];
+        {
+            double qm[2][NEDGE], qp[2][NEDGE];
+            load_edge_2(S.QM[T], NC, c, qm);
+            load_edge_2(S.QP[T], NC, c, qp);
+            const D2 cl = ldg2(Cp, c - st), cr = ldg2(Cp, c);
+            f1_solve_2<T, GEN>(qm, qp, cl, cr, wall_fac<T>(g, ijk[T]), P, A);
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * 256 + th] = A[w][n];
+        f1_at_2<T, GEN>(t, Q, S, g, P, c + st, ijk[T] + 1, A);
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int n = 0; n < NF1; ++n) park[((1 * 2 + w) * NF1 + n) * 256 + th] = A[w][n];
+    }
+    __syncthreads();
+
+    const bool tin = owner && ijk[T] >= t.lo[T] && ijk[T] <= t.hi[T];
+    double fr[NF1], fl[NF1];
+    // ---- N = x
+    {
+        const bool m0 = tin && ijk[0] >= t.lo[0], m1 = tin && v1 && ijk[0] + 1 >= t.lo[0];
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            load_edge_2(S.QM[0], NC, c, q);
+            const int tl = th > 0 ? th - 1 : 0;    // thread 0 owns nothing
+            park_get(park, 1, 1, tl, fr); park_get(park, 0, 1, tl, fl);
+            trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qmo[0]);
+            park_get(park, 1, 0, th, fr); park_get(park, 0, 0, th, fl);
+            trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qmo[1]);
+            load_edge_2(S.QP[0], NC, c, q);
+            trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qpo[0]);
+            park_get(park, 1, 1, th, fr); park_get(park, 0, 1, th, fl);
+            trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qpo[1]);
+            const D2 cl = ldg2(Cp, c - 8u), cr = ldg2(Cp, c);
+            double bnd[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
+            trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
+        }
+    }
+    // ---- N = O
+    {
+        const bool m0 = tin && ijk[O] >= t.lo[O], m1 = m0 && v1;
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            {
+                double B0[2][NF1], B1[2][NF1];
+                f1_at_2<T, GEN>(t, Q, S, g, P, c - so, ijk[T], B0);
+                f1_at_2<T, GEN>(t, Q, S, g, P, c - so + st, ijk[T] + 1, B1);
+                load_edge_2(S.QM[O], NC, c, q);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) trans_single<T>(q[w], B1[w], B0[w], P.gamma, cdtdt, P, qmo[w]);
+            }
+            load_edge_2(S.QP[O], NC, c, q);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                park_get(park, 1, w, th, fr); park_get(park, 0, w, th, fl);
+                trans_single<T>(q[w], fr, fl, P.gamma, cdtdt, P, qpo[w]);
+            }
+            const D2 cl = ldg2(Cp, c - so), cr = ldg2(Cp, c);
+            double bnd[2];
+            bnd[0] = bnd[1] = wall_fac<O>(g, ijk[O]);
+            trans1_solve_store<O, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
+        }
+    }
+}
+
+// T = x part shared by both fold kernels: the first x solve comes from the trace kernel (F1[x] in memory), as in k_trans1
+template <int GEN>
+__device__ __forceinline__ void trans1_fold_tx(const Tile& t, const int ijk[3], bool v1, unsigned c, const double* __restrict__ Q,
+                                               const DevScratch& S, const DevGeom& g, double cdtdx, const DevParams& P)
+{
+    const Str s = gstr(t);
+#pragma unroll
+    for (int Nn = 1; Nn <= 2; ++Nn) {
+        bool in_t[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int ix = ijk[0] + w;
+            in_t[w] = ((w == 0) || v1) && ijk[Nn] >= t.lo[Nn] && ix >= t.lo[0] && ix <= t.hi[0];
+        }
+        if (!in_t[0] && !in_t[1]) continue;
+        const unsigned sn = (Nn == 1) ? s.y : s.z;
+        double qm[2][NEDGE], qp[2][NEDGE];
+        const double* QMn = (Nn == 1) ? S.QM[1] : S.QM[2];
+        const double* QPn = (Nn == 1) ? S.QP[1] : S.QP[2];
+        load_edge_2(QMn, t.NC, c, qm);
+        load_edge_2(QPn, t.NC, c, qp);
+        const D2 cl = ldg2(Q + PC * t.NC, c - sn), cr = ldg2(Q + PC * t.NC, c);
+        double bnd[2];
+        if (Nn == 1) {
+            bnd[0] = bnd[1] = wall_fac<1>(g, ijk[1]);
+            trans1_pair<1, 0, false, GEN>(t, S, c, sn, 8u, qm, qp, cl, cr, bnd, cdtdx, in_t[0], in_t[1], P);
+        } else {
+            bnd[0] = bnd[1] = wall_fac<2>(g, ijk[2]);
+            trans1_pair<2, 0, false, GEN>(t, S, c, sn, 8u, qm, qp, cl, cr, bnd, cdtdx, in_t[0], in_t[1], P);
+        }
+    }
+}
+
+template <int GEN>
+__global__ void __launch_bounds__(256) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                         double cdtdx, double cdtdy, double cdtdz, DevParams P)
+{
+    __shared__ double park[2 * 2 * NF1 * 256];
+    DT_THIRDS_FROM_DEVICE();
+    int ijk[3];
+    bool owner;
+    fold_thread_wg(b, ijk[0], ijk[1], ijk[2], owner);
+    const bool v1 = ijk[0] + 1 <= b.hi0;
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    trans1_fold_dir_lds<1, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdy, P, park);
+    trans1_fold_dir_lds<2, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdz, P, park);
+    if (!owner) return;
+    trans1_fold_tx<GEN>(t, ijk, v1, c, Q, S, g, cdtdx, P);
+}
+
+#ifdef FOLD_ONE_WAVE        // A/B: 286 registers (VGPR + AGPR), one wave per SIMD, no spills
+#define FOLD_WAVES CG_TWO_WAVES
+#else                       // two waves per SIMD: 256 VGPRs, 28 spilled to scratch
+#define FOLD_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+template <int GEN>
+__global__ void __launch_bounds__(256) FOLD_WAVES k_trans1_fold(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                     double cdtdx, double cdtdy, double cdtdz, DevParams P)
+{
+    DT_THIRDS_FROM_DEVICE();
+    int ijk[3];
+    bool owner;
+    fold_thread(b, ijk[0], ijk[1], ijk[2], owner);
+    const bool v1 = ijk[0] + 1 <= b.hi0;
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    trans1_fold_dir<1, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdy, P);
+    trans1_fold_dir<2, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdz, P);
+    if (!owner) return;
+    trans1_fold_tx<GEN>(t, ijk, v1, c, Q, S, g, cdtdx, P);
+}
+
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one
 // kernel instead of two (F1[T] serves the two N != T), the other reads hit in L2.
 template <bool RE, int NMASK = 7, int GEN = 2>
@@ -1642,6 +2059,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_trans1(Tile t, LinBox b, c
 {
     int ijk[3];
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
+    DT_THIRDS_FROM_DEVICE();
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second zone of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     if (NMASK & 1) trans1_body<0, RE, GEN>(t, ijk, v1, c, Q, S, g, cdtdy, cdtdz, P);
@@ -1762,8 +2180,15 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, co
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
                                                int acc_hi, int assign, DevParams P)
 {
+    RETURN_IF_BATCH_FAILED();
     int ijk[3];
     if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
+    if (P.dtp) {                                  // hdtdx = 0.5*dt/dx as on the host
+        constexpr int T1 = (N == 0) ? 1 : 0, T2 = (N == 2) ? 1 : 2;
+        dt = P.dtp[6];
+        hdtdx_t1 = 0.5 * dt / g.dx[T1];
+        hdtdx_t2 = 0.5 * dt / g.dx[T2];
+    }
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     double R[2][NFIN];
@@ -1939,9 +2364,11 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
                                                 int from_sborder, DevParams P, int ntimes,
                                                 double dx0, double dx1, double dx2, double* red)
 {
+    RETURN_IF_BATCH_FAILED();
+    if (P.dtp) dt = P.dtp[6];
     int i, j, k;
     const bool valid = box_thread(b, i, j, k);
-    double dtmin = 1.e200, rmin_raw = 1.e300;
+    double dtmin = 1.e200, rmin_raw = 1.e300, dtmin1 = 1.e200;
     if (valid) {
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
@@ -1996,8 +2423,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 
     if (CLEAN) {
         rmin_raw = nan_guard(un[URHO]);
-        clean_zone(P, ntimes, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEDEN], un[UEINT], un[UTEMP], un[UFS]);
-        dtmin = nan_guard(zone_dt_cfl(P, dx0, dx1, dx2, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEINT]));
+        clean_zone_dt(P, ntimes, dx0, dx1, dx2, un[URHO], un[UMX], un[UMY], un[UMZ], un[UEDEN], un[UEINT], un[UTEMP], un[UFS], dtmin1, dtmin);
     }
 #pragma unroll
     for (int m = 0; m < NUM_STATE; ++m) {
@@ -2005,7 +2431,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
         stg(Unew.p + m * Unew.sn, cn, un[m]);
     }
     }
-    if (CLEAN && red) block_min2_atomic(dtmin, rmin_raw, red);
+    if (CLEAN && red) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2028,6 +2454,8 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
                                                        int acc_hi, int assign, int from_sborder, DevParams P, int ntimes,
                                                        double* red)
 {
+    RETURN_IF_BATCH_FAILED();
+    if (P.dtp) { dt = P.dtp[6]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
     unsigned bid = blockIdx.x;
     bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
     const int lane = threadIdx.x & 63;
@@ -2067,7 +2495,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
     for (int m = 0; m < NFIN; ++m) Rn[m] = __shfl_down(R[0][m], 1, 64);
 
     // Castro::consup_hydro (Castro_ctu.cpp:11-86) for the zones i and i+1
-    double dtmin = 1.e200, rmin_raw = 1.e300;
+    double dtmin = 1.e200, rmin_raw = 1.e300, dtmin1 = 1.e200;
     if (zA) {
         const Str s = gstr(t);
         const unsigned sy = s.y, sz = s.z;
@@ -2110,8 +2538,10 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
             for (int w = 0; w < 2; ++w) {
                 if (w == 1 && !zB) continue;
                 rmin_raw = fmin(rmin_raw, nan_guard(un[w][URHO]));
-                clean_zone(P, ntimes, un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS]);
-                dtmin = fmin(dtmin, nan_guard(zone_dt_cfl(P, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEINT])));
+                double d1, d2;
+                clean_zone_dt(P, ntimes, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS], d1, d2);
+                dtmin1 = fmin(dtmin1, d1);
+                dtmin = fmin(dtmin, d2);
             }
         }
 #pragma unroll
@@ -2121,7 +2551,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
             else stg(Unew.p + m * Unew.sn, cn, un[0][m]);
         }
     }
-    if (CLEAN && red) block_min2_atomic(dtmin, rmin_raw, red);
+    if (CLEAN && red) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2175,7 +2605,7 @@ __global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const 
     const bool zA = owner && ijk[0] <= b.hi0, zB = owner && ijk[0] + 1 <= b.hi0; // zones of bx (z-face pairs too)
     const Str s = gstr(t);
     double* pk = park + threadIdx.x;
-    double dtmin = 1.e200, rmin_raw = 1.e300;
+    double dtmin = 1.e200, rmin_raw = 1.e300, dtmin1 = 1.e200;
 
     {   // the lowest z face of the chunk: this chunk stores its outputs
         ijk[2] = k0;
@@ -2255,8 +2685,10 @@ __global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const 
                 for (int w = 0; w < 2; ++w) {
                     if (w == 1 && !zB) continue;
                     rmin_raw = fmin(rmin_raw, nan_guard(un[w][URHO]));
-                    clean_zone(P, ntimes, un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS]);
-                    dtmin = fmin(dtmin, nan_guard(zone_dt_cfl(P, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEINT])));
+                    double d1, d2;
+                    clean_zone_dt(P, ntimes, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS], d1, d2);
+                    dtmin1 = fmin(dtmin1, d1);
+                    dtmin = fmin(dtmin, d2);
                 }
             }
 #pragma unroll
@@ -2267,12 +2699,18 @@ __global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const 
             }
         }
     }
-    if (CLEAN && red) block_min2_atomic(dtmin, rmin_raw, red);
+    if (CLEAN && red) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
 }
 
 // ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
+int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
+int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: 2 = k_trans1_fold_lds (records parked in LDS;
+                          // -0.35 ms per 256^3 step), 1 = k_trans1_fold (records in registers, 28 spilled: break-even), 0 = two k_riemann1
+                          // launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
+int g_side_stream = 0;    // 1: k_divu runs on the context's side stream beside the trace kernel (CASTRO_AMD_SIDE_STREAM); measured: no gain,
+                          // two independent pipelines on two streams take as long as one after the other (tools/concurrency_probe.py)
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
 int g_trace_tile_rows = 64;   // rows per y-tile of the trace launch (its L2 holds only Q now that the stores are non-temporal: 2.72 -> 2.60 ms; -1: g_tile_rows)
 
@@ -2414,7 +2852,8 @@ static int shell_boxes(const int olo[3], const int ohi[3], const int ilo[3], con
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,
                      const DFab fluxes[3], const DFab mass[3], const DFab qe[3],
                      const DevGeom& g, const DevParams& P, double dt, int flags, const int acc_hi[3],
-                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr)
+                     int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr,
+                     const LaunchAux& aux)
 {
     // Staged execution (CASTRO_AMD_STAGE_A / _B): A = what needs no ghost zone of Sborder -- ctoprim on the valid
     // zones, PPM tracing on grow(bx, -3) -- so that a caller can run it while the halo exchange is in flight;
@@ -2475,7 +2914,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 
     if (stage_a) {
         if (splittable) {
-            KL("k_ctoprim", k_ctoprim, t.lo, t.hi, Sborder, S.Q, P, d_status, none);
+            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0);
             if (inner_ok) trace_with_xriemann(inner_box.lo, inner_box.hi);
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -2484,9 +2923,11 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     int slo[6][3], shi[6][3];
     if (second_half) {
         const int ns = shell_boxes(qlo, qhi, t.lo, t.hi, slo, shi);
-        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim, slo[m], shi[m], Sborder, S.Q, P, d_status, none);
+        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0);
+    } else if (aux.sb_clean > 0) {
+        KL("k_ctoprim_clean", k_ctoprim<true>, qlo, qhi, Sborder, S.Q, P, d_status, none, aux.sb_clean);
     } else {
-        KL("k_ctoprim", k_ctoprim, qlo, qhi, Sborder, S.Q, P, d_status, none);
+        KL("k_ctoprim", k_ctoprim<false>, qlo, qhi, Sborder, S.Q, P, d_status, none, 0);
     }
 
     int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
@@ -2498,8 +2939,26 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             nhi[d][e] = (e == d) ? t.hi[e] + 1 : t.hi[e];
         }
 
+    // div(u) depends on Q only and is first read by the final stage: on the context's side stream it runs beside the
+    // trace kernel (forked from and joined to `stream` by events; the hybrid solver's shock flags are read by the first
+    // Riemann solves already, so that form stays in line)
+    bool divu_forked = false;
     if (P.hybrid_riemann == 1) { KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, S.SHK, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]); }
+    else if (aux.side && g_side_stream) {
+        hipEventRecord(aux.ev_fork, stream);
+        hipStreamWaitEvent(aux.side, aux.ev_fork, 0);
+        {
+            hipStream_t main_stream = stream;
+            hipStream_t stream = aux.side;      // KL2 launches on `stream`
+            (void)main_stream;
+            KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+        }
+        hipEventRecord(aux.ev_join, aux.side);
+        divu_forked = true;
+    }
     else { KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]); }
+    // the join must precede the first reader of DIV (and every return path after this point)
+    auto join_divu = [&]() { if (divu_forked) { hipStreamWaitEvent(stream, aux.ev_join, 0); divu_forked = false; } };
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
@@ -2530,16 +2989,23 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     }
     (void)staged;
 
+    // the first y / z solves folded into the transverse stage (k_trans1_fold): default solver set, default final-stage form
+    const bool fold_r1 = g_fold_r1 && solv == 0 && !tfix && P.reset_rhoe != 1 && g_fuse_consup;
+    // the LDS-brick and z-marching forms of the final stage (experiments, off by default) take dt by value only
+    if (P.dtp && (g_fuse_consup == 2 || (!g_fuse_consup && g_final_lds))) return -2;
     if (tfix) {
         KL2("k_riemann1", (k_riemann1<0, true>), flo[0], fhi[0], S.Q, S, g, P);
         KL2("k_riemann1", (k_riemann1<1, true>), flo[1], fhi[1], S.Q, S, g, P);
         KL2("k_riemann1", (k_riemann1<2, true>), flo[2], fhi[2], S.Q, S, g, P);
     } else {
         if (!x_done) KL2_SOLV("k_riemann1", K_R1_0, flo[0], fhi[0], S.Q, S, g, P);
-        KL2_SOLV("k_riemann1", K_R1_1, flo[1], fhi[1], S.Q, S, g, P);
-        KL2_SOLV("k_riemann1", K_R1_2, flo[2], fhi[2], S.Q, S, g, P);
+        if (!fold_r1) {
+            KL2_SOLV("k_riemann1", K_R1_1, flo[1], fhi[1], S.Q, S, g, P);
+            KL2_SOLV("k_riemann1", K_R1_2, flo[2], fhi[2], S.Q, S, g, P);
+        }
     }
 
+    join_divu();
     // cdtdx = dt/dx/3 (Castro_ctu_hydro.cpp:688-690); hdtdx = 0.5*dt/dx (:684-686)
     const double cdtdx = dt / g.dx[0] / 3.0, cdtdy = dt / g.dx[1] / 3.0, cdtdz = dt / g.dx[2] / 3.0;
     const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
@@ -2583,6 +3049,26 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         KL2("k_trans1_y", (k_trans1<false, 2>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
         KL2("k_trans1_z", (k_trans1<false, 4>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
 #else
+        if (fold_r1) {
+            long n_;
+            struct RowsGuard2 { int keep; RowsGuard2() : keep(tl_tile_rows) { if (g_fold_tile_rows >= 0) tl_tile_rows = g_fold_tile_rows; }
+                                ~RowsGuard2() { tl_tile_rows = keep; } } rows_guard2;
+            LinBox b_ = linbox2(olo, ohi, n_);
+            if (n_ > 0) {
+                prof_begin(prof, "k_trans1_fold", stream);
+                if (g_fold_r1 == 2) {
+                    b_.nb = (unsigned)((n_ + 254) / 255);        // 255 new slots per workgroup, see fold_thread_wg
+                    if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
+                    hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(256), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                } else {
+                    const long waves_ = (n_ + 62) / 63;          // 63 new slots per wave, see fold_thread
+                    b_.nb = (unsigned)((waves_ + 3) / 4);
+                    if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
+                    hipLaunchKernelGGL(k_trans1_fold<0>, dim3(b_.nb), dim3(256), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                }
+                prof_end(prof, stream);
+            }
+        } else
         KL2_SOLV("k_trans1", K_T1, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
 #endif
         if (g_fuse_consup == 2) {

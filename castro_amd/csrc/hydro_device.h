@@ -45,6 +45,10 @@ struct DevParams {
     double cfl, speed_limit;
     int limit_small_dens, limit_large_vel;
     int source_term_predictor;
+    // Host-free stepping (castro_amd_hydro_opts.d_dt): when not null the kernels take the time step from this device
+    // double instead of their by-value argument, and derive dt/dx, dt/dx/3, dt/dx/2 from it with the host's expressions
+    // (IEEE division on both sides: the same bits).
+    const double* dtp;
 };
 
 // amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument
@@ -331,6 +335,43 @@ __device__ __forceinline__ void block_min2_atomic(double a, double b, double* ou
 
 
 // ---------------------------------------------------------------------------------------
+// block-wide min of three values: [CFL estimate after the last clean_state, raw minimum density, CFL estimate after the first]
+__device__ __forceinline__ void block_min3_atomic(double a, double b, double c3, double* out)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fmin(a, __shfl_down(a, off, 64));
+        b = fmin(b, __shfl_down(b, off, 64));
+        c3 = fmin(c3, __shfl_down(c3, off, 64));
+    }
+    __shared__ double sa[4], sb[4], sc[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sa[wave] = a; sb[wave] = b; sc[wave] = c3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_min_double(out, fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3])));
+        atomic_min_double(out + 1, fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3])));
+        atomic_min_double(out + 2, fmin(fmin(sc[0], sc[1]), fmin(sc[2], sc[3])));
+    }
+}
+
+// clean_state x ntimes (>= 1) on one zone with the CFL term taken twice: after the FIRST application -- the state the
+// validity check of do_advance_ctu sees (clean_state(S_new) then estTimeStep, Castro_advance_ctu.cpp:221-225, 386-392) --
+// and after the LAST, the state estTimeStep of the next coarse step sees (post_timestep has cleaned once more by then,
+// Castro.cpp:1909-1916).  A second clean_state is not always the identity (the dual-energy reset can flip its branch once
+// eden has been floored), so the two are reduced separately.
+__device__ __forceinline__ void clean_zone_dt(const DevParams& P, int ntimes, double dx0, double dx1, double dx2,
+                                              double& rho, double& mx, double& my, double& mz, double& eden, double& eint,
+                                              double& temp, double& rX, double& dt_first, double& dt_last)
+{
+    clean_zone(P, 1, rho, mx, my, mz, eden, eint, temp, rX);
+    dt_first = nan_guard(zone_dt_cfl(P, dx0, dx1, dx2, rho, mx, my, mz, eint));
+    dt_last = dt_first;
+    if (ntimes > 1) {
+        clean_zone(P, ntimes - 1, rho, mx, my, mz, eden, eint, temp, rX);
+        dt_last = nan_guard(zone_dt_cfl(P, dx0, dx1, dx2, rho, mx, my, mz, eint));
+    }
+}
+
 // PLM slopes (Source/hydro/slope.H); q[0..4] = zones i-2..i+2
 // ---------------------------------------------------------------------------------------
 // slope.H:27-121

@@ -116,9 +116,12 @@ class HipHydro:
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
                                    update_from_sborder=False, src=None, src_box=None, stream=None,
-                                   clean_ntimes=0, red=None, flux_assign=False, stage=None):
+                                   clean_ntimes=0, red=None, flux_assign=False, stage=None, sborder_clean=0, d_dt=None):
         """clean_ntimes > 0 selects castro_amd_ctu_hydro_clean_fab: the update is followed, in the same
-        pass, by S_new.min(URHO), clean_state x clean_ntimes and the CFL estimate, reduced into `red`."""
+        pass, by S_new.min(URHO), clean_state x clean_ntimes and the CFL estimate, reduced into `red`.
+        sborder_clean > 0 (castro_amd_ctu_hydro_fab_ex): clean_state that many times on every zone of Sborder, in place,
+        inside the pass that reads it.  d_dt: a device tensor whose first element is the time step (host-free stepping;
+        `dt` is ignored)."""
         bxlo, bxhi = bx
         vlo, vhi = vbx if vbx is not None else bx
         fb = (L.Fab * 3)()
@@ -139,6 +142,15 @@ class HipHydro:
             flags |= L.FLUX_ASSIGN
         if stage is not None:         # "A": the ghost-free part (overlaps the halo exchange); "B": the rest
             flags |= {"A": L.STAGE_A, "B": L.STAGE_B}[stage]
+        if sborder_clean > 0 or d_dt is not None:
+            o = L.HydroOpts(flags, int(clean_ntimes), red.data_ptr() if red is not None else None, int(sborder_clean),
+                            d_dt.data_ptr() if d_dt is not None else None)
+            rc = self.lib.castro_amd_ctu_hydro_fab_ex(
+                self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),
+                C.byref(L.fab_of(Sborder, *sb_box)), C.byref(sfab), C.byref(L.fab_of(S_new, *snew_box)),
+                fb, mb, qb, C.byref(geom), C.byref(params), float(time), float(dt), C.byref(o), _stream_ptr(stream))
+            L.check(rc, "ctu_hydro_fab_ex")
+            return
         if clean_ntimes > 0:
             rc = self.lib.castro_amd_ctu_hydro_clean_fab(
                 self.h, L.i3(bxlo), L.i3(bxhi), L.i3(vlo), L.i3(vhi),
@@ -268,6 +280,13 @@ class HipHydro:
                                                C.byref(L.fab_of(der, *der_box)), int(dcomp), L.i3(lo), L.i3(hi),
                                                C.byref(geom), C.byref(params), C.byref(ctr), _stream_ptr(stream)),
                 "derive_fab")
+
+    def step_control(self, red, ctl, params, max_dt=1.e200, fixed_dt=-1.0, stop_time=-1.0, use_retry=False, stream=None):
+        """castro_amd_step_control: do_advance_ctu's checks, time += dt and computeNewDt on the device (one thread)."""
+        L.check(self.lib.castro_amd_step_control(self.h, C.c_void_p(red.data_ptr()), C.c_void_p(ctl.data_ptr()), C.byref(params),
+                                                 float(max_dt), float(fixed_dt), float(stop_time), 1 if use_retry else 0,
+                                                 _stream_ptr(stream)),
+                "step_control")
 
     # ---- Castro::clean_state ---------------------------------------------------------------
     def clean_state(self, state, box, lo, hi, params, ntimes=1, stream=None):

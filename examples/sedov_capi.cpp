@@ -55,7 +55,7 @@ int main(int argc, char** argv)
     double *A = nullptr, *B = nullptr, *d_red = nullptr;
     HK(hipMalloc(&A, ng * NS * sizeof(double)));
     HK(hipMalloc(&B, ng * NS * sizeof(double)));
-    HK(hipMalloc(&d_red, 2 * sizeof(double)));
+    HK(hipMalloc(&d_red, 3 * sizeof(double)));
     HK(hipMemset(A, 0, ng * NS * sizeof(double)));
     HK(hipMemset(B, 0, ng * NS * sizeof(double)));
     double* fl[3]; double* mf[3];
@@ -106,7 +106,7 @@ int main(int argc, char** argv)
         CK(castro_amd_clean_state_fab(ctx, &S_old, lo, hi, &P, 2, nullptr));
         CK(castro_amd_bc_fill_fab(ctx, &S_old, &G, nullptr));
         // hydro update + S_new.min(URHO) + clean_state(S_new) + estTimeStep in one pass
-        const double init[2] = { 1.e200, 1.e200 };
+        const double init[3] = { 1.e200, 1.e200, 1.e200 };   // [estimate after the last clean, min density, estimate after the first]
         HK(hipMemcpyAsync(d_red, init, sizeof(init), hipMemcpyHostToDevice, nullptr));
         CK(castro_amd_ctu_hydro_clean_fab(ctx, lo, hi, lo, hi, &S_old, &nosrc, &S_new, flux, mass, noqe, &G, &P, time, dts,
                                           CASTRO_AMD_UPDATE_FROM_SBORDER | CASTRO_AMD_FLUX_ASSIGN, 1, d_red, nullptr));

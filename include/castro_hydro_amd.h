@@ -181,10 +181,13 @@ int castro_amd_ctu_hydro_fab(castro_amd_ctx *ctx,
  * (Source/driver/Castro_advance_ctu.cpp:168-225, 386-392):
  *   d_out[1] = min(d_out[1], density of the updated zone)         (S_new.min(URHO))
  *   clean_state applied `clean_ntimes` (>= 1) times               (Castro::clean_state)
- *   d_out[0] = min(d_out[0], dx/(c+|u|) of the cleaned zone)      (Castro::estdt_cfl)
+ *   d_out[2] = min(d_out[2], dx/(c+|u|) of the zone cleaned ONCE) (Castro::estdt_cfl as the validity check of
+ *                                                                  do_advance_ctu sees it, :386-392)
+ *   d_out[0] = min(d_out[0], dx/(c+|u|) of the zone after the LAST clean_state)   (what estTimeStep of the next coarse
+ *                                                                  step sees when post_timestep's clean_state rides along)
  * The result equals castro_amd_ctu_hydro_fab + castro_amd_clean_state_reduce_fab on bx, without the
  * second pass over S_new.  clean_ntimes == 0 is exactly castro_amd_ctu_hydro_fab; d_out may be NULL
- * (no reduction) and otherwise points to 2 device doubles initialised by the caller.
+ * (no reduction) and otherwise points to 3 device doubles initialised by the caller.
  */
 int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx *ctx,
                                    const int bxlo[3], const int bxhi[3],
@@ -200,6 +203,71 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx *ctx,
                                    double time, double dt, int flags,
                                    int clean_ntimes, double *d_out, void *stream);
 
+/*
+ * The general form of the two calls above.  Fields beyond those of castro_amd_ctu_hydro_clean_fab:
+ *   sborder_clean_ntimes  > 0: Castro::clean_state is applied that many times, IN PLACE, to every zone of
+ *                         grow(bx, 4) of Sborder inside the pass that reads it (k_ctoprim) -- the clean_state(S_old) of
+ *                         initialize_advance plus the clean_state(Sborder) after FillPatch
+ *                         (Castro_advance.cpp:311, :186) without their own sweeps.  clean_state is zone-local, and
+ *                         the ghost zones of a single level are copies (or mirror images) of valid zones, so
+ *                         "FillPatch the uncleaned state, then clean everything" equals the reference's "clean, FillPatch,
+ *                         clean".  Only for whole-box calls (bx == vbx, one tile per FAB: overlapping tiles would clean
+ *                         shared ghost zones twice) without CASTRO_AMD_STAGE_A/B; Sborder is written.
+ */
+typedef struct castro_amd_hydro_opts {
+    int flags;                  /* CASTRO_AMD_UPDATE_* | CASTRO_AMD_FLUX_ASSIGN | CASTRO_AMD_STAGE_* */
+    int clean_ntimes;           /* as in castro_amd_ctu_hydro_clean_fab */
+    double *d_out;              /* as in castro_amd_ctu_hydro_clean_fab (device, 2 doubles) or NULL */
+    int sborder_clean_ntimes;   /* see above; 0 = Sborder is read only */
+    const double *d_dt;         /* not NULL: castro_amd_step_control's DEVICE vector `ctl` -- the kernels read the time step
+                                 * from ctl[CASTRO_AMD_CTL_DTHYDRO] (the `dt` argument is ignored), and when
+                                 * ctl[CASTRO_AMD_CTL_STATUS] != 0 (an earlier step of the batch was rejected) the call
+                                 * leaves Sborder, S_new and the flux arrays untouched */
+} castro_amd_hydro_opts;
+int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx *ctx,
+                                const int bxlo[3], const int bxhi[3],
+                                const int vbxlo[3], const int vbxhi[3],
+                                const castro_amd_fab *Sborder,
+                                const castro_amd_fab *src,
+                                const castro_amd_fab *S_new,
+                                const castro_amd_fab flux_out[3],
+                                const castro_amd_fab mass_flux_out[3],
+                                const castro_amd_fab qe_out[3],
+                                const castro_amd_geom *geom,
+                                const castro_amd_params *params,
+                                double time, double dt, const castro_amd_hydro_opts *opts, void *stream);
+
+/*
+ * Host-free time stepping of a single level (no retries, no sources): one thread on the device does what the host does
+ * between two hydro updates -- the tail of Castro::do_advance_ctu (Castro_advance_ctu.cpp:168-216, 386-392), the
+ * time / step bookkeeping of Amr::coarseTimeStep and Castro::computeNewDt (Castro.cpp:1629-1819) for the next step:
+ *   red (3 doubles, as written by castro_amd_ctu_hydro_clean_fab; reset to 1e200 on exit)
+ *   ctl[CASTRO_AMD_CTL_DT]     in: the step just taken; out: the next step's dt
+ *                              = min(cfl * red[0], change_max * dt) clipped to stop_time (fixed_dt > 0: fixed_dt)
+ *   ctl[CASTRO_AMD_CTL_DTHYDRO] the dt the hydro kernels of that step use: dt, or with use_retry != 0 the single
+ *                              subcycle of Castro::subcycle_advance_ctu, (time + dt) - time (Castro_advance_ctu.cpp:463-471),
+ *                              which differs from dt in the last bit now and then; the validity check uses it too
+ *   ctl[CASTRO_AMD_CTL_TIME]   += dt;   ctl[CASTRO_AMD_CTL_NSTEP] += 1
+ *   ctl[CASTRO_AMD_CTL_STATUS] |= 1 if red[1] < small_dens (the step would be rejected),
+ *                              |= 2 if change_max * cfl * red[2] < dt (timestep validity check); sticky: once set,
+ *                              time, step count and dt stop changing, so that the host finds the first failure
+ *   ctl[CASTRO_AMD_CTL_HIST + n % CASTRO_AMD_CTL_NHIST] = dt of step n (for hosts that want the sequence)
+ * The hydro calls of the next step take their dt from ctl[CASTRO_AMD_CTL_DTHYDRO] (castro_amd_hydro_opts.d_dt = ctl).  The host
+ * reads ctl when it wants to (one synchronisation per batch of steps instead of one per step).
+ */
+#define CASTRO_AMD_CTL_DT 0
+#define CASTRO_AMD_CTL_TIME 1
+#define CASTRO_AMD_CTL_NSTEP 2
+#define CASTRO_AMD_CTL_STATUS 3
+#define CASTRO_AMD_CTL_RHOMIN 4
+#define CASTRO_AMD_CTL_EST 5
+#define CASTRO_AMD_CTL_DTHYDRO 6
+#define CASTRO_AMD_CTL_HIST 8
+#define CASTRO_AMD_CTL_NHIST 56
+#define CASTRO_AMD_CTL_SIZE 64
+int castro_amd_step_control(castro_amd_ctx *ctx, double *d_red, double *d_ctl, const castro_amd_params *params,
+                            double max_dt, double fixed_dt, double stop_time, int use_retry, void *stream);
+
 /* Castro::clean_state on one FAB region (Source/driver/Castro.cpp:4238-4278):
  * enforce_min_density, normalize_species, reset_internal_energy, computeTemp,
  * applied `ntimes` times in a row to every zone of [lo,hi] (the reference runs it
@@ -211,8 +279,9 @@ int castro_amd_clean_state_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
 /* The post-hydro sequence of Castro::do_advance_ctu fused into one pass over the zones of [lo,hi]:
  *   d_out[1] = min(d_out[1], min density of the state AS GIVEN)   (S_new.min(URHO), Castro_advance_ctu.cpp:168)
  *   clean_state applied `ntimes` times                            (Castro_advance_ctu.cpp:221-225)
- *   d_out[0] = min(d_out[0], min dx/(c+|u|) of the cleaned state) (estTimeStep, Castro_advance_ctu.cpp:386)
- * d_out: device pointer to 2 doubles initialised by the caller (see castro_amd_estdt_fab). */
+ *   d_out[2] = min(d_out[2], min dx/(c+|u|) after the first application), d_out[0] = ... after the last
+ *                                                                 (estTimeStep, Castro_advance_ctu.cpp:386)
+ * d_out: device pointer to 3 doubles initialised by the caller (castro_amd_estdt_fab writes [0] and [1] only). */
 int castro_amd_clean_state_reduce_fab(castro_amd_ctx *ctx, const castro_amd_fab *state,
                                       const int lo[3], const int hi[3], const castro_amd_geom *geom,
                                       const castro_amd_params *params, int ntimes, double *d_out, void *stream);

@@ -27,6 +27,9 @@ def hip():
     h.close()
 
 
+LIB_DEFAULT_FOLD_R1 = "2"        # g_fold_r1 of ctu_kernels.hip
+
+
 def _to_dev(h, a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).to(h.device)
@@ -389,7 +392,7 @@ def test_ctu_hydro_clean_fab_equals_two_passes(hip, oracle):
     est = L.ora_estdt_cfl(oracle.i3(bxlo), oracle.i3(bxhi), a, Go, Po)
 
     Ud, Snew_d = _to_dev(hip, U), _to_dev(hip, U[sl])
-    red = torch.full((2,), 1.e200, dtype=torch.float64, device=hip.device)
+    red = torch.full((3,), 1.e200, dtype=torch.float64, device=hip.device)
     for bx in [((0, 0, 0), (7, 11, 9)), ((8, 0, 0), (15, 11, 4)), ((8, 0, 5), (15, 11, 9))]:
         hip.construct_ctu_hydro_source(bx, Ud, (sb_lo, sb_hi), Snew_d, (bxlo, bxhi), Gh, Ph, 0.0, dt,
                                        vbx=(bxlo, bxhi), clean_ntimes=1, red=red)
@@ -397,7 +400,7 @@ def test_ctu_hydro_clean_fab_equals_two_passes(hip, oracle):
     hip.status()
     assert (Snew_o[0] == 0.45).any(), "test does not reach the enforce_min_density branch"
     _assert_exact({"S_new": (Snew_d.cpu().numpy(), Snew_o)}, "fused clean")
-    assert red.tolist() == [est, rmin]
+    assert red.tolist() == [est, rmin, est]          # one clean_state: the estimates after the first and the last coincide
 
 
 def test_unsupported_options_fail_loudly(hip):
@@ -475,9 +478,13 @@ def test_clean_state_estdt_bcfill_pack(hip, oracle):
 
             # fused post-hydro pass: raw min density + clean + estdt
             Ud2 = _to_dev(hip, U)
-            red2 = torch.full((2,), 1e200, dtype=torch.float64, device=hip.device)
+            red2 = torch.full((3,), 1e200, dtype=torch.float64, device=hip.device)
             hip.clean_state_reduce(Ud2, (glo, ghi), lo, hi, Gh, Ph, red2, ntimes=ntimes)
             torch.cuda.synchronize()
+            # [2]: the CFL estimate of the state cleaned ONCE (what do_advance_ctu's validity check sees)
+            U1 = U.copy()
+            oracle.lib().ora_clean_state(oracle.i3(lo), oracle.i3(hi), oracle.a4(U1, glo, ghi), C.byref(Po))
+            assert red2[2].item() == oracle.lib().ora_estdt_cfl(oracle.i3(lo), oracle.i3(hi), oracle.a4(U1, glo, ghi), C.byref(Go), C.byref(Po))
             raw_min = oracle.lib().ora_min_density(oracle.i3(lo), oracle.i3(hi), oracle.a4(U.copy(), glo, ghi))
             sl_v = (slice(None),) + tuple(slice(lo[2 - a] - glo[2 - a], hi[2 - a] - glo[2 - a] + 1) for a in range(3))
             assert np.array_equal(Ud2.cpu().numpy()[sl_v], Uo[sl_v])
@@ -883,7 +890,7 @@ def test_320_cubed_against_oracle_where_mirror_symmetry_is_inexact(oracle):
         lev.step(0.01)
         assert c.dt == lev.dt
     torch.cuda.synchronize()
-    A, B = c.S_new().cpu().numpy(), lev.state()
+    A, B = c.S_new().cpu().numpy(), np.array(lev.state())     # a copy: the view dies with the level
     lev.close()
     _assert_exact({"S_new": (A, B)}, "320^3")
     asym_dev = [float(np.abs(A[0] - np.flip(A[0], axis=d)).max()) for d in range(3)]
@@ -915,6 +922,82 @@ def test_nan_zone_in_the_initial_data_does_not_become_a_time_step():
         c.estTimeStep()
     with pytest.raises(AdvanceFailure):
         c.computeInitialDt()
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["launches", "hipgraph"])
+def test_host_free_steps_equal_the_stepwise_driver(oracle, graph):
+    """Castro.run_steps: dt, time and the step checks stay on the device (castro_amd_step_control, kernels reading dt from
+    device memory), one host synchronisation per batch, optionally a captured pair of steps replayed as a hipGraph.  The
+    state, the time, the step count and the whole dt sequence must equal step() -- and the oracle's level driver -- bit for
+    bit; a batch that ends exactly at stop_time clips its last step like computeNewDt does."""
+    import torch
+    import castro_amd
+    n = (32, 32, 32)
+    kw = dict(r_init=0.1, nsub=4)
+    a, b = castro_amd.Castro(n), castro_amd.Castro(n)
+    lev = oracle.Level(n, oracle.make_geom(n), oracle.default_params(), nthreads=8)
+    for c in (a, b):
+        c.initData("sedov", **kw)
+    lev.init_sedov(**kw)
+    assert a.host_free_ok()
+    dts = []
+    for _ in range(9):
+        b.step()
+        lev.step()
+        dts.append(b.dt)
+        assert b.dt == lev.dt
+    a.run_steps(9, graph=graph)
+    assert a.nstep == 9 and a.time == b.time and a.dt == b.dt
+    assert a.dt_history == dts
+    _assert_exact({"S_new": (a.S_new().cpu().numpy(), b.S_new().cpu().numpy()), "oracle": (a.S_new().cpu().numpy(), lev.state()),
+                   "flux0": (a.fluxes[0].cpu().numpy(), b.fluxes[0].cpu().numpy())}, "host-free batch")
+    # a second batch (odd length: the buffers change roles), then stepwise again, then a batch into stop_time
+    a.run_steps(5, graph=graph)
+    for _ in range(5):
+        b.step()
+    assert a.time == b.time and a.dt == b.dt
+    a.step()
+    b.step()
+    assert a.dt == b.dt
+    stop = b.time + 2.5 * b.dt
+    a.run_steps(3, stop_time=stop, graph=graph)
+    for _ in range(3):
+        b.step(stop)
+    assert a.time == b.time == stop and a.nstep == b.nstep and a.dt == b.dt
+    _assert_exact({"S_new": (a.S_new().cpu().numpy(), b.S_new().cpu().numpy())}, "host-free batch into stop_time")
+    lev.close()
+
+
+def test_host_free_batch_latches_a_rejected_step():
+    """A step the host path rejects (timestep validity check, Castro_advance_ctu.cpp:386-392) stops a host-free batch at
+    the same step: the status is latched on the device and the launches after it leave the state alone.  Without
+    castro.use_retry run_steps raises like step(); with it the host redoes the step with the reference's subcycling
+    (retry_advance_ctu) and the batch goes on -- bit for bit the stepwise driver, retries and subcycles included."""
+    import torch
+    import castro_amd
+    from castro_amd.castro import AdvanceFailure
+    n = (16, 16, 16)
+    kw = dict(initial_dt=6.0e-3)                    # four times the CFL limit of the blast: the first step is rejected
+    a, b = (castro_amd.Castro(n, use_retry=False, **kw) for _ in range(2))
+    for c in (a, b):
+        c.initData("sedov", r_init=0.1, nsub=4)
+    with pytest.raises(AdvanceFailure):
+        b.step()
+    with pytest.raises(AdvanceFailure):
+        a.run_steps(4, graph=False)
+    assert a.nstep == 0 and a.time == 0.0
+    for graph in (False, True):
+        a, b = (castro_amd.Castro(n, use_retry=True, max_subcycles=64, **kw) for _ in range(2))
+        for c in (a, b):
+            c.initData("sedov", r_init=0.1, nsub=4)
+        assert a.host_free_ok()
+        for _ in range(7):
+            b.step()
+        assert b.nretries == 0 and b.nstep == 7
+        a.run_steps(7, graph=graph)
+        assert a.nstep == 7 and a.time == b.time and a.dt == b.dt
+        _assert_exact({"S_new": (a.S_new().cpu().numpy(), b.S_new().cpu().numpy()),
+                       "flux0": (a.fluxes[0].cpu().numpy(), b.fluxes[0].cpu().numpy())}, "host-free batch with a retried step")
 
 
 def test_two_level_amr_on_the_device_matches_oracle_backend(oracle):
@@ -1655,10 +1738,10 @@ def test_hydro_call_is_hipgraph_capturable(hip):
         hip.construct_ctu_hydro_source((bxlo, bxhi), U, sb, Sn, (bxlo, bxhi), G, P, 0.0, 8e-4, update_from_sborder=True,
                                        clean_ntimes=1, red=red)
 
-    ref, red_ref = hip.alloc(8, bxlo, bxhi), torch.full((2,), 1e200, dtype=torch.float64, device="cuda")
+    ref, red_ref = hip.alloc(8, bxlo, bxhi), torch.full((3,), 1e200, dtype=torch.float64, device="cuda")
     call(ref, red_ref)                                   # also reserves the scratch
     torch.cuda.synchronize()
-    Sn, red = hip.alloc(8, bxlo, bxhi), torch.full((2,), 1e200, dtype=torch.float64, device="cuda")
+    Sn, red = hip.alloc(8, bxlo, bxhi), torch.full((3,), 1e200, dtype=torch.float64, device="cuda")
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         call(Sn, red)
@@ -1847,16 +1930,18 @@ def test_randomised_option_combinations_match_the_oracle():
                                  {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1", "CASTRO_AMD_BRICK": "5,3,2"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "1", "CASTRO_AMD_XPAD": "12"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "32"},
-                                 {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "3"}],
+                                 {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "3"},
+                                 {"CASTRO_AMD_FOLD_R1": "1"}, {"CASTRO_AMD_FOLD_R1": "2"}, {"CASTRO_AMD_FOLD_R1": "0"}],
                          ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows",
-                              "z-marching", "z-marching-short-chunks"])
+                              "z-marching", "z-marching-short-chunks", "first-yz-solves-folded-into-trans1", "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches"])
 def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
     """The final stage has three forms: k_final<x,y,z> + k_consup (round 1), k_final_lds (transverse flux records staged
     in LDS bricks; measured slower, kept as the measured experiment of DESIGN.md section 9) and the default
     k_final<y,z> + k_finalx_consup.  Each must match the oracle bit for bit, odd extents and several tiles included."""
     import castro_amd
     from castro_amd.hydro import HipHydro
-    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD", "CASTRO_AMD_MARCH_PLANES")
+    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD", "CASTRO_AMD_MARCH_PLANES",
+            "CASTRO_AMD_FOLD_R1")
     old = {k: os.environ.get(k) for k in keys}
     try:
         os.environ.update(env)
@@ -1890,6 +1975,7 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
             os.environ[k] = v
         os.environ["CASTRO_AMD_BRICK"] = "0,0,0"
         os.environ["CASTRO_AMD_MARCH_PLANES"] = "32"
+        os.environ["CASTRO_AMD_FOLD_R1"] = old["CASTRO_AMD_FOLD_R1"] if old["CASTRO_AMD_FOLD_R1"] is not None else LIB_DEFAULT_FOLD_R1
         HipHydro(0).close()                   # restore the library's defaults for the tests that follow
         for k in keys:
             if old[k] is None:

@@ -5,5 +5,5 @@ for v in default $(ls castro_amd/libvariant_*.so 2>/dev/null); do
   if [ "$v" = default ]; then unset CASTRO_AMD_LIB; else export CASTRO_AMD_LIB=$PWD/$v; fi
   python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-contract-leg 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k={a: b['ms_per_step'] for a, b in d['roofline']['kernel_utilisation'].items()}; print('$v', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items() if a in ('k_trace','k_trans1','k_trans1_x','k_trans1_y','k_trans1_z','k_final_x','k_final_y','k_final_z','k_finalx_consup','k_riemann1','k_consup_clean')})"
+d=json.loads(sys.stdin.read()); k={a: b['ms_per_step'] for a, b in d['roofline']['kernel_utilisation'].items()}; print('$v', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items()})"
 done; done

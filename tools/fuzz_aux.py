@@ -85,7 +85,7 @@ for case in range(ncases):
     a, b = both(U)
     hip.clean_state(a, gb, bx[0], bx[1], Ph, ntimes=nt); ora.clean_state(b, gb, bx[0], bx[1], Po, ntimes=nt)
     check("clean_state", {"U": (a, b)}, info)
-    ra, rb = torch.full((2,), 1e200, dtype=torch.float64, device="cuda"), torch.full((2,), 1e200, dtype=torch.float64)
+    ra, rb = torch.full((3,), 1e200, dtype=torch.float64, device="cuda"), torch.full((3,), 1e200, dtype=torch.float64)
     hip.estdt_cfl(a, gb, bx[0], bx[1], Gh, Ph, ra); ora.estdt_cfl(b, gb, bx[0], bx[1], Go, Po, rb)
     check("estdt", {"red": (ra, rb)}, info)
     a, b = both(U)
