@@ -205,6 +205,8 @@ int ora_ctu_hydro_tile(const int bxlo[3], const int bxhi[3], const int vlo[3], c
 void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_params *P);
 void ora_set_state_threads(int n);
 double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P);
+/* the same with a NaN zone entering the minimum as -1e300: the form of the checks inside an advance */
+double ora_estdt_cfl_guarded(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P);
 double ora_min_density(const int lo[3], const int hi[3], ora_a4 u);
 void ora_bc_fill(ora_a4 u, const ora_geom *G);   /* physical-BC ghost fill, SURVEY D.2 */
 void ora_fill_interior_copy(ora_a4 dst, ora_a4 src, const int lo[3], const int hi[3]);

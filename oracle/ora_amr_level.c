@@ -242,7 +242,10 @@ static int advance_level(ora_amr *A, int l, double time, double dt, double a)
     ora_construct_ctu_hydro_source(L->lo, L->hi, Sb, nosrc, Sn, fl, mf, qe, &L->G, P, time, dts, tile, A->nthreads);
     if (ora_min_density(L->lo, L->hi, Sn) < P->small_dens) return -1;
     ora_clean_state(L->lo, L->hi, Sn, P);
-    if (P->change_max * est_time_step(A, l) < dts) return -2;
+    {   /* the check inside the advance: guarded minimum (a NaN zone rejects the step) */
+        double e = ora_estdt_cfl_guarded(L->lo, L->hi, a4_new(L), &L->G, &A->P) * A->P.cfl;
+        if (P->change_max * (e < 1.e200 ? e : 1.e200) < dts) return -2;
+    }
     /* finalize_advance: FluxRegCrseInit, FluxRegFineAdd */
     if (l + 1 < A->nlev) {
         amr_lev *F = &A->L[l + 1];

@@ -243,8 +243,12 @@ static int level_do_advance(ora_level *L, double time, double dt)
         ora_clean_state(L->lo, L->hi, S_new, P);
     }
 
-    /* timestep validity check (:386-392) */
-    double new_dt = ora_level_est_time_step(L);
+    /* timestep validity check (:386-392); the guarded minimum: a NaN zone rejects the step */
+    double new_dt = 1.e200;
+    {
+        double e = ora_estdt_cfl_guarded(L->lo, L->hi, ora_make_a4(L->S_new, L->lo, L->hi, NUM_STATE), &L->G, &L->P) * L->P.cfl;
+        if (e < new_dt) new_dt = e;
+    }
     if (P->change_max * new_dt < dt) return 2;
     return 0;
 }

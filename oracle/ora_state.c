@@ -137,7 +137,11 @@ void ora_clean_state(const int lo[3], const int hi[3], ora_a4 u, const ora_param
 }
 
 /* ------------------------------------------------------------------ */
-double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P)
+/* guard != 0: the form the checks INSIDE an advance use (a NaN zone enters as -1e300, so that the step is rejected --
+ * the deliberate deviation described in ora_internal.h).  guard == 0: Castro::estdt_cfl as the reference has it
+ * (timestep.cpp:131-137: a std::min fold, which drops a NaN) -- what estTimeStep returns outside an advance, where
+ * nothing could retry. */
+static double estdt_cfl_impl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P, int guard)
 {
     double estdt = 1.e200;
     _Pragma("omp parallel for num_threads(ora_state_threads) schedule(static) reduction(min:estdt)")
@@ -164,10 +168,20 @@ double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom 
         double dt3 = G->dx[2] / (c + fabs(uz));
 
         double d = amin3(dt1, dt2, dt3);
-        d = ora_nan_guard(d);
+        if (guard) d = ora_nan_guard(d);
         estdt = amin(estdt, d);
     }
     return estdt;
+}
+
+double ora_estdt_cfl(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P)
+{
+    return estdt_cfl_impl(lo, hi, u, G, P, 0);
+}
+
+double ora_estdt_cfl_guarded(const int lo[3], const int hi[3], ora_a4 u, const ora_geom *G, const ora_params *P)
+{
+    return estdt_cfl_impl(lo, hi, u, G, P, 1);
 }
 
 double ora_min_density(const int lo[3], const int hi[3], ora_a4 u)

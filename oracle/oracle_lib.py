@@ -91,6 +91,8 @@ def lib():
         L.ora_clean_state.argtypes = [I3, I3, A4, C.POINTER(Params)]
         L.ora_estdt_cfl.restype = C.c_double
         L.ora_estdt_cfl.argtypes = [I3, I3, A4, C.POINTER(Geom), C.POINTER(Params)]
+        L.ora_estdt_cfl_guarded.restype = C.c_double
+        L.ora_estdt_cfl_guarded.argtypes = [I3, I3, A4, C.POINTER(Geom), C.POINTER(Params)]
         L.ora_derive.argtypes = [C.c_int, I3, I3, A4, A4, C.POINTER(Geom), C.POINTER(Params), C.POINTER(C.c_double * 3)]
         L.ora_min_density.restype = C.c_double
         L.ora_min_density.argtypes = [I3, I3, A4]

@@ -151,10 +151,10 @@ class OracleBackend:
         r = O.lib().ora_min_density(O.i3(lo), O.i3(hi), a)
         # [2]: the estimate after the first clean_state (the validity check of do_advance_ctu), [0]: after the last
         self.clean_state(state, box, lo, hi, params, ntimes=1)
-        e1 = e = O.lib().ora_estdt_cfl(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))
+        e1 = e = O.lib().ora_estdt_cfl_guarded(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))
         if ntimes > 1:
             self.clean_state(state, box, lo, hi, params, ntimes=ntimes - 1)
-            e = O.lib().ora_estdt_cfl(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))
+            e = O.lib().ora_estdt_cfl_guarded(O.i3(lo), O.i3(hi), a, C.byref(geom), C.byref(params))
         out[0] = min(out[0].item(), e)
         out[1] = min(out[1].item(), r)
         if out.numel() > 2:
