@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = (
     "castro_amd_default_params", "castro_amd_finalize_params",
     "castro_amd_ctx_create", "castro_amd_ctx_destroy", "castro_amd_ctx_reserve",
     "castro_amd_ctx_scratch_bytes", "castro_amd_ctx_status", "castro_amd_ctx_poison_scratch", "castro_amd_ctx_set_source_corrector",
-    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_ctu_hydro_fab_ex", "castro_amd_step_control", "castro_amd_derive_fab",
+    "castro_amd_ctu_hydro_fab", "castro_amd_ctu_hydro_clean_fab", "castro_amd_ctu_hydro_fab_ex", "castro_amd_step_control", "castro_amd_ctu_hydro_mf", "castro_amd_fab_ops_p",
+    "castro_amd_derive_fab",
     "castro_amd_error_tag_fab", "castro_amd_cc_interp_fab", "castro_amd_lincomb_fab", "castro_amd_avgdown_fab", "castro_amd_fluxreg_crse_init_fab",
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
     "castro_amd_old_rotation_source_fab", "castro_amd_new_rotation_source_fab",
@@ -54,6 +55,12 @@ class HydroOpts(C.Structure):
     """castro_amd_hydro_opts"""
     _fields_ = [("flags", C.c_int), ("clean_ntimes", C.c_int), ("d_out", C.c_void_p), ("sborder_clean_ntimes", C.c_int),
                 ("d_dt", C.c_void_p)]
+
+
+class HydroBox(C.Structure):
+    """castro_amd_hydro_box: one box of a castro_amd_ctu_hydro_mf call"""
+    _fields_ = [("bxlo", C.c_int * 3), ("bxhi", C.c_int * 3), ("vbxlo", C.c_int * 3), ("vbxhi", C.c_int * 3),
+                ("Sborder", Fab), ("src", Fab), ("S_new", Fab), ("flux", Fab * 3), ("mass_flux", Fab * 3), ("qe", Fab * 3)]
 
 
 class Rotation(C.Structure):
@@ -102,7 +109,7 @@ class FabOp(C.Structure):
                 ("side", C.c_int), ("a", C.c_double), ("b", C.c_double), ("dst", Fab), ("src", Fab), ("src2", Fab)]
 
 
-OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX = 0, 1, 2, 3, 4
+OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN = 0, 1, 2, 3, 4, 5, 6
 
 _lib = None
 
@@ -139,6 +146,10 @@ def load():
     L.castro_amd_ctu_hydro_fab_ex.argtypes = [
         C.c_void_p, I3, I3, I3, I3, PF, PF, PF, PF, PF, PF, C.POINTER(Geom), C.POINTER(Params),
         C.c_double, C.c_double, C.POINTER(HydroOpts), C.c_void_p]
+    L.castro_amd_ctu_hydro_mf.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(HydroBox), C.c_int,
+                                          C.POINTER(Geom), C.POINTER(Params), C.c_double, C.c_double, C.POINTER(HydroOpts),
+                                          C.c_void_p]
+    L.castro_amd_fab_ops_p.argtypes = [C.c_void_p, C.c_int, C.POINTER(FabOp), C.POINTER(Params), C.c_void_p]
     L.castro_amd_step_control.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_double, C.c_double,
                                           C.c_double, C.c_int, C.c_void_p]
     L.castro_amd_clean_state_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]

@@ -275,9 +275,15 @@ class _Level:
             for i in range(n):
                 arr[i].a, arr[i].b = 1.0 - a, a
             h.fab_ops(ops)
-        # 2. interpolation + clean_state of the ghost shell, one launch per box
-        for b in (self.boxes if self.l > 0 else ()):
-            h.fillpatch_shell(b.ctmp, b.cbox, getattr(b, which), b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1)
+        # 2. interpolation + clean_state of the ghost shells: one launch for the level (six slab operations per box)
+        if self.l > 0 and self._level_calls():
+            sp2 = tuple(getattr(b, which).data_ptr() for b in self.boxes)
+            h.fab_ops(self._cached_ops(("shell", which), sp2, lambda: h.make_ops(
+                [(L.OP_INTERP_CLEAN, 0, NUM_STATE, lo, hi, 1.0, 0.0, (getattr(b, which), b.gbox), (b.ctmp, b.cbox), None)
+                 for b in self.boxes for lo, hi in b.shell if all(hi[d] >= lo[d] for d in range(3))])), params=self.params)
+        else:
+            for b in (self.boxes if self.l > 0 else ()):
+                h.fillpatch_shell(b.ctmp, b.cbox, getattr(b, which), b.gbox, b.lo, b.hi, NUM_GROW, b.params, ntimes=1)
         # 3. valid zones of the siblings (final only after every box's clean pass), all boxes in a few launches
         sp = tuple(getattr(b, which).data_ptr() for b in self.boxes)
         h.fab_ops(self._cached_ops(("sib", which), sp, lambda: h.make_ops(
@@ -456,17 +462,17 @@ class _Level:
             # a later subcycle of a retried step: the coarse data are interpolated to ITS old time, not the step's
             self.alpha = self._alpha0 + (time - self._t0) / self._dt_parent
         if self._pending_cleans > 0:           # see Castro.do_advance_ctu
-            for b in self.mine:
-                b.clean_state(b.S_old_b, self._pending_cleans)
+            self._clean_boxes("S_old_b", self._pending_cleans)
         self._pending_cleans = 0
         self.red.fill_(1.e200)
         self.fill("S_old_b")
         if self.have_sources:
             return self._advance_with_sources(time, dt)
-        def hydro(b):
-            b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
-            b._flux_clear = False
-        self._hydro_calls(hydro)
+        if not self._hydro_level(time, dt):
+            def hydro(b):
+                b.construct_ctu_hydro_source(time, dt, fuse_clean=self.fuse_clean)
+                b._flux_clear = False
+            self._hydro_calls(hydro)
         if not self.fuse_clean:
             for b in self.mine:
                 self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
@@ -487,8 +493,45 @@ class _Level:
         return min(self.max_dt, checked_estimate(self.red.tolist()[0], empty_ok=not self.boxes) * self.params.cfl)
 
     def clean_new(self):
+        self._clean_boxes("S_new_b", 1)
+
+    def _level_calls(self):
+        """One library call per level instead of one per box (castro_amd_ctu_hydro_mf, castro_amd_fab_ops_p): the device
+        backend with every box on this rank; CASTRO_AMD_LEVEL_CALLS=0 keeps the per-box calls."""
+        return (getattr(self, "batched", False) and hasattr(self.hydro, "construct_ctu_hydro_source_mf")
+                and os.environ.get("CASTRO_AMD_LEVEL_CALLS", "1") != "0")
+
+    def _clean_boxes(self, which, ntimes):
+        """Castro::clean_state x ntimes on the valid zones of S_old_b / S_new_b (`which`) of every box of this rank."""
+        if not self._level_calls() or len(self.mine) < 2:
+            for b in self.mine:
+                b.clean_state(getattr(b, which), ntimes)
+            return
+        sp = tuple(getattr(b, which).data_ptr() for b in self.mine)
+        ops = self._cached_ops(("clean", which, ntimes), sp, lambda: self.hydro.make_ops(
+            [(L.OP_CLEAN, 0, NUM_STATE, b.lo, b.hi, float(ntimes), 0.0, (getattr(b, which), b.gbox), (getattr(b, which), b.gbox), None)
+             for b in self.mine]))
+        self.hydro.fab_ops(ops, params=self.params)
+
+    def _hydro_level(self, time, dt):
+        """The hydro update of every box of the level through ONE library call (the MFIter loop of
+        construct_ctu_hydro_source in C++: boxes dealt round robin to the contexts / streams of the box-stream pool, forked
+        from and joined to the current stream inside the call).  False: not applicable, the caller loops over the boxes."""
+        if not self._level_calls() or not self.mine:
+            return False
+        fa = [bool(b.flux_assign and b._flux_clear) for b in self.mine]
+        if any(x != fa[0] for x in fa) or any(b.have_sources or b.fuse_post_clean for b in self.mine):
+            return False
+        sp = tuple(t.data_ptr() for b in self.mine for t in (b.S_old_b, b.S_new_b))
+        boxes = self._cached_ops(("hydro_mf",), sp, lambda: self.hydro.make_hydro_boxes(
+            [(b.bx, b.bx, (b.S_old_b, b.gbox), (b.S_new_b, b.gbox), b.fluxes, b.flux_boxes, b.mass_fluxes) for b in self.mine]))
+        pool = self.amr._stream_pool(self.l) if len(self.mine) > 1 else None
+        self.hydro.construct_ctu_hydro_source_mf(pool, boxes, self.mine[0].geom, self.params, time, dt, update_from_sborder=True,
+                                                 flux_assign=fa[0], clean_ntimes=1 if self.fuse_clean else 0,
+                                                 red=self.red if self.fuse_clean else None)
         for b in self.mine:
-            b.clean_state(b.S_new_b, 1)
+            b._flux_clear = False
+        return True
 
 
 _TAG_KINDS = {"value_greater": 0, "value_less": 1, "gradient": 2, "relative_gradient": 3}

@@ -2,6 +2,7 @@
 // clean_state, CFL/min-density reduction, physical-BC ghost fill, FAB copy / halo pack,
 // problem initial data.  Reference locations are cited per kernel.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include "../../include/castro_hydro_amd.h"
 #include "hydro_device.h"
 #include "ctu_kernels.h"
@@ -808,19 +809,50 @@ __global__ void __launch_bounds__(256) k_lincomb(DFab D, DFab X, DFab Y, Box3 b,
 struct FabOp { DFab D, X, Y; int lo[3], n[3]; int kind, dir, ncomp, side; double a, b; };
 struct FabOps { int n; long start[FABOPS_MAX + 1]; FabOp op[FABOPS_MAX]; };
 
-__global__ void __launch_bounds__(256) k_fab_ops(FabOps T)
+__device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevParams& P);
+
+__global__ void __launch_bounds__(256) k_fab_ops(FabOps T, DevParams P)
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= T.start[T.n]) return;
     int r = 0;
     while (tid >= T.start[r + 1]) ++r;
-    const FabOp& o = T.op[r];
-    const long t = tid - T.start[r];
+    fab_op_thread(T.op[r], tid - T.start[r], P);
+}
+
+// the same with the table in device memory (any number of operations): binary search of the thread's operation
+__global__ void __launch_bounds__(256) k_fab_ops_mem(const FabOp* __restrict__ ops, const long* __restrict__ start, int n, DevParams P)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= start[n]) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= tid) lo = mid; else hi = mid - 1;
+    }
+    const FabOp o = ops[lo];
+    fab_op_thread(o, tid - start[lo], P);
+}
+
+__device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevParams& P)
+{
     int c[3];
     c[0] = o.lo[0] + (int)(t % o.n[0]);
     const long q = t / o.n[0];
     c[1] = o.lo[1] + (int)(q % o.n[1]);
     c[2] = o.lo[2] + (int)(q / o.n[1]);
+    if (o.kind == CASTRO_AMD_OP_CLEAN || o.kind == CASTRO_AMD_OP_INTERP_CLEAN) {
+        double u[NUM_STATE];
+        if (o.kind == CASTRO_AMD_OP_INTERP_CLEAN) {
+            for (int n = 0; n < NUM_STATE; ++n) u[n] = cc_interp_value(o.X, c[0], c[1], c[2], n);
+        } else {
+            for (int n = 0; n < NUM_STATE; ++n) u[n] = o.D.p[fidx(o.D, c[0], c[1], c[2], n)];
+        }
+        const int ntimes = (int)o.a;
+        if (ntimes > 0) clean_zone(P, ntimes, u[URHO], u[UMX], u[UMY], u[UMZ], u[UEDEN], u[UEINT], u[UTEMP], u[UFS]);
+        for (int n = 0; n < NUM_STATE; ++n) o.D.p[fidx(o.D, c[0], c[1], c[2], n)] = u[n];
+        return;
+    }
     if (o.kind == CASTRO_AMD_OP_REFLUX) {
         int z[3] = { c[0], c[1], c[2] };
         if (o.side == 0) z[o.dir] -= 1;
@@ -854,28 +886,67 @@ __global__ void __launch_bounds__(256) k_fab_ops(FabOps T)
 }
 
 int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
-                   const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof)
+                   const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof,
+                   const DevParams* Pp, FabOpsArena* arena)
 {
+    DevParams P;
+    if (Pp) P = *Pp; else std::memset(&P, 0, sizeof(P));
+    auto fill = [&](FabOp& o, int r, long& n) {
+        n = 1;
+        int nn[3];
+        for (int d = 0; d < 3; ++d) { nn[d] = hi[3 * r + d] - lo[3 * r + d] + 1; n *= nn[d] > 0 ? nn[d] : 0; }
+        if (n <= 0) return false;
+        o.D = D[r]; o.X = X[r]; o.Y = Y[r];
+        for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * r + d]; o.n[d] = nn[d]; }
+        o.kind = kind[r]; o.dir = dir[r]; o.side = side[r]; o.ncomp = ncomp[r]; o.a = a[r]; o.b = b[r];
+        return true;
+    };
+    if (arena && nops > FABOPS_MAX) {
+        // one launch for the whole table: operations and their thread offsets go through a device buffer of the context
+        // (pageable source: the runtime stages the bytes before hipMemcpyAsync returns; the copy is ordered on `stream`
+        // behind the kernel that read the previous table)
+        std::vector<FabOp> ops;
+        std::vector<long> start(1, 0);
+        ops.reserve(nops);
+        for (int r = 0; r < nops; ++r) {
+            FabOp o;
+            long n;
+            if (!fill(o, r, n)) continue;
+            ops.push_back(o);
+            start.push_back(start.back() + n);
+        }
+        if (ops.empty()) return 0;
+        const size_t bo = ops.size() * sizeof(FabOp), bs = start.size() * sizeof(long);
+        const size_t need = ((bo + 255) & ~(size_t)255) + bs;
+        if (need > arena->bytes) {
+            if (arena->p) { hipStreamSynchronize(stream); hipFree(arena->p); arena->p = nullptr; arena->bytes = 0; }
+            if (hipMalloc(&arena->p, 2 * need) != hipSuccess) return -3;
+            arena->bytes = 2 * need;
+        }
+        char* base = (char*)arena->p;
+        long* dstart = (long*)(base + ((bo + 255) & ~(size_t)255));
+        if (hipMemcpyAsync(base, ops.data(), bo, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
+        if (hipMemcpyAsync(dstart, start.data(), bs, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
+        prof_begin(prof, "k_fab_ops", stream);
+        hipLaunchKernelGGL(k_fab_ops_mem, dim3((unsigned)((start.back() + 255) / 256)), dim3(256), 0, stream,
+                           (const FabOp*)base, (const long*)dstart, (int)ops.size(), P);
+        prof_end(prof, stream);
+        return launch_status();
+    }
     int done = 0;
     while (done < nops) {
         FabOps T;
         T.n = 0;
         T.start[0] = 0;
         for (; done < nops && T.n < FABOPS_MAX; ++done) {
-            long n = 1;
-            int nn[3];
-            for (int d = 0; d < 3; ++d) { nn[d] = hi[3 * done + d] - lo[3 * done + d] + 1; n *= nn[d] > 0 ? nn[d] : 0; }
-            if (n <= 0) continue;
-            FabOp& o = T.op[T.n];
-            o.D = D[done]; o.X = X[done]; o.Y = Y[done];
-            for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * done + d]; o.n[d] = nn[d]; }
-            o.kind = kind[done]; o.dir = dir[done]; o.side = side[done]; o.ncomp = ncomp[done]; o.a = a[done]; o.b = b[done];
+            long n;
+            if (!fill(T.op[T.n], done, n)) continue;
             T.start[T.n + 1] = T.start[T.n] + n;
             ++T.n;
         }
         if (T.n == 0) continue;
         prof_begin(prof, "k_fab_ops", stream);
-        hipLaunchKernelGGL(k_fab_ops, dim3((unsigned)((T.start[T.n] + 255) / 256)), dim3(256), 0, stream, T);
+        hipLaunchKernelGGL(k_fab_ops, dim3((unsigned)((T.start[T.n] + 255) / 256)), dim3(256), 0, stream, T, P);
         prof_end(prof, stream);
     }
     return launch_status();

@@ -25,6 +25,8 @@ struct castro_amd_ctx {
     // kernel), forked from and joined to the caller's stream with events inside one call: CASTRO_AMD_SIDE_STREAM=0 turns it off
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    FabOpsArena ops_arena;                          // device table of castro_amd_fab_ops_p calls with more than 16 operations
+    hipEvent_t mf_fork = nullptr, mf_join = nullptr;   // castro_amd_ctu_hydro_mf: fork from / join to the caller's stream
 };
 
 namespace cad {
@@ -242,6 +244,9 @@ void castro_amd_ctx_destroy(castro_amd_ctx* c)
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->mf_fork) hipEventDestroy(c->mf_fork);
+    if (c->mf_join) hipEventDestroy(c->mf_join);
+    if (c->ops_arena.p) hipFree(c->ops_arena.p);
     prof_collect(&c->prof);
     for (auto e : c->prof.pool) hipEventDestroy(e);
     if (c->arena) hipFree(c->arena);
@@ -573,7 +578,20 @@ int castro_amd_cc_interp_fab(castro_amd_ctx* c, const castro_amd_fab* crse, cons
     return launch_cc_interp(to_dfab(crse), to_dfab(fine), lo, hi, ncomp, (hipStream_t)stream, &c->prof);
 }
 
+static int fab_ops_impl(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops, const castro_amd_params* params, void* stream);
+
 int castro_amd_fab_ops(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops, void* stream)
+{
+    return fab_ops_impl(c, nops, ops, nullptr, stream);
+}
+
+int castro_amd_fab_ops_p(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops, const castro_amd_params* params, void* stream)
+{
+    if (!params) return CASTRO_AMD_ERR_ARG;
+    return fab_ops_impl(c, nops, ops, params, stream);
+}
+
+static int fab_ops_impl(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops, const castro_amd_params* params, void* stream)
 {
     if (!c || nops < 0 || (nops > 0 && !ops)) return CASTRO_AMD_ERR_ARG;
     if (nops == 0) return CASTRO_AMD_OK;
@@ -585,6 +603,16 @@ int castro_amd_fab_ops(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops
         if (o.ncomp < 1 || !fab_ok(&o.dst, o.ncomp) || !fab_ok(&o.src, o.ncomp)) return CASTRO_AMD_ERR_ARG;
         if (o.kind != CASTRO_AMD_OP_REFLUX && !fab_contains(&o.dst, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
         switch (o.kind) {
+        case CASTRO_AMD_OP_CLEAN:
+            if (!params || o.ncomp != NUM_STATE || o.dst.ncomp != NUM_STATE || o.a < 0.0) return CASTRO_AMD_ERR_ARG;
+            break;
+        case CASTRO_AMD_OP_INTERP_CLEAN: {
+            if (!params || o.ncomp != NUM_STATE || o.dst.ncomp != NUM_STATE || o.src.ncomp != NUM_STATE || o.a < 0.0) return CASTRO_AMD_ERR_ARG;
+            // the coarse zones under the region, grown by one (the slopes of cell_cons_interp)
+            int clo[3], chi[3];
+            for (int d = 0; d < 3; ++d) { clo[d] = (o.lo[d] >= 0 ? o.lo[d] / 2 : -((-o.lo[d] + 1) / 2)) - 1; chi[d] = (o.hi[d] >= 0 ? o.hi[d] / 2 : -((-o.hi[d] + 1) / 2)) + 1; }
+            if (!fab_contains(&o.src, clo, chi)) return CASTRO_AMD_ERR_ARG;
+            break; }
         case CASTRO_AMD_OP_REFLUX: {
             if (o.dir < 0 || o.dir > 2 || o.side < 0 || o.side > 1 || !fab_contains(&o.src, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
             int zlo[3] = { o.lo[0], o.lo[1], o.lo[2] }, zhi[3] = { o.hi[0], o.hi[1], o.hi[2] };
@@ -613,8 +641,48 @@ int castro_amd_fab_ops(castro_amd_ctx* c, int nops, const castro_amd_fab_op* ops
         kind[r] = o.kind; dir[r] = o.dir; side[r] = o.side; ncomp[r] = o.ncomp; a[r] = o.a; b[r] = o.b;
     }
     hipSetDevice(c->device);
+    DevParams P;
+    if (params) P = to_devparams(params);
     return launch_fab_ops(nops, D.data(), X.data(), Y.data(), lo.data(), hi.data(), kind.data(), dir.data(), side.data(), ncomp.data(),
-                          a.data(), b.data(), (hipStream_t)stream, &c->prof);
+                          a.data(), b.data(), (hipStream_t)stream, &c->prof, params ? &P : nullptr, &c->ops_arena);
+}
+
+int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, int nctx,
+                            const castro_amd_hydro_box* boxes, int nboxes,
+                            const castro_amd_geom* geom, const castro_amd_params* params,
+                            double time, double dt, const castro_amd_hydro_opts* opts, void* stream)
+{
+    if (!ctxs || !streams || nctx < 1 || nboxes < 0 || (nboxes > 0 && !boxes) || !geom || !params || !opts) return CASTRO_AMD_ERR_ARG;
+    for (int k = 0; k < nctx; ++k) if (!ctxs[k]) return CASTRO_AMD_ERR_ARG;
+    if (nboxes == 0) return CASTRO_AMD_OK;
+    hipStream_t main_s = (hipStream_t)stream;
+    const int used = nboxes < nctx ? nboxes : nctx;
+    const bool forked = !(used == 1 && (hipStream_t)streams[0] == main_s);
+    castro_amd_ctx* c0 = ctxs[0];
+    hipSetDevice(c0->device);
+    if (forked) {
+        if (!c0->mf_fork && hipEventCreateWithFlags(&c0->mf_fork, hipEventDisableTiming) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+        hipEventRecord(c0->mf_fork, main_s);
+        for (int k = 0; k < used; ++k)
+            if ((hipStream_t)streams[k] != main_s) hipStreamWaitEvent((hipStream_t)streams[k], c0->mf_fork, 0);
+    }
+    int rc = CASTRO_AMD_OK;
+    for (int i = 0; i < nboxes && rc == CASTRO_AMD_OK; ++i) {
+        const castro_amd_hydro_box& b = boxes[i];
+        rc = castro_amd_ctu_hydro_fab_ex(ctxs[i % nctx], b.bxlo, b.bxhi, b.vbxlo, b.vbxhi, &b.Sborder, &b.src, &b.S_new,
+                                         b.flux, b.mass_flux, b.qe, geom, params, time, dt, opts, streams[i % nctx]);
+    }
+    if (forked) {
+        // join even after an error: the caller's stream must not run ahead of launches already made
+        for (int k = 0; k < used; ++k) {
+            if ((hipStream_t)streams[k] == main_s) continue;
+            castro_amd_ctx* ck = ctxs[k];
+            if (!ck->mf_join && hipEventCreateWithFlags(&ck->mf_join, hipEventDisableTiming) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+            hipEventRecord(ck->mf_join, (hipStream_t)streams[k]);
+            hipStreamWaitEvent(main_s, ck->mf_join, 0);
+        }
+    }
+    return rc;
 }
 
 int castro_amd_fillpatch_shell_fab(castro_amd_ctx* c, const castro_amd_fab* crse, const castro_amd_fab* fine,

@@ -94,8 +94,11 @@ int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const
                           const ::castro_amd_rotation* r, const ::castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof);
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
+// device buffer for operation tables longer than a kernel argument holds (owned by the context)
+struct FabOpsArena { void* p = nullptr; size_t bytes = 0; };
 int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
-                   const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof);
+                   const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof,
+                   const DevParams* P = nullptr, FabOpsArena* arena = nullptr);
 int launch_apply_source(const DFab& D, const DFab& B, const DFab& S, const int lo[3], const int hi[3], double a, int nsrc,
                         const DevParams& P, int ntimes, hipStream_t stream, Profiler* prof);
 int launch_cc_interp(const DFab& C, const DFab& F, const int lo[3], const int hi[3], int ncomp, hipStream_t stream, Profiler* prof);

@@ -243,11 +243,50 @@ class HipHydro:
             o.src2 = L.fab_of(src2[0], *src2[1]) if src2 is not None else o.src
         return arr, len(specs)
 
-    def fab_ops(self, ops, stream=None):
-        """Independent FAB-to-FAB region operations (make_ops), sixteen per launch."""
+    def fab_ops(self, ops, stream=None, params=None):
+        """Independent FAB-to-FAB region operations (make_ops): one launch for up to sixteen, and with `params`
+        (castro_amd_fab_ops_p: needed by OP_CLEAN / OP_INTERP_CLEAN) one launch for any number."""
         arr, n = ops
         if n:
-            L.check(self.lib.castro_amd_fab_ops(self.h, n, arr, _stream_ptr(stream)), "fab_ops")
+            if params is not None:
+                L.check(self.lib.castro_amd_fab_ops_p(self.h, n, arr, C.byref(params), _stream_ptr(stream)), "fab_ops_p")
+            else:
+                L.check(self.lib.castro_amd_fab_ops(self.h, n, arr, _stream_ptr(stream)), "fab_ops")
+
+    @staticmethod
+    def make_hydro_boxes(specs):
+        """ctypes array of castro_amd_hydro_box from (bx, vbx, (Sborder, box), (S_new, box), fluxes, flux_boxes, mass_fluxes)."""
+        arr = (L.HydroBox * max(len(specs), 1))()
+        for hb, (bx, vbx, sb, sn, fluxes, flux_boxes, mass_fluxes) in zip(arr, specs):
+            for d in range(3):
+                hb.bxlo[d], hb.bxhi[d], hb.vbxlo[d], hb.vbxhi[d] = bx[0][d], bx[1][d], vbx[0][d], vbx[1][d]
+                hb.flux[d] = L.fab_of(fluxes[d], *flux_boxes[d])
+                hb.mass_flux[d] = L.fab_of(mass_fluxes[d], *flux_boxes[d])
+                hb.qe[d] = L.fab_of(None, *flux_boxes[d])
+            hb.Sborder, hb.S_new = L.fab_of(sb[0], *sb[1]), L.fab_of(sn[0], *sn[1])
+            hb.src = L.fab_desc(None, bx[0], bx[1], 0)
+        return arr, len(specs)
+
+    def construct_ctu_hydro_source_mf(self, pool, boxes, geom, params, time, dt, update_from_sborder=True, flux_assign=False,
+                                      clean_ntimes=0, red=None, stream=None):
+        """castro_amd_ctu_hydro_mf: the hydro update of every box of a level in one call (the MFIter loop).
+        pool: [(HipHydro, torch stream)] the boxes are dealt to round robin, or None for this context on the current stream."""
+        arr, n = boxes
+        if not n:
+            return
+        flags = L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD
+        if flux_assign:
+            flags |= L.FLUX_ASSIGN
+        o = L.HydroOpts(flags, int(clean_ntimes), red.data_ptr() if red is not None else None, 0, None)
+        main = _stream_ptr(stream)
+        if pool:
+            ctxs = (C.c_void_p * len(pool))(*[h.h for h, _ in pool])
+            sts = (C.c_void_p * len(pool))(*[C.c_void_p(st.cuda_stream) for _, st in pool])
+            k = len(pool)
+        else:
+            ctxs, sts, k = (C.c_void_p * 1)(self.h), (C.c_void_p * 1)(main), 1
+        L.check(self.lib.castro_amd_ctu_hydro_mf(ctxs, sts, k, arr, n, C.byref(geom), C.byref(params), float(time), float(dt),
+                                                 C.byref(o), main), "ctu_hydro_mf")
 
     def lincomb(self, dst, dst_box, a, x, x_box, b, y, y_box, ncomp, lo, hi, stream=None):
         L.check(self.lib.castro_amd_lincomb_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(x, *x_box)),

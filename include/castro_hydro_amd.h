@@ -363,6 +363,10 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
 #define CASTRO_AMD_OP_FLUXREG_CRSE_INIT 2
 #define CASTRO_AMD_OP_FLUXREG_FINE_ADD 3
 #define CASTRO_AMD_OP_REFLUX 4
+#define CASTRO_AMD_OP_CLEAN 5           /* Castro::clean_state x (int)a on the region of dst (ncomp 8); needs castro_amd_fab_ops_p */
+#define CASTRO_AMD_OP_INTERP_CLEAN 6    /* dst (fine, ncomp 8) = cell_cons_interp of src (coarse data under it) on the region,
+                                         * then clean_state x (int)a: one slab of a FillPatch ghost shell
+                                         * (castro_amd_fillpatch_shell_fab does the six slabs of one box); castro_amd_fab_ops_p */
 typedef struct castro_amd_fab_op {
     int kind;
     int dir;                     /* FLUXREG_FINE_ADD, REFLUX */
@@ -373,6 +377,28 @@ typedef struct castro_amd_fab_op {
     castro_amd_fab dst, src, src2;   /* src2: LINCOMB only */
 } castro_amd_fab_op;
 int castro_amd_fab_ops(castro_amd_ctx *ctx, int nops, const castro_amd_fab_op *ops, void *stream);
+/* The same with the runtime parameters the CLEAN kinds need.  Any number of operations: up to sixteen travel as a kernel
+ * argument, longer tables through a device buffer of the context, ONE launch either way -- the per-box sweeps of a level
+ * of many small boxes (clean_state of every box, the ghost shells of every box) become one launch per level. */
+int castro_amd_fab_ops_p(castro_amd_ctx *ctx, int nops, const castro_amd_fab_op *ops, const castro_amd_params *params,
+                         void *stream);
+
+/*
+ * The MFIter loop itself (Source/hydro/Castro_ctu_hydro.cpp:130-1480): castro_amd_ctu_hydro_fab_ex for every box of a level
+ * in one call.  Box i runs on ctxs[i % nctx] / streams[i % nctx] (each context has its own scratch; small boxes fill a
+ * fraction of the chip, so several are kept in flight); the streams are forked from `stream` and joined to it with
+ * events inside the call, so the caller sees one asynchronous operation on `stream`.  nctx == 1 with streams[0] == stream
+ * is a plain loop.  opts applies to every box (d_out: one reduction vector for the level).
+ */
+typedef struct castro_amd_hydro_box {
+    int bxlo[3], bxhi[3], vbxlo[3], vbxhi[3];
+    castro_amd_fab Sborder, src, S_new;
+    castro_amd_fab flux[3], mass_flux[3], qe[3];
+} castro_amd_hydro_box;
+int castro_amd_ctu_hydro_mf(castro_amd_ctx *const *ctxs, void *const *streams, int nctx,
+                            const castro_amd_hydro_box *boxes, int nboxes,
+                            const castro_amd_geom *geom, const castro_amd_params *params,
+                            double time, double dt, const castro_amd_hydro_opts *opts, void *stream);
 
 int castro_amd_fillpatch_shell_fab(castro_amd_ctx *ctx, const castro_amd_fab *crse, const castro_amd_fab *fine,
                                    const int vlo[3], const int vhi[3], int ngrow, const castro_amd_params *params,
