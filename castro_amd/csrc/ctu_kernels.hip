@@ -184,16 +184,22 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     if (CLEAN) {
         eint = ldg(U.p + UEINT * U.sn, cu);
         double temp = ldg(U.p + UTEMP * U.sn, cu);
+        const double o0 = rho, o1 = mx, o2 = my, o3 = mz, o4 = eden, o5 = eint, o6 = temp, o7 = rX;
         clean_zone(P, clean_n, rho, mx, my, mz, eden, eint, temp, rX);
+        // Only components whose bits changed go back: the state arrives cleaned twice by the update that produced it, and
+        // the applications here almost always reproduce it (8 planes less to write; a plane nobody changes stays clean in L2).
         double* up = U.p;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + URHO * U.sn) + cu) = rho;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UMX * U.sn) + cu) = mx;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UMY * U.sn) + cu) = my;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UMZ * U.sn) + cu) = mz;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UEDEN * U.sn) + cu) = eden;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UEINT * U.sn) + cu) = eint;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UTEMP * U.sn) + cu) = temp;
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(up + UFS * U.sn) + cu) = rX;
+#define PUT_IF_CHANGED(comp, o, v) \
+        if (__double_as_longlong(o) != __double_as_longlong(v)) *reinterpret_cast<double*>(reinterpret_cast<char*>(up + (comp) * U.sn) + cu) = (v)
+        PUT_IF_CHANGED(URHO, o0, rho);
+        PUT_IF_CHANGED(UMX, o1, mx);
+        PUT_IF_CHANGED(UMY, o2, my);
+        PUT_IF_CHANGED(UMZ, o3, mz);
+        PUT_IF_CHANGED(UEDEN, o4, eden);
+        PUT_IF_CHANGED(UEINT, o5, eint);
+        PUT_IF_CHANGED(UTEMP, o6, temp);
+        PUT_IF_CHANGED(UFS, o7, rX);
+#undef PUT_IF_CHANGED
     }
     if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
 
@@ -1123,11 +1129,56 @@ __device__ __forceinline__ bool face_shock(const DevScratch& S, const DevParams&
     return static_cast<int>(ldg(S.SHK, c - sd) + ldg(S.SHK, c)) >= 1;
 }
 
+// Records of the transverse stages.  Two forms:
+//   flux form (8 planes): the six fluxes in global component order + Godunov normal velocity and pressure;
+//   state form (QI, 7 planes): the interface state (rho, un, ut, utt, p, rho e, X) the CGF solver returned -- the fluxes
+//     are recomputed from it by the reader with compute_flux_q's expressions (riemann_solvers.H:14-211, as in
+//     interface_flux), bit for bit: one plane less per record to write and to read (F1[x] 8 -> 7, F2 48 -> 42 planes).
+//     Only where every kernel of the call is the default-solver instantiation (GEN == 0, see launch_ctu_hydro: `solv`):
+//     the HLLC / HLL fluxes are not functions of one interface state.
+#ifdef FLUX_FORM_ONLY            // A/B: every record in the 8-plane flux form
+constexpr bool kQI = false;
+#else
+constexpr bool kQI = true;
+#endif
+constexpr int QRHO = 0, QUN = 1, QUT = 2, QUTT = 3, QPG = 4, QREG = 5, QXG = 6, NQI = 7;
+
+template <int D>
+__device__ __forceinline__ void qstate_to_rec(double rho, double un, double ut, double utt, double p, double rhoe, double Xg,
+                                              double r[NF1])
+{
+    // interface_flux (hydro_device.h) after the Riemann solve, same order of operations
+    const double frho = rho * un;
+    double fmn = frho * un;
+    const double fmt = frho * ut;
+    const double fmtt = frho * utt;
+    fmn += p;
+    const double rhoetot = rhoe + 0.5 * rho * (un * un + ut * ut + utt * utt);
+    r[FRHO] = frho;
+    r[FMX + RDir<D>::n] = fmn;
+    r[FMX + RDir<D>::t] = fmt;
+    r[FMX + RDir<D>::tt] = fmtt;
+    r[FE] = un * (rhoetot + p);
+    r[FX] = frho * Xg;
+    r[FUG] = un;
+    r[FPG] = p;
+}
+
 // write a transverse-stage flux record at face offset c (global component order)
 // FEI: plane of the (rho e) flux, nullptr unless transverse_reset_rhoe = 1
-template <int D>
+template <int D, bool QI = false>
 __device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsigned c, const IFlux& f, double* __restrict__ FEI = nullptr)
 {
+    if (QI) {
+        stg(F + QRHO * NC, c, f.rho_g);
+        stg(F + QUN * NC, c, f.ugd);
+        stg(F + QUT * NC, c, f.ut);
+        stg(F + QUTT * NC, c, f.utt);
+        stg(F + QPG * NC, c, f.pgd);
+        stg(F + QREG * NC, c, f.rhoe_g);
+        stg(F + QXG * NC, c, f.X_g);
+        return;
+    }
     if (FEI) stg(FEI, c, f.eint);
     stg(F + FRHO * NC, c, f.rho);
     stg(F + (FMX + RDir<D>::n) * NC, c, f.mn);
@@ -1153,9 +1204,19 @@ __device__ __forceinline__ void load_edge(const double* __restrict__ E, long NC,
 
 __host__ __device__ constexpr int f2_slot(int N, int T) { return N * 2 + ((T > N) ? T - 1 : T); }
 
-// pair (two x-adjacent faces) forms of the record loads / stores
+// pair (two x-adjacent faces) forms of the record loads / stores; D: the direction the record's face is normal to
+template <int D = 0, bool QI = false>
 __device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC, unsigned c, double r[2][NF1])
 {
+    if (QI) {
+        double q[2][NQI];
+#pragma unroll
+        for (int n = 0; n < NQI; ++n) { const D2 v = ldg2(F + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b; }
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+            qstate_to_rec<D>(q[w][QRHO], q[w][QUN], q[w][QUT], q[w][QUTT], q[w][QPG], q[w][QREG], q[w][QXG], r[w]);
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NF1; ++n) { const D2 v = ldg2(F + (long)n * NC, c); r[0][n] = v.a; r[1][n] = v.b; }
 }
@@ -1173,10 +1234,26 @@ __device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long N
     }
 }
 
-template <int D>
+template <int D, bool QI = false>
 __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1,
                                            double* __restrict__ FEI = nullptr)
 {
+    if (QI) {
+        if (m0 && m1) {
+            stg2(F + QRHO * NC, c, f[0].rho_g, f[1].rho_g);
+            stg2(F + QUN * NC, c, f[0].ugd, f[1].ugd);
+            stg2(F + QUT * NC, c, f[0].ut, f[1].ut);
+            stg2(F + QUTT * NC, c, f[0].utt, f[1].utt);
+            stg2(F + QPG * NC, c, f[0].pgd, f[1].pgd);
+            stg2(F + QREG * NC, c, f[0].rhoe_g, f[1].rhoe_g);
+            stg2(F + QXG * NC, c, f[0].X_g, f[1].X_g);
+        } else if (m0) {
+            store_f1<D, true>(F, NC, c, f[0]);
+        } else if (m1) {
+            store_f1<D, true>(F, NC, c + 8u, f[1]);
+        }
+        return;
+    }
     if (FEI) {
         if (m0 && m1) stg2(FEI, c, f[0].eint, f[1].eint);
         else if (m0) stg(FEI, c, f[0].eint);
@@ -1236,7 +1313,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
         interface_flux<D, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<D>(g, idx),
                           face_shock(S, P, c + 8u * w, sd), P, f[w]);
     }
-    store_f1_2<D>(S.F1[D], t.NC, c, f, true, v1, S.F1E[D]);
+    store_f1_2<D, (kQI && GEN == 0)>(S.F1[D], t.NC, c, f, true, v1, S.F1E[D]);
 }
 
 // shared tail of the final stage for a pair of x-adjacent faces: flux in conserved order, artificial
@@ -1479,7 +1556,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             rstate_from_edge<0>(qm[0], P.gamma, ql, Xl);
             rstate_from_edge<0>(qp[1], P.gamma, qr, Xr);
             interface_flux<0, GEN>(ql, qr, Xl, Xr, cc01.a, cc01.b, wall_fac<0>(g, i + 1), face_shock(S, P, c + 8u, 8u), P, f[1]);
-            store_f1_2<0>(S.F1[0], NC, c, f, mA, mB, S.F1E[0]);
+            store_f1_2<0, (kQI && GEN == 0)>(S.F1[0], NC, c, f, mA, mB, S.F1E[0]);
         }
     }
 
@@ -1520,7 +1597,7 @@ __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, c
     const double cr = ldg(Q + PC * t.NC, c);
     IFlux f;
     interface_flux<0, GEN>(ql, qr, Xl, Xr, cl, cr, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f);
-    store_f1<0>(S.F1[0], t.NC, c, f, S.F1E[0]);
+    store_f1<0, (kQI && GEN == 0)>(S.F1[0], t.NC, c, f, S.F1E[0]);
 }
 
 
@@ -1535,7 +1612,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 
     // minus states live in zones c - sn; their T-faces are (c - sn) and (c - sn + st)
 #ifdef DIAG_F1_REUSE      // timing diagnostic (wrong results): one record load per (N,T) instead of four
-    load_f1_2(S.F1[T], t.NC, c, fl);
+    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c, fl);
 #pragma unroll
     for (int w = 0; w < 2; ++w)
 #pragma unroll
@@ -1547,8 +1624,8 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 #pragma unroll
         for (int n = 0; n < NF1; ++n) { fr[w][n] = 1e-3 * (double)((c + n + w) & 255u); fl[w][n] = 1e-3 * (double)((c + st + n) & 255u); }
 #else
-    load_f1_2(S.F1[T], t.NC, c - sn + st, fr);
-    load_f1_2(S.F1[T], t.NC, c - sn, fl);
+    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c - sn + st, fr);
+    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c - sn, fl);
 #endif
 #endif
     if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
@@ -1562,8 +1639,8 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 
     // plus states live in zones c
 #if !defined(DIAG_F1_REUSE) && !defined(DIAG_T1_NOLOAD)
-    load_f1_2(S.F1[T], t.NC, c + st, fr);
-    load_f1_2(S.F1[T], t.NC, c, fl);
+    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c + st, fr);
+    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c, fl);
 #endif
     if (RE && P.reset_rhoe == 1) {
         const D2 er = ldg2(S.F1E[T], c + st), el = ldg2(S.F1E[T], c);
@@ -1609,7 +1686,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 #ifdef DIAG_T1_NOSTORE    // timing diagnostic: the stores behind a condition that never holds
     if (f[0].rho == 1.2345e300)
 #endif
-    store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, RE ? S.F2E[f2_slot(N, T)] : nullptr);
+    store_f1_2<N, (kQI && GEN == 0)>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, RE ? S.F2E[f2_slot(N, T)] : nullptr);
 }
 
 // one normal direction of the transverse stage for the faces (ijk) and (ijk + x) -- `v1`: the second face exists
@@ -1750,7 +1827,7 @@ __device__ __forceinline__ void trans1_solve_store(const Tile& t, const DevScrat
         rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
         interface_flux<N, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w], false, P, f[w]);
     }
-    store_f1_2<N>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, nullptr);
+    store_f1_2<N, (kQI && GEN == 0)>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, nullptr);
 }
 
 // slot -> zone pair for the launches whose waves overlap by one slot: lane 0 of a wave repeats the last slot of the wave
@@ -2094,17 +2171,17 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     load_edge_2(S.QM[N], NC, c, q);
     if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }   // changed by its first solve
 #ifdef DIAG_F2_REUSE      // timing diagnostic (wrong results): two record loads per face pair instead of eight
-    load_f1_2(F12, NC, c, f1l);
-    load_f1_2(F21, NC, c, f2l);
+    load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c, f1l);
+    load_f1_2<T2, (kQI && GEN == 0)>(F21, NC, c, f2l);
 #pragma unroll
     for (int w = 0; w < 2; ++w)
 #pragma unroll
         for (int n = 0; n < NF1; ++n) { f1r[w][n] = f1l[w][n] * 1.01; f2r[w][n] = f2l[w][n] * 0.99; }
 #else
-    load_f1_2(F12, NC, c - sn + s1, f1r);
-    load_f1_2(F12, NC, c - sn, f1l);
-    load_f1_2(F21, NC, c - sn + s2, f2r);
-    load_f1_2(F21, NC, c - sn, f2l);
+    load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c - sn + s1, f1r);
+    load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c - sn, f1l);
+    load_f1_2<T2, (kQI && GEN == 0)>(F21, NC, c - sn + s2, f2r);
+    load_f1_2<T2, (kQI && GEN == 0)>(F21, NC, c - sn, f2l);
 #endif
     if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
         const double* E12 = S.F2E[f2_slot(T1, T2)];
@@ -2121,10 +2198,10 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     load_edge_2(S.QP[N], NC, c, q);
     if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }
 #ifndef DIAG_F2_REUSE
-    load_f1_2(F12, NC, c + s1, f1r);
-    load_f1_2(F12, NC, c, f1l);
-    load_f1_2(F21, NC, c + s2, f2r);
-    load_f1_2(F21, NC, c, f2l);
+    load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c + s1, f1r);
+    load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c, f1l);
+    load_f1_2<T2, (kQI && GEN == 0)>(F21, NC, c + s2, f2r);
+    load_f1_2<T2, (kQI && GEN == 0)>(F21, NC, c, f2l);
 #endif
     if (RE && P.reset_rhoe == 1) {
         const double* E12 = S.F2E[f2_slot(T1, T2)];
@@ -2864,7 +2941,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // hybrid_riemann = 1: the fused x solve of stage A would read the shock flags, which k_divu writes in stage B
     const bool splittable = !Src.p && P.ppm_type == 1 && !tfix && P.hybrid_riemann != 1;
     // which solvers the kernels of the default-option path contain (interface_flux<D, SOLV>): 0 default only, 1 all but CG, 2 all
-    const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1) ? 1 : 0);
+    // GEN == 0 instantiations keep their transverse-stage records in the 7-plane state form (store_f1: QI), so they are
+    // used only where EVERY kernel of the call is one: the all-default path.  A non-default final stage, the flux
+    // limiters, transverse_reset_rhoe and ppm_temp_fix run kernels of the full solver set (flux-form records).
+    const bool plain_path = !(P.ppm_temp_fix == 2 && P.riemann_solver != 2) && P.reset_rhoe != 1 && g_fuse_consup == 1
+                            && P.limit_small_dens != 1 && P.limit_large_vel != 1;
+    const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1 || !plain_path) ? 1 : 0);
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
     const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
     SkipBox valid_box, inner_box;

@@ -1053,7 +1053,9 @@ __device__ __forceinline__ double vsq_global(double un, double ut, double utt)
     return ut * ut + utt * utt + un * un;                  // (u,v,w) = (ut,utt,un)
 }
 
-struct IFlux { double rho, mn, mt, mtt, E, eint, X, ugd, ut, utt, pgd; };
+struct IFlux { double rho, mn, mt, mtt, E, eint, X, ugd, ut, utt, pgd;
+               double rho_g, rhoe_g, X_g; };   // Godunov density, (rho e) and passive of the CGF / CG branch: with ugd, ut, utt, pgd the
+                                               // whole interface state, from which the fluxes above follow (qstate_to_rec)
 
 // riemann.H:442-501 compute_flux, normal frame, Cartesian (pressure in the normal momentum flux)
 struct CState { double rho, mn, mt, mtt, E, eint, X; };
@@ -1320,6 +1322,8 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
         F.ut = qint.ut;
         F.utt = qint.utt;
         F.pgd = qint.p;
+        F.rho_g = qint.rho;
+        F.rhoe_g = qint.rhoe;
 
         double sgnm = sign_of(qint.un);
         if (qint.un == 0.0) sgnm = 0.0;
@@ -1329,6 +1333,7 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
 
         double X_int = fp * Xl + fm * Xr;
         F.X = F.rho * X_int;
+        F.X_g = X_int;
     }
 
     if (SOLV >= 1 && P.hybrid_riemann == 1 && is_shock) {

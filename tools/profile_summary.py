@@ -51,7 +51,7 @@ for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 
 # per-kernel HBM-side traffic per launch and per step, gfx950 correction applied (MI355X_MICROARCH.md, HBM section):
 # FETCH_SIZE is reported in KiB and counts 128-B requests as 64 B for coalesced streams (x2);
-# WRITE_SIZE (KiB) is exact.  Kernel template instances are kept apart (k_final<0|1|2>); steps = launches of k_trans1.
+# WRITE_SIZE (KiB) is exact.  Kernel template instances are kept apart (k_final<0|1|2>); steps = launches of k_finalx_consup.
 import json
 import re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -71,7 +71,7 @@ for which, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         k = re.sub(r"<(\d).*", r"<\1>", k) if k.startswith("k_final<") or k.startswith("k_riemann1<") else re.sub(r"<.*", "", k)
         acc[k][0] += float(r["Counter_Value"])
         acc[k][1] += 1
-    nsteps[ctr] = max(1, acc.get("k_trans1", [0, 1])[1])
+    nsteps[ctr] = max(1, acc.get("k_finalx_consup", acc.get("k_trans1", [0, 1]))[1])      # one launch per step
     for k, (v, n) in acc.items():
         vals.setdefault(k, {})[ctr] = (v / n, n)
 step_bytes = 0.0
