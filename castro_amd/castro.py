@@ -803,7 +803,8 @@ class Castro:
         self.red.fill_(1.e200)
         n0 = self.nstep
         if graph is None:
-            graph = self.comm.size == 1 and nsteps >= 4 and os.environ.get("CASTRO_AMD_STEP_GRAPH", "1") != "0"
+            # no capture across ranks: the collectives of a distributed run stay ordinary stream-ordered RCCL calls
+            graph = isinstance(self.comm, SingleComm) and nsteps >= 4 and os.environ.get("CASTRO_AMD_STEP_GRAPH", "1") != "0"
         left = nsteps
         if graph:
             if not self._eager_done:

@@ -2272,6 +2272,28 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, co
     final_body<N, RE, LIM, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R);
 }
 
+// The y and z faces of the final stage in one launch (experiment, CASTRO_AMD_FINAL_YZ=1): a thread does the y faces
+// (i, i+1; j; k) and then the z faces of the same index -- Sborder, div(u) and the sound speeds of the zone are fetched once
+// for both.  The launch box is the union of the two face boxes; each body masks the faces outside its own.
+template <int GEN>
+__global__ void __launch_bounds__(256) CG_TWO_WAVES k_final_yz(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+                                                  DFab U, DFab fluxes1, DFab mass1, DFab qe1, DFab fluxes2, DFab mass2, DFab qe2,
+                                                  double hdtdx, double hdtdy, double hdtdz, double dt, double area1, double area2,
+                                                  int acc_hi1, int acc_hi2, int assign, DevParams P)
+{
+    RETURN_IF_BATCH_FAILED();
+    int ijk[3];
+    if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
+    if (P.dtp) { dt = P.dtp[6]; hdtdx = 0.5 * dt / g.dx[0]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
+    const bool v1 = ijk[0] + 1 <= b.hi0;
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    double R[2][NFIN];
+    if (ijk[2] <= t.hi[2])          // y faces: j in [lo, hi + 1], k in [lo, hi]
+        final_body<1, false, false, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes1, mass1, qe1, hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi1, assign, P, R);
+    if (ijk[1] <= t.hi[1])          // z faces: j in [lo, hi], k in [lo, hi + 1]
+        final_body<2, false, false, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes2, mass2, qe2, hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi2, assign, P, R);
+}
+
 // ---------------------------------------------------------------------------------------
 // Brick launches: a workgroup owns a tile of tx2 x-pairs by ty by tz faces (or zones) and stages the flux records its
 // threads share -- every record of the transverse stage is read by eight threads -- in LDS, once, with 16-byte loads
@@ -2782,6 +2804,7 @@ __global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const 
 // ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
+int g_final_yz = 0;       // 1: the y and z faces of the final stage in one launch (k_final_yz; CASTRO_AMD_FINAL_YZ)
 int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
 int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: 2 = k_trans1_fold_lds (records parked in LDS;
                           // -0.35 ms per 256^3 step), 1 = k_trans1_fold (records in registers, 28 spilled: break-even), 0 = two k_riemann1
@@ -3157,6 +3180,10 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         } else if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+        } else if (g_final_yz && solv == 0) {
+            const int ulo[3] = { t.lo[0], t.lo[1], t.lo[2] }, uhi[3] = { t.hi[0], t.hi[1] + 1, t.hi[2] + 1 };
+            KL2("k_final_yz", k_final_yz<0>, ulo, uhi, S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], fluxes[2], mass[2], qe[2],
+                hdtdx, hdtdy, hdtdz, dt, area1, area2, acc_hi[1], acc_hi[2], (flags & 2) ? 1 : 0, P);
         } else {
             KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);

@@ -1077,6 +1077,10 @@ def _rccl_worker(rank, world, port, out_path):
         c = castro_amd.Castro((24, 16, 32), comm=castro_amd.DistComm(), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
         c.initData("sedov", r_init=0.1, nsub=4)
         dts = [c.step(0.01) for _ in range(3)]
+        # host-free steps with the RCCL communicator: the all_reduce(MIN) is enqueued on the device, no host read per step
+        assert c.host_free_ok()
+        c.run_steps(4, stop_time=0.01)
+        dts += c.dt_history
         c.comm.barrier()
         # the grouped point-to-point call of the halo exchange (batch_isend_irecv => ncclGroupStart / ncclSend / ncclRecv),
         # two messages to the only peer there is -- this rank -- posted in different orders on the two sides
@@ -1104,7 +1108,7 @@ def test_rccl_process_group_of_one_rank(tmp_path):
     got = np.load(out)
     c = castro_amd.Castro((24, 16, 32), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
     c.initData("sedov", r_init=0.1, nsub=4)
-    dts = [c.step(0.01) for _ in range(3)]
+    dts = [c.step(0.01) for _ in range(7)]
     torch.cuda.synchronize()
     assert np.array_equal(got["dts"], np.array(dts)) and np.array_equal(got["S"], c.S_new().cpu().numpy())
 
@@ -1931,9 +1935,10 @@ def test_randomised_option_combinations_match_the_oracle():
                                  {"CASTRO_AMD_FUSE_CONSUP": "1", "CASTRO_AMD_XPAD": "12"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "32"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "3"},
-                                 {"CASTRO_AMD_FOLD_R1": "1"}, {"CASTRO_AMD_FOLD_R1": "2"}, {"CASTRO_AMD_FOLD_R1": "0"}],
+                                 {"CASTRO_AMD_FOLD_R1": "1"}, {"CASTRO_AMD_FOLD_R1": "2"}, {"CASTRO_AMD_FOLD_R1": "0"},
+                                 {"CASTRO_AMD_FINAL_YZ": "1"}],
                          ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows",
-                              "z-marching", "z-marching-short-chunks", "first-yz-solves-folded-into-trans1", "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches"])
+                              "z-marching", "z-marching-short-chunks", "first-yz-solves-folded-into-trans1", "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches", "final-y-and-z-in-one-launch"])
 def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
     """The final stage has three forms: k_final<x,y,z> + k_consup (round 1), k_final_lds (transverse flux records staged
     in LDS bricks; measured slower, kept as the measured experiment of DESIGN.md section 9) and the default
@@ -1941,7 +1946,7 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
     import castro_amd
     from castro_amd.hydro import HipHydro
     keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD", "CASTRO_AMD_MARCH_PLANES",
-            "CASTRO_AMD_FOLD_R1")
+            "CASTRO_AMD_FOLD_R1", "CASTRO_AMD_FINAL_YZ")
     old = {k: os.environ.get(k) for k in keys}
     try:
         os.environ.update(env)
@@ -1976,6 +1981,7 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
         os.environ["CASTRO_AMD_BRICK"] = "0,0,0"
         os.environ["CASTRO_AMD_MARCH_PLANES"] = "32"
         os.environ["CASTRO_AMD_FOLD_R1"] = old["CASTRO_AMD_FOLD_R1"] if old["CASTRO_AMD_FOLD_R1"] is not None else LIB_DEFAULT_FOLD_R1
+        os.environ["CASTRO_AMD_FINAL_YZ"] = old["CASTRO_AMD_FINAL_YZ"] if old["CASTRO_AMD_FINAL_YZ"] is not None else "0"
         HipHydro(0).close()                   # restore the library's defaults for the tests that follow
         for k in keys:
             if old[k] is None:
