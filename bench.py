@@ -34,15 +34,17 @@ PATH_BYTES_ASSIGN = 344.0
 # (roofline.kernel_utilisation); the roofline figure itself is the SURVEY 8(d) contract above.
 KERNEL_BYTES_PER_UNIT = {
     "k_ctoprim": 8 * (8 + 8),
+    "k_ctoprim_clean": 8 * (8 + 8),                       # + the pending clean_states; only changed components of U are written back
     "k_divu": 8 * (3 + 1),
-    "k_trace": 8 * (8 + 42 + 8),                          # + F1[x]: the first x Riemann solve is fused in
+    "k_trace": 8 * (8 + 42 + 7),                          # + F1[x] (7-plane state form): the first x Riemann solve is fused in
     "k_riemann1": 8 * (14 + 1 + 8),
     "k_trans1": 8 * (42 + 24 + 1 + 48),                   # all three normal directions in one launch
-    "k_trans1_fold": 8 * (42 + 8 + 1 + 48),               # + the first y / z solves: F1[y], F1[z] are neither written nor read
-    "k_final_rmw": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 17),    # fluxes read-modify-write (8 read + 8 write + mass)
-    "k_final_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 9),  # fluxes written only
-    "k_finalx_consup_rmw": 8 * (14 + 16 + 1 + 1 + 8 + 17 + 18 + 8),   # x faces + consup: + FL[y], FL[z] read, S_new written
-    "k_finalx_consup_assign": 8 * (14 + 16 + 1 + 1 + 8 + 9 + 18 + 8),
+    "k_trans1_fold": 8 * (42 + 7 + 1 + 42),               # + the first y / z solves: F1[y], F1[z] are neither written nor read;
+                                                          #   F1[x] and F2 in the 7-plane state form
+    "k_final_rmw": 8 * (14 + 14 + 1 + 1 + 8 + 9 + 17),    # fluxes read-modify-write (8 read + 8 write + mass); F2: 2 x 7 planes
+    "k_final_assign": 8 * (14 + 14 + 1 + 1 + 8 + 9 + 9),  # fluxes written only
+    "k_finalx_consup_rmw": 8 * (14 + 14 + 1 + 1 + 8 + 17 + 18 + 8),   # x faces + consup: + FL[y], FL[z] read, S_new written
+    "k_finalx_consup_assign": 8 * (14 + 14 + 1 + 1 + 8 + 9 + 18 + 8),
     "k_consup": 8 * (27 + 8 + 8),
     "k_consup_clean": 8 * (27 + 8 + 8),
     "k_clean_state": 8 * (8 + 8),
@@ -62,6 +64,7 @@ def kernel_units(name, n):
     nx, ny, nz = n
     return {
         "k_ctoprim": (nx + 8) * (ny + 8) * (nz + 8),
+        "k_ctoprim_clean": (nx + 8) * (ny + 8) * (nz + 8),
         "k_divu": (nx + 2) * (ny + 2) * (nz + 2),
         "k_trace": (nx + 2) * (ny + 2) * (nz + 2),
         "k_riemann1": ((nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 2.0,     # y and z launches

@@ -431,9 +431,11 @@ class Castro:
         """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
         and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
         self.red, which the caller has initialised.  When the attempt covers the whole step of a single level,
-        the clean_state of Castro::post_timestep (Castro.cpp:1909-1916) is applied in the same pass (a second
-        clean_state changes neither the density check nor the CFL estimate: both are taken from rho, momentum and
-        (rho e), which the first application has already fixed)."""
+        the clean_state of Castro::post_timestep (Castro.cpp:1909-1916) is applied in the same pass.  A second
+        clean_state is not always the identity (the dual-energy reset can take its other branch once eden has been
+        floored), so the pass reduces the CFL estimate twice: after the first application (red[2]: what the validity
+        check of do_advance_ctu sees) and after the last (red[0]: what estTimeStep of the next coarse step sees); the
+        density check uses the raw update (red[1])."""
         h = self.hydro
         post_clean = fuse_clean and self.fuse_post_clean and getattr(self, "_whole_step", False) and stage != "A"
         if post_clean:
