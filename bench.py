@@ -215,16 +215,27 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    def run(contract_mode, steps, warmup, kernel_pass):
+    def run(contract_mode, steps, warmup, kernel_pass, stepwise=None):
         """W untimed warm-up steps, K timed steps (no profiling events in the timed region), then -- untimed -- a second
         pass of min(K, 5) steps with hipEvents around every kernel on its launch stream for the per-kernel table."""
+        if stepwise is None and (args.stepwise or world > 1):
+            stepwise = bool(args.stepwise)
+        if stepwise is None:
+            try:
+                return run(contract_mode, steps, warmup, kernel_pass, stepwise=False)
+            except castro_amd.AdvanceFailure:
+                raise
+            except Exception as e:          # a box whose runtime refuses the graph capture: the stepwise form measures the same kernels
+                print("bench.py: host-free batch failed (%s: %s); falling back to --stepwise" % (type(e).__name__, e), file=sys.stderr)
+                torch.cuda.synchronize()
+                return run(contract_mode, steps, warmup, kernel_pass, stepwise=True)
         c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc, overlap=overlap,
                               fuse_clean=not contract_mode, flux_assign=not contract_mode)
         c.initData("sedov")                      # synthetic input, generated on the device
         # host-free stepping (Castro.run_steps): dt, time and the step checks stay on the device, one host
         # synchronisation per batch; on one rank a captured pair of steps is replayed as a hipGraph.  --stepwise keeps
         # the round-1/2 form (one allreduce + host read per step).  Same kernels, same dt, bit-identical states.
-        host_free = (not args.stepwise) and c.host_free_ok()
+        host_free = (not stepwise) and c.host_free_ok()
         if host_free:
             c.run_steps(warmup)
             if world == 1 and warmup >= 2:
