@@ -683,10 +683,10 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         alpha0r = un > 0.0 ? 0.0 : -alpha0r;
         alpha0e_g = un > 0.0 ? 0.0 : -alpha0e_g;
 
-        qp[PRHO] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
+        qp[PRHO] = amax_hw(P.small_dens, rho_ref + alphap + alpham + alpha0r);      // positive parameter first (hydro_device.h)
         qp[QUN] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
-        qp[PRE] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
-        qp[PP] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        qp[PRE] = amax_hw(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
+        qp[PP] = amax_hw(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
         qp[QUT] = w.Im_ut[1];
         qp[QUTT] = w.Im_utt[1];
         qp[PX] = w.Im_X[1];
@@ -727,10 +727,10 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         alpha0r = un > 0.0 ? -alpha0r : 0.0;
         alpha0e_g = un > 0.0 ? -alpha0e_g : 0.0;
 
-        qm[PRHO] = amax(P.small_dens, rho_ref + alphap + alpham + alpha0r);
+        qm[PRHO] = amax_hw(P.small_dens, rho_ref + alphap + alpham + alpha0r);
         qm[QUN] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
-        qm[PRE] = amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
-        qm[PP] = amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        qm[PRE] = amax_hw(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
+        qm[PP] = amax_hw(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
         qm[QUT] = w.Ip_ut[1];
         qm[QUTT] = w.Ip_utt[1];
         qm[PX] = w.Ip_X[1];

@@ -54,6 +54,21 @@ struct DevParams {
 // amrex::min/max == std::min/max: ties (and signed zeros) resolve to the FIRST argument
 __device__ __forceinline__ double amin(double a, double b) { return (b < a) ? b : a; }
 __device__ __forceinline__ double amax(double a, double b) { return (a < b) ? b : a; }
+// The same through the hardware minimum / maximum (one v_min_f64 / v_max_f64 instead of a compare and two selects; a third of
+// the trace kernel's VALU instructions were such selects) -- ONLY where it returns the same bits as the ternary:
+//   * the FIRST argument is never a NaN (a NaN in the second is dropped by both forms: (a < NaN) is false; minNum keeps a),
+//   * the two can never be zeros of opposite sign in the order the forms disagree on (amin(+0, -0) keeps +0, v_min gives -0;
+//     amax(-0, +0) keeps -0, v_max gives +0): a positive constant first, or both arguments results of fabs.
+// Every use below says why it qualifies.  Measured (profiles/r03o_ab_hw_minmax.txt): 7 % fewer static instructions in the
+// trace kernel, no change in time (2.58 vs 2.56 ms; the dynamic count even rises 5 % with the canonicalising v_max the
+// compiler adds in IEEE mode) -- so the default build keeps the ternaries everywhere and `-DHW_MINMAX_ON` selects these.
+#ifndef HW_MINMAX_ON
+__device__ __forceinline__ double amin_hw(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double amax_hw(double a, double b) { return (a < b) ? b : a; }
+#else
+__device__ __forceinline__ double amin_hw(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double amax_hw(double a, double b) { return __builtin_fmax(a, b); }
+#endif
 // copysign(1.0, x) as the reference's x86-64 CPU build evaluates it when x is a NaN.  The sign of a NaN is outside
 // IEEE 754's value semantics, but the Riemann solvers branch on it: `sgnm = copysign(1.0, ustar)` decides
 // `spout = co - sgnm*uo`, and `spout < 0` returns the (finite) upwind state even when ustar is a NaN (met with
@@ -97,9 +112,9 @@ __device__ __forceinline__ double flatten_1d(const double p[7], const double u[5
     double dp = p[4] - p[2];
     const bool up = dp > 0.0;                 // ishft = up ? 1 : -1
 
-    double denom = amax(small_pres, fabs(p[5] - p[1]));
+    double denom = amax_hw(small_pres, fabs(p[5] - p[1]));     // positive constant first
     double zeta = fabs(dp) / denom;
-    double z = amin(1.0, amax(0.0, dzcut * (zeta - zcut1)));
+    double z = amin_hw(1.0, amax_hw(0.0, dzcut * (zeta - zcut1)));      // constants first; amax(+0, -0) = +0 in both forms
 
     double tst = 0.0;
     if (u[1] - u[3] >= 0.0) tst = 1.0;
@@ -119,9 +134,9 @@ __device__ __forceinline__ double flatten_1d(const double p[7], const double u[5
 
     dp = pp1 - pm1;
 
-    denom = amax(small_pres, fabs(pp2 - pm2));
+    denom = amax_hw(small_pres, fabs(pp2 - pm2));
     zeta = fabs(dp) / denom;
-    double z2 = amin(1.0, amax(0.0, dzcut * (zeta - zcut1)));
+    double z2 = amin_hw(1.0, amax_hw(0.0, dzcut * (zeta - zcut1)));
 
     tst = 0.0;
     if (um1 - up1 >= 0.0) tst = 1.0;
@@ -143,10 +158,12 @@ __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn,
     double dsl = 2.0 * (s[1] - s[0]);
     double dsr = 2.0 * (s[2] - s[1]);
 
+    // inside `dsl * dsr > 0` neither difference is a NaN (a NaN or an inf - inf makes the product NaN or negative), so dsc is
+    // none either, and fabs leaves no negative zero: amin_hw is exact
     double dsvl_l = 0.0;
     if (dsl * dsr > 0.0) {
         double dsc = 0.5 * (s[2] - s[0]);
-        dsvl_l = copysign(1.0, dsc) * amin(fabs(dsc), amin(fabs(dsl), fabs(dsr)));
+        dsvl_l = copysign(1.0, dsc) * amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr)));
     }
 
     dsl = 2.0 * (s[2] - s[1]);
@@ -155,7 +172,7 @@ __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn,
     double dsvl_r = 0.0;
     if (dsl * dsr > 0.0) {
         double dsc = 0.5 * (s[3] - s[1]);
-        dsvl_r = copysign(1.0, dsc) * amin(fabs(dsc), amin(fabs(dsl), fabs(dsr)));
+        dsvl_r = copysign(1.0, dsc) * amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr)));
     }
 
     sm = 0.5 * (s[2] + s[1]) - (1.0 / 6.0) * (dsvl_r - dsvl_l);
@@ -173,7 +190,7 @@ __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn,
     dsvl_r = 0.0;
     if (dsl * dsr > 0.0) {
         double dsc = 0.5 * (s[4] - s[2]);
-        dsvl_r = copysign(1.0, dsc) * amin(fabs(dsc), amin(fabs(dsl), fabs(dsr)));
+        dsvl_r = copysign(1.0, dsc) * amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr)));
     }
 
     sp = 0.5 * (s[3] + s[2]) - (1.0 / 6.0) * (dsvl_r - dsvl_l);
@@ -505,8 +522,9 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
 
     double wsmall = P.small_dens * raux.csmall;
 
-    double wl = amax(wsmall, sqrt(fabs(ql.gamc * ql.p * ql.rho)));
-    double wr = amax(wsmall, sqrt(fabs(qr.gamc * qr.p * qr.rho)));
+    // wsmall = small_dens * csmall is finite and >= +0, the square roots are >= +0 or NaN: amax_hw is exact
+    double wl = amax_hw(wsmall, sqrt(fabs(ql.gamc * ql.p * ql.rho)));
+    double wr = amax_hw(wsmall, sqrt(fabs(qr.gamc * qr.p * qr.rho)));
 
     double wwinv = 1.0 / (wl + wr);
     double pstar = ((wr * ql.p + wl * qr.p) + wl * wr * (ql.un - qr.un)) * wwinv;
@@ -530,12 +548,12 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     double reo = fp * ql.rhoe + fm * qr.rhoe;
     double gamco = fp * ql.gamc + fm * qr.gamc;
 
-    ro = amax(P.small_dens, ro);
+    ro = amax_hw(P.small_dens, ro);                // positive parameter first
 
     double roinv = 1.0 / ro;
 
     double co = sqrt(fabs(gamco * po * roinv));
-    co = amax(raux.csmall, co);
+    co = amax_hw(raux.csmall, co);                 // csmall = amax(small, ...) is a positive finite number
     double co2inv = 1.0 / (co * co);
 
     qint.ut = fp * ql.ut + fm * qr.ut;
@@ -543,7 +561,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
 
     double drho = (pstar - po) * co2inv;
     double rstar = ro + drho;
-    rstar = amax(P.small_dens, rstar);
+    rstar = amax_hw(P.small_dens, rstar);
 
     double entho = (reo + po) * roinv * co2inv;
     double estar = reo + (pstar - po) * entho;
@@ -567,7 +585,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     }
 
     double frac = (1.0 + (spout + spin) / scr) * 0.5;
-    frac = amax(0.0, amin(1.0, frac));
+    frac = amax_hw(0.0, amin_hw(1.0, frac));       // constants first
 
     qint.rho = frac * rstar + (1.0 - frac) * ro;
     qint.un = frac * ustar + (1.0 - frac) * uo;
