@@ -2804,6 +2804,7 @@ __global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const 
 // ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
+int g_trace_single = 0;   // 1: one zone per thread in the trace launch (k_trace<false,false>) + k_riemann1<x> (CASTRO_AMD_TRACE_SINGLE)
 int g_final_yz = 0;       // 1: the y and z faces of the final stage in one launch (k_final_yz; CASTRO_AMD_FINAL_YZ)
 int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
 int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: 2 = k_trans1_fold_lds (records parked in LDS;
@@ -3065,6 +3066,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // the join must precede the first reader of DIV (and every return path after this point)
     auto join_divu = [&]() { if (divu_forked) { hipStreamWaitEvent(stream, aux.ev_join, 0); divu_forked = false; } };
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
+    bool trace_single_done = false;
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
@@ -3074,6 +3076,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
         else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none); }
+        else if (g_trace_single && !second_half) {
+            // experiment (CASTRO_AMD_TRACE_SINGLE=1): one zone per thread (153 VGPRs, three waves per SIMD), the first x solve as
+            // a k_riemann1 launch of its own
+            KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P);
+            trace_single_done = true;
+        }
         else if (second_half) {
             if (inner_ok) {
                 const int ns = shell_boxes(olo, ohi, inner_box.lo, inner_box.hi, slo, shi);
@@ -3090,7 +3098,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         } else {
             trace_with_xriemann(olo, ohi);
         }
-        x_done = P.ppm_type != 0 && !tfix;
+        x_done = P.ppm_type != 0 && !tfix && !trace_single_done;
     }
     (void)staged;
 
