@@ -1159,6 +1159,49 @@ def test_fab_ops_equal_the_single_operations(hip):
         hip.fab_ops(bad)
 
 
+def test_level_wide_clean_and_ghost_shell_ops_equal_the_per_box_calls(hip):
+    """castro_amd_fab_ops_p (round 3): clean_state of many boxes and the six ghost-shell slabs of many boxes as ONE launch
+    each -- more operations than a kernel argument holds, so the table travels through the context's device buffer --
+    against castro_amd_clean_state_fab / castro_amd_fillpatch_shell_fab box by box, bit for bit; a CLEAN operation without
+    parameters is refused."""
+    import torch
+    import castro_amd
+    from castro_amd import _lib as L
+    rng = np.random.default_rng(31)
+    P = castro_amd.default_params(small_dens=0.3)
+    nbox, g = 20, 4
+    vlo, vhi = (2, 4, 6), (9, 9, 11)
+    flo, fhi = tuple(x - g for x in vlo), tuple(x + g for x in vhi)
+    clo, chi = tuple(x // 2 - 1 for x in flo), tuple(x // 2 + 1 for x in fhi)
+    fbox, cbox = (flo, fhi), (clo, chi)
+    shell = [((flo[0], flo[1], flo[2]), (fhi[0], fhi[1], vlo[2] - 1)), ((flo[0], flo[1], vhi[2] + 1), (fhi[0], fhi[1], fhi[2])),
+             ((flo[0], flo[1], vlo[2]), (fhi[0], vlo[1] - 1, vhi[2])), ((flo[0], vhi[1] + 1, vlo[2]), (fhi[0], fhi[1], vhi[2])),
+             ((flo[0], vlo[1], vlo[2]), (vlo[0] - 1, vhi[1], vhi[2])), ((vhi[0] + 1, vlo[1], vlo[2]), (fhi[0], vhi[1], vhi[2]))]
+    crse, fine_a, fine_b = [], [], []
+    for i in range(nbox):
+        c = physical_state(rng, clo, chi, smooth=False)
+        c[0] *= rng.uniform(0.2, 1.0, size=c[0].shape)              # some densities below small_dens, rho X != rho
+        f = physical_state(rng, flo, fhi, smooth=False)
+        f[0] *= rng.uniform(0.2, 1.0, size=f[0].shape)
+        crse.append(_to_dev(hip, c))
+        fine_a.append(_to_dev(hip, f))
+        fine_b.append(_to_dev(hip, f))
+    for i in range(nbox):                                           # box by box
+        hip.fillpatch_shell(crse[i], cbox, fine_a[i], fbox, vlo, vhi, g, P, ntimes=1)
+        hip.clean_state(fine_a[i], fbox, vlo, vhi, P, ntimes=2)
+    shell_ops = hip.make_ops([(L.OP_INTERP_CLEAN, 0, 8, lo, hi, 1.0, 0.0, (fine_b[i], fbox), (crse[i], cbox), None)
+                              for i in range(nbox) for lo, hi in shell])
+    clean_ops = hip.make_ops([(L.OP_CLEAN, 0, 8, vlo, vhi, 2.0, 0.0, (fine_b[i], fbox), (fine_b[i], fbox), None) for i in range(nbox)])
+    assert shell_ops[1] == 6 * nbox and clean_ops[1] == nbox
+    hip.fab_ops(shell_ops, params=P)
+    hip.fab_ops(clean_ops, params=P)
+    torch.cuda.synchronize()
+    for i in range(nbox):
+        assert torch.equal(fine_a[i], fine_b[i]), i
+    with pytest.raises(RuntimeError, match="bad argument"):
+        hip.fab_ops(clean_ops)                                      # castro_amd_fab_ops: no runtime parameters
+
+
 def test_fillpatch_shell_equals_interp_then_clean(hip, oracle):
     """castro_amd_fillpatch_shell_fab (one launch) == cc_interp on the six ghost slabs followed by clean_state there,
     on the device and in the oracle; the valid zones are not touched."""
