@@ -1811,6 +1811,17 @@ __device__ __forceinline__ void f1_at_2(const Tile& t, const double* __restrict_
     f1_solve_2<D, GEN>(qm, qp, cl, cr, wall_fac<D>(g, idx), P, r);
 }
 
+// ... with the sound speeds either side handed in (the caller has them already)
+template <int D, int GEN>
+__device__ __forceinline__ void f1_at_2c(const Tile& t, const DevScratch& S, const DevGeom& g, const DevParams& P, unsigned cf, int idx,
+                                         const D2& cl, const D2& cr, double r[2][NF1])
+{
+    double qm[2][NEDGE], qp[2][NEDGE];
+    load_edge_2(S.QM[D], t.NC, cf, qm);
+    load_edge_2(S.QP[D], t.NC, cf, qp);
+    f1_solve_2<D, GEN>(qm, qp, cl, cr, wall_fac<D>(g, idx), P, r);
+}
+
 // second-stage Riemann solve of trans1_pair on already corrected states
 template <int N, int T, int GEN>
 __device__ __forceinline__ void trans1_solve_store(const Tile& t, const DevScratch& S, unsigned c,
@@ -1974,10 +1985,11 @@ __device__ __forceinline__ void park_get(const double* __restrict__ park, int f,
     for (int n = 0; n < NF1; ++n) r[n] = park[((f * 2 + w) * NF1 + n) * 256 + th];
 }
 
-template <int T, int GEN>
+template <int T, int GEN, bool TX_HERE>
 __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
                                                     const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
-                                                    double cdtdt, const DevParams& P, double* __restrict__ park)
+                                                    double cdtdt, double cdtdx, const DevParams& P, double* __restrict__ park,
+                                                    const D2& c0)          // sound speeds of the thread's own zones
 {
     constexpr int O = (T == 1) ? 2 : 1;
     const Str s = gstr(t);
@@ -1993,14 +2005,29 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
             double qm[2][NEDGE], qp[2][NEDGE];
             load_edge_2(S.QM[T], NC, c, qm);
             load_edge_2(S.QP[T], NC, c, qp);
-            const D2 cl = ldg2(Cp, c - st), cr = ldg2(Cp, c);
+            const D2 cl = ldg2(Cp, c - st), cr = c0;
             f1_solve_2<T, GEN>(qm, qp, cl, cr, wall_fac<T>(g, ijk[T]), P, A);
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * 256 + th] = A[w][n];
+            // the same edge states are the N = T states of the (T | x) combination, whose transverse flux F1[x] comes from
+            // memory: done here, while they are in registers, instead of loading them a third time (trans1_fold_tx)
+            if (TX_HERE) {
+                bool in_t[2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const int ix = ijk[0] + w;
+                    in_t[w] = owner && ((w == 0) || v1) && ijk[T] >= t.lo[T] && ix >= t.lo[0] && ix <= t.hi[0];
+                }
+                if (in_t[0] || in_t[1]) {
+                    double bnd[2];
+                    bnd[0] = bnd[1] = wall_fac<T>(g, ijk[T]);
+                    trans1_pair<T, 0, false, GEN>(t, S, c, st, 8u, qm, qp, cl, cr, bnd, cdtdx, in_t[0], in_t[1], P);
+                }
+            }
         }
-#pragma unroll
-        for (int w = 0; w < 2; ++w)
-#pragma unroll
-            for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * 256 + th] = A[w][n];
-        f1_at_2<T, GEN>(t, Q, S, g, P, c + st, ijk[T] + 1, A);
+        f1_at_2c<T, GEN>(t, S, g, P, c + st, ijk[T] + 1, c0, ldg2(Cp, c + st), A);
 #pragma unroll
         for (int w = 0; w < 2; ++w)
 #pragma unroll
@@ -2025,9 +2052,9 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
             trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qpo[0]);
             park_get(park, 1, 1, th, fr); park_get(park, 0, 1, th, fl);
             trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qpo[1]);
-            const D2 cl = ldg2(Cp, c - 8u), cr = ldg2(Cp, c);
+            const D2 cl = ldg2(Cp, c - 8u);
             double bnd[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
-            trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
+            trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, cl, c0, bnd, m0, m1, P);
         }
     }
     // ---- N = O
@@ -2035,10 +2062,11 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
         const bool m0 = tin && ijk[O] >= t.lo[O], m1 = m0 && v1;
         if (m0 || m1) {
             double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            const D2 cso = ldg2(Cp, c - so);       // sound speeds of the zones below: three uses
             {
                 double B0[2][NF1], B1[2][NF1];
-                f1_at_2<T, GEN>(t, Q, S, g, P, c - so, ijk[T], B0);
-                f1_at_2<T, GEN>(t, Q, S, g, P, c - so + st, ijk[T] + 1, B1);
+                f1_at_2c<T, GEN>(t, S, g, P, c - so, ijk[T], ldg2(Cp, c - so - st), cso, B0);
+                f1_at_2c<T, GEN>(t, S, g, P, c - so + st, ijk[T] + 1, cso, ldg2(Cp, c - so + st), B1);
                 load_edge_2(S.QM[O], NC, c, q);
 #pragma unroll
                 for (int w = 0; w < 2; ++w) trans_single<T>(q[w], B1[w], B0[w], P.gamma, cdtdt, P, qmo[w]);
@@ -2049,10 +2077,9 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
                 park_get(park, 1, w, th, fr); park_get(park, 0, w, th, fl);
                 trans_single<T>(q[w], fr, fl, P.gamma, cdtdt, P, qpo[w]);
             }
-            const D2 cl = ldg2(Cp, c - so), cr = ldg2(Cp, c);
             double bnd[2];
             bnd[0] = bnd[1] = wall_fac<O>(g, ijk[O]);
-            trans1_solve_store<O, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
+            trans1_solve_store<O, T, GEN>(t, S, c, qmo, qpo, cso, c0, bnd, m0, m1, P);
         }
     }
 }
@@ -2101,10 +2128,16 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_trans1_fold_lds(Tile t, Li
     fold_thread_wg(b, ijk[0], ijk[1], ijk[2], owner);
     const bool v1 = ijk[0] + 1 <= b.hi0;
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    trans1_fold_dir_lds<1, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdy, P, park);
-    trans1_fold_dir_lds<2, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdz, P, park);
+    const D2 c0 = ldg2(Q + PC * t.NC, c);
+#ifdef FOLD_TX_SEPARATE     // A/B: the (y | x), (z | x) combinations after the two folded directions, edge states loaded once more
+    trans1_fold_dir_lds<1, GEN, false>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
+    trans1_fold_dir_lds<2, GEN, false>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
     if (!owner) return;
     trans1_fold_tx<GEN>(t, ijk, v1, c, Q, S, g, cdtdx, P);
+#else
+    trans1_fold_dir_lds<1, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
+    trans1_fold_dir_lds<2, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
+#endif
 }
 
 #ifdef FOLD_ONE_WAVE        // A/B: 286 registers (VGPR + AGPR), one wave per SIMD, no spills
