@@ -968,6 +968,26 @@ def test_host_free_steps_equal_the_stepwise_driver(oracle, graph):
     lev.close()
 
 
+def test_host_free_steps_with_the_staged_halo_overlap():
+    """run_steps through the staged-overlap branch (periodic self-neighbours on one GPU stand in for the ranks of a
+    decomposed run: halo exchange and BC fill on the communication stream while stage A runs, castro_amd_hydro_opts.d_dt in
+    both stages), captured as a hipGraph with its second stream: bit for bit the stepwise driver."""
+    import torch
+    import castro_amd
+    n = (48, 40, 32)
+    kw = dict(lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), overlap=True, use_retry=False)
+    a, b = castro_amd.Castro(n, **kw), castro_amd.Castro(n, **kw)
+    for c in (a, b):
+        c.initData("sedov", r_init=0.1, nsub=4)
+    assert a.overlap and a._comm_stream is not None and a.neighbors and a.host_free_ok()
+    for _ in range(7):
+        b.step()
+    a.run_steps(7)
+    torch.cuda.synchronize()
+    assert a.time == b.time and a.dt == b.dt and a.nstep == b.nstep
+    assert torch.equal(a.S_new_b, b.S_new_b)
+
+
 def test_host_free_batch_latches_a_rejected_step():
     """A step the host path rejects (timestep validity check, Castro_advance_ctu.cpp:386-392) stops a host-free batch at
     the same step: the status is latched on the device and the launches after it leave the state alone.  Without
