@@ -853,8 +853,29 @@ class Castro:
             self.nstep += 1
             self.run_steps(nsteps - done - 1, stop_time, graph=graph)
 
-    def evolve(self, stop_time, max_step=10 ** 9):
+    def evolve(self, stop_time, max_step=10 ** 9, host_free=None):
+        """Amr::coarseTimeStep until stop_time (or max_step).  host_free (default: whenever host_free_ok()): the steps go out
+        in batches through run_steps, each batch as long as the steps are certain not to reach stop_time -- dt grows by at
+        most change_max per step, so k steps cover at most dt * cm * (cm^k - 1) / (cm - 1) -- with one host synchronisation per
+        batch; the last steps, where the clipping to stop_time decides, go one by one.  Same states, same dt sequence."""
+        import math
         eps = 2.220446049250313e-16
+        if host_free is None:
+            host_free = self.host_free_ok()
         while self.nstep < max_step and self.time < stop_time - eps:
-            self.step(stop_time)
+            k = 0
+            if host_free and self.nstep > 0 and self.fixed_dt <= 0.0 and self.dt > 0.0:
+                cm = self.params.change_max
+                remaining = stop_time - self.time
+                if cm > 1.0:
+                    # largest k with dt * cm * (cm^k - 1) / (cm - 1) < 0.99 * remaining
+                    x = 1.0 + 0.99 * remaining * (cm - 1.0) / (self.dt * cm)
+                    k = int(math.floor(math.log(x) / math.log(cm))) if x > 1.0 else 0
+                else:
+                    k = int(0.99 * remaining / self.dt)
+                k = min(k, max_step - self.nstep, 4 * L.CTL_NHIST)
+            if k >= 2:
+                self.run_steps(k, stop_time)
+            else:
+                self.step(stop_time)
         return self.nstep

@@ -968,6 +968,25 @@ def test_host_free_steps_equal_the_stepwise_driver(oracle, graph):
     lev.close()
 
 
+def test_evolve_in_host_free_batches_equals_stepwise_evolve():
+    """Castro.evolve(stop_time) sends its steps out in host-free batches as long as they cannot reach stop_time and takes
+    the last ones singly: the same number of steps, the same final time (exactly stop_time) and state as the stepwise loop."""
+    import torch
+    import castro_amd
+    n = (24, 24, 24)
+    a, b = castro_amd.Castro(n), castro_amd.Castro(n)
+    for c in (a, b):
+        c.initData("sedov", r_init=0.1, nsub=4)
+    calls = []
+    orig = a.run_steps
+    a.run_steps = lambda k, *args, **kw: (calls.append(k), orig(k, *args, **kw))[1]
+    a.evolve(2.0e-3)
+    b.evolve(2.0e-3, host_free=False)
+    assert calls and max(calls) >= 4, calls
+    assert a.nstep == b.nstep and a.time == b.time == 2.0e-3 and a.dt == b.dt
+    assert torch.equal(a.S_new_b, b.S_new_b)
+
+
 def test_host_free_steps_with_the_staged_halo_overlap():
     """run_steps through the staged-overlap branch (periodic self-neighbours on one GPU stand in for the ranks of a
     decomposed run: halo exchange and BC fill on the communication stream while stage A runs, castro_amd_hydro_opts.d_dt in
