@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile_rows; extern int g_final_yz; extern int g_trace_single; }
+namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile_rows; extern int g_final_yz; extern int g_trace_single; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
 
 using namespace cad;
 
@@ -226,6 +226,9 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_R1")) g_fold_r1 = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE_ROWS")) g_fold_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_YZ")) g_final_yz = std::atoi(e);
+    if (const char* e = std::getenv("CASTRO_AMD_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_wg = v; }
+    if (const char* e = std::getenv("CASTRO_AMD_FUSED_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_fused_wg = v; }
+    if (const char* e = std::getenv("CASTRO_AMD_FINAL_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_final_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_TRACE_SINGLE")) g_trace_single = std::atoi(e);
     if (g_side_stream) {
         if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||

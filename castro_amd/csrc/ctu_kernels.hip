@@ -116,7 +116,7 @@ __device__ __forceinline__ unsigned dstr(const Str& s, int d) { return d == 0 ? 
 // dispatcher, so id -> (id % 8) * (nb / 8) + id / 8 hands each XCD one contiguous run of rows, and
 // the rows are enumerated y-tile by y-tile (ty rows), z-plane by z-plane inside a tile, so that the
 // workgroups resident on one XCD at a time share their y and z stencil neighbours through that XCD's L2.
-struct LinBox { int lo[3], n[3]; int ty; unsigned nb; int w, hi0; };   // w zones per thread along x (n[0] counts threads)
+struct LinBox { int lo[3], n[3]; int ty; unsigned nb; int w, hi0; unsigned wg; };   // w zones per thread along x (n[0] counts threads); wg threads per workgroup
 
 __device__ __forceinline__ bool box_thread_at(const LinBox& b, unsigned bid, unsigned thr, int& i, int& j, int& k)
 {
@@ -124,7 +124,7 @@ __device__ __forceinline__ bool box_thread_at(const LinBox& b, unsigned bid, uns
         const unsigned per = b.nb >> 3;          // nb is a multiple of 8 in this mode
         bid = (bid & 7u) * per + (bid >> 3);
     }
-    const unsigned tid = bid * 256u + thr;
+    const unsigned tid = bid * b.wg + thr;
     const unsigned total = (unsigned)b.n[0] * (unsigned)b.n[1] * (unsigned)b.n[2];
     if (tid >= total) return false;
     const unsigned ii = tid % (unsigned)b.n[0];
@@ -1843,6 +1843,7 @@ __device__ __forceinline__ void trans1_solve_store(const Tile& t, const DevScrat
 
 // slot -> zone pair for the launches whose waves overlap by one slot: lane 0 of a wave repeats the last slot of the wave
 // before it (it only hands its records to lane 1), lanes 1..63 own 63 new slots.  Same XCD-tiled row order as LinBox.
+template <int WAVES = 4>
 __device__ __forceinline__ void fold_thread(const LinBox& b, int& i, int& j, int& k, bool& owner)
 {
     unsigned bid = blockIdx.x;
@@ -1852,7 +1853,7 @@ __device__ __forceinline__ void fold_thread(const LinBox& b, int& i, int& j, int
     }
     const int lane = threadIdx.x & 63;
     const long total = (long)b.n[0] * b.n[1] * b.n[2];
-    long sl = (long)(bid * 4u + (threadIdx.x >> 6)) * 63 + lane - 1;
+    long sl = (long)(bid * (unsigned)WAVES + (threadIdx.x >> 6)) * 63 + lane - 1;
     owner = lane >= 1 && sl < total;
     if (sl < 0) sl = 0;
     if (sl >= total) sl = total - 1;
@@ -1978,13 +1979,27 @@ __device__ __forceinline__ void fold_thread_wg(const LinBox& b, int& i, int& j, 
     }
 }
 
+// FOLD_WG: threads per workgroup of that launch (a wave's 16 KB of slots are its own)
+#ifndef FOLD_WG
+#define FOLD_WG 256
+#endif
 // record (face f, zone w) of thread `th`
 __device__ __forceinline__ void park_get(const double* __restrict__ park, int f, int w, int th, double r[NF1])
 {
 #pragma unroll
-    for (int n = 0; n < NF1; ++n) r[n] = park[((f * 2 + w) * NF1 + n) * 256 + th];
+    for (int n = 0; n < NF1; ++n) r[n] = park[((f * 2 + w) * NF1 + n) * FOLD_WG + th];
 }
 
+// The waves of k_trans1_fold_lds overlap by one slot each (fold_thread: 63 new slots per wave): the only foreign slot a lane
+// reads is its left neighbour's, in the same wave, and LDS is in order per wave -- no workgroup barrier, the waves of a CU run
+// their load and compute phases independently (4.52 -> 4.39 ms, profiles/r03x_*).  -DFOLD_WG_SYNC: the form before (workgroups
+// overlap by one slot, 255 new slots each, __syncthreads between parking and reading).
+#ifndef FOLD_WG_SYNC
+#define FOLD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define FOLD_SYNC() __syncthreads()
+#endif
 template <int T, int GEN, bool TX_HERE>
 __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
                                                     const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
@@ -1998,7 +2013,7 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
     const double* Cp = Q + PC * NC;
     const int th = threadIdx.x;
 
-    __syncthreads();                               // the readers of the previous direction's records are done
+    FOLD_SYNC();                                   // the readers of the previous direction's records are done
     {
         double A[2][NF1];
         {
@@ -2010,7 +2025,7 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
 #pragma unroll
             for (int w = 0; w < 2; ++w)
 #pragma unroll
-                for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * 256 + th] = A[w][n];
+                for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n];
             // the same edge states are the N = T states of the (T | x) combination, whose transverse flux F1[x] comes from
             // memory: done here, while they are in registers, instead of loading them a third time (trans1_fold_tx)
             if (TX_HERE) {
@@ -2031,9 +2046,9 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
 #pragma unroll
         for (int w = 0; w < 2; ++w)
 #pragma unroll
-            for (int n = 0; n < NF1; ++n) park[((1 * 2 + w) * NF1 + n) * 256 + th] = A[w][n];
+            for (int n = 0; n < NF1; ++n) park[((1 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n];
     }
-    __syncthreads();
+    FOLD_SYNC();
 
     const bool tin = owner && ijk[T] >= t.lo[T] && ijk[T] <= t.hi[T];
     double fr[NF1], fl[NF1];
@@ -2118,14 +2133,18 @@ __device__ __forceinline__ void trans1_fold_tx(const Tile& t, const int ijk[3], 
 }
 
 template <int GEN>
-__global__ void __launch_bounds__(256) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+__global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                          double cdtdx, double cdtdy, double cdtdz, DevParams P)
 {
-    __shared__ double park[2 * 2 * NF1 * 256];
+    __shared__ double park[2 * 2 * NF1 * FOLD_WG];
     DT_THIRDS_FROM_DEVICE();
     int ijk[3];
     bool owner;
+#ifndef FOLD_WG_SYNC
+    fold_thread<FOLD_WG / 64>(b, ijk[0], ijk[1], ijk[2], owner);
+#else
     fold_thread_wg(b, ijk[0], ijk[1], ijk[2], owner);
+#endif
     const bool v1 = ijk[0] + 1 <= b.hi0;
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const D2 c0 = ldg2(Q + PC * t.NC, c);
@@ -2576,7 +2595,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 //   k_final<1>, k_final<2> have written before this launch.  Saves, per zone and step: FL[0] written and read (18
 //   plane passes), Sborder read once instead of twice, one launch.
 // ---------------------------------------------------------------------------------------
-struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; };
+struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; unsigned wv; };   // wv: waves per workgroup
 
 template <bool LIM, bool CLEAN, int GEN = 2>
 __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
@@ -2592,7 +2611,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
     bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
     const int lane = threadIdx.x & 63;
     const unsigned total = (unsigned)b.nslot * (unsigned)b.ny * (unsigned)b.nz;
-    unsigned sl = (bid * 4u + (threadIdx.x >> 6)) * 63u + (unsigned)lane;
+    unsigned sl = (bid * b.wv + (threadIdx.x >> 6)) * 63u + (unsigned)lane;
     const bool live = sl < total;
     if (!live) sl = total - 1u;                       // keeps every lane inside the arrays; it stores nothing
     const unsigned row = sl / (unsigned)b.nslot;
@@ -2683,7 +2702,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
             else stg(Unew.p + m * Unew.sn, cn, un[0][m]);
         }
     }
-    if (CLEAN && red) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
+    if (CLEAN && red) wave_min3_atomic(dtmin, rmin_raw, dtmin1, red);     // per wave: no barrier, any workgroup size
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2852,6 +2871,11 @@ int g_trace_tile_rows = 64;   // rows per y-tile of the trace launch (its L2 hol
 // and its block-start fix-up must agree on one workgroup order); thread-local, so that host threads driving their own
 // contexts never see each other's choice.  The g_* knobs themselves are written by castro_amd_ctx_create only.
 static thread_local int tl_tile_rows = -1;
+// threads per workgroup of the launches the calling thread is building (A/B: CASTRO_AMD_FINAL_WG for k_final<y,z>)
+static thread_local unsigned tl_wg = 0;     // 0: g_wg
+int g_wg = 256;           // CASTRO_AMD_WG: every launch built by linbox / linbox2 (64, 128 or 256)
+int g_final_wg = 0;       // CASTRO_AMD_FINAL_WG: k_final<y>, k_final<z> only (0: g_wg)
+int g_fused_wg = 128;     // CASTRO_AMD_FUSED_WG: k_finalx_consup (its waves share nothing: 2.16-2.20 ms at 256, 2.04-2.05 at 128 / 64 threads, profiles/r03x_*)
 
 static LinBox linbox(const int lo[3], const int hi[3], long& n)
 {
@@ -2861,7 +2885,8 @@ static LinBox linbox(const int lo[3], const int hi[3], long& n)
     b.ty = tl_tile_rows >= 0 ? tl_tile_rows : g_tile_rows;
     b.w = 1;
     b.hi0 = hi[0];
-    b.nb = (unsigned)((n + 255) / 256);
+    b.wg = tl_wg ? tl_wg : (unsigned)g_wg;
+    b.nb = (unsigned)((n + b.wg - 1) / b.wg);
     if (b.ty > 0) b.nb = (b.nb + 7u) & ~7u;
     return b;
 }
@@ -2873,7 +2898,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
     b.w = 2;
     b.n[0] = (b.n[0] + 1) / 2;
     n = (long)b.n[0] * b.n[1] * b.n[2];
-    b.nb = (unsigned)((n + 255) / 256);
+    b.nb = (unsigned)((n + b.wg - 1) / b.wg);
     if (b.ty > 0) b.nb = (b.nb + 7u) & ~7u;
     return b;
 }
@@ -2884,7 +2909,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox2(lo, hi, n_);                                                     \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(b_.wg), 0, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)
@@ -2909,7 +2934,7 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         LinBox b_ = linbox(lo, hi, n_);                                                      \
         if (n_ > 0) {                                                                        \
             prof_begin(prof, name, stream);                                                  \
-            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(256), 0, stream, t, b_, __VA_ARGS__); \
+            hipLaunchKernelGGL(kern, dim3(b_.nb), dim3(b_.wg), 0, stream, t, b_, __VA_ARGS__); \
             prof_end(prof, stream);                                                          \
         }                                                                                    \
     } while (0)
@@ -3203,9 +3228,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             if (n_ > 0) {
                 prof_begin(prof, "k_trans1_fold", stream);
                 if (g_fold_r1 == 2) {
+#ifndef FOLD_WG_SYNC
+                    b_.nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));   // 63 new slots per wave, see fold_thread
+#else
                     b_.nb = (unsigned)((n_ + 254) / 255);        // 255 new slots per workgroup, see fold_thread_wg
+#endif
                     if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
-                    hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(256), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                    hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(FOLD_WG), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
                 } else {
                     const long waves_ = (n_ + 62) / 63;          // 63 new slots per wave, see fold_thread
                     b_.nb = (unsigned)((waves_ + 3) / 4);
@@ -3226,6 +3255,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             KL2("k_final_yz", k_final_yz<0>, ulo, uhi, S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], fluxes[2], mass[2], qe[2],
                 hdtdx, hdtdy, hdtdz, dt, area1, area2, acc_hi[1], acc_hi[2], (flags & 2) ? 1 : 0, P);
         } else {
+            struct WgGuard { unsigned keep; WgGuard() : keep(tl_wg) { if (g_final_wg > 0) tl_wg = (unsigned)g_final_wg; } ~WgGuard() { tl_wg = keep; } } wg_guard;
             KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
         }
@@ -3263,11 +3293,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         xr.ty = g_fused_tile_rows;
         const long slots = (long)xr.nslot * xr.ny * xr.nz;
         const long waves = (slots + 62) / 63;
-        xr.nb = ((unsigned)((waves + 3) / 4) + 7u) & ~7u;
+        xr.wv = (unsigned)g_fused_wg / 64u;
+        xr.nb = ((unsigned)((waves + xr.wv - 1) / xr.wv) + 7u) & ~7u;
         const double vol_ = g.dx[0] * g.dx[1] * g.dx[2];
         prof_begin(prof, "k_finalx_consup", stream);
 #define FXC(LIM, CLEAN, GENF, nt, rd)                                                                                        \
-        hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN, GENF>), dim3(xr.nb), dim3(256), 0, stream, t, xr, S.Q, S, g, Sborder,      \
+        hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN, GENF>), dim3(xr.nb), dim3(64u * xr.wv), 0, stream, t, xr, S.Q, S, g, Sborder,      \
                            fluxes[0], mass[0], qe[0], Snew, hdtdy, hdtdz, dt, area0, area1, area2, vol_, acc_hi[0],      \
                            (flags & 2) ? 1 : 0, (flags & 1) ? 1 : 0, P, nt, rd)
         if (clean_ntimes > 0) {

@@ -371,6 +371,22 @@ __device__ __forceinline__ void block_min3_atomic(double a, double b, double c3,
     }
 }
 
+// the same with one atomic set per wave: no LDS, no barrier, any workgroup size (the early-out read of atomic_min_double makes
+// all but the first few a load)
+__device__ __forceinline__ void wave_min3_atomic(double a, double b, double c3, double* out)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fmin(a, __shfl_down(a, off, 64));
+        b = fmin(b, __shfl_down(b, off, 64));
+        c3 = fmin(c3, __shfl_down(c3, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomic_min_double(out, a);
+        atomic_min_double(out + 1, b);
+        atomic_min_double(out + 2, c3);
+    }
+}
+
 // clean_state x ntimes (>= 1) on one zone with the CFL term taken twice: after the FIRST application -- the state the
 // validity check of do_advance_ctu sees (clean_state(S_new) then estTimeStep, Castro_advance_ctu.cpp:221-225, 386-392) --
 // and after the LAST, the state estTimeStep of the next coarse step sees (post_timestep has cleaned once more by then,

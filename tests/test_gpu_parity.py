@@ -28,6 +28,8 @@ def hip():
 
 
 LIB_DEFAULT_FOLD_R1 = "2"        # g_fold_r1 of ctu_kernels.hip
+LIB_DEFAULT_WG = "256"           # g_wg (g_final_wg follows it)
+LIB_DEFAULT_FUSED_WG = "128"     # g_fused_wg
 
 
 def _to_dev(h, a):
@@ -2018,9 +2020,12 @@ def test_randomised_option_combinations_match_the_oracle():
                                  {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "32"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "3"},
                                  {"CASTRO_AMD_FOLD_R1": "1"}, {"CASTRO_AMD_FOLD_R1": "2"}, {"CASTRO_AMD_FOLD_R1": "0"},
-                                 {"CASTRO_AMD_FINAL_YZ": "1"}],
+                                 {"CASTRO_AMD_FINAL_YZ": "1"},
+                                 {"CASTRO_AMD_WG": "64", "CASTRO_AMD_FUSED_WG": "64"},
+                                 {"CASTRO_AMD_WG": "128", "CASTRO_AMD_FINAL_WG": "64", "CASTRO_AMD_FUSED_WG": "256"}],
                          ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows",
-                              "z-marching", "z-marching-short-chunks", "first-yz-solves-folded-into-trans1", "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches", "final-y-and-z-in-one-launch"])
+                              "z-marching", "z-marching-short-chunks", "first-yz-solves-folded-into-trans1", "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches", "final-y-and-z-in-one-launch",
+                              "one-wave-workgroups", "mixed-workgroup-sizes"])
 def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
     """The final stage has three forms: k_final<x,y,z> + k_consup (round 1), k_final_lds (transverse flux records staged
     in LDS bricks; measured slower, kept as the measured experiment of DESIGN.md section 9) and the default
@@ -2028,7 +2033,7 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
     import castro_amd
     from castro_amd.hydro import HipHydro
     keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD", "CASTRO_AMD_MARCH_PLANES",
-            "CASTRO_AMD_FOLD_R1", "CASTRO_AMD_FINAL_YZ")
+            "CASTRO_AMD_FOLD_R1", "CASTRO_AMD_FINAL_YZ", "CASTRO_AMD_WG", "CASTRO_AMD_FINAL_WG", "CASTRO_AMD_FUSED_WG")
     old = {k: os.environ.get(k) for k in keys}
     try:
         os.environ.update(env)
@@ -2064,6 +2069,8 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
         os.environ["CASTRO_AMD_MARCH_PLANES"] = "32"
         os.environ["CASTRO_AMD_FOLD_R1"] = old["CASTRO_AMD_FOLD_R1"] if old["CASTRO_AMD_FOLD_R1"] is not None else LIB_DEFAULT_FOLD_R1
         os.environ["CASTRO_AMD_FINAL_YZ"] = old["CASTRO_AMD_FINAL_YZ"] if old["CASTRO_AMD_FINAL_YZ"] is not None else "0"
+        for k, v in (("CASTRO_AMD_WG", LIB_DEFAULT_WG), ("CASTRO_AMD_FINAL_WG", LIB_DEFAULT_WG), ("CASTRO_AMD_FUSED_WG", LIB_DEFAULT_FUSED_WG)):
+            os.environ[k] = old[k] if old[k] is not None else v
         HipHydro(0).close()                   # restore the library's defaults for the tests that follow
         for k in keys:
             if old[k] is None:
