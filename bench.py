@@ -151,6 +151,58 @@ def cpu_baseline(ncell, steps):
             "seconds": wall}
 
 
+def self_launch(nproc):
+    """One rank per GPU of this node under torch.distributed.run (rendezvous on 127.0.0.1, a free port), as a child process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(p.stdout[-4000:])
+    sys.stdout.flush()
+    return p.returncode if p.returncode else (0 if lines else 1)
+
+
+def noise_state(torch, n, device):
+    """A rough but physical conserved state (NUM_STATE, nz, ny, nx), generated on the device: a smooth background, an oblique
+    density / pressure jump and zone-to-zone noise of +-20 % in rho and p -- every limiter, the flattening and all wave
+    patterns of the Riemann solver are exercised in every zone (the form of tests/util.physical_state(smooth=False))."""
+    nx, ny, nz = n
+    g = torch.Generator(device=device)
+    g.manual_seed(1234)
+    f64 = dict(dtype=torch.float64, device=device)
+    z = torch.arange(nz, **f64).view(nz, 1, 1)
+    y = torch.arange(ny, **f64).view(1, ny, 1)
+    x = torch.arange(nx, **f64).view(1, 1, nx)
+
+    def rnd(lo, hi):
+        return lo + (hi - lo) * torch.rand((nz, ny, nx), generator=g, **f64)
+    rho = 1.0 + 0.3 * torch.sin(0.37 * x + 0.3) * torch.cos(0.29 * y + 1.1) + 0.2 * torch.sin(0.41 * z + 2.0)
+    p = 1.0 + 0.4 * torch.cos(0.31 * x + 0.23 * y + 0.7) + 0.2 * torch.sin(0.33 * z + 1.9)
+    s = (x - nx / 2) + 0.6 * (y - ny / 2) - 0.4 * (z - nz / 2)
+    rho = torch.where(s > 0, rho * 0.2, rho) * rnd(0.8, 1.25)
+    p = torch.where(s > 0, p * 0.05, p) * rnd(0.8, 1.25)
+    u = 0.5 * torch.sin(0.21 * x + 0.4) + rnd(-0.05, 0.05)
+    v = 0.4 * torch.cos(0.27 * y + 0.3) + rnd(-0.05, 0.05)
+    w = 0.3 * torch.sin(0.19 * z + 1.1) + rnd(-0.05, 0.05)
+    eint = p / 0.4
+    U = torch.empty((8, nz, ny, nx), **f64)
+    U[0], U[1], U[2], U[3] = rho, rho * u, rho * v, rho * w
+    U[4] = eint + 0.5 * rho * (u * u + v * v + w * w)
+    U[5], U[6], U[7] = eint, 1.0, rho * rnd(0.999, 1.0)
+    return U
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +224,18 @@ def main():
                     "host-free batch (Castro.run_steps)")
     ap.add_argument("--reference-contract", action="store_true",
                     help="zero-fill + accumulate fluxes and run clean_state/estdt as separate passes (600 B/cell form)")
+    ap.add_argument("--numerics", choices=("exact", "contract"), default=os.environ.get("CASTRO_AMD_BENCH_NUMERICS", "contract"),
+                    help="build of the kernel library the headline is measured on: `contract` (FMA contraction, reciprocal "
+                         "division, rsq sqrt; rtol 1e-10 against the oracle on every plotfile field: tests/test_gpu_contract.py) "
+                         "or `exact` (bit-identical to the oracle: tests/test_gpu_parity.py); the other one is timed as a leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (developed Sedov state, noisy state, "
+                    "per-step medians) of the default single-GPU run")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD torch.distributed.run (never an exec, and
+    # before this process has imported torch or touched the GPU), relay rank 0's JSON line and exit with the child's code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import castro_amd
@@ -197,7 +260,15 @@ def main():
         else:
             dist.init_process_group(backend=backend)
         comm = castro_amd.DistComm()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        ranks_seen, backend_name = dist.get_world_size(), dist.get_backend()
+    else:
+        ranks_seen, backend_name = 1, "none"
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (
+        world, args.gpus, args.gpus)
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = None
 
     grid = castro_amd.default_grid(world)
     if args.weak:
@@ -215,23 +286,28 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    def run(contract_mode, steps, warmup, kernel_pass, stepwise=None):
+    def run(contract_mode, steps, warmup, kernel_pass, stepwise=None, state="sedov", per_step=False, numerics=None):
         """W untimed warm-up steps, K timed steps (no profiling events in the timed region), then -- untimed -- a second
         pass of min(K, 5) steps with hipEvents around every kernel on its launch stream for the per-kernel table."""
         if stepwise is None and (args.stepwise or world > 1):
             stepwise = bool(args.stepwise)
         if stepwise is None:
             try:
-                return run(contract_mode, steps, warmup, kernel_pass, stepwise=False)
+                return run(contract_mode, steps, warmup, kernel_pass, stepwise=False, state=state, per_step=per_step, numerics=numerics)
             except castro_amd.AdvanceFailure:
                 raise
             except Exception as e:          # a box whose runtime refuses the graph capture: the stepwise form measures the same kernels
                 print("bench.py: host-free batch failed (%s: %s); falling back to --stepwise" % (type(e).__name__, e), file=sys.stderr)
                 torch.cuda.synchronize()
-                return run(contract_mode, steps, warmup, kernel_pass, stepwise=True)
+                return run(contract_mode, steps, warmup, kernel_pass, stepwise=True, state=state, per_step=per_step, numerics=numerics)
         c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc, overlap=overlap,
-                              fuse_clean=not contract_mode, flux_assign=not contract_mode)
-        c.initData("sedov")                      # synthetic input, generated on the device
+                              fuse_clean=not contract_mode, flux_assign=not contract_mode, numerics=numerics or args.numerics)
+        if state == "noise":
+            c.set_state(noise_state(torch, n_cell, torch.device("cuda", local_rank)))
+        else:
+            c.initData("sedov")                  # synthetic input, generated on the device
+        if state == "developed":
+            c.evolve(0.01)                       # untimed: the blast wave at the reference's stop_time (about 1000 steps at 256^3)
         # host-free stepping (Castro.run_steps): dt, time and the step checks stay on the device, one host
         # synchronisation per batch; on one rank a captured pair of steps is replayed as a hipGraph.  --stepwise keeps
         # the round-1/2 form (one allreduce + host read per step).  Same kernels, same dt, bit-identical states.
@@ -245,7 +321,15 @@ def main():
                 c.step()
         sync()
         t0 = time.perf_counter()
-        if host_free:
+        per = []
+        if per_step:
+            # one synchronised wall time per step, for the median
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                c.step()
+                sync()
+                per.append(time.perf_counter() - t1)
+        elif host_free:
             c.run_steps(steps)
         else:
             for _ in range(steps):
@@ -269,7 +353,8 @@ def main():
         info = {"zones_per_gpu": c.n[0] * c.n[1] * c.n[2], "sim_time": c.time, "nstep": c.nstep, "n": c.n,
                 "overlap_halo": ("tiles" if c.overlap == "tiles" else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
                 "halo": c.halo_stats() if hasattr(c, "halo_stats") else None, "host_free": host_free,
-                "step_graph": bool(host_free and getattr(c, "_graphs", None))}
+                "step_graph": bool(host_free and getattr(c, "_graphs", None)), "per_step": per,
+                "numerics": c.hydro.numerics, "library": c.hydro.lib.castro_amd_version().decode()}
         del c
         torch.cuda.empty_cache()
         return wall, prof, ksteps, info
@@ -310,6 +395,39 @@ def main():
         roof["contract_600B"] = {"ms_per_step": w6 / max(5, args.steps // 2) * 1e3, "value": v6,
                                  "achieved": v6 * PATH_BYTES_CONTRACT / 1e9, "frac": v6 * PATH_BYTES_CONTRACT / 1e9 / HBM_PEAK_GBS}
 
+    # the other build of the same sources, same workload, timed in the same process (both libraries are loaded side by side)
+    other_leg = None
+    if world == 1 and not args.no_extras:
+        other = "exact" if args.numerics == "contract" else "contract"
+        try:
+            w_o, _, _, i_o = run(contract, args.steps, args.warmup, False, numerics=other)
+            other_leg = {"numerics": i_o["numerics"], "ms_per_step": w_o / args.steps * 1e3, "value": total_cells * args.steps / w_o,
+                         "frac": total_cells * args.steps / w_o * bytes_per_cell / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:
+            other_leg = {"numerics": other, "error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
+    extras = None
+    if world == 1 and not contract and not args.no_extras:
+        # untimed extras (the headline above is unchanged): the same step on states that are not
+        # 99.9 % ambient gas, and per-step medians as BASELINE.md section 3 words the protocol
+        ks = max(10, min(args.steps, 50))
+        extras = {"steps_each": ks}
+        w_med, _, _, i_med = run(False, max(50, args.steps), 2, False, stepwise=True, per_step=True)
+        ps = sorted(i_med["per_step"])
+        extras["stepwise_median_ms"] = ps[len(ps) // 2] * 1e3
+        extras["stepwise_mean_ms"] = sum(ps) / len(ps) * 1e3
+        extras["stepwise_steps"] = len(ps)
+        for st in ("developed", "noise"):
+            try:
+                w_x, _, _, i_x = run(False, ks, 4, False, state=st)
+                extras[st + "_ms_per_step"] = w_x / ks * 1e3
+                extras[st + "_sim_time"] = i_x["sim_time"]
+                extras[st + "_nstep"] = i_x["nstep"]
+            except Exception as e:
+                extras[st + "_ms_per_step"] = None
+                extras[st + "_error"] = "%s: %s" % (type(e).__name__, e)
+                torch.cuda.synchronize()
+
     out = {
         "metric": "cell-updates/sec, Sedov 3D 256\u00b3 single-level at 1/2/4/8 MI355X; % HBM roofline",
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -321,7 +439,12 @@ def main():
                    "overlap_halo": info["overlap_halo"], "sim_time": info["sim_time"], "nstep": info["nstep"],
                    "flux_mode": "accumulate (600 B/cell contract)" if contract else "assign (344 B/cell, declared)",
                    "fused_clean_state": not contract, "halo": info["halo"],
-                   "host_free_steps": info["host_free"], "step_graph": info["step_graph"]},
+                   "host_free_steps": info["host_free"], "step_graph": info["step_graph"],
+                   "ranks_seen": ranks_seen, "backend": backend_name, "rccl_version": rccl,
+                   "numerics": info["numerics"], "library": info["library"],
+                   "numerics_parity": {"contract": "rtol 1e-10 on all 33 plotfile fields vs the CPU oracle (tests/test_gpu_contract.py)",
+                                       "exact": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}[info["numerics"]],
+                   "other_numerics_leg": other_leg, "other_states": extras},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,26 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CASTRO_AMD_LIB", os.path.join(_HERE, "libcastro_hydro_amd.so"))   # override: A/B builds
+# Two builds of the same sources and the same ABI (castro_amd/csrc/Makefile):
+#   exact     libcastro_hydro_amd.so            -ffp-contract=off, IEEE division / sqrt: bit-identical to the CPU restatement the tests check against
+#   contract  libcastro_hydro_amd_contract.so   FMA contraction, reciprocal division, rsq-based sqrt: rtol 1e-10, faster
+# CASTRO_AMD_NUMERICS picks the process default (exact); HipHydro(device, numerics=...) picks per context; both libraries can
+# be loaded side by side.  CASTRO_AMD_LIB overrides the path for every mode (A/B builds).
+NUMERICS_MODES = ("exact", "contract")
+DEFAULT_NUMERICS = os.environ.get("CASTRO_AMD_NUMERICS", "exact")
+_LIB_FILES = {"exact": "libcastro_hydro_amd.so", "contract": "libcastro_hydro_amd_contract.so"}
+
+
+def lib_path(numerics=None):
+    mode = numerics or DEFAULT_NUMERICS
+    if mode not in NUMERICS_MODES:
+        raise ValueError("CASTRO_AMD_NUMERICS / numerics must be one of %s, not %r" % (NUMERICS_MODES, mode))
+    if os.environ.get("CASTRO_AMD_LIB"):             # A/B builds (tools/ab_variants.sh): one library whatever the mode asked for
+        return os.environ["CASTRO_AMD_LIB"]
+    return os.path.join(_HERE, _LIB_FILES[mode])
+
+
+LIB_PATH = lib_path()
 
 NUM_STATE, NGDNV, NUM_GROW = 8, 4, 4
 URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
@@ -35,7 +54,10 @@ EXPORTED_SYMBOLS = (
     "castro_amd_estdt_fab",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
     "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab", "castro_amd_fillpatch_shell_fab", "castro_amd_apply_source_fab", "castro_amd_fab_ops",
-    "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version",
+    "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version", "castro_amd_abi_version", "castro_amd_numerics",
+    "castro_amd_comm_version", "castro_amd_comm_unique_id", "castro_amd_comm_create", "castro_amd_comm_adopt", "castro_amd_comm_rank",
+    "castro_amd_comm_size", "castro_amd_comm_destroy", "castro_amd_halo_plan_create", "castro_amd_halo_plan_destroy",
+    "castro_amd_halo_plan_bytes_sent", "castro_amd_fill_boundary", "castro_amd_allreduce_min",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
     "castro_amd_cmpflx_points", "castro_amd_ppm_points", "castro_amd_flatten_points", "castro_amd_trans_points",
@@ -49,6 +71,12 @@ class Fab(C.Structure):
 
 # castro_amd_step_control's ctl vector (include/castro_hydro_amd.h)
 CTL_DT, CTL_TIME, CTL_NSTEP, CTL_STATUS, CTL_RHOMIN, CTL_EST, CTL_DTHYDRO, CTL_HIST, CTL_NHIST, CTL_SIZE = 0, 1, 2, 3, 4, 5, 6, 8, 56, 64
+
+
+class HaloRegion(C.Structure):
+    """castro_amd_halo_region"""
+    _fields_ = [("peer", C.c_int), ("sbox_lo", C.c_int * 3), ("sbox_hi", C.c_int * 3), ("rbox_lo", C.c_int * 3),
+                ("rbox_hi", C.c_int * 3), ("send_tag", C.c_int), ("recv_tag", C.c_int)]
 
 
 class HydroOpts(C.Structure):
@@ -111,19 +139,33 @@ class FabOp(C.Structure):
 
 OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN = 0, 1, 2, 3, 4, 5, 6
 
-_lib = None
+_libs = {}
+ABI_VERSION = 4          # CASTRO_AMD_ABI_VERSION of include/castro_hydro_amd.h this binding was written against
 
 
-def load():
-    """Load the shared library (raises if it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def numerics_of(L):
+    """"exact" / "contract" as the loaded library reports it (castro_amd_numerics)"""
+    return L.castro_amd_numerics().decode()
+
+
+def load(numerics=None):
+    """Load the shared library of a numerics mode (raises if it has not been built)."""
+    mode = numerics or DEFAULT_NUMERICS
+    if mode in _libs:
+        return _libs[mode]
+    path = lib_path(mode)
+    if not os.path.exists(path):
         raise ImportError(
             "castro_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C castro_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "or `make -C castro_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    L.castro_amd_abi_version.restype = C.c_int
+    if L.castro_amd_abi_version() != ABI_VERSION:
+        raise ImportError("castro_amd: %s has ABI version %d, this binding expects %d: rebuild it"
+                          % (path, L.castro_amd_abi_version(), ABI_VERSION))
+    L.castro_amd_numerics.restype = C.c_char_p
+    if not os.environ.get("CASTRO_AMD_LIB") and numerics_of(L) != mode:
+        raise ImportError("castro_amd: %s is a %r build, expected %r" % (path, numerics_of(L), mode))
     I3 = C.POINTER(C.c_int)
     PF = C.POINTER(Fab)
     L.castro_amd_version.restype = C.c_char_p
@@ -188,6 +230,19 @@ def load():
                                             C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
     L.castro_amd_sod_init_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params)] + \
         [C.c_double] * 6 + [C.c_int, C.c_double, C.c_void_p]
+    L.castro_amd_comm_version.restype = C.c_char_p
+    L.castro_amd_comm_unique_id.argtypes = [C.c_void_p]
+    L.castro_amd_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.castro_amd_comm_adopt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+    L.castro_amd_comm_rank.argtypes = [C.c_void_p]
+    L.castro_amd_comm_size.argtypes = [C.c_void_p]
+    L.castro_amd_comm_destroy.argtypes = [C.c_void_p]
+    L.castro_amd_halo_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.POINTER(HaloRegion), C.c_int]
+    L.castro_amd_halo_plan_destroy.argtypes = [C.c_void_p]
+    L.castro_amd_halo_plan_bytes_sent.argtypes = [C.c_void_p]
+    L.castro_amd_halo_plan_bytes_sent.restype = C.c_longlong
+    L.castro_amd_fill_boundary.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
+    L.castro_amd_allreduce_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.castro_amd_ctx_profile.argtypes = [C.c_void_p, C.c_int]
     L.castro_amd_ctx_profile_count.argtypes = [C.c_void_p]
     L.castro_amd_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int,
@@ -199,7 +254,7 @@ def load():
     L.castro_amd_flatten_points.argtypes = [C.c_longlong, V, V, V, V]
     L.castro_amd_trans_points.argtypes = [C.c_longlong, C.c_int, C.c_int, V, V, V, V, V, V, C.c_double, C.c_double,
                                           C.POINTER(Params), V, V]
-    _lib = L
+    _libs[mode] = L
     return L
 
 

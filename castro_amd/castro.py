@@ -30,9 +30,25 @@ NUM_STATE, NUM_GROW = L.NUM_STATE, L.NUM_GROW
 # --------------------------------------------------------------------------------------------
 # communicators
 # --------------------------------------------------------------------------------------------
+def _use_c_halo(default):
+    """CASTRO_AMD_C_HALO: 1 = the FillBoundary of the C ABI (castro_amd_fill_boundary: RCCL send / recv issued by the kernel
+    library), 0 = torch.distributed.batch_isend_irecv; default: the C form whenever the backend is RCCL."""
+    v = os.environ.get("CASTRO_AMD_C_HALO")
+    return default if v is None else v not in ("0", "")
+
+
 class SingleComm:
     rank, size = 0, 1
     device_side = True          # no collective ever touches the host
+
+    def c_comm(self, hydro):
+        """A one-rank RCCL communicator of the C ABI when CASTRO_AMD_C_HALO=1 (periodic wraps and the code path of a
+        multi-rank run on one GPU), else None."""
+        if not _use_c_halo(False):
+            return None
+        if getattr(self, "_ccomm", None) is None:
+            self._ccomm = hydro.comm_create(1, 0, hydro.comm_unique_id())
+        return self._ccomm
 
     def exchange(self, sends, recvs):
         assert not sends and not recvs
@@ -58,6 +74,19 @@ class DistComm:
         self.size = dist.get_world_size(group)
         # RCCL collectives are enqueued on the device (the host does not wait for them); gloo moves host memory
         self.device_side = dist.get_backend(group) == "nccl"
+        self._ccomm = None
+
+    def c_comm(self, hydro):
+        """The RCCL communicator of the C ABI over the same ranks (castro_amd_comm_create; the unique id travels through
+        torch.distributed), or None when the backend is not RCCL / CASTRO_AMD_C_HALO=0."""
+        if not _use_c_halo(self.device_side) or not self.device_side:
+            return None
+        if self._ccomm is None:
+            box = [hydro.comm_unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                            group=self.group)
+            self._ccomm = hydro.comm_create(self.size, self.rank, box[0])
+        return self._ccomm
 
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer_rank, tag, tensor).  Grouped point-to-point."""
@@ -132,15 +161,15 @@ class Castro:
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
                  do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0, max_dt=1.e200,
-                 alloc=True):
-        """alloc=False: the geometry and bookkeeping of a box another rank owns (castro_amd/amr.py), no device memory."""
+                 alloc=True, numerics=None):
+        """numerics: "exact" | "contract" for the HipHydro this object creates (castro_amd/_lib.py).  alloc=False: the geometry and bookkeeping of a box another rank owns (castro_amd/amr.py), no device memory."""
         self.n_cell = tuple(int(x) for x in n_cell)
         self.owned = bool(alloc)
         self.comm = comm if comm is not None else SingleComm()
         if hydro is None:
             from .hydro import HipHydro
             dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
-            hydro = HipHydro(dev)          # raises without a GPU: no CPU fallback
+            hydro = HipHydro(dev, numerics=numerics)          # raises without a GPU: no CPU fallback
         self.hydro = hydro
         self.params = params if params is not None else (make_params() if make_params else L.default_params())
         self.geom = (hydro.make_geom if hasattr(hydro, "make_geom") else L.make_geom)(
@@ -312,6 +341,10 @@ class Castro:
             src = {nb["send_tag"]: nb for nb in local}
             plan["unpack_local"] = h.region_table([nb["rbox"] for nb in local], [src[nb["recv_tag"]]["off"] for nb in local]) if local else None
             plan["unpack_remote"] = h.region_table([nb["rbox"] for nb in remote], [nb["off"] for nb in remote]) if remote else None
+            # the same exchange issued by the kernel library itself (castro_amd_fill_boundary) when the ranks talk RCCL
+            ccomm = self.comm.c_comm(h) if hasattr(self.comm, "c_comm") and hasattr(h, "halo_plan") else None
+            if ccomm is not None:
+                plan["cplan"] = h.halo_plan(ccomm, [(nb["peer"], nb["sbox"], nb["rbox"], nb["send_tag"], nb["recv_tag"]) for nb in out], ncomp)
             self._plans[id(out)] = plan
         return out
 
@@ -322,6 +355,9 @@ class Castro:
         box = self.gbox if box is None else box
         neighbors = self.neighbors if neighbors is None else neighbors
         plan = self._plans.get(id(neighbors))
+        if plan is not None and "cplan" in plan:
+            h.fill_boundary(plan["cplan"], S, box, self.geom)
+            return
         if plan is not None:
             h.pack_regions(S, box, plan["pack"], plan["sall"])
             sends = [(nb["peer"], nb["send_tag"], nb["sbuf"]) for nb in neighbors if nb["peer"] != self.comm.rank]
@@ -365,8 +401,11 @@ class Castro:
         torch.cuda.synchronize()
         self.comm.barrier()
         ms = (time.perf_counter() - t0) / repeats * 1e3
+        plan = self._plans.get(id(self.neighbors))
         return {"regions": len(self.neighbors), "remote_regions": len(remote), "bytes_sent_per_step": nbytes,
-                "fillboundary_ms": ms}
+                "fillboundary_ms": ms,
+                "issued_by": "castro_amd_fill_boundary (C ABI, %s)" % self.hydro.comm_version() if plan is not None and "cplan" in plan
+                else "torch.distributed.batch_isend_irecv"}
 
     # ---- Castro::clean_state ---------------------------------------------------------------
     def clean_state(self, S, ntimes=1):

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_brick[3]; extern int g_final_lds; extern int g_brick_lds_budget; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_march_planes; extern int g_trace_split; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile_rows; extern int g_final_yz; extern int g_trace_single; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
+namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
 
 using namespace cad;
 
@@ -153,7 +153,14 @@ static constexpr int kPlanesResetRhoe = 9;     // F1E[3] + F2E[6], only with tra
 
 extern "C" {
 
-const char* castro_amd_version(void) { return "castro_hydro_amd 0.3 (gfx950, round 3)"; }
+#ifdef CAD_NUMERICS_CONTRACT
+#define CAD_NUMERICS_NAME "contract"
+#else
+#define CAD_NUMERICS_NAME "exact"
+#endif
+const char* castro_amd_version(void) { return "castro_hydro_amd 0.4 (gfx950, round 4, numerics=" CAD_NUMERICS_NAME ")"; }
+int castro_amd_abi_version(void) { return CASTRO_AMD_ABI_VERSION; }
+const char* castro_amd_numerics(void) { return CAD_NUMERICS_NAME; }
 
 // Source/driver/_cpp_parameters defaults + Exec/hydro_tests/Sedov/inputs.3d.sph(.testsuite)
 void castro_amd_default_params(castro_amd_params* p)
@@ -208,28 +215,16 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
     if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
-    if (const char* e = std::getenv("CASTRO_AMD_MARCH_PLANES")) { g_march_planes = std::atoi(e); if (g_march_planes < 1) g_march_planes = 1; }
     if (const char* e = std::getenv("CASTRO_AMD_FUSED_TILE_ROWS")) g_fused_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FUSE_CONSUP")) g_fuse_consup = std::atoi(e);   // 0: k_final<x> + k_consup
-    if (const char* e = std::getenv("CASTRO_AMD_FINAL_LDS")) g_final_lds = std::atoi(e);   // 0: the plain k_final
     if (const char* e = std::getenv("CASTRO_AMD_TRACE_TILE_ROWS")) g_trace_tile_rows = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_TRACE_SPLIT")) g_trace_split = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_XPAD")) g_xpad = std::atoi(e);             // unused columns in front of every scratch row
-    if (const char* e = std::getenv("CASTRO_AMD_BRICK_LDS")) g_brick_lds_budget = std::atoi(e);   // bytes per workgroup
-    if (const char* e = std::getenv("CASTRO_AMD_BRICK")) {                                   // "tx2,ty,tz" of the brick kernels
-        int a = 0, b = 0, c2 = 0;
-        if (std::sscanf(e, "%d,%d,%d", &a, &b, &c2) == 3 && a >= 0 && b >= 0 && c2 >= 0 && a * b * c2 <= 256) {
-            g_brick[0] = a; g_brick[1] = b; g_brick[2] = c2;          // 0,0,0: chosen per launch
-        }
-    }
     if (const char* e = std::getenv("CASTRO_AMD_SIDE_STREAM")) g_side_stream = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_R1")) g_fold_r1 = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE_ROWS")) g_fold_tile_rows = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_FINAL_YZ")) g_final_yz = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_FUSED_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_fused_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_final_wg = v; }
-    if (const char* e = std::getenv("CASTRO_AMD_TRACE_SINGLE")) g_trace_single = std::atoi(e);
     if (g_side_stream) {
         if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -682,7 +677,14 @@ int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, i
         for (int k = 0; k < used; ++k) {
             if ((hipStream_t)streams[k] == main_s) continue;
             castro_amd_ctx* ck = ctxs[k];
-            if (!ck->mf_join && hipEventCreateWithFlags(&ck->mf_join, hipEventDisableTiming) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+            if (!ck->mf_join && hipEventCreateWithFlags(&ck->mf_join, hipEventDisableTiming) != hipSuccess) {
+                // no event for this stream: join it the slow way (never under capture: the events exist after the first
+                // eager call), record the error and keep joining the others
+                hipStreamSynchronize((hipStream_t)streams[k]);
+                ck->mf_join = nullptr;
+                if (rc == CASTRO_AMD_OK) rc = CASTRO_AMD_ERR_HIP;
+                continue;
+            }
             hipEventRecord(ck->mf_join, (hipStream_t)streams[k]);
             hipStreamWaitEvent(main_s, ck->mf_join, 0);
         }

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     }
     if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
 
-    const double rhoinv = 1.0 / rho;
+    const double rhoinv = frcp(rho);               // rho >= small_dens > 0 (else the status flag above is raised)
     const double u = mx * rhoinv;
     const double v = my * rhoinv;
     const double w = mz * rhoinv;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
 
     // eos(eos_input_re): p = (gamma-1) rho e ; cs = sqrt(gamma p / rho)
     const double p = (P.gamma - 1.0) * rho * e;
-    const double cs = sqrt(P.gamma * p / rho);
+    const double cs = kContract ? fsqrt(P.gamma * p * rhoinv) : sqrt(P.gamma * p / rho);
 
     stg(Q + PRHO * NC, c, rho);
     stg(Q + PU * NC, c, u);
@@ -522,13 +522,14 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         double p_ref = SADD(Im_p0, Ims_p[0]);
         double rhoe_g_ref = SADD(Im_re0, Ims_re[0]);
 
+        // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
         rho_ref = amax(rho_ref, P.small_dens);
-        double rho_ref_inv = 1.0 / rho_ref;
+        double rho_ref_inv = frcp(rho_ref);
         p_ref = amax(p_ref, P.small_pres);
 
         double csq_ref = gam * p_ref * rho_ref_inv;
-        double cc_ref = sqrt(csq_ref);
-        double cc_ref_inv = 1.0 / cc_ref;
+        double cc_ref = fsqrt(csq_ref);
+        double cc_ref_inv = frcp(cc_ref);
         double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
 
         double dum = SSUB(un_ref - Im_un_0, Ims_un[0]);
@@ -543,8 +544,15 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
 
         double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
         double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
-        double alpha0r = drho - dptot / csq_ref;
-        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        double alpha0r, alpha0e_g;
+        if (kContract) {
+            const double csq_inv = cc_ref_inv * cc_ref_inv;
+            alpha0r = drho - dptot * csq_inv;
+            alpha0e_g = drhoe_g - dptot * h_g_ref * csq_inv;
+        } else {
+            alpha0r = drho - dptot / csq_ref;
+            alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        }
 
         alpham = un - cc > 0.0 ? 0.0 : -alpham;
         alphap = un + cc > 0.0 ? 0.0 : -alphap;
@@ -567,13 +575,14 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         double p_ref = SADD(Ip_p2, Ips_p[2]);
         double rhoe_g_ref = SADD(Ip_re2, Ips_re[2]);
 
+        // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
         rho_ref = amax(rho_ref, P.small_dens);
-        double rho_ref_inv = 1.0 / rho_ref;
+        double rho_ref_inv = frcp(rho_ref);
         p_ref = amax(p_ref, P.small_pres);
 
         double csq_ref = gam * p_ref * rho_ref_inv;
-        double cc_ref = sqrt(csq_ref);
-        double cc_ref_inv = 1.0 / cc_ref;
+        double cc_ref = fsqrt(csq_ref);
+        double cc_ref_inv = frcp(cc_ref);
         double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
 
         double dum = SSUB(un_ref - Ip_un_0, Ips_un[0]);
@@ -588,8 +597,15 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
 
         double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
         double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
-        double alpha0r = drho - dptot / csq_ref;
-        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        double alpha0r, alpha0e_g;
+        if (kContract) {
+            const double csq_inv = cc_ref_inv * cc_ref_inv;
+            alpha0r = drho - dptot * csq_inv;
+            alpha0e_g = drhoe_g - dptot * h_g_ref * csq_inv;
+        } else {
+            alpha0r = drho - dptot / csq_ref;
+            alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        }
 
         alpham = un - cc > 0.0 ? -alpham : 0.0;
         alphap = un + cc > 0.0 ? -alphap : 0.0;
@@ -654,13 +670,14 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         double p_ref = w.Im_p[0];
         double rhoe_g_ref = w.Im_re[0];
 
+        // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
         rho_ref = amax(rho_ref, P.small_dens);
-        double rho_ref_inv = 1.0 / rho_ref;
+        double rho_ref_inv = frcp(rho_ref);
         p_ref = amax(p_ref, P.small_pres);
 
         double csq_ref = gam * p_ref * rho_ref_inv;
-        double cc_ref = sqrt(csq_ref);
-        double cc_ref_inv = 1.0 / cc_ref;
+        double cc_ref = fsqrt(csq_ref);
+        double cc_ref_inv = frcp(cc_ref);
         double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
 
         double dum = un_ref - w.Im_un[0];
@@ -675,8 +692,15 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 
         double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
         double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
-        double alpha0r = drho - dptot / csq_ref;
-        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        double alpha0r, alpha0e_g;
+        if (kContract) {
+            const double csq_inv = cc_ref_inv * cc_ref_inv;
+            alpha0r = drho - dptot * csq_inv;
+            alpha0e_g = drhoe_g - dptot * h_g_ref * csq_inv;
+        } else {
+            alpha0r = drho - dptot / csq_ref;
+            alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        }
 
         alpham = un - cc > 0.0 ? 0.0 : -alpham;
         alphap = un + cc > 0.0 ? 0.0 : -alphap;
@@ -698,13 +722,14 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         double p_ref = w.Ip_p[2];
         double rhoe_g_ref = w.Ip_re[2];
 
+        // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
         rho_ref = amax(rho_ref, P.small_dens);
-        double rho_ref_inv = 1.0 / rho_ref;
+        double rho_ref_inv = frcp(rho_ref);
         p_ref = amax(p_ref, P.small_pres);
 
         double csq_ref = gam * p_ref * rho_ref_inv;
-        double cc_ref = sqrt(csq_ref);
-        double cc_ref_inv = 1.0 / cc_ref;
+        double cc_ref = fsqrt(csq_ref);
+        double cc_ref_inv = frcp(cc_ref);
         double h_g_ref = (p_ref + rhoe_g_ref) * rho_ref_inv;
 
         double dum = un_ref - w.Ip_un[0];
@@ -719,8 +744,15 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 
         double alpham = 0.5 * (dptotm * rho_ref_inv * cc_ref_inv - dum) * rho_ref * cc_ref_inv;
         double alphap = 0.5 * (dptotp * rho_ref_inv * cc_ref_inv + dup) * rho_ref * cc_ref_inv;
-        double alpha0r = drho - dptot / csq_ref;
-        double alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        double alpha0r, alpha0e_g;
+        if (kContract) {
+            const double csq_inv = cc_ref_inv * cc_ref_inv;
+            alpha0r = drho - dptot * csq_inv;
+            alpha0e_g = drhoe_g - dptot * h_g_ref * csq_inv;
+        } else {
+            alpha0r = drho - dptot / csq_ref;
+            alpha0e_g = drhoe_g - dptot * h_g_ref / csq_ref;
+        }
 
         alpham = un - cc > 0.0 ? -alpham : 0.0;
         alphap = un + cc > 0.0 ? -alphap : 0.0;
@@ -751,11 +783,49 @@ __device__ __forceinline__ void store_edge_2(double* __restrict__ E, long NC, un
     }
 }
 
+// x-direction stencils from lanes (k_trace_pair): consecutive lanes of a wave hold consecutive zone pairs of a row, so the
+// pairs to the left and right of a lane's own are its neighbours' -- one DPP wave shift each instead of a load.  Only
+// the lanes at a wave boundary (0, 63) or at a row end have no such neighbour; they fetch the missing pair in ONE masked
+// load (left pair for `nl` lanes, right pair for `nr` lanes; a lane that is both -- a row of one pair -- loads twice).
+// Every lane of the wave must be active (the default trace launch has no early exit).
+struct XLane { bool nl, nr; };
+__device__ __forceinline__ double lane_shr1(double v)      // value of lane - 1
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_shl1(double v)      // value of lane + 1
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void lane_pairs(const double* __restrict__ a, unsigned c, const XLane& xl, D2& l, const D2& m, D2& r)
+{
+    l.a = lane_shr1(m.a); l.b = lane_shr1(m.b);
+    r.a = lane_shl1(m.a); r.b = lane_shl1(m.b);
+    if (xl.nl || xl.nr) {
+        const D2 f = ldg2(a, xl.nl ? c - 16u : c + 16u);
+        if (xl.nl) l = f; else r = f;
+        if (xl.nl && xl.nr) r = ldg2(a, c + 16u);
+    }
+}
+
 // five-point stencils of two x-adjacent zones along direction D
 template <int D>
-__device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, unsigned c, unsigned sd, double sA[5], double sB[5])
+__device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, unsigned c, unsigned sd, double sA[5], double sB[5],
+                                               const XLane* xl = nullptr)
 {
-    if (D == 0) {
+    if (D == 0 && xl) {
+        const D2 m = ldg2(a, c);
+        D2 l, r;
+        lane_pairs(a, c, *xl, l, m, r);
+        sA[0] = l.a; sA[1] = l.b; sA[2] = m.a; sA[3] = m.b; sA[4] = r.a;
+        sB[0] = l.b; sB[1] = m.a; sB[2] = m.b; sB[3] = r.a; sB[4] = r.b;
+    } else if (D == 0) {
         const D2 l = ldg2(a, c - 16u), m = ldg2(a, c), r = ldg2(a, c + 16u);
         sA[0] = l.a; sA[1] = l.b; sA[2] = m.a; sA[3] = m.b; sA[4] = r.a;
         sB[0] = l.b; sB[1] = m.a; sB[2] = m.b; sB[3] = r.a; sB[4] = r.b;
@@ -774,7 +844,7 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
                                                const bool do_plus[2], const bool do_minus[2],
                                                double* __restrict__ QMd, double* __restrict__ QPd,
                                                double qp[2][NEDGE], double qm[2][NEDGE],
-                                               double aA[5], double aB[5], double bA[5], double bB[5])
+                                               double aA[5], double aB[5], double bA[5], double bB[5], const XLane* xl = nullptr)
 {
     constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
     constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
@@ -791,23 +861,23 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     ppm_waves<2>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_un, w[0].Im_un);
     ppm_waves<2>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
 
-    load_stencil_2<D>(Q + (long)PP * NC, c, sd, aA, aB);
+    load_stencil_2<D>(Q + (long)PP * NC, c, sd, aA, aB, xl);
     ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
     ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
 
-    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB);
+    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB, xl);
     ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
     ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
 
-    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, aA, aB);
+    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, aA, aB, xl);
     ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_re, w[0].Im_re);
     ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_re, w[1].Im_re);
 
-    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, bA, bB);
+    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, bA, bB, xl);
     ppm_waves<1>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
     ppm_waves<1>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
 
-    load_stencil_2<D>(Q + (long)PX * NC, c, sd, aA, aB);
+    load_stencil_2<D>(Q + (long)PX * NC, c, sd, aA, aB, xl);
     ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
     ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
 
@@ -1142,6 +1212,17 @@ constexpr bool kQI = false;
 constexpr bool kQI = true;
 #endif
 constexpr int QRHO = 0, QUN = 1, QUT = 2, QUTT = 3, QPG = 4, QREG = 5, QXG = 6, NQI = 7;
+
+// The y and z flux records consup_hydro needs (FL[1], FL[2]: 7 fluxes + Godunov un, p per face) are, up to the factor
+// dt * area of scale_flux, what k_final<y>, k_final<z> have just written to the caller's fluxes[1], fluxes[2] in assign mode.
+// The `contract` build lets k_finalx_consup read those instead and k_final<y,z> store only the two Godunov planes: 14 plane
+// passes less per step (1.9 GB at 256^3).  F = fluxes / (dt * area) is one rounding away from the stored flux, so the `exact`
+// build, which reproduces consup_hydro's own expression bit for bit, keeps the full records.
+#ifdef CAD_NUMERICS_CONTRACT
+constexpr bool kFluxOutConsup = true;
+#else
+constexpr bool kFluxOutConsup = false;
+#endif
 
 template <int D>
 __device__ __forceinline__ void qstate_to_rec(double rho, double un, double ut, double utt, double p, double rhoe, double Xg,
@@ -1478,6 +1559,17 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const long NC = t.NC;
+#ifdef TRACE_X_LANES            // A/B (round 4): x stencils from the neighbouring lanes by DPP instead of three 16-byte loads per
+                                // variable.  Bit-exact, 16 fewer full loads per wave -- and slower: 2.61 vs 2.49 ms (contract build),
+                                // the neighbours' lines are L1 hits, the DPP moves, selects and masked loads are not free
+                                // (profiles/r04c_*).  Off by default.
+    XLane xlane;
+    xlane.nl = (threadIdx.x & 63u) == 0u || i == b.lo[0];
+    xlane.nr = (threadIdx.x & 63u) == 63u || i + 2 > b.hi0;
+    const XLane* const xl = XRIEM ? &xlane : nullptr;
+#else
+    const XLane* const xl = nullptr;
+#endif
 
     // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
     double flat[2];
@@ -1487,7 +1579,21 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
         // all three directions' stencils are requested before the first coefficient is evaluated
         const double* Pp = Q + PP * NC;
         double pxA[7], pxB[7], uxA[5], uxB[5], pyA[7], pyB[7], uyA[5], uyB[5], pzA[7], pzB[7], uzA[5], uzB[5];
-        {
+        if (xl) {
+            // p(i-3 .. i+4) from the own pair, the neighbours' pairs and one value of the next lanes but one
+            const D2 m = ldg2(Pp, c);
+            D2 l, r;
+            lane_pairs(Pp, c, *xl, l, m, r);
+            double pm3 = lane_shr1(l.b), pp4 = lane_shl1(r.a);      // valid where the neighbour's pair is the adjacent one
+            if (xl->nl || xl->nr) {
+                const double f = ldg(Pp, xl->nl ? c - 24u : c + 32u);
+                if (xl->nl) pm3 = f; else pp4 = f;
+                if (xl->nl && xl->nr) pp4 = ldg(Pp, c + 32u);
+            }
+            pxA[0] = pm3; pxA[1] = l.a; pxA[2] = l.b; pxA[3] = m.a; pxA[4] = m.b; pxA[5] = r.a; pxA[6] = r.b;
+            pxB[0] = l.a; pxB[1] = l.b; pxB[2] = m.a; pxB[3] = m.b; pxB[4] = r.a; pxB[5] = r.b; pxB[6] = pp4;
+            load_stencil_2<0>(Q + PU * NC, c, s.x, uxA, uxB, xl);
+        } else {
             const D2 p0 = ldg2(Pp, c - 24u), p1 = ldg2(Pp, c - 8u), p2 = ldg2(Pp, c + 8u), p3 = ldg2(Pp, c + 24u);
             pxA[0] = p0.a; pxA[1] = p0.b; pxA[2] = p1.a; pxA[3] = p1.b; pxA[4] = p2.a; pxA[5] = p2.b; pxA[6] = p3.a;
             pxB[0] = p0.b; pxB[1] = p1.a; pxB[2] = p1.b; pxB[3] = p2.a; pxB[4] = p2.b; pxB[5] = p3.a; pxB[6] = p3.b;
@@ -1515,9 +1621,9 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
     double sa[2][5], sb[2][5];
     if (DMASK & 1) {
-        load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1]);
-        load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1]);
-        trace_pair_dir<0, (DMASK & 2) ? 1 : -1>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+        load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1], xl);
+        load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1], xl);
+        trace_pair_dir<0, (DMASK & 2) ? 1 : -1>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1], xl);
     }
 
     if (XRIEM && (DMASK & 1))
@@ -1876,109 +1982,9 @@ __device__ __forceinline__ void fold_thread(const LinBox& b, int& i, int& j, int
     }
 }
 
-// the two (N, T) combinations of one transverse direction T = y or z whose first solves are folded in:
-// N = x (minus zones: the left neighbour, by shuffle) and N = O, the other transverse direction (minus zones: re-solved)
-template <int T, int GEN>
-__device__ __forceinline__ void trans1_fold_dir(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
-                                                const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
-                                                double cdtdt, const DevParams& P)
-{
-    constexpr int O = (T == 1) ? 2 : 1;            // the other transverse direction of N = x
-    const Str s = gstr(t);
-    const unsigned st = dstr(s, T), so = dstr(s, O);
-    const long NC = t.NC;
-    const double* Cp = Q + PC * NC;
-
-    // records A: the T-faces (low, high) of this thread's own two zones.  Every lane computes them: the neighbour may need them.
-    double A0[2][NF1], A1[2][NF1];
-    {
-        double qm[2][NEDGE], qp[2][NEDGE];
-        load_edge_2(S.QM[T], NC, c, qm);
-        load_edge_2(S.QP[T], NC, c, qp);
-        const D2 cl = ldg2(Cp, c - st), cr = ldg2(Cp, c);
-        f1_solve_2<T, GEN>(qm, qp, cl, cr, wall_fac<T>(g, ijk[T]), P, A0);
-    }
-    f1_at_2<T, GEN>(t, Q, S, g, P, c + st, ijk[T] + 1, A1);
-    double L0[NF1], L1[NF1];                       // the same for zone i - 1: the second zone of the lane to the left
-#pragma unroll
-    for (int n = 0; n < NF1; ++n) { L0[n] = __shfl_up(A0[1][n], 1, 64); L1[n] = __shfl_up(A1[1][n], 1, 64); }
-
-    const bool tin = owner && ijk[T] >= t.lo[T] && ijk[T] <= t.hi[T];      // T index inside bx: the (N|T) states exist
-    // ---- N = x: minus states live in the zones (i - 1, i), plus states in (i, i + 1)
-    {
-        const bool m0 = tin && ijk[0] >= t.lo[0], m1 = tin && v1 && ijk[0] + 1 >= t.lo[0];
-        if (m0 || m1) {
-            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
-            load_edge_2(S.QM[0], NC, c, q);
-            trans_single<T>(q[0], L1, L0, P.gamma, cdtdt, P, qmo[0]);
-            trans_single<T>(q[1], A1[0], A0[0], P.gamma, cdtdt, P, qmo[1]);
-            load_edge_2(S.QP[0], NC, c, q);
-#pragma unroll
-            for (int w = 0; w < 2; ++w) trans_single<T>(q[w], A1[w], A0[w], P.gamma, cdtdt, P, qpo[w]);
-            const D2 cl = ldg2(Cp, c - 8u), cr = ldg2(Cp, c);
-            double bnd[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
-            trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
-        }
-    }
-    // ---- N = O: faces between the zones c - so and c; the T-faces of the zones c - so are solved here (records B)
-    {
-        const bool m0 = tin && ijk[O] >= t.lo[O], m1 = m0 && v1;
-        if (m0 || m1) {
-            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
-            {
-                double B0[2][NF1], B1[2][NF1];
-                f1_at_2<T, GEN>(t, Q, S, g, P, c - so, ijk[T], B0);
-                f1_at_2<T, GEN>(t, Q, S, g, P, c - so + st, ijk[T] + 1, B1);
-                load_edge_2(S.QM[O], NC, c, q);
-#pragma unroll
-                for (int w = 0; w < 2; ++w) trans_single<T>(q[w], B1[w], B0[w], P.gamma, cdtdt, P, qmo[w]);
-            }
-            load_edge_2(S.QP[O], NC, c, q);
-#pragma unroll
-            for (int w = 0; w < 2; ++w) trans_single<T>(q[w], A1[w], A0[w], P.gamma, cdtdt, P, qpo[w]);
-            const D2 cl = ldg2(Cp, c - so), cr = ldg2(Cp, c);
-            double bnd[2];
-            bnd[0] = bnd[1] = wall_fac<O>(g, ijk[O]);
-            trans1_solve_store<O, T, GEN>(t, S, c, qmo, qpo, cl, cr, bnd, m0, m1, P);
-        }
-    }
-}
-
-// ---- the same with the A records parked in LDS (64 KB per workgroup, thread-private slots [face][zone][component][thread]):
-// they are needed three times over the life of a direction and cost 64 VGPRs held in registers (28 spilled at two waves
-// per SIMD).  The left neighbour's records are then an LDS read of slot tid - 1, so only thread 0 of a WORKGROUP repeats
-// the slot before it (255 new slots per workgroup).
-__device__ __forceinline__ void fold_thread_wg(const LinBox& b, int& i, int& j, int& k, bool& owner)
-{
-    unsigned bid = blockIdx.x;
-    if (b.ty > 0) {
-        const unsigned per = b.nb >> 3;
-        bid = (bid & 7u) * per + (bid >> 3);
-    }
-    const long total = (long)b.n[0] * b.n[1] * b.n[2];
-    long sl = (long)bid * 255 + (long)threadIdx.x - 1;
-    owner = threadIdx.x >= 1 && sl < total;
-    if (sl < 0) sl = 0;
-    if (sl >= total) sl = total - 1;
-    const unsigned tid = (unsigned)sl;
-    const unsigned ii = tid % (unsigned)b.n[0];
-    const unsigned r = tid / (unsigned)b.n[0];
-    i = b.lo[0] + b.w * (int)ii;
-    if (b.ty > 0) {
-        const unsigned rpt = (unsigned)b.ty * (unsigned)b.n[2];
-        const unsigned yt = r / rpt;
-        const unsigned rem = r - yt * rpt;
-        const unsigned left = (unsigned)b.n[1] - yt * (unsigned)b.ty;
-        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
-        const unsigned kk = rem / tyh;
-        j = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - kk * tyh));
-        k = b.lo[2] + (int)kk;
-    } else {
-        j = b.lo[1] + (int)(r % (unsigned)b.n[1]);
-        k = b.lo[2] + (int)(r / (unsigned)b.n[1]);
-    }
-}
-
+// k_trans1_fold_lds: the A records of a direction are parked in LDS (64 KB per workgroup, thread-private slots
+// [face][zone][component][thread]): they are needed three times over the life of a direction and would cost 64 VGPRs held in
+// registers (measured: 28 spilled at two waves per SIMD, break-even; profiles/EXPERIMENTS.md).
 // FOLD_WG: threads per workgroup of that launch (a wave's 16 KB of slots are its own)
 #ifndef FOLD_WG
 #define FOLD_WG 256
@@ -1992,14 +1998,10 @@ __device__ __forceinline__ void park_get(const double* __restrict__ park, int f,
 
 // The waves of k_trans1_fold_lds overlap by one slot each (fold_thread: 63 new slots per wave): the only foreign slot a lane
 // reads is its left neighbour's, in the same wave, and LDS is in order per wave -- no workgroup barrier, the waves of a CU run
-// their load and compute phases independently (4.52 -> 4.39 ms, profiles/r03x_*).  -DFOLD_WG_SYNC: the form before (workgroups
-// overlap by one slot, 255 new slots each, __syncthreads between parking and reading).
-#ifndef FOLD_WG_SYNC
+// their load and compute phases independently (4.52 -> 4.39 ms against workgroups overlapping by one slot with __syncthreads,
+// profiles/r03x_*).
 #define FOLD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#else
-#define FOLD_SYNC() __syncthreads()
-#endif
 template <int T, int GEN, bool TX_HERE>
 __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
                                                     const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
@@ -2099,39 +2101,6 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
     }
 }
 
-// T = x part shared by both fold kernels: the first x solve comes from the trace kernel (F1[x] in memory), as in k_trans1
-template <int GEN>
-__device__ __forceinline__ void trans1_fold_tx(const Tile& t, const int ijk[3], bool v1, unsigned c, const double* __restrict__ Q,
-                                               const DevScratch& S, const DevGeom& g, double cdtdx, const DevParams& P)
-{
-    const Str s = gstr(t);
-#pragma unroll
-    for (int Nn = 1; Nn <= 2; ++Nn) {
-        bool in_t[2];
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const int ix = ijk[0] + w;
-            in_t[w] = ((w == 0) || v1) && ijk[Nn] >= t.lo[Nn] && ix >= t.lo[0] && ix <= t.hi[0];
-        }
-        if (!in_t[0] && !in_t[1]) continue;
-        const unsigned sn = (Nn == 1) ? s.y : s.z;
-        double qm[2][NEDGE], qp[2][NEDGE];
-        const double* QMn = (Nn == 1) ? S.QM[1] : S.QM[2];
-        const double* QPn = (Nn == 1) ? S.QP[1] : S.QP[2];
-        load_edge_2(QMn, t.NC, c, qm);
-        load_edge_2(QPn, t.NC, c, qp);
-        const D2 cl = ldg2(Q + PC * t.NC, c - sn), cr = ldg2(Q + PC * t.NC, c);
-        double bnd[2];
-        if (Nn == 1) {
-            bnd[0] = bnd[1] = wall_fac<1>(g, ijk[1]);
-            trans1_pair<1, 0, false, GEN>(t, S, c, sn, 8u, qm, qp, cl, cr, bnd, cdtdx, in_t[0], in_t[1], P);
-        } else {
-            bnd[0] = bnd[1] = wall_fac<2>(g, ijk[2]);
-            trans1_pair<2, 0, false, GEN>(t, S, c, sn, 8u, qm, qp, cl, cr, bnd, cdtdx, in_t[0], in_t[1], P);
-        }
-    }
-}
-
 template <int GEN>
 __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                          double cdtdx, double cdtdy, double cdtdz, DevParams P)
@@ -2140,44 +2109,12 @@ __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t
     DT_THIRDS_FROM_DEVICE();
     int ijk[3];
     bool owner;
-#ifndef FOLD_WG_SYNC
     fold_thread<FOLD_WG / 64>(b, ijk[0], ijk[1], ijk[2], owner);
-#else
-    fold_thread_wg(b, ijk[0], ijk[1], ijk[2], owner);
-#endif
     const bool v1 = ijk[0] + 1 <= b.hi0;
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const D2 c0 = ldg2(Q + PC * t.NC, c);
-#ifdef FOLD_TX_SEPARATE     // A/B: the (y | x), (z | x) combinations after the two folded directions, edge states loaded once more
-    trans1_fold_dir_lds<1, GEN, false>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
-    trans1_fold_dir_lds<2, GEN, false>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
-    if (!owner) return;
-    trans1_fold_tx<GEN>(t, ijk, v1, c, Q, S, g, cdtdx, P);
-#else
     trans1_fold_dir_lds<1, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
     trans1_fold_dir_lds<2, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
-#endif
-}
-
-#ifdef FOLD_ONE_WAVE        // A/B: 286 registers (VGPR + AGPR), one wave per SIMD, no spills
-#define FOLD_WAVES CG_TWO_WAVES
-#else                       // two waves per SIMD: 256 VGPRs, 28 spilled to scratch
-#define FOLD_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
-template <int GEN>
-__global__ void __launch_bounds__(256) FOLD_WAVES k_trans1_fold(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                     double cdtdx, double cdtdy, double cdtdz, DevParams P)
-{
-    DT_THIRDS_FROM_DEVICE();
-    int ijk[3];
-    bool owner;
-    fold_thread(b, ijk[0], ijk[1], ijk[2], owner);
-    const bool v1 = ijk[0] + 1 <= b.hi0;
-    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    trans1_fold_dir<1, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdy, P);
-    trans1_fold_dir<2, GEN>(t, ijk, v1, owner, c, Q, S, g, cdtdz, P);
-    if (!owner) return;
-    trans1_fold_tx<GEN>(t, ijk, v1, c, Q, S, g, cdtdx, P);
 }
 
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one
@@ -2205,7 +2142,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
                                            const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                            const DFab& U, const DFab& fluxes, const DFab& mass, const DFab& qe,
                                            double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
-                                           int acc_hi, int assign, const DevParams& P, double R[2][NFIN])
+                                           int acc_hi, int assign, const DevParams& P, double R[2][NFIN], bool fl_godunov_only = false)
 {
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
@@ -2289,6 +2226,13 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
                             ijk[0], ijk[1], ijk[2], dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
     if (!STORE_FL) return;
     double* FL = S.FL[N];
+    if (kFluxOutConsup && fl_godunov_only) {
+        // the fluxes themselves reach consup through fluxes[N] (see kFluxOutConsup)
+        if (v0 && v1) { stg2(FL + (long)GUG * NC, c, R[0][GUG], R[1][GUG]); stg2(FL + (long)GPG * NC, c, R[0][GPG], R[1][GPG]); }
+        else if (v0) { stg(FL + (long)GUG * NC, c, R[0][GUG]); stg(FL + (long)GPG * NC, c, R[0][GPG]); }
+        else { stg(FL + (long)GUG * NC, c + 8u, R[1][GUG]); stg(FL + (long)GPG * NC, c + 8u, R[1][GPG]); }
+        return;
+    }
     if (v0 && v1) {
 #pragma unroll
         for (int n = 0; n < NFIN; ++n) stg2(FL + (long)n * NC, c, R[0][n], R[1][n]);
@@ -2321,186 +2265,9 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, co
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     double R[2][NFIN];
-    final_body<N, RE, LIM, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R);
-}
-
-// The y and z faces of the final stage in one launch (experiment, CASTRO_AMD_FINAL_YZ=1): a thread does the y faces
-// (i, i+1; j; k) and then the z faces of the same index -- Sborder, div(u) and the sound speeds of the zone are fetched once
-// for both.  The launch box is the union of the two face boxes; each body masks the faces outside its own.
-template <int GEN>
-__global__ void __launch_bounds__(256) CG_TWO_WAVES k_final_yz(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                  DFab U, DFab fluxes1, DFab mass1, DFab qe1, DFab fluxes2, DFab mass2, DFab qe2,
-                                                  double hdtdx, double hdtdy, double hdtdz, double dt, double area1, double area2,
-                                                  int acc_hi1, int acc_hi2, int assign, DevParams P)
-{
-    RETURN_IF_BATCH_FAILED();
-    int ijk[3];
-    if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
-    if (P.dtp) { dt = P.dtp[6]; hdtdx = 0.5 * dt / g.dx[0]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
-    const bool v1 = ijk[0] + 1 <= b.hi0;
-    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    double R[2][NFIN];
-    if (ijk[2] <= t.hi[2])          // y faces: j in [lo, hi + 1], k in [lo, hi]
-        final_body<1, false, false, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes1, mass1, qe1, hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi1, assign, P, R);
-    if (ijk[1] <= t.hi[1])          // z faces: j in [lo, hi], k in [lo, hi + 1]
-        final_body<2, false, false, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes2, mass2, qe2, hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi2, assign, P, R);
-}
-
-// ---------------------------------------------------------------------------------------
-// Brick launches: a workgroup owns a tile of tx2 x-pairs by ty by tz faces (or zones) and stages the flux records its
-// threads share -- every record of the transverse stage is read by eight threads -- in LDS, once, with 16-byte loads
-// along the x pencil.  The records of one array are kept component by component (SoA like the scratch planes), the x
-// extent padded to an even number of doubles so that a thread's two faces are one 16-byte LDS access.
-// Workgroup ids map to tiles XCD by XCD like LinBox does: id -> (id % 8) * (nb / 8) + id / 8, tiles x fastest.
-// ---------------------------------------------------------------------------------------
-struct Brick {
-    int lo[3], hi[3];      // faces (zones) the launch covers
-    int tx2, ty, tz;       // pair-threads along x, rows in y and z of one workgroup (tx2 * ty * tz <= 256)
-    int ntx, nty, ntz;     // tiles per direction
-    unsigned nb;           // workgroups launched, a multiple of 8
-    int exs[2], ey[2], ez[2];   // LDS extents of the two staged arrays (exs even)
-};
-
-// stage the records of plane set A (NF1 components) for the region [o, o + e) into LDS: rows of e0 doubles as
-// ceil(e0 / 2) 16-byte loads; 32 lanes per row, 8 rows per pass
-__device__ __forceinline__ void brick_stage(const Tile& t, const double* __restrict__ A, double* __restrict__ L,
-                                            const int o[3], const int e[3], int exs, int ey, int ez)
-{
-    const int lane = threadIdx.x & 31, rsel = threadIdx.x >> 5;      // 8 row slots of 32 lanes
-    const int units = (e[0] + 1) >> 1;
-    const int nrow = e[1] * e[2];
-    const int cs = exs * ey * ez;
-    for (int u0 = 0; u0 < units; u0 += 32) {
-        const int u = u0 + lane;
-        for (int r = rsel; r < nrow; r += 8) {
-            const int z = r / e[1], y = r - z * e[1];
-            if (u < units) {
-                const unsigned c = goff(t, o[0] + 2 * u, o[1] + y, o[2] + z);
-                const int li = (z * ey + y) * exs + 2 * u;
-#pragma unroll
-                for (int n = 0; n < NF1; ++n) {
-                    const D2 v = ldg2(A + (long)n * t.NC, c);
-                    L[n * cs + li] = v.a;
-                    L[n * cs + li + 1] = v.b;
-                }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void lds_rec2(const double* __restrict__ L, int cs, int idx, double r[2][NF1])
-{
-#pragma unroll
-    for (int n = 0; n < NF1; ++n) { r[0][n] = L[n * cs + idx]; r[1][n] = L[n * cs + idx + 1]; }
-}
-
-// k_final<N> with the two transverse flux arrays F^{T1|T2}, F^{T2|T1} staged in LDS (default options only: the
-// transverse_reset_rhoe / ppm_temp_fix instantiations keep the plain kernel)
-template <int N, bool LIM>
-__global__ void __launch_bounds__(256) k_final_lds(Tile t, Brick b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                   DFab U, DFab fluxes, DFab mass, DFab qe,
-                                                   double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
-                                                   int acc_hi, int assign, DevParams P)
-{
-    constexpr int T1 = (N == 0) ? 1 : 0;
-    constexpr int T2 = (N == 2) ? 1 : 2;
-    extern __shared__ double lds[];
-
-    unsigned bid = blockIdx.x;
-    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
-    if (bid >= (unsigned)(b.ntx * b.nty * b.ntz)) return;
-    const int tX = (int)(bid % (unsigned)b.ntx);
-    const unsigned rr = bid / (unsigned)b.ntx;
-    const int tY = (int)(rr % (unsigned)b.nty), tZ = (int)(rr / (unsigned)b.nty);
-    int l[3] = { b.lo[0] + tX * 2 * b.tx2, b.lo[1] + tY * b.ty, b.lo[2] + tZ * b.tz };
-    int n[3] = { 2 * b.tx2, b.ty, b.tz };
-#pragma unroll
-    for (int d = 0; d < 3; ++d) if (l[d] + n[d] - 1 > b.hi[d]) n[d] = b.hi[d] - l[d] + 1;
-
-    // staged regions: zones c - sn and c of every face of the tile, low and high face of the array's own direction
-    int o0[3], e0[3], o1[3], e1[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        o0[d] = o1[d] = l[d] - (d == N ? 1 : 0);
-        e0[d] = n[d] + (d == N ? 1 : 0) + (d == T1 ? 1 : 0);
-        e1[d] = n[d] + (d == N ? 1 : 0) + (d == T2 ? 1 : 0);
-    }
-    double* L0 = lds;
-    const int cs0 = b.exs[0] * b.ey[0] * b.ez[0], cs1 = b.exs[1] * b.ey[1] * b.ez[1];
-    double* L1 = lds + NF1 * cs0;
-    brick_stage(t, S.F2[f2_slot(T1, T2)], L0, o0, e0, b.exs[0], b.ey[0], b.ez[0]);
-    brick_stage(t, S.F2[f2_slot(T2, T1)], L1, o1, e1, b.exs[1], b.ey[1], b.ez[1]);
-
-    // this thread's faces
-    const int px = (int)(threadIdx.x % (unsigned)b.tx2);
-    const int rw = (int)(threadIdx.x / (unsigned)b.tx2);
-    const int ry = rw % b.ty, rz = rw / b.ty;
-    const int i = l[0] + 2 * px, j = l[1] + ry, k = l[2] + rz;
-    const bool v0 = 2 * px < n[0] && ry < n[1] && rz < n[2];
-    const bool v1 = v0 && 2 * px + 1 < n[0];
-
-    const Str s = gstr(t);
-    const unsigned sn = dstr(s, N), s1 = dstr(s, T1), s2 = dstr(s, T2);
-    const long NC = t.NC;
-    const unsigned c = goff(t, i, j, k);
-    double qm[2][NEDGE], qp[2][NEDGE];
-    D2 cl, cr;
-    if (v0) {
-        // issued before the barrier: in flight while the tile is being staged
-        load_edge_2(S.QM[N], NC, c, qm);
-        load_edge_2(S.QP[N], NC, c, qp);
-        cl = ldg2(Q + PC * NC, c - sn);
-        cr = ldg2(Q + PC * NC, c);
-    }
-    __syncthreads();
-    if (!v0) return;
-
-    // LDS index of (face i, j, k) in the two arrays; the offsets of the four records around it
-    const int b0 = ((k - o0[2]) * b.ey[0] + (j - o0[1])) * b.exs[0] + (i - o0[0]);
-    const int b1 = ((k - o1[2]) * b.ey[1] + (j - o1[1])) * b.exs[1] + (i - o1[0]);
-    const int st0[3] = { 1, b.exs[0], b.exs[0] * b.ey[0] }, st1[3] = { 1, b.exs[1], b.exs[1] * b.ey[1] };
-    const int n0 = st0[N], n1 = st1[N], h0 = st0[T1], h1 = st1[T2];
-
-    double ql[2][NEDGE], qr[2][NEDGE];
-    double f1r[2][NF1], f1l[2][NF1], f2r[2][NF1], f2l[2][NF1];
-    // minus states (zones c - sn)
-    lds_rec2(L0, cs0, b0 - n0 + h0, f1r);
-    lds_rec2(L0, cs0, b0 - n0, f1l);
-    lds_rec2(L1, cs1, b1 - n1 + h1, f2r);
-    lds_rec2(L1, cs1, b1 - n1, f2l);
-#pragma unroll
-    for (int w = 0; w < 2; ++w) trans_final(qm[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, ql[w]);
-    // plus states (zones c)
-    lds_rec2(L0, cs0, b0 + h0, f1r);
-    lds_rec2(L0, cs0, b0, f1l);
-    lds_rec2(L1, cs1, b1 + h1, f2r);
-    lds_rec2(L1, cs1, b1, f2l);
-#pragma unroll
-    for (int w = 0; w < 2; ++w) trans_final(qp[w], f1r[w], f1l[w], f2r[w], f2l[w], P.gamma, hdtdx_t1, hdtdx_t2, P, qr[w]);
-
-    const unsigned usn = 8u * (N == 0 ? 1u : N == 1 ? (unsigned)U.sy : (unsigned)U.sz);
-    double R[2][NFIN];
-    IFlux f[2];
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        RState rl, rrs;
-        double Xl, Xr;
-        rstate_from_edge<N>(ql[w], P.gamma, rl, Xl);
-        rstate_from_edge<N>(qr[w], P.gamma, rrs, Xr);
-        const int idxN = (N == 0) ? i + w : (N == 1) ? j : k;
-        interface_flux<N>(rl, rrs, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
-                          face_shock(S, P, c + 8u * w, sn), P, f[w]);
-    }
-    final_flux_tail<N, LIM>(t, S, f, c, s1, s2, U, foff(U, i, j, k), usn, fluxes, mass, qe,
-                            i, j, k, dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
-    double* FL = S.FL[N];
-    if (v1) {
-#pragma unroll
-        for (int m = 0; m < NFIN; ++m) stg2(FL + (long)m * NC, c, R[0][m], R[1][m]);
-    } else {
-#pragma unroll
-        for (int m = 0; m < NFIN; ++m) stg(FL + (long)m * NC, c, R[0][m]);
-    }
+    // assign & 2: consup will take this direction's fluxes from fluxes[N] (kFluxOutConsup): only the Godunov planes of FL[N]
+    final_body<N, RE, LIM, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R,
+                                      (assign & 2) != 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2582,7 +2349,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
         stg(Unew.p + m * Unew.sn, cn, un[m]);
     }
     }
-    if (CLEAN && red) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
+    if (CLEAN && red) wave_min3_atomic(dtmin, rmin_raw, dtmin1, red);      // per wave: any workgroup size (CASTRO_AMD_WG)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2603,7 +2370,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
                                                        double hdtdy, double hdtdz, double dt,
                                                        double area0, double area1, double area2, double vol,
                                                        int acc_hi, int assign, int from_sborder, DevParams P, int ntimes,
-                                                       double* red)
+                                                       double* red, DFab fluxes_y, DFab fluxes_z)
 {
     RETURN_IF_BATCH_FAILED();
     if (P.dtp) { dt = P.dtp[6]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
@@ -2658,15 +2425,27 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
         const unsigned ci = foff(U, ijk[0], ijk[1], ijk[2]);
         constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
         double un[2][NUM_STATE];
+        // kFluxOutConsup (assign & 2): the y / z fluxes, already scaled by dt * area, from the caller's flux arrays
+        const bool from_out = kFluxOutConsup && (assign & 2) != 0;
+        const unsigned cfy = from_out ? foff(fluxes_y, ijk[0], ijk[1], ijk[2]) : 0u, cfz = from_out ? foff(fluxes_z, ijk[0], ijk[1], ijk[2]) : 0u;
+        const unsigned fsy = 8u * (unsigned)fluxes_y.sy, fsz = 8u * (unsigned)fluxes_z.sz;
+        const double dtarea0 = dt * area0;
 #pragma unroll
         for (int m = 0; m < NUM_STATE; ++m) {
             const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
             if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }       // zero flux
             const int r = rec[m];
+            if (from_out) {
+                const D2 y0 = ldg2(fluxes_y.p + m * fluxes_y.sn, cfy), y1 = ldg2(fluxes_y.p + m * fluxes_y.sn, cfy + fsy);
+                const D2 z0 = ldg2(fluxes_z.p + m * fluxes_z.sn, cfz), z1 = ldg2(fluxes_z.p + m * fluxes_z.sn, cfz + fsz);
+                un[0][m] = u0.a + (dtarea0 * (R[0][r] - R[1][r]) + (y0.a - y1.a) + (z0.a - z1.a)) * volinv;
+                un[1][m] = u0.b + (dtarea0 * (R[1][r] - Rn[r]) + (y0.b - y1.b) + (z0.b - z1.b)) * volinv;
+            } else {
             const D2 y0 = ldg2(F1 + (long)r * NC, c), y1 = ldg2(F1 + (long)r * NC, c + sy);
             const D2 z0 = ldg2(F2 + (long)r * NC, c), z1 = ldg2(F2 + (long)r * NC, c + sz);
             un[0][m] = u0.a + dt * (R[0][r] * area0 - R[1][r] * area0 + y0.a * area1 - y1.a * area1 + z0.a * area2 - z1.a * area2) * volinv;
             un[1][m] = u0.b + dt * (R[1][r] * area0 - Rn[r] * area0 + y0.b * area1 - y1.b * area1 + z0.b * area2 - z1.b * area2) * volinv;
+            }
             if (m == UEINT) {
                 const D2 py0 = ldg2(F1 + GPG * NC, c), py1 = ldg2(F1 + GPG * NC, c + sy);
                 const D2 uy0 = ldg2(F1 + GUG * NC, c), uy1 = ldg2(F1 + GUG * NC, c + sy);
@@ -2706,162 +2485,11 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
 }
 
 // ---------------------------------------------------------------------------------------
-// k_final<z>, k_final<x> and consup_hydro in one kernel, marching along z.
-//   The thread of k_finalx_consup (x-faces i, i+1 and zones i, i+1 of one row) walks up a chunk of mz planes: per plane
-//   it solves the z face ABOVE its zones and their two x faces, and updates the zones with the z record of the face
-//   below kept from the plane before.  The two z records (2 x 9 x 2 doubles per thread) are parked in thread-private
-//   LDS slots between their use -- the register file is full with one final_body (230 VGPRs).  A chunk starts by
-//   solving its lowest z face; the face above its last plane belongs to the next chunk, which solves it again (1 / mz
-//   redundant z solves) and stores its outputs.  Saves FL[z] written and read (18 passes), one read of Sborder and
-//   div(u), one launch.  The y records still come from FL[y].
-// ---------------------------------------------------------------------------------------
-struct XZRows { int lo[3]; int hi0, hi2; int nslot, ny, nchunk, mz; int ty; unsigned nb; };
-
-template <bool LIM, bool CLEAN>
-__global__ void __launch_bounds__(256) k_finalxz_consup(Tile t, XZRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                        DFab U, DFab fluxes0, DFab mass0, DFab qe0, DFab fluxes2, DFab mass2, DFab qe2,
-                                                        DFab Unew, double hdtdx, double hdtdy, double hdtdz, double dt,
-                                                        double area0, double area1, double area2, double vol,
-                                                        int acc_hi0, int acc_hi2, int assign, int from_sborder, DevParams P,
-                                                        int ntimes, double* red)
-{
-    __shared__ double park[2 * 2 * NFIN * 256];        // [buffer][face of the pair][component][thread]
-    unsigned bid = blockIdx.x;
-    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
-    const int lane = threadIdx.x & 63;
-    const unsigned total = (unsigned)b.nslot * (unsigned)b.ny * (unsigned)b.nchunk;
-    unsigned sl = (bid * 4u + (threadIdx.x >> 6)) * 63u + (unsigned)lane;
-    const bool live = sl < total;
-    if (!live) sl = total - 1u;
-    const unsigned row = sl / (unsigned)b.nslot;
-    const int p = (int)(sl - row * (unsigned)b.nslot);
-    int ijk[3];
-    ijk[0] = b.lo[0] + 2 * p;
-    unsigned chunk;
-    if (b.ty > 0) {                                    // rows y-tile by y-tile, chunk by chunk inside a tile
-        const unsigned rpt = (unsigned)b.ty * (unsigned)b.nchunk;
-        const unsigned yt = row / rpt;
-        const unsigned rem = row - yt * rpt;
-        const unsigned left = (unsigned)b.ny - yt * (unsigned)b.ty;
-        const unsigned tyh = left < (unsigned)b.ty ? left : (unsigned)b.ty;
-        chunk = rem / tyh;
-        ijk[1] = b.lo[1] + (int)(yt * (unsigned)b.ty + (rem - chunk * tyh));
-    } else {
-        ijk[1] = b.lo[1] + (int)(row % (unsigned)b.ny);
-        chunk = row / (unsigned)b.ny;
-    }
-    const int k0 = b.lo[2] + (int)chunk * b.mz;
-    const bool owner = live && lane < 63;
-    const bool f0 = ijk[0] <= b.hi0 + 1, f1 = ijk[0] + 1 <= b.hi0 + 1;          // x faces of nodal(bx, x)
-    const bool zA = owner && ijk[0] <= b.hi0, zB = owner && ijk[0] + 1 <= b.hi0; // zones of bx (z-face pairs too)
-    const Str s = gstr(t);
-    double* pk = park + threadIdx.x;
-    double dtmin = 1.e200, rmin_raw = 1.e300, dtmin1 = 1.e200;
-
-    {   // the lowest z face of the chunk: this chunk stores its outputs
-        ijk[2] = k0;
-        double Rz[2][NFIN];
-        final_body<2, false, LIM, false>(t, ijk, zA, zB, goff(t, ijk[0], ijk[1], k0), Q, S, g, U, fluxes2, mass2, qe2, hdtdx, hdtdy,
-                                         dt, area2, g.dx[2], acc_hi2, assign, P, Rz);
-#pragma unroll
-        for (int w = 0; w < 2; ++w)
-#pragma unroll
-            for (int m = 0; m < NFIN; ++m) pk[((0 * 2 + w) * NFIN + m) * 256] = Rz[w][m];
-    }
-
-    for (int mm = 0; mm < b.mz; ++mm) {
-        const bool inz = k0 + mm <= b.hi2;             // false only in the planes a short last chunk does not have
-        const int k = inz ? k0 + mm : b.hi2;           // (they recompute the top plane and store nothing)
-        const int lo_buf = mm & 1, hi_buf = lo_buf ^ 1;
-        {
-            // the z face above.  Faces k0+1 .. k0+mz-1 are stored here; the face above the chunk's last plane belongs to
-            // the next chunk (its lowest face) unless it is the top face of the box
-            ijk[2] = k + 1;
-            const bool store = inz && (k == b.hi2 || mm + 1 < b.mz);
-            double Rz[2][NFIN];
-            final_body<2, false, LIM, false>(t, ijk, zA && store, zB && store, goff(t, ijk[0], ijk[1], k + 1), Q, S, g, U,
-                                             fluxes2, mass2, qe2, hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi2, assign, P, Rz);
-#pragma unroll
-            for (int w = 0; w < 2; ++w)
-#pragma unroll
-                for (int m = 0; m < NFIN; ++m) pk[((hi_buf * 2 + w) * NFIN + m) * 256] = Rz[w][m];
-        }
-        ijk[2] = k;
-        const unsigned c = goff(t, ijk[0], ijk[1], k);
-        double R[2][NFIN];
-        final_body<0, false, LIM, false>(t, ijk, owner && f0 && inz, owner && f1 && inz, c, Q, S, g, U, fluxes0, mass0, qe0,
-                                         hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi0, assign, P, R);
-        double Rn[NFIN];                               // x face i+2
-#pragma unroll
-        for (int m = 0; m < NFIN; ++m) Rn[m] = __shfl_down(R[0][m], 1, 64);
-
-        if (zA && inz) {
-            const unsigned sy = s.y;
-            const long NC = t.NC;
-            const double volinv = 1.0 / vol;
-            const double* F1 = S.FL[1];
-            const unsigned cn = foff(Unew, ijk[0], ijk[1], k);
-            const unsigned ci = foff(U, ijk[0], ijk[1], k);
-            constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
-#define ZL(w, r) pk[((lo_buf * 2 + (w)) * NFIN + (r)) * 256]
-#define ZH(w, r) pk[((hi_buf * 2 + (w)) * NFIN + (r)) * 256]
-            double un[2][NUM_STATE];
-#pragma unroll
-            for (int m = 0; m < NUM_STATE; ++m) {
-                const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
-                if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }
-                const int r = rec[m];
-                const D2 y0 = ldg2(F1 + (long)r * NC, c), y1 = ldg2(F1 + (long)r * NC, c + sy);
-                un[0][m] = u0.a + dt * (R[0][r] * area0 - R[1][r] * area0 + y0.a * area1 - y1.a * area1 + ZL(0, r) * area2 - ZH(0, r) * area2) * volinv;
-                un[1][m] = u0.b + dt * (R[1][r] * area0 - Rn[r] * area0 + y0.b * area1 - y1.b * area1 + ZL(1, r) * area2 - ZH(1, r) * area2) * volinv;
-                if (m == UEINT) {
-                    const D2 py0 = ldg2(F1 + GPG * NC, c), py1 = ldg2(F1 + GPG * NC, c + sy);
-                    const D2 uy0 = ldg2(F1 + GUG * NC, c), uy1 = ldg2(F1 + GUG * NC, c + sy);
-                    double pdu = (R[1][GPG] + R[0][GPG]) * (R[1][GUG] * area0 - R[0][GUG] * area0);
-                    pdu += (py1.a + py0.a) * (uy1.a * area1 - uy0.a * area1);
-                    pdu += (ZH(0, GPG) + ZL(0, GPG)) * (ZH(0, GUG) * area2 - ZL(0, GUG) * area2);
-                    pdu = 0.5 * pdu * volinv;
-                    un[0][m] = un[0][m] - dt * pdu;
-                    pdu = (Rn[GPG] + R[1][GPG]) * (Rn[GUG] * area0 - R[1][GUG] * area0);
-                    pdu += (py1.b + py0.b) * (uy1.b * area1 - uy0.b * area1);
-                    pdu += (ZH(1, GPG) + ZL(1, GPG)) * (ZH(1, GUG) * area2 - ZL(1, GUG) * area2);
-                    pdu = 0.5 * pdu * volinv;
-                    un[1][m] = un[1][m] - dt * pdu;
-                }
-            }
-#undef ZL
-#undef ZH
-            if (CLEAN) {
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    if (w == 1 && !zB) continue;
-                    rmin_raw = fmin(rmin_raw, nan_guard(un[w][URHO]));
-                    double d1, d2;
-                    clean_zone_dt(P, ntimes, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS], d1, d2);
-                    dtmin1 = fmin(dtmin1, d1);
-                    dtmin = fmin(dtmin, d2);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < NUM_STATE; ++m) {
-                if (m == UTEMP && !CLEAN && !from_sborder) continue;
-                if (zB) stg2(Unew.p + m * Unew.sn, cn, un[0][m], un[1][m]);
-                else stg(Unew.p + m * Unew.sn, cn, un[0][m]);
-            }
-        }
-    }
-    if (CLEAN && red) block_min3_atomic(dtmin, rmin_raw, dtmin1, red);
-}
-
-// ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
-int g_trace_single = 0;   // 1: one zone per thread in the trace launch (k_trace<false,false>) + k_riemann1<x> (CASTRO_AMD_TRACE_SINGLE)
-int g_final_yz = 0;       // 1: the y and z faces of the final stage in one launch (k_final_yz; CASTRO_AMD_FINAL_YZ)
 int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
-int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: 2 = k_trans1_fold_lds (records parked in LDS;
-                          // -0.35 ms per 256^3 step), 1 = k_trans1_fold (records in registers, 28 spilled: break-even), 0 = two k_riemann1
-                          // launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
+int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: != 0 = k_trans1_fold_lds (records parked in LDS;
+                          // -0.35 ms per 256^3 step), 0 = two k_riemann1 launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
 int g_side_stream = 0;    // 1: k_divu runs on the context's side stream beside the trace kernel (CASTRO_AMD_SIDE_STREAM); measured: no gain,
                           // two independent pipelines on two streams take as long as one after the other (tools/concurrency_probe.py)
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
@@ -2939,57 +2567,9 @@ static LinBox linbox2(const int lo[3], const int hi[3], long& n)
         }                                                                                    \
     } while (0)
 
-// brick geometry for a launch over [lo,hi]: x-tiles of equal width (at most 64 faces), the rows of a 256-thread
-// workgroup arranged ty x tz as squarely as the box allows; CASTRO_AMD_BRICK="tx2,ty,tz" overrides.
-// grow[a][d]: extra extent of staged array a in direction d (0, 1 or 2)
-int g_brick[3] = { 0, 0, 0 };
 int g_xpad = 0;            // see capi.hip scratch_nx
-int g_final_lds = 0;       // 1: k_final_lds (transverse flux records staged in LDS; measured slower)
 int g_fused_tile_rows = 16; // rows per y-tile of the k_finalx_consup row order (0: plain)
-int g_march_planes = 32;  // planes per chunk of k_finalxz_consup
-int g_trace_split = 0;    // experiment: 1 = one trace launch per direction, 2 = x and y+z
 int g_fuse_consup = 1;    // 1: k_finalx_consup (the x faces of the final stage and consup_hydro in one kernel)
-int g_brick_lds_budget = 80 * 1024;     // bytes of LDS per workgroup: two workgroups per CU
-static Brick make_brick(const int lo[3], const int hi[3], const int grow[2][3], size_t& lds_bytes)
-{
-    Brick b;
-    int n[3];
-    for (int d = 0; d < 3; ++d) { b.lo[d] = lo[d]; b.hi[d] = hi[d]; n[d] = hi[d] - lo[d] + 1; }
-    auto lds_of = [&](int tx2, int ty, int tz) {
-        size_t doubles = 0;
-        for (int a = 0; a < 2; ++a)
-            doubles += (size_t)NF1 * ((2 * tx2 + grow[a][0] + 1) & ~1) * (ty + grow[a][1]) * (tz + grow[a][2]);
-        return doubles * sizeof(double);
-    };
-    if (g_brick[0] > 0) { b.tx2 = g_brick[0]; b.ty = g_brick[1]; b.tz = g_brick[2]; }
-    else {
-        const int pairs = (n[0] + 1) / 2;
-        const int ntx = (pairs + 31) / 32;
-        b.tx2 = (pairs + ntx - 1) / ntx;
-        const int rows = 256 / b.tx2;
-        double best = -1.0;
-        b.ty = b.tz = 1;
-        for (int tz = 1; tz <= rows && tz <= n[2]; ++tz)
-            for (int ty = 1; ty * tz <= rows && ty <= n[1]; ++ty) {
-                if (lds_of(b.tx2, ty, tz) > (size_t)g_brick_lds_budget) continue;
-                // faces per workgroup over the halo factor of the staged records
-                const double score = (double)(ty * tz) * (double)(ty * tz) / (double)((ty + 1) * (tz + 1));
-                if (score > best) { best = score; b.ty = ty; b.tz = tz; }
-            }
-    }
-    b.ntx = (n[0] + 2 * b.tx2 - 1) / (2 * b.tx2);
-    b.nty = (n[1] + b.ty - 1) / b.ty;
-    b.ntz = (n[2] + b.tz - 1) / b.tz;
-    b.nb = ((unsigned)(b.ntx * b.nty * b.ntz) + 7u) & ~7u;
-    for (int a = 0; a < 2; ++a) {
-        b.exs[a] = (2 * b.tx2 + grow[a][0] + 1) & ~1;
-        b.ey[a] = b.ty + grow[a][1];
-        b.ez[a] = b.tz + grow[a][2];
-    }
-    lds_bytes = lds_of(b.tx2, b.ty, b.tz);
-    return b;
-}
-
 // outer box minus inner box as up to six slabs: z slabs over the full x,y extent, y slabs over the inner z range,
 // x slabs over the inner y,z range (thin in x: a wavefront then covers many rows, no idle lanes)
 static int shell_boxes(const int olo[3], const int ohi[3], const int ilo[3], const int ihi[3], int lo[6][3], int hi[6][3])
@@ -3051,16 +2631,6 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         // the trace launch and the block-start fix-up share one workgroup order: both see the trace's rows per y-tile
         struct RowsGuard { int keep; RowsGuard() : keep(tl_tile_rows) { if (g_trace_tile_rows >= 0) tl_tile_rows = g_trace_tile_rows; }
                            ~RowsGuard() { tl_tile_rows = keep; } } rows_guard;
-#ifdef EXPERIMENT_TRACE_SPLIT       // tools/build_variant.sh split "-DEXPERIMENT_TRACE_SPLIT"; measured slower, DESIGN.md section 9
-        if (g_trace_split == 1) {
-            KL2("k_trace_x", (k_trace_pair<true, 1>), lo, hi, S.Q, S, g, dt, P, none);
-            KL2("k_trace_y", (k_trace_pair<false, 2>), lo, hi, S.Q, S, g, dt, P, none);
-            KL2("k_trace_z", (k_trace_pair<false, 4>), lo, hi, S.Q, S, g, dt, P, none);
-        } else if (g_trace_split == 2) {
-            KL2("k_trace_x", (k_trace_pair<true, 1>), lo, hi, S.Q, S, g, dt, P, none);
-            KL2("k_trace_yz", (k_trace_pair<false, 6>), lo, hi, S.Q, S, g, dt, P, none);
-        } else
-#endif
         {
 #define K_(V) (k_trace_pair<true, 7, V>)
             KL2_SOLV("k_trace", K_, lo, hi, S.Q, S, g, dt, P, none);
@@ -3124,7 +2694,6 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // the join must precede the first reader of DIV (and every return path after this point)
     auto join_divu = [&]() { if (divu_forked) { hipStreamWaitEvent(stream, aux.ev_join, 0); divu_forked = false; } };
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
-    bool trace_single_done = false;
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
@@ -3134,12 +2703,6 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
         else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none); }
-        else if (g_trace_single && !second_half) {
-            // experiment (CASTRO_AMD_TRACE_SINGLE=1): one zone per thread (153 VGPRs, three waves per SIMD), the first x solve as
-            // a k_riemann1 launch of its own
-            KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P);
-            trace_single_done = true;
-        }
         else if (second_half) {
             if (inner_ok) {
                 const int ns = shell_boxes(olo, ohi, inner_box.lo, inner_box.hi, slo, shi);
@@ -3156,14 +2719,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         } else {
             trace_with_xriemann(olo, ohi);
         }
-        x_done = P.ppm_type != 0 && !tfix && !trace_single_done;
+        x_done = P.ppm_type != 0 && !tfix;
     }
     (void)staged;
 
     // the first y / z solves folded into the transverse stage (k_trans1_fold): default solver set, default final-stage form
     const bool fold_r1 = g_fold_r1 && solv == 0 && !tfix && P.reset_rhoe != 1 && g_fuse_consup;
-    // the LDS-brick and z-marching forms of the final stage (experiments, off by default) take dt by value only
-    if (P.dtp && (g_fuse_consup == 2 || (!g_fuse_consup && g_final_lds))) return -2;
     if (tfix) {
         KL2("k_riemann1", (k_riemann1<0, true>), flo[0], fhi[0], S.Q, S, g, P);
         KL2("k_riemann1", (k_riemann1<1, true>), flo[1], fhi[1], S.Q, S, g, P);
@@ -3196,30 +2757,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     } while (0)
     // the flux limiters (non-default too) share one extra pair of instantiations: both flags are tested inside
     const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
-    // default options: the final stage stages its transverse flux records in LDS (k_final_lds)
-#define FINAL_LDS(NN, LIM, h1, h2, ar)                                                                           \
-    do {                                                                                                          \
-        constexpr int T1_ = (NN == 0) ? 1 : 0, T2_ = (NN == 2) ? 1 : 2;                                           \
-        int grow_[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };                                                           \
-        grow_[0][NN] += 1; grow_[0][T1_] += 1; grow_[1][NN] += 1; grow_[1][T2_] += 1;                             \
-        size_t lds_;                                                                                              \
-        Brick b_ = make_brick(nlo[NN], nhi[NN], grow_, lds_);                                                     \
-        static const bool attr_ = (hipFuncSetAttribute((const void*)k_final_lds<NN, LIM>,                         \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
-        (void)attr_;                                                                                              \
-        prof_begin(prof, NN == 0 ? "k_final_x" : NN == 1 ? "k_final_y" : "k_final_z", stream);                    \
-        hipLaunchKernelGGL((k_final_lds<NN, LIM>), dim3(b_.nb), dim3(256), lds_, stream, t, b_, S.Q, S, g, Sborder, \
-                           fluxes[NN], mass[NN], qe[NN], h1, h2, dt, ar, g.dx[NN], acc_hi[NN], (flags & 2) ? 1 : 0, P); \
-        prof_end(prof, stream);                                                                                   \
-    } while (0)
     if (P.reset_rhoe == 1 || tfix) { if (lim) TRANSVERSE_STAGES(true, true); else TRANSVERSE_STAGES(true, false); }
     else if (g_fuse_consup) {
         // y and z first (they write FL[1], FL[2]), then the x faces with the conservative update fused in
-#ifdef EXPERIMENT_TRANS1_SPLIT     // one launch per normal direction (46 instead of 114 concurrent planes): DESIGN.md section 9
-        KL2("k_trans1_x", (k_trans1<false, 1>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-        KL2("k_trans1_y", (k_trans1<false, 2>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-        KL2("k_trans1_z", (k_trans1<false, 4>), olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-#else
         if (fold_r1) {
             long n_;
             struct RowsGuard2 { int keep; RowsGuard2() : keep(tl_tile_rows) { if (g_fold_tile_rows >= 0) tl_tile_rows = g_fold_tile_rows; }
@@ -3227,63 +2767,25 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             LinBox b_ = linbox2(olo, ohi, n_);
             if (n_ > 0) {
                 prof_begin(prof, "k_trans1_fold", stream);
-                if (g_fold_r1 == 2) {
-#ifndef FOLD_WG_SYNC
-                    b_.nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));   // 63 new slots per wave, see fold_thread
-#else
-                    b_.nb = (unsigned)((n_ + 254) / 255);        // 255 new slots per workgroup, see fold_thread_wg
-#endif
-                    if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
-                    hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(FOLD_WG), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-                } else {
-                    const long waves_ = (n_ + 62) / 63;          // 63 new slots per wave, see fold_thread
-                    b_.nb = (unsigned)((waves_ + 3) / 4);
-                    if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
-                    hipLaunchKernelGGL(k_trans1_fold<0>, dim3(b_.nb), dim3(256), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-                }
+                b_.nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));   // 63 new slots per wave, see fold_thread
+                if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
+                hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(FOLD_WG), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
                 prof_end(prof, stream);
             }
         } else
         KL2_SOLV("k_trans1", K_T1, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-#endif
-        if (g_fuse_consup == 2) {
-        } else if (lim) {
+        // kFluxOutConsup: whole-box calls in assign mode with both flux arrays present (a tile whose high y / z faces belong
+        // to its neighbour would read fluxes another launch writes)
+        const bool flux_out_consup = kFluxOutConsup && (flags & 2) && !lim && fluxes[1].p && fluxes[2].p &&
+                                     acc_hi[1] == t.hi[1] + 1 && acc_hi[2] == t.hi[2] + 1;
+        const int assign_yz = ((flags & 2) ? 1 : 0) | (flux_out_consup ? 2 : 0);
+        if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
             KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
-        } else if (g_final_yz && solv == 0) {
-            const int ulo[3] = { t.lo[0], t.lo[1], t.lo[2] }, uhi[3] = { t.hi[0], t.hi[1] + 1, t.hi[2] + 1 };
-            KL2("k_final_yz", k_final_yz<0>, ulo, uhi, S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], fluxes[2], mass[2], qe[2],
-                hdtdx, hdtdy, hdtdz, dt, area1, area2, acc_hi[1], acc_hi[2], (flags & 2) ? 1 : 0, P);
         } else {
             struct WgGuard { unsigned keep; WgGuard() : keep(tl_wg) { if (g_final_wg > 0) tl_wg = (unsigned)g_final_wg; } ~WgGuard() { tl_wg = keep; } } wg_guard;
-            KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
-            KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
-        }
-        if (g_fuse_consup == 2) {
-            // k_final<y> (writes FL[y]), then the z and x faces and the conservative update marching along z
-            if (lim) KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
-            else KL2("k_final_y", (k_final<1, false, false>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
-            XZRows xz;
-            for (int d = 0; d < 3; ++d) xz.lo[d] = t.lo[d];
-            xz.hi0 = t.hi[0]; xz.hi2 = t.hi[2];
-            const int nx_ = t.hi[0] - t.lo[0] + 1, nz_ = t.hi[2] - t.lo[2] + 1;
-            xz.nslot = (nx_ + 1) / 2 + 1; xz.ny = t.hi[1] - t.lo[1] + 1;
-            xz.mz = g_march_planes < nz_ ? g_march_planes : nz_;
-            xz.nchunk = (nz_ + xz.mz - 1) / xz.mz;
-            xz.ty = g_fused_tile_rows;
-            const long slots_ = (long)xz.nslot * xz.ny * xz.nchunk;
-            xz.nb = ((unsigned)(((slots_ + 62) / 63 + 3) / 4) + 7u) & ~7u;
-            const double vol2_ = g.dx[0] * g.dx[1] * g.dx[2];
-            prof_begin(prof, "k_finalxz_consup", stream);
-#define FXZ(LIM, CLEAN, nt, rd)                                                                                          \
-            hipLaunchKernelGGL((k_finalxz_consup<LIM, CLEAN>), dim3(xz.nb), dim3(256), 0, stream, t, xz, S.Q, S, g, Sborder, \
-                               fluxes[0], mass[0], qe[0], fluxes[2], mass[2], qe[2], Snew, hdtdx, hdtdy, hdtdz, dt,      \
-                               area0, area1, area2, vol2_, acc_hi[0], acc_hi[2], (flags & 2) ? 1 : 0, (flags & 1) ? 1 : 0, P, nt, rd)
-            if (clean_ntimes > 0) { if (lim) FXZ(true, true, clean_ntimes, red); else FXZ(false, true, clean_ntimes, red); }
-            else { if (lim) FXZ(true, false, 0, (double*)nullptr); else FXZ(false, false, 0, (double*)nullptr); }
-#undef FXZ
-            prof_end(prof, stream);
-            return hipGetLastError() == hipSuccess ? 0 : -4;
+            KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], assign_yz, P);
+            KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], assign_yz, P);
         }
         XRows xr;
         for (int d = 0; d < 3; ++d) xr.lo[d] = t.lo[d];
@@ -3300,7 +2802,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 #define FXC(LIM, CLEAN, GENF, nt, rd)                                                                                        \
         hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN, GENF>), dim3(xr.nb), dim3(64u * xr.wv), 0, stream, t, xr, S.Q, S, g, Sborder,      \
                            fluxes[0], mass[0], qe[0], Snew, hdtdy, hdtdz, dt, area0, area1, area2, vol_, acc_hi[0],      \
-                           (flags & 2) ? 1 : 0, (flags & 1) ? 1 : 0, P, nt, rd)
+                           assign_yz, (flags & 1) ? 1 : 0, P, nt, rd, fluxes[1], fluxes[2])
         if (clean_ntimes > 0) {
             if (lim) FXC(true, true, 2, clean_ntimes, red);
             else if (solv == 2) FXC(false, true, 2, clean_ntimes, red);
@@ -3316,13 +2818,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         prof_end(prof, stream);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    else if (g_final_lds) {
-        KL2("k_trans1", k_trans1<false>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-        if (lim) { FINAL_LDS(0, true, hdtdy, hdtdz, area0); FINAL_LDS(1, true, hdtdx, hdtdz, area1); FINAL_LDS(2, true, hdtdx, hdtdy, area2); }
-        else { FINAL_LDS(0, false, hdtdy, hdtdz, area0); FINAL_LDS(1, false, hdtdx, hdtdz, area1); FINAL_LDS(2, false, hdtdx, hdtdy, area2); }
-    }
     else { if (lim) TRANSVERSE_STAGES(false, true); else TRANSVERSE_STAGES(false, false); }
-#undef FINAL_LDS
 #undef TRANSVERSE_STAGES
 
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];

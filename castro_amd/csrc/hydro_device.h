@@ -7,6 +7,47 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Numerics modes.  The default build is `exact`: -ffp-contract=off, IEEE division and sqrt, bit-identical
+// to the CPU restatement of the reference the tests check against.  The `contract` build (-DCAD_NUMERICS_CONTRACT with
+// -ffp-contract=fast -fassociative-math) additionally replaces the divisions and square roots of the hot device functions by
+// frcp / fdiv / fsqrt below -- v_rcp_f64 / v_rsq_f64 plus Newton steps, <= 1.5 ulp, no range scaling -- at the sites whose
+// operands are bounded away from the denormal and overflow ranges by the floors of the scheme (every call site says by which);
+// all other divisions and roots stay IEEE.  Agreement with `exact`: rtol 1e-10 on every plotfile field (tests/test_gpu_contract.py).
+namespace cad {
+#ifdef CAD_NUMERICS_CONTRACT
+constexpr bool kContract = true;
+// 1 / b for 2^-1000 <= |b| <= 2^1000 (v_rcp_f64 is good to ~24 bits; two Newton steps)
+__device__ __forceinline__ double frcp(double b)
+{
+    double x = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, x, 1.0);
+    x = __builtin_fma(e, x, x);
+    e = __builtin_fma(-b, x, 1.0);
+    return __builtin_fma(e, x, x);
+}
+__device__ __forceinline__ double fdiv(double a, double b) { return a * frcp(b); }
+// sqrt(x) for x = 0 or 2^-767 <= x < inf (the bound above which LLVM's own lowering uses v_rsq_f64 unscaled): one Goldschmidt
+// step and one residual correction on v_rsq_f64; +-0 and +inf return themselves, negative and NaN inputs give NaN
+__device__ __forceinline__ double fsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260 /* +-0, +inf */) ? x : g;
+}
+#else
+constexpr bool kContract = false;
+__device__ __forceinline__ double frcp(double b) { return 1.0 / b; }
+__device__ __forceinline__ double fdiv(double a, double b) { return a / b; }
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+#endif
+}
+
 namespace cad {
 
 // state / primitive indices of the Sedov build
@@ -113,7 +154,7 @@ __device__ __forceinline__ double flatten_1d(const double p[7], const double u[5
     const bool up = dp > 0.0;                 // ishft = up ? 1 : -1
 
     double denom = amax_hw(small_pres, fabs(p[5] - p[1]));     // positive constant first
-    double zeta = fabs(dp) / denom;
+    double zeta = fdiv(fabs(dp), denom);             // denom >= 1e-200
     double z = amin_hw(1.0, amax_hw(0.0, dzcut * (zeta - zcut1)));      // constants first; amax(+0, -0) = +0 in both forms
 
     double tst = 0.0;
@@ -135,7 +176,7 @@ __device__ __forceinline__ double flatten_1d(const double p[7], const double u[5
     dp = pp1 - pm1;
 
     denom = amax_hw(small_pres, fabs(pp2 - pm2));
-    zeta = fabs(dp) / denom;
+    zeta = fdiv(fabs(dp), denom);
     double z2 = amin_hw(1.0, amax_hw(0.0, dzcut * (zeta - zcut1)));
 
     tst = 0.0;
@@ -270,13 +311,13 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
             rX = amax(P.small_x * rho, amin(rho, rX));
             double rhoX_sum = 0.0;
             rhoX_sum += rX;
-            double fac = rho / rhoX_sum;
+            double fac = fdiv(rho, rhoX_sum);          // rhoX_sum >= small_x * rho, rho >= small_dens
             rX *= fac;
         }
 
         // reset_internal_energy
         {
-            double rhoInv = 1.0 / rho;
+            double rhoInv = frcp(rho);                 // rho >= small_dens after enforce_min_density
             double Up = mx * rhoInv;
             double Vp = my * rhoInv;
             double Wp = mz * rhoInv;
@@ -296,7 +337,7 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
 
         // computeTemp
         {
-            double rhoInv = 1.0 / rho;
+            double rhoInv = frcp(rho);
             double e = eint * rhoInv;
             temp = eos_T_of_e(P, e, rX * rhoInv);                            // Castro.cpp:3694
         }
@@ -308,14 +349,15 @@ __device__ __forceinline__ void clean_zone(const DevParams& P, int ntimes, doubl
 __device__ __forceinline__ double zone_dt_cfl(const DevParams& P, double dx0, double dx1, double dx2,
                                               double rho, double mx, double my, double mz, double eint)
 {
-    double rhoInv = 1.0 / rho;
+    // cleaned zones: rho >= small_dens, e >= small_e > 0, so cs is a normal positive number
+    double rhoInv = frcp(rho);
     double e = eint * rhoInv;
     double p = (P.gamma - 1.0) * rho * e;
-    double cs = sqrt(P.gamma * p / rho);
+    double cs = kContract ? fsqrt(P.gamma * p * rhoInv) : sqrt(P.gamma * p / rho);
     double ux = mx * rhoInv, uy = my * rhoInv, uz = mz * rhoInv;
-    double dt1 = dx0 / (cs + fabs(ux));
-    double dt2 = dx1 / (cs + fabs(uy));
-    double dt3 = dx2 / (cs + fabs(uz));
+    double dt1 = fdiv(dx0, cs + fabs(ux));
+    double dt2 = fdiv(dx1, cs + fabs(uy));
+    double dt3 = fdiv(dx2, cs + fabs(uz));
     return amin(amin(dt1, dt2), dt3);
 }
 
@@ -539,10 +581,12 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     double wsmall = P.small_dens * raux.csmall;
 
     // wsmall = small_dens * csmall is finite and >= +0, the square roots are >= +0 or NaN: amax_hw is exact
-    double wl = amax_hw(wsmall, sqrt(fabs(ql.gamc * ql.p * ql.rho)));
-    double wr = amax_hw(wsmall, sqrt(fabs(qr.gamc * qr.p * qr.rho)));
+    // contract: a product below 2^-767 (both floors at work) may come out of fsqrt as a NaN, which amax_hw drops for wsmall;
+    // wl + wr >= 2 small_dens csmall; ro, rstar >= small_dens; co >= csmall >= 1e-8
+    double wl = amax_hw(wsmall, fsqrt(fabs(ql.gamc * ql.p * ql.rho)));
+    double wr = amax_hw(wsmall, fsqrt(fabs(qr.gamc * qr.p * qr.rho)));
 
-    double wwinv = 1.0 / (wl + wr);
+    double wwinv = frcp(wl + wr);
     double pstar = ((wr * ql.p + wl * qr.p) + wl * wr * (ql.un - qr.un)) * wwinv;
     double ustar = ((wl * ql.un + wr * qr.un) + (ql.p - qr.p)) * wwinv;
 
@@ -566,11 +610,11 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
 
     ro = amax_hw(P.small_dens, ro);                // positive parameter first
 
-    double roinv = 1.0 / ro;
+    double roinv = frcp(ro);
 
-    double co = sqrt(fabs(gamco * po * roinv));
+    double co = fsqrt(fabs(gamco * po * roinv));
     co = amax_hw(raux.csmall, co);                 // csmall = amax(small, ...) is a positive finite number
-    double co2inv = 1.0 / (co * co);
+    double co2inv = frcp(co * co);
 
     qint.ut = fp * ql.ut + fm * qr.ut;
     qint.utt = fp * ql.utt + fm * qr.utt;
@@ -582,7 +626,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     double entho = (reo + po) * roinv * co2inv;
     double estar = reo + (pstar - po) * entho;
 
-    double cstar = sqrt(fabs(gamco * pstar / rstar));
+    double cstar = fsqrt(fabs(gamco * fdiv(pstar, rstar)));      // pstar >= small_pres, small_dens <= rstar: far above 2^-767
     cstar = amax(cstar, raux.csmall);
 
     double spout = co - sgnm * uo;
@@ -595,7 +639,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
         spout = ushock;
     }
 
-    double scr = spout - spin;
+    double scr = spout - spin;                     // may be a denormal difference: its division stays IEEE
     if (spout - spin == 0.0) {
         scr = small * raux.cavg;
     }
@@ -1423,7 +1467,7 @@ __device__ __forceinline__ void trans_single(const double q[NEDGE], const double
                                              double fer = 0.0, double fel = 0.0)
 {
     // passive :171-189
-    {
+    if (!kContract) {
         double rrnew = q[PRHO] - cdtdx * (fr[FRHO] - fl[FRHO]);
         double compu = q[PRHO] * q[PX] - cdtdx * (fr[FX] - fl[FX]);
         qo[PX] = compu / rrnew;
@@ -1462,7 +1506,15 @@ __device__ __forceinline__ void trans_single(const double q[NEDGE], const double
     }
 
     qo[PRHO] = rrnewn;
-    double rhoinv = 1.0 / rrnewn;
+    // contract: one reciprocal of the corrected density for the passive and the velocities.  A transverse correction that
+    // leaves |rho| below 2^-1000 of a state of order one does not occur with CFL-limited steps (and with transverse_reset_density
+    // a negative one is reset above).
+    double rhoinv = frcp(rrnewn);
+    if (kContract) {
+        // the passive is divided by the density BEFORE a reset, like the reference's compu / rrnew
+        const double rix = reset_state ? frcp(rrn - cdtdx * (fr[FRHO] - fl[FRHO])) : rhoinv;
+        qo[PX] = (q[PRHO] * q[PX] - cdtdx * (fr[FX] - fl[FX])) * rix;
+    }
     qo[PU] = runewn * rhoinv;
     qo[PV] = rvnewn * rhoinv;
     qo[PW] = rwnewn * rhoinv;
@@ -1495,7 +1547,7 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
                                             const DevParams& P, double qo[NEDGE],
                                             double fe1r = 0.0, double fe1l = 0.0, double fe2r = 0.0, double fe2l = 0.0)
 {
-    {
+    if (!kContract) {
         double rrn = q[PRHO];
         double compn = rrn * q[PX];
         double rrnewn = rrn - cdtdx_t1 * (f1r[FRHO] - f1l[FRHO]) - cdtdx_t2 * (f2r[FRHO] - f2l[FRHO]);
@@ -1540,11 +1592,23 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
     }
 
     qo[PRHO] = rrnewn;
+    double rhoekenn;
+    if (kContract) {
+        // one reciprocal instead of five divisions by the corrected density (see trans_single)
+        const double rhoinv = frcp(rrnewn);
+        const double rix = reset_state ? frcp(rrn - cdtdx_t1 * (f1r[FRHO] - f1l[FRHO]) - cdtdx_t2 * (f2r[FRHO] - f2l[FRHO])) : rhoinv;
+        qo[PX] = (rrn * q[PX] - cdtdx_t1 * (f1r[FX] - f1l[FX]) - cdtdx_t2 * (f2r[FX] - f2l[FX])) * rix;
+        qo[PU] = runewn * rhoinv;
+        qo[PV] = rvnewn * rhoinv;
+        qo[PW] = rwnewn * rhoinv;
+        rhoekenn = 0.5 * (runewn * runewn + rvnewn * rvnewn + rwnewn * rwnewn) * rhoinv;
+    } else {
     qo[PU] = runewn / rrnewn;
     qo[PV] = rvnewn / rrnewn;
     qo[PW] = rwnewn / rrnewn;
 
-    double rhoekenn = 0.5 * (runewn * runewn + rvnewn * rvnewn + rwnewn * rwnewn) / rrnewn;
+    rhoekenn = 0.5 * (runewn * runewn + rvnewn * rvnewn + rwnewn * rwnewn) / rrnewn;
+    }
     qo[PRE] = renewn - rhoekenn;
 
     if (!reset_state) {

@@ -30,11 +30,14 @@ class HipHydro:
 
     name = "hip"
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, numerics=None):
+        """numerics: "exact" | "contract" (None: CASTRO_AMD_NUMERICS, default exact) -- which build of the kernel library
+        this context runs (castro_amd/_lib.py)."""
         if not torch.cuda.is_available():
             raise RuntimeError("castro_amd.HipHydro needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
-        self.lib = L.load()
+        self.lib = L.load(numerics)
+        self.numerics = L.numerics_of(self.lib)
         self.device = torch.device("cuda", device)
         h = C.c_void_p()
         L.check(self.lib.castro_amd_ctx_create(C.byref(h), int(device)), "ctx_create")
@@ -384,6 +387,55 @@ class HipHydro:
         n, lo, hi, off = table
         L.check(self.lib.castro_amd_unpack_regions_fab(self.h, C.byref(L.fab_of(state, *box)), n, lo, hi, off,
                                                        C.c_void_p(buf.data_ptr()), _stream_ptr(stream)), "unpack_regions_fab")
+
+    # ---- FillBoundary on RCCL behind the C ABI (castro_amd/csrc/halo_rccl.hip) -----------------------------------
+    def comm_version(self):
+        return self.lib.castro_amd_comm_version().decode()
+
+    def comm_unique_id(self):
+        """ncclGetUniqueId: 128 bytes for the host to hand to every rank"""
+        buf = C.create_string_buffer(128)
+        L.check(self.lib.castro_amd_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf.raw)
+
+    def comm_create(self, nranks, rank, unique_id):
+        """ncclCommInitRank (collective over the ranks): an opaque castro_amd_comm handle"""
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        L.check(self.lib.castro_amd_comm_create(C.byref(h), int(nranks), int(rank), buf, int(self.device.index or 0)), "comm_create")
+        return h
+
+    def comm_destroy(self, comm):
+        if comm:
+            self.lib.castro_amd_comm_destroy(comm)
+
+    def halo_plan(self, comm, regions, ncomp):
+        """regions: [(peer, sbox (lo, hi), rbox (lo, hi), send_tag, recv_tag)] -> castro_amd_halo_plan handle"""
+        n = len(regions)
+        arr = (L.HaloRegion * max(n, 1))()
+        for r, (peer, sbox, rbox, stag, rtag) in zip(arr, regions):
+            r.peer, r.send_tag, r.recv_tag = int(peer), int(stag), int(rtag)
+            for d in range(3):
+                r.sbox_lo[d], r.sbox_hi[d] = int(sbox[0][d]), int(sbox[1][d])
+                r.rbox_lo[d], r.rbox_hi[d] = int(rbox[0][d]), int(rbox[1][d])
+        h = C.c_void_p()
+        L.check(self.lib.castro_amd_halo_plan_create(C.byref(h), comm, n, arr, int(ncomp)), "halo_plan_create")
+        return h
+
+    def halo_plan_destroy(self, plan):
+        if plan:
+            self.lib.castro_amd_halo_plan_destroy(plan)
+
+    def halo_plan_bytes_sent(self, plan):
+        return int(self.lib.castro_amd_halo_plan_bytes_sent(plan))
+
+    def fill_boundary(self, plan, state, box, geom=None, stream=None):
+        """pack -> grouped ncclSend / ncclRecv -> unpack -> physical BC fill, enqueued on the stream"""
+        L.check(self.lib.castro_amd_fill_boundary(self.h, plan, C.byref(L.fab_of(state, *box)),
+                                                  C.byref(geom) if geom is not None else None, _stream_ptr(stream)), "fill_boundary")
+
+    def allreduce_min_c(self, comm, t, stream=None):
+        L.check(self.lib.castro_amd_allreduce_min(comm, C.c_void_p(t.data_ptr()), int(t.numel()), _stream_ptr(stream)), "allreduce_min")
 
     def sedov_init(self, state, box, lo, hi, geom, params, r_init=0.01, p_ambient=1.e-5, exp_energy=1.0,
                    dens_ambient=1.0, nsub=10, stream=None):

@@ -46,6 +46,15 @@
 extern "C" {
 #endif
 
+/* ABI version of this header: bumped whenever the meaning or the SIZE of anything a caller allocates changes.
+ *   3: reduction vectors (`d_out`) are THREE device doubles (0.2 had two): castro_amd_ctu_hydro_clean_fab,
+ *      castro_amd_ctu_hydro_fab_ex / _mf (opts.d_out), castro_amd_clean_state_reduce_fab.
+ *   4: castro_amd_numerics(), castro_amd_fill_boundary*(), castro_amd_abi_version().
+ * A caller checks `castro_amd_abi_version() == CASTRO_AMD_ABI_VERSION` once after loading the library; a mismatch means
+ * the library was built from another revision of this header (a 0.2 caller with 2-double vectors would be written 8 bytes
+ * out of bounds by a 0.3 library). */
+#define CASTRO_AMD_ABI_VERSION 4
+
 #define CASTRO_AMD_NUM_STATE 8
 #define CASTRO_AMD_NGDNV 4
 #define CASTRO_AMD_NUM_GROW 4
@@ -217,7 +226,7 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx *ctx,
 typedef struct castro_amd_hydro_opts {
     int flags;                  /* CASTRO_AMD_UPDATE_* | CASTRO_AMD_FLUX_ASSIGN | CASTRO_AMD_STAGE_* */
     int clean_ntimes;           /* as in castro_amd_ctu_hydro_clean_fab */
-    double *d_out;              /* as in castro_amd_ctu_hydro_clean_fab (device, 2 doubles) or NULL */
+    double *d_out;              /* as in castro_amd_ctu_hydro_clean_fab (device, THREE doubles) or NULL */
     int sborder_clean_ntimes;   /* see above; 0 = Sborder is read only */
     const double *d_dt;         /* not NULL: castro_amd_step_control's DEVICE vector `ctl` -- the kernels read the time step
                                  * from ctl[CASTRO_AMD_CTL_DTHYDRO] (the `dt` argument is ignored), and when
@@ -504,8 +513,60 @@ int castro_amd_sod_init_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, co
                             double rho_l, double u_l, double p_l, double rho_r, double u_r, double p_r,
                             int idir, double frac, void *stream);
 
+/*
+ * FillBoundary on RCCL: the same-level ghost exchange of AmrLevel::FillPatch as Castro::expand_state uses it
+ * (Source/driver/Castro.cpp:4201-4209) followed by the physical-boundary fill
+ * (Source/problems/Castro_bc_fill_nd.cpp:11-125), for hosts without torch.distributed (castro_amd/csrc/halo_rccl.hip).
+ * One rank per GPU; librccl is bound at run time (dlopen), so a single-GPU host never needs it.
+ *
+ *   castro_amd_comm        an RCCL communicator: created here from a 128-byte unique id that the host distributes with
+ *                          whatever it has (MPI_Bcast, a file, torch.distributed), or adopted from the host's own ncclComm_t;
+ *   castro_amd_halo_plan   the regions of ONE FAB shape (<= 26 neighbours), with the packed send / receive buffers: built
+ *                          once per level and box, reused every step;
+ *   castro_amd_fill_boundary   pack (1 launch) -> ncclGroupStart / ncclRecv.. / ncclSend.. / ncclGroupEnd -> unpack
+ *                          (<= 2 launches) -> physical BC fill, all enqueued on `stream`: nothing synchronises, nothing allocates.
+ *
+ * A region sends the zones `sbox` of this rank's FAB to `peer` and receives the ghost zones `rbox` from the same peer
+ * (equal shapes).  send_tag / recv_tag order the messages between a pair of ranks: the recv_tag of the region that
+ * receives a message must equal the send_tag of the region that sent it (e.g. tag = 1 + ox + 3 (1 + oy) + 9 (1 + oz) of the
+ * direction the message TRAVELS in).  peer == own rank (a periodic wrap onto this rank) is a local copy.
+ */
+typedef struct castro_amd_comm castro_amd_comm;
+typedef struct castro_amd_halo_plan castro_amd_halo_plan;
+#define CASTRO_AMD_UNIQUE_ID_BYTES 128
+typedef struct castro_amd_halo_region {
+    int peer;
+    int sbox_lo[3], sbox_hi[3];
+    int rbox_lo[3], rbox_hi[3];
+    int send_tag, recv_tag;
+} castro_amd_halo_region;
+const char *castro_amd_comm_version(void);                       /* "RCCL x.y.z" of the library bound at run time */
+int castro_amd_comm_unique_id(void *id);                         /* ncclGetUniqueId: id = CASTRO_AMD_UNIQUE_ID_BYTES host bytes */
+int castro_amd_comm_create(castro_amd_comm **out, int nranks, int rank, const void *id, int device);   /* ncclCommInitRank (collective) */
+int castro_amd_comm_adopt(castro_amd_comm **out, void *nccl_comm, int device);   /* wrap the host's ncclComm_t; not destroyed here */
+int castro_amd_comm_rank(const castro_amd_comm *comm);
+int castro_amd_comm_size(const castro_amd_comm *comm);
+int castro_amd_comm_destroy(castro_amd_comm *comm);
+int castro_amd_halo_plan_create(castro_amd_halo_plan **out, castro_amd_comm *comm, int nregions,
+                                const castro_amd_halo_region *regions, int ncomp);
+int castro_amd_halo_plan_destroy(castro_amd_halo_plan *plan);
+long long castro_amd_halo_plan_bytes_sent(const castro_amd_halo_plan *plan);   /* bytes this rank sends to OTHER ranks per exchange */
+/* geom == NULL: no physical-boundary fill (interior boxes of a level, or a caller that fills them itself) */
+int castro_amd_fill_boundary(castro_amd_ctx *ctx, castro_amd_halo_plan *plan, const castro_amd_fab *state,
+                             const castro_amd_geom *geom, void *stream);
+/* ncclAllReduce(MIN) in place on n device doubles: the [dt estimate, min density, ...] reduction of a step */
+int castro_amd_allreduce_min(castro_amd_comm *comm, double *d_buf, int n, void *stream);
+
 /* Library/version introspection */
 const char *castro_amd_version(void);
+/* CASTRO_AMD_ABI_VERSION the library was built with (see the macro above) */
+int castro_amd_abi_version(void);
+/* Numerics mode of this build of the library:
+ *   "exact"    -ffp-contract=off, IEEE division / sqrt: bit-identical to the reference's CPU expression order ;
+ *   "contract" FMA contraction, reciprocal-based division and rsq-based sqrt (<= 1 ulp each): agrees with `exact` to the
+ *              north-star tolerance (rtol 1e-10 on every plotfile field, tests/test_gpu_parity.py) and is faster.
+ * Both builds export the same ABI; castro_amd/_lib.py picks by CASTRO_AMD_NUMERICS. */
+const char *castro_amd_numerics(void);
 /* Name and average device time (ms) of the most recent launch of each hot-path
  * kernel when profiling is enabled with castro_amd_ctx_profile(ctx, 1): the
  * library brackets every kernel with hipEvents on `stream`. */

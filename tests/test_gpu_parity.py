@@ -1131,13 +1131,20 @@ def _rccl_worker(rank, world, port, out_path):
         c.comm.exchange([(0, 5, b), (0, 3, a)], [(0, 3, ra), (0, 5, rb)])
         torch.cuda.synchronize()
         assert torch.equal(ra, a) and torch.equal(rb, b)
-        np.savez(out_path, S=c.S_new().cpu().numpy(), dts=np.array(dts))
+        plan = c._plans.get(id(c.neighbors))
+        np.savez(out_path, S=c.S_new().cpu().numpy(), dts=np.array(dts),
+                 halo_path="c_abi" if plan is not None and "cplan" in plan else "torch")
     finally:
         dist.destroy_process_group()
 
 
-def test_rccl_process_group_of_one_rank(tmp_path):
-    """The collective calls of the N > 1 path on the real backend (backend "nccl" is RCCL here): process-group
+@pytest.mark.parametrize("halo", ["c_abi", "c_abi_self_send", "torch"])
+def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
+    """halo: who issues the exchange -- castro_amd_fill_boundary of the C ABI (round 4: ncclSend / ncclRecv from the kernel
+    library on its own communicator; `self_send`: the periodic wraps onto this rank travel through RCCL as well, so the
+    send / receive path runs on one GPU) or torch.distributed.batch_isend_irecv.  All three must give the same bits.
+
+    The collective calls of the N > 1 path on the real backend (backend "nccl" is RCCL here): process-group
     creation bound to the device, the 2-double all_reduce(MIN) of [dt, min rho] in FP64, barrier, and the grouped
     send/recv of the halo exchange (to itself) -- with a group of one rank, which is all a one-GPU box allows.  Same steps and state as a run without a communicator."""
     import torch
@@ -1145,8 +1152,12 @@ def test_rccl_process_group_of_one_rank(tmp_path):
     import castro_amd
     from tests.test_driver_cpu import _free_port
     out = str(tmp_path / "rccl.npz")
+    monkeypatch.setenv("CASTRO_AMD_C_HALO", "0" if halo == "torch" else "1")
+    monkeypatch.setenv("CASTRO_AMD_HALO_SELF_SEND", "1" if halo == "c_abi_self_send" else "0")
     mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    monkeypatch.setenv("CASTRO_AMD_C_HALO", "0")
     got = np.load(out)
+    assert str(got["halo_path"]) == ("torch" if halo == "torch" else "c_abi")
     c = castro_amd.Castro((24, 16, 32), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
     c.initData("sedov", r_init=0.1, nsub=4)
     dts = [c.step(0.01) for _ in range(7)]
@@ -2013,27 +2024,23 @@ def test_randomised_option_combinations_match_the_oracle():
     assert "mismatching 0" in r.stdout
 
 
-@pytest.mark.parametrize("env", [{"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "0"},
-                                 {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1"},
-                                 {"CASTRO_AMD_FUSE_CONSUP": "0", "CASTRO_AMD_FINAL_LDS": "1", "CASTRO_AMD_BRICK": "5,3,2"},
+@pytest.mark.parametrize("env", [{"CASTRO_AMD_FUSE_CONSUP": "0"},
                                  {"CASTRO_AMD_FUSE_CONSUP": "1", "CASTRO_AMD_XPAD": "12"},
-                                 {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "32"},
-                                 {"CASTRO_AMD_FUSE_CONSUP": "2", "CASTRO_AMD_MARCH_PLANES": "3"},
-                                 {"CASTRO_AMD_FOLD_R1": "1"}, {"CASTRO_AMD_FOLD_R1": "2"}, {"CASTRO_AMD_FOLD_R1": "0"},
-                                 {"CASTRO_AMD_FINAL_YZ": "1"},
+                                 {"CASTRO_AMD_FOLD_R1": "2"}, {"CASTRO_AMD_FOLD_R1": "0"},
                                  {"CASTRO_AMD_WG": "64", "CASTRO_AMD_FUSED_WG": "64"},
                                  {"CASTRO_AMD_WG": "128", "CASTRO_AMD_FINAL_WG": "64", "CASTRO_AMD_FUSED_WG": "256"}],
-                         ids=["plain-final-and-consup", "lds-final", "lds-final-small-bricks", "fused-x-consup-padded-rows",
-                              "z-marching", "z-marching-short-chunks", "first-yz-solves-folded-into-trans1", "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches", "final-y-and-z-in-one-launch",
+                         ids=["plain-final-and-consup", "fused-x-consup-padded-rows",
+                              "first-yz-solves-folded-lds-parked", "first-yz-solves-as-launches",
                               "one-wave-workgroups", "mixed-workgroup-sizes"])
 def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
-    """The final stage has three forms: k_final<x,y,z> + k_consup (round 1), k_final_lds (transverse flux records staged
-    in LDS bricks; measured slower, kept as the measured experiment of DESIGN.md section 9) and the default
-    k_final<y,z> + k_finalx_consup.  Each must match the oracle bit for bit, odd extents and several tiles included."""
+    """The forms of the transverse and final stages that remain selectable: k_final<x,y,z> + k_consup (round 1; what the
+    non-default option sets run) against the default k_final<y,z> + k_finalx_consup, the first y / z solves as k_riemann1
+    launches + k_trans1 against the default k_trans1_fold_lds, padded scratch rows, other workgroup sizes.  Each must match
+    the oracle bit for bit, odd extents and several tiles included.  (The LDS-brick, z-marching, register-resident fold and
+    one-launch y+z forms of rounds 2-3 were measured, lost and removed in round 4: profiles/EXPERIMENTS.md.)"""
     import castro_amd
     from castro_amd.hydro import HipHydro
-    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_FINAL_LDS", "CASTRO_AMD_BRICK", "CASTRO_AMD_XPAD", "CASTRO_AMD_MARCH_PLANES",
-            "CASTRO_AMD_FOLD_R1", "CASTRO_AMD_FINAL_YZ", "CASTRO_AMD_WG", "CASTRO_AMD_FINAL_WG", "CASTRO_AMD_FUSED_WG")
+    keys = ("CASTRO_AMD_FUSE_CONSUP", "CASTRO_AMD_XPAD", "CASTRO_AMD_FOLD_R1", "CASTRO_AMD_WG", "CASTRO_AMD_FINAL_WG", "CASTRO_AMD_FUSED_WG")
     old = {k: os.environ.get(k) for k in keys}
     try:
         os.environ.update(env)
@@ -2063,12 +2070,8 @@ def test_alternative_final_stage_kernels_are_bit_exact(oracle, env):
             else:
                 os.environ[k] = v
         os.environ.setdefault("CASTRO_AMD_XPAD", "0")
-        for k, v in (("CASTRO_AMD_FUSE_CONSUP", "1"), ("CASTRO_AMD_FINAL_LDS", "0")):
-            os.environ[k] = v
-        os.environ["CASTRO_AMD_BRICK"] = "0,0,0"
-        os.environ["CASTRO_AMD_MARCH_PLANES"] = "32"
+        os.environ["CASTRO_AMD_FUSE_CONSUP"] = "1"
         os.environ["CASTRO_AMD_FOLD_R1"] = old["CASTRO_AMD_FOLD_R1"] if old["CASTRO_AMD_FOLD_R1"] is not None else LIB_DEFAULT_FOLD_R1
-        os.environ["CASTRO_AMD_FINAL_YZ"] = old["CASTRO_AMD_FINAL_YZ"] if old["CASTRO_AMD_FINAL_YZ"] is not None else "0"
         for k, v in (("CASTRO_AMD_WG", LIB_DEFAULT_WG), ("CASTRO_AMD_FINAL_WG", LIB_DEFAULT_WG), ("CASTRO_AMD_FUSED_WG", LIB_DEFAULT_FUSED_WG)):
             os.environ[k] = old[k] if old[k] is not None else v
         HipHydro(0).close()                   # restore the library's defaults for the tests that follow

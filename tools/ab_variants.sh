@@ -3,7 +3,7 @@
 for rep in 1 2; do
 for v in default $(ls castro_amd/libvariant_*.so 2>/dev/null); do
   if [ "$v" = default ]; then unset CASTRO_AMD_LIB; else export CASTRO_AMD_LIB=$PWD/$v; fi
-  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-contract-leg 2>/dev/null | python -c "
+  python bench.py --numerics exact --steps 10 --warmup 3 --no-cpu-baseline --no-contract-leg --no-extras 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k={a: b['ms_per_step'] for a, b in d['roofline']['kernel_utilisation'].items()}; print('$v', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items()})"
 done; done

@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_p$i -- python3 $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_p$i.log 2>&1 || tail -3 $OUT/${TAG}_p$i.log
+  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_p$i -- python3 $REPO/bench.py --numerics exact --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-contract-leg > $OUT/${TAG}_p$i.log 2>&1 || tail -3 $OUT/${TAG}_p$i.log
 done
 cd $REPO
 python3 - <<PY
