@@ -26,6 +26,7 @@ struct castro_amd_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     FabOpsArena ops_arena;                          // device table of castro_amd_fab_ops_p calls with more than 16 operations
+    FabOpsArena level_arena;                        // device table of a level-wide hydro launch (castro_amd_ctu_hydro_mf)
     hipEvent_t mf_fork = nullptr, mf_join = nullptr;   // castro_amd_ctu_hydro_mf: fork from / join to the caller's stream
 };
 
@@ -247,6 +248,7 @@ void castro_amd_ctx_destroy(castro_amd_ctx* c)
     if (c->mf_fork) hipEventDestroy(c->mf_fork);
     if (c->mf_join) hipEventDestroy(c->mf_join);
     if (c->ops_arena.p) hipFree(c->ops_arena.p);
+    if (c->level_arena.p) hipFree(c->level_arena.p);
     prof_collect(&c->prof);
     for (auto e : c->prof.pool) hipEventDestroy(e);
     if (c->arena) hipFree(c->arena);
@@ -313,18 +315,23 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx* c, const int bxlo[3], const i
                                        geom, params, time, dt, &o, stream);
 }
 
-int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3],
-                                const int vbxlo[3], const int vbxhi[3],
-                                const castro_amd_fab* Sborder, const castro_amd_fab* src,
-                                const castro_amd_fab* S_new, const castro_amd_fab flux_out[3],
-                                const castro_amd_fab mass_flux_out[3], const castro_amd_fab qe_out[3],
-                                const castro_amd_geom* geom, const castro_amd_params* params,
-                                double time, double dt, const castro_amd_hydro_opts* opts, void* stream)
+// One box of a hydro call, checked and translated: what castro_amd_ctu_hydro_fab_ex and the level-wide launch of
+// castro_amd_ctu_hydro_mf have in common.
+struct PreparedBox {
+    Tile t;
+    DFab dS, dN, dSrc, dF[3], dM[3], dQ[3], dCorr;
+    int acc_hi[3];
+    int nx, ny, nz;
+    bool reset_rhoe;
+};
+
+static int prepare_box(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3], const int vbxlo[3], const int vbxhi[3],
+                       const castro_amd_fab* Sborder, const castro_amd_fab* src, const castro_amd_fab* S_new,
+                       const castro_amd_fab flux_out[3], const castro_amd_fab mass_flux_out[3], const castro_amd_fab qe_out[3],
+                       const castro_amd_geom* geom, const castro_amd_params* params, const castro_amd_hydro_opts* opts, PreparedBox& B)
 {
-    (void)time;
     if (!opts) return CASTRO_AMD_ERR_ARG;
     const int flags = opts->flags, clean_ntimes = opts->clean_ntimes, sb_clean = opts->sborder_clean_ntimes;
-    double* d_out = opts->d_out;
     if (clean_ntimes < 0 || sb_clean < 0) return CASTRO_AMD_ERR_ARG;
     if (sb_clean > 0) {
         // in-place cleaning of Sborder: whole-box calls only, never staged (see the header)
@@ -341,7 +348,7 @@ int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int 
     if (params->hybrid_riemann != 0 && params->hybrid_riemann != 1) return CASTRO_AMD_ERR_ARG;
     if (params->ppm_temp_fix < 0 || params->ppm_temp_fix > 2) return CASTRO_AMD_ERR_ARG;    // 1 is a no-op in the CTU path
 
-    Tile t;
+    Tile& t = B.t;
     int glo[3], ghi[3];
     for (int d = 0; d < 3; ++d) {
         if (bxhi[d] < bxlo[d]) return CASTRO_AMD_ERR_ARG;
@@ -350,6 +357,7 @@ int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int 
         ghi[d] = bxhi[d] + CASTRO_AMD_NUM_GROW;
     }
     const int nx = bxhi[0] - bxlo[0] + 1, ny = bxhi[1] - bxlo[1] + 1, nz = bxhi[2] - bxlo[2] + 1;
+    B.nx = nx; B.ny = ny; B.nz = nz;
     t.glo[0] -= g_xpad;
     t.NX = scratch_nx(nx); t.NY = ny + 8; t.NZ = nz + 8;
     t.NC = (long)plane_doubles(nx, ny, nz);
@@ -376,14 +384,39 @@ int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int 
         for (int d = 0; d < 3; ++d) { s3lo[d] = bxlo[d] - 3; s3hi[d] = bxhi[d] + 3; }
         if (src->ncomp < 6 || !fab_contains(src, s3lo, s3hi)) return CASTRO_AMD_ERR_ARG;
     }
+    B.reset_rhoe = params->transverse_reset_rhoe == 1;
+    B.dS = to_dfab(Sborder); B.dN = to_dfab(S_new); B.dSrc = to_dfab(src);
+    for (int d = 0; d < 3; ++d) {
+        int flo[3] = { bxlo[0], bxlo[1], bxlo[2] }, fhi[3] = { bxhi[0], bxhi[1], bxhi[2] };
+        fhi[d] += 1;
+        // mfi.nodaltilebox(d): the high face belongs to this tile only at the valid box's high end
+        B.acc_hi[d] = bxhi[d] + 1;
+        if (vbxhi && B.acc_hi[d] <= vbxhi[d]) B.acc_hi[d] -= 1;
+        fhi[d] = B.acc_hi[d];
+        const castro_amd_fab* f = flux_out ? &flux_out[d] : nullptr;
+        const castro_amd_fab* m = mass_flux_out ? &mass_flux_out[d] : nullptr;
+        const castro_amd_fab* q = qe_out ? &qe_out[d] : nullptr;
+        if (f && f->p && (f->ncomp != NUM_STATE || !fab_contains(f, flo, fhi))) return CASTRO_AMD_ERR_ARG;
+        if (m && m->p && (m->ncomp != 1 || !fab_contains(m, flo, fhi))) return CASTRO_AMD_ERR_ARG;
+        if (q && q->p && (q->ncomp != NGDNV || !fab_contains(q, flo, fhi))) return CASTRO_AMD_ERR_ARG;
+        B.dF[d] = to_dfab(f); B.dM[d] = to_dfab(m); B.dQ[d] = to_dfab(q);
+    }
+    B.dCorr = to_dfab(nullptr);
+    // the reference always has source_corrector defined when the predictor is on (Castro_advance_ctu.cpp:60-62):
+    // running without it would silently drop the predictor
+    if (params->source_term_predictor == 1 && src && src->p && !c->src_corr.p) return CASTRO_AMD_ERR_ARG;
+    if (params->source_term_predictor == 1 && c->src_corr.p && src && src->p) {
+        int s3lo[3], s3hi[3];
+        for (int d = 0; d < 3; ++d) { s3lo[d] = bxlo[d] - 3; s3hi[d] = bxhi[d] + 3; }
+        if (!fab_contains(&c->src_corr, s3lo, s3hi)) return CASTRO_AMD_ERR_ARG;
+        B.dCorr = to_dfab(&c->src_corr);
+    }
+    return CASTRO_AMD_OK;
+}
 
-    hipSetDevice(c->device);
-    const bool reset_rhoe = params->transverse_reset_rhoe == 1;
-    int rc = reserve_planes(c, nx, ny, nz, kPlanes + (reset_rhoe ? kPlanesResetRhoe : 0));
-    if (rc != CASTRO_AMD_OK) return rc;
-
-    DevScratch S;
-    double* p = c->arena;
+// the scratch arrays of one box, carved from p; returns the first double behind them
+static double* carve_scratch(double* p, const Tile& t, bool reset_rhoe, DevScratch& S)
+{
     const size_t NC = (size_t)t.NC;
     S.Q = p; p += NC * NPRIM;
     S.DIV = p; p += NC;
@@ -395,44 +428,33 @@ int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int 
     for (int d = 0; d < 3; ++d) { S.FL[d] = p; p += NC * NFIN; }
     for (int d = 0; d < 3; ++d) { S.F1E[d] = reset_rhoe ? p : nullptr; if (reset_rhoe) p += NC; }
     for (int d = 0; d < 6; ++d) { S.F2E[d] = reset_rhoe ? p : nullptr; if (reset_rhoe) p += NC; }
+    return p;
+}
 
-    DFab dS = to_dfab(Sborder), dN = to_dfab(S_new);
-    DFab dF[3], dM[3], dQ[3];
-    int acc_hi[3];
-    for (int d = 0; d < 3; ++d) {
-        int flo[3] = { bxlo[0], bxlo[1], bxlo[2] }, fhi[3] = { bxhi[0], bxhi[1], bxhi[2] };
-        fhi[d] += 1;
-        // mfi.nodaltilebox(d): the high face belongs to this tile only at the valid box's high end
-        acc_hi[d] = bxhi[d] + 1;
-        if (vbxhi && acc_hi[d] <= vbxhi[d]) acc_hi[d] -= 1;
-        (void)vbxlo;
-        fhi[d] = acc_hi[d];
-        const castro_amd_fab* f = flux_out ? &flux_out[d] : nullptr;
-        const castro_amd_fab* m = mass_flux_out ? &mass_flux_out[d] : nullptr;
-        const castro_amd_fab* q = qe_out ? &qe_out[d] : nullptr;
-        if (f && f->p && (f->ncomp != NUM_STATE || !fab_contains(f, flo, fhi))) return CASTRO_AMD_ERR_ARG;
-        if (m && m->p && (m->ncomp != 1 || !fab_contains(m, flo, fhi))) return CASTRO_AMD_ERR_ARG;
-        if (q && q->p && (q->ncomp != NGDNV || !fab_contains(q, flo, fhi))) return CASTRO_AMD_ERR_ARG;
-        dF[d] = to_dfab(f); dM[d] = to_dfab(m); dQ[d] = to_dfab(q);
-    }
-
-    DFab dCorr = to_dfab(nullptr);
-    // the reference always has source_corrector defined when the predictor is on (Castro_advance_ctu.cpp:60-62):
-    // running without it would silently drop the predictor
-    if (params->source_term_predictor == 1 && src && src->p && !c->src_corr.p) return CASTRO_AMD_ERR_ARG;
-    if (params->source_term_predictor == 1 && c->src_corr.p && src && src->p) {
-        int s3lo[3], s3hi[3];
-        for (int d = 0; d < 3; ++d) { s3lo[d] = bxlo[d] - 3; s3hi[d] = bxhi[d] + 3; }
-        if (!fab_contains(&c->src_corr, s3lo, s3hi)) return CASTRO_AMD_ERR_ARG;
-        dCorr = to_dfab(&c->src_corr);
-    }
+int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3],
+                                const int vbxlo[3], const int vbxhi[3],
+                                const castro_amd_fab* Sborder, const castro_amd_fab* src,
+                                const castro_amd_fab* S_new, const castro_amd_fab flux_out[3],
+                                const castro_amd_fab mass_flux_out[3], const castro_amd_fab qe_out[3],
+                                const castro_amd_geom* geom, const castro_amd_params* params,
+                                double time, double dt, const castro_amd_hydro_opts* opts, void* stream)
+{
+    (void)time;
+    PreparedBox B;
+    int rc = prepare_box(c, bxlo, bxhi, vbxlo, vbxhi, Sborder, src, S_new, flux_out, mass_flux_out, qe_out, geom, params, opts, B);
+    if (rc != CASTRO_AMD_OK) return rc;
+    hipSetDevice(c->device);
+    rc = reserve_planes(c, B.nx, B.ny, B.nz, kPlanes + (B.reset_rhoe ? kPlanesResetRhoe : 0));
+    if (rc != CASTRO_AMD_OK) return rc;
+    DevScratch S;
+    carve_scratch(c->arena, B.t, B.reset_rhoe, S);
     LaunchAux aux;
-    aux.sb_clean = sb_clean;
+    aux.sb_clean = opts->sborder_clean_ntimes;
     aux.side = c->side; aux.ev_fork = c->ev_fork; aux.ev_join = c->ev_join;
     DevParams devP = to_devparams(params);
     devP.dtp = opts->d_dt;
-    return launch_ctu_hydro(t, S, dS, to_dfab(src), dN, dF, dM, dQ, to_devgeom(geom), devP, dt, flags,
-                            acc_hi, c->d_status, (hipStream_t)stream, &c->prof, clean_ntimes, d_out, dCorr, aux);
+    return launch_ctu_hydro(B.t, S, B.dS, B.dSrc, B.dN, B.dF, B.dM, B.dQ, to_devgeom(geom), devP, dt, opts->flags,
+                            B.acc_hi, c->d_status, (hipStream_t)stream, &c->prof, opts->clean_ntimes, opts->d_out, B.dCorr, aux);
 }
 
 int castro_amd_step_control(castro_amd_ctx* c, double* d_red, double* d_ctl, const castro_amd_params* params,
@@ -656,6 +678,46 @@ int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, i
     for (int k = 0; k < nctx; ++k) if (!ctxs[k]) return CASTRO_AMD_ERR_ARG;
     if (nboxes == 0) return CASTRO_AMD_OK;
     hipStream_t main_s = (hipStream_t)stream;
+    // The whole level as ONE grid per kernel (default options, no source terms: launch_ctu_hydro_level): every box gets
+    // its own scratch inside the first context's arena, the per-box arguments travel in a device table, 8 launches on the
+    // caller's stream whatever the number of boxes.  CASTRO_AMD_LEVEL_GRID=0 keeps the per-box launches on nctx streams.
+    {
+        static const bool level_grid = [] { const char* e = std::getenv("CASTRO_AMD_LEVEL_GRID"); return !e || std::atoi(e) != 0; }();
+        bool ok = level_grid && nboxes >= 2;
+        for (int i = 0; i < nboxes && ok; ++i) ok = !(boxes[i].src.p);
+        DevParams devP = to_devparams(params);
+        devP.dtp = opts->d_dt;
+        if (ok && level_launch_supported(devP, opts->flags)) {
+            castro_amd_ctx* c0 = ctxs[0];
+            hipSetDevice(c0->device);
+            std::vector<PreparedBox> pb((size_t)nboxes);
+            size_t need = 0;
+            for (int i = 0; i < nboxes; ++i) {
+                const castro_amd_hydro_box& b = boxes[i];
+                int rc = prepare_box(c0, b.bxlo, b.bxhi, b.vbxlo, b.vbxhi, &b.Sborder, &b.src, &b.S_new, b.flux, b.mass_flux, b.qe,
+                                     geom, params, opts, pb[(size_t)i]);
+                if (rc != CASTRO_AMD_OK) return rc;
+                need += (size_t)pb[(size_t)i].t.NC * (size_t)kPlanes;
+            }
+            if (need > c0->arena_doubles) {
+                if (c0->arena) { hipDeviceSynchronize(); hipFree(c0->arena); c0->arena = nullptr; c0->arena_doubles = 0; }
+                if (hipMalloc(&c0->arena, need * sizeof(double)) != hipSuccess) return CASTRO_AMD_ERR_NOMEM;
+                c0->arena_doubles = need;
+            }
+            std::vector<LevelBoxDesc> lb((size_t)nboxes);
+            double* p = c0->arena;
+            for (int i = 0; i < nboxes; ++i) {
+                const PreparedBox& B = pb[(size_t)i];
+                LevelBoxDesc& L = lb[(size_t)i];
+                L.t = B.t;
+                p = carve_scratch(p, B.t, false, L.S);
+                L.U = B.dS; L.Unew = B.dN;
+                for (int d = 0; d < 3; ++d) { L.fl[d] = B.dF[d]; L.mass[d] = B.dM[d]; L.qe[d] = B.dQ[d]; L.acc_hi[d] = B.acc_hi[d]; }
+            }
+            return launch_ctu_hydro_level(nboxes, lb.data(), &c0->level_arena, to_devgeom(geom), devP, dt, opts->flags, c0->d_status,
+                                          main_s, &c0->prof, opts->clean_ntimes, opts->d_out, opts->sborder_clean_ntimes);
+        }
+    }
     const int used = nboxes < nctx ? nboxes : nctx;
     const bool forked = !(used == 1 && (hipStream_t)streams[0] == main_s);
     castro_amd_ctx* c0 = ctxs[0];

@@ -75,6 +75,21 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                      int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr,
                      const LaunchAux& aux);
 
+// device buffer for operation tables longer than a kernel argument holds (owned by the context)
+struct FabOpsArena { void* p = nullptr; size_t bytes = 0; };
+
+// One box of a level-wide launch (castro_amd_ctu_hydro_mf): its tile, its own scratch, the caller's arrays
+struct LevelBoxDesc {
+    Tile t;
+    DevScratch S;
+    DFab U, Unew, fl[3], mass[3], qe[3];
+    int acc_hi[3];
+};
+// default options only (PPM, CGF solver, no source terms, no staging, the default kernel forms): else box by box
+bool level_launch_supported(const DevParams& P, int flags);
+int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* table, const DevGeom& g, const DevParams& P, double dt,
+                           int flags, int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, int sb_clean);
+
 // auxiliary per-FAB kernels (aux_kernels.hip)
 int launch_clean_state(const DFab& U, const int lo[3], const int hi[3], const DevParams& P, int ntimes,
                        hipStream_t stream, Profiler* prof);
@@ -94,8 +109,6 @@ int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const
                           const ::castro_amd_rotation* r, const ::castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof);
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
-// device buffer for operation tables longer than a kernel argument holds (owned by the context)
-struct FabOpsArena { void* p = nullptr; size_t bytes = 0; };
 int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
                    const int* dir, const int* side, const int* ncomp, const double* a, const double* b, hipStream_t stream, Profiler* prof,
                    const DevParams* P = nullptr, FabOpsArena* arena = nullptr);

@@ -152,6 +152,37 @@ __device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int&
 }
 
 // ---------------------------------------------------------------------------------------
+// A whole level in one launch (castro_amd_ctu_hydro_mf, round 4).  The kernels of the default path take an optional box
+// table: workgroup ids are then cut into per-box ranges by a prefix array (every range a multiple of 8 workgroups, so the
+// round-robin XCD dealing that LinBox::ty relies on holds inside each range), and the per-box arguments -- tile, launch
+// geometry, scratch and caller arrays -- come from the table instead of the kernel arguments.  A level of 56 boxes of ~45^3
+// zones is then 8 launches that fill the chip instead of ~450 that each fill a fraction of it.
+// ---------------------------------------------------------------------------------------
+struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; unsigned wv; };   // k_finalx_consup; wv: waves per workgroup
+enum : int { LB_CTOPRIM = 0, LB_DIVU = 1, LB_TRACE = 2, LB_FOLD = 3, LB_FY = 4, LB_FZ = 5, LB_FX = 6, LB_BSTART = 7, NLB = 8 };
+struct LevelBox {
+    Tile t;
+    DevScratch S;
+    DFab U, Unew, fl[3], mass[3], qe[3];
+    int acc_hi[3];
+    LinBox b[6];           // LB_CTOPRIM .. LB_FZ
+    XRows xr;              // LB_FX
+};
+struct LevelTab { const LevelBox* box; const unsigned* start; int nbox; };   // start: nbox + 1 entries of THIS launch; box == nullptr: one box, kernel arguments
+
+// the box a workgroup belongs to; vb becomes its id inside that box's range
+__device__ __forceinline__ const LevelBox& level_box(const LevelTab& lv, unsigned& vb)
+{
+    int lo = 0, hi = lv.nbox;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lv.start[mid] <= vb) lo = mid; else hi = mid;
+    }
+    vb -= lv.start[lo];
+    return lv.box[lo];
+}
+
+// ---------------------------------------------------------------------------------------
 // Castro::ctoprim (Source/hydro/advection_util.cpp:26-200) with the gamma-law EOS inlined
 // ---------------------------------------------------------------------------------------
 // zones inside [lo,hi] are left to another launch (staged execution, see launch_ctu_hydro); empty = none
@@ -166,11 +197,13 @@ __device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
 // state anyway.  Plain stores: k_final / k_finalx_consup read the cleaned zones again.
 template <bool CLEAN>
 __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                 SkipBox skip, int clean_n)
+                                                 SkipBox skip, int clean_n, LevelTab lv)
 {
     RETURN_IF_BATCH_FAILED();
+    unsigned vb = blockIdx.x;
+    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
     int i, j, k;
-    if (!box_thread(b, i, j, k)) return;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     if (in_skip(skip, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const unsigned cu = foff(U, i, j, k);
@@ -350,10 +383,12 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
 // the same for two x-adjacent nodes per thread (no shock flag): per velocity plane and row one 16-byte load of the
 // zones (i, i+1) and one 8-byte load of zone i-1 instead of four 8-byte loads
 __global__ void __launch_bounds__(256) k_divu_pair(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
-                                                   double dxinv, double dyinv, double dzinv)
+                                                   double dxinv, double dyinv, double dzinv, LevelTab lv)
 {
+    unsigned vb = blockIdx.x;
+    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_DIVU]; Q = B.S.Q; DIV = B.S.DIV; }
     int i, j, k;
-    if (!box_thread(b, i, j, k)) return;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     const bool v1 = i + 1 <= b.hi0;
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
@@ -1215,10 +1250,11 @@ constexpr int QRHO = 0, QUN = 1, QUT = 2, QUTT = 3, QPG = 4, QREG = 5, QXG = 6, 
 
 // The y and z flux records consup_hydro needs (FL[1], FL[2]: 7 fluxes + Godunov un, p per face) are, up to the factor
 // dt * area of scale_flux, what k_final<y>, k_final<z> have just written to the caller's fluxes[1], fluxes[2] in assign mode.
-// The `contract` build lets k_finalx_consup read those instead and k_final<y,z> store only the two Godunov planes: 14 plane
-// passes less per step (1.9 GB at 256^3).  F = fluxes / (dt * area) is one rounding away from the stored flux, so the `exact`
-// build, which reproduces consup_hydro's own expression bit for bit, keeps the full records.
-#ifdef CAD_NUMERICS_CONTRACT
+// -DCAD_FLUX_OUT_CONSUP (contract builds only: F = fluxes / (dt * area) is one rounding away from the stored flux) lets
+// k_finalx_consup read those instead and k_final<y,z> store only the two Godunov planes: 14 plane passes less per step
+// (1.9 GB at 256^3).  Measured (profiles/r04d_*): k_final<y>, <z> -0.03 ms each, k_finalx_consup +0.2 ms -- the face-box rows of
+// the caller's arrays do not line up with the scratch rows the rest of that kernel streams.  Off.
+#if defined(CAD_NUMERICS_CONTRACT) && defined(CAD_FLUX_OUT_CONSUP)
 constexpr bool kFluxOutConsup = true;
 #else
 constexpr bool kFluxOutConsup = false;
@@ -1542,11 +1578,13 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 template <bool XRIEM, int DMASK = 7, int GEN = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : 2)))
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                    double dt, DevParams P, SkipBox skip)
+                                                    double dt, DevParams P, SkipBox skip, LevelTab lv)
 {
     if (P.dtp) dt = P.dtp[6];
+    unsigned vb = blockIdx.x;
+    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
     int i, j, k;
-    bool valid = box_thread(b, i, j, k);           // no early exit when XRIEM: the block synchronises below
+    bool valid = box_thread_at(b, vb, threadIdx.x, i, j, k);           // no early exit when XRIEM: the block synchronises below
     if (!valid) { i = b.lo[0]; j = b.lo[1]; k = b.lo[2]; }
     bool v1 = valid && i + 1 <= b.hi0;
     if (!XRIEM) {
@@ -1687,9 +1725,11 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
 // the x-faces k_trace_pair leaves out: face i of the first thread of every workgroup of that launch
 template <int GEN = 2>
 __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
-                                                             DevGeom g, DevParams P)
+                                                             DevGeom g, DevParams P, LevelTab lv)
 {
-    const unsigned blk = blockIdx.x * blockDim.x + threadIdx.x;      // workgroup index of the k_trace_pair launch
+    unsigned vb = blockIdx.x;
+    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
+    const unsigned blk = vb * blockDim.x + threadIdx.x;      // workgroup index of the k_trace_pair launch
     if (blk >= b.nb) return;
     int i, j, k;
     if (!box_thread_at(b, blk, 0u, i, j, k)) return;
@@ -1950,9 +1990,8 @@ __device__ __forceinline__ void trans1_solve_store(const Tile& t, const DevScrat
 // slot -> zone pair for the launches whose waves overlap by one slot: lane 0 of a wave repeats the last slot of the wave
 // before it (it only hands its records to lane 1), lanes 1..63 own 63 new slots.  Same XCD-tiled row order as LinBox.
 template <int WAVES = 4>
-__device__ __forceinline__ void fold_thread(const LinBox& b, int& i, int& j, int& k, bool& owner)
+__device__ __forceinline__ void fold_thread(const LinBox& b, unsigned bid, int& i, int& j, int& k, bool& owner)
 {
-    unsigned bid = blockIdx.x;
     if (b.ty > 0) {
         const unsigned per = b.nb >> 3;
         bid = (bid & 7u) * per + (bid >> 3);
@@ -2103,13 +2142,15 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
 
 template <int GEN>
 __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                         double cdtdx, double cdtdy, double cdtdz, DevParams P)
+                                                         double cdtdx, double cdtdy, double cdtdz, DevParams P, LevelTab lv)
 {
     __shared__ double park[2 * 2 * NF1 * FOLD_WG];
     DT_THIRDS_FROM_DEVICE();
+    unsigned vb = blockIdx.x;
+    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_FOLD]; S = B.S; Q = B.S.Q; }
     int ijk[3];
     bool owner;
-    fold_thread<FOLD_WG / 64>(b, ijk[0], ijk[1], ijk[2], owner);
+    fold_thread<FOLD_WG / 64>(b, vb, ijk[0], ijk[1], ijk[2], owner);
     const bool v1 = ijk[0] + 1 <= b.hi0;
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const D2 c0 = ldg2(Q + PC * t.NC, c);
@@ -2251,11 +2292,16 @@ template <int N, bool RE, bool LIM, int GEN = 2>
 __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
-                                               int acc_hi, int assign, DevParams P)
+                                               int acc_hi, int assign, DevParams P, LevelTab lv)
 {
     RETURN_IF_BATCH_FAILED();
+    unsigned vb = blockIdx.x;
+    if (lv.box) {
+        const LevelBox& B = level_box(lv, vb);
+        t = B.t; b = B.b[N == 1 ? LB_FY : LB_FZ]; S = B.S; Q = B.S.Q; U = B.U; fluxes = B.fl[N]; mass = B.mass[N]; qe = B.qe[N]; acc_hi = B.acc_hi[N];
+    }
     int ijk[3];
-    if (!box_thread(b, ijk[0], ijk[1], ijk[2])) return;
+    if (!box_thread_at(b, vb, threadIdx.x, ijk[0], ijk[1], ijk[2])) return;
     if (P.dtp) {                                  // hdtdx = 0.5*dt/dx as on the host
         constexpr int T1 = (N == 0) ? 1 : 0, T2 = (N == 2) ? 1 : 2;
         dt = P.dtp[6];
@@ -2362,19 +2408,22 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 //   k_final<1>, k_final<2> have written before this launch.  Saves, per zone and step: FL[0] written and read (18
 //   plane passes), Sborder read once instead of twice, one launch.
 // ---------------------------------------------------------------------------------------
-struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; unsigned wv; };   // wv: waves per workgroup
-
 template <bool LIM, bool CLEAN, int GEN = 2>
 __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                        DFab U, DFab fluxes, DFab mass, DFab qe, DFab Unew,
                                                        double hdtdy, double hdtdz, double dt,
                                                        double area0, double area1, double area2, double vol,
                                                        int acc_hi, int assign, int from_sborder, DevParams P, int ntimes,
-                                                       double* red, DFab fluxes_y, DFab fluxes_z)
+                                                       double* red, DFab fluxes_y, DFab fluxes_z, LevelTab lv)
 {
     RETURN_IF_BATCH_FAILED();
     if (P.dtp) { dt = P.dtp[6]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
     unsigned bid = blockIdx.x;
+    if (lv.box) {
+        const LevelBox& B = level_box(lv, bid);
+        t = B.t; b = B.xr; S = B.S; Q = B.S.Q; U = B.U; fluxes = B.fl[0]; mass = B.mass[0]; qe = B.qe[0]; Unew = B.Unew; acc_hi = B.acc_hi[0];
+        fluxes_y = B.fl[1]; fluxes_z = B.fl[2];
+    }
     bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
     const int lane = threadIdx.x & 63;
     const unsigned total = (unsigned)b.nslot * (unsigned)b.ny * (unsigned)b.nz;
@@ -2594,6 +2643,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                      int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, const DFab& SrcCorr,
                      const LaunchAux& aux)
 {
+    const LevelTab nolv = { nullptr, nullptr, 0 };       // one box: the kernels take their arguments as passed
     // Staged execution (CASTRO_AMD_STAGE_A / _B): A = what needs no ghost zone of Sborder -- ctoprim on the valid
     // zones, PPM tracing on grow(bx, -3) -- so that a caller can run it while the halo exchange is in flight;
     // B = the rest (ctoprim on the ghost shell, tracing on the remaining zones, everything downstream).
@@ -2633,7 +2683,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                            ~RowsGuard() { tl_tile_rows = keep; } } rows_guard;
         {
 #define K_(V) (k_trace_pair<true, 7, V>)
-            KL2_SOLV("k_trace", K_, lo, hi, S.Q, S, g, dt, P, none);
+            KL2_SOLV("k_trace", K_, lo, hi, S.Q, S, g, dt, P, none, nolv);
 #undef K_
         }
         long n_;
@@ -2641,14 +2691,14 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         if (n_ > 0) {
             prof_begin(prof, "k_riemann1_blockstart", stream);
             auto kbs = solv == 2 ? k_riemann1_blockstart<2> : solv == 1 ? k_riemann1_blockstart<1> : k_riemann1_blockstart<0>;
-            hipLaunchKernelGGL(kbs, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P);
+            hipLaunchKernelGGL(kbs, dim3((b_.nb + 255) / 256), dim3(256), 0, stream, t, b_, S.Q, S, g, P, nolv);
             prof_end(prof, stream);
         }
     };
 
     if (stage_a) {
         if (splittable) {
-            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0);
+            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv);
             if (inner_ok) trace_with_xriemann(inner_box.lo, inner_box.hi);
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -2657,11 +2707,11 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     int slo[6][3], shi[6][3];
     if (second_half) {
         const int ns = shell_boxes(qlo, qhi, t.lo, t.hi, slo, shi);
-        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0);
+        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0, nolv);
     } else if (aux.sb_clean > 0) {
-        KL("k_ctoprim_clean", k_ctoprim<true>, qlo, qhi, Sborder, S.Q, P, d_status, none, aux.sb_clean);
+        KL("k_ctoprim_clean", k_ctoprim<true>, qlo, qhi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv);
     } else {
-        KL("k_ctoprim", k_ctoprim<false>, qlo, qhi, Sborder, S.Q, P, d_status, none, 0);
+        KL("k_ctoprim", k_ctoprim<false>, qlo, qhi, Sborder, S.Q, P, d_status, none, 0, nolv);
     }
 
     int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
@@ -2685,12 +2735,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             hipStream_t main_stream = stream;
             hipStream_t stream = aux.side;      // KL2 launches on `stream`
             (void)main_stream;
-            KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
+            KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], nolv);
         }
         hipEventRecord(aux.ev_join, aux.side);
         divu_forked = true;
     }
-    else { KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]); }
+    else { KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], nolv); }
     // the join must precede the first reader of DIV (and every return path after this point)
     auto join_divu = [&]() { if (divu_forked) { hipStreamWaitEvent(stream, aux.ev_join, 0); divu_forked = false; } };
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
@@ -2702,7 +2752,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
-        else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none); }
+        else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none, nolv); }
         else if (second_half) {
             if (inner_ok) {
                 const int ns = shell_boxes(olo, ohi, inner_box.lo, inner_box.hi, slo, shi);
@@ -2749,11 +2799,11 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     do {                                                                                                          \
         KL2("k_trans1", k_trans1<RE>, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);                              \
         KL2("k_final_x", (k_final<0, RE, LIM>), nlo[0], nhi[0], S.Q, S, g, Sborder, fluxes[0], mass[0], qe[0],      \
-            hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P);                                 \
+            hdtdy, hdtdz, dt, area0, g.dx[0], acc_hi[0], (flags & 2) ? 1 : 0, P, nolv);                                 \
         KL2("k_final_y", (k_final<1, RE, LIM>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1],      \
-            hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);                                 \
+            hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P, nolv);                                 \
         KL2("k_final_z", (k_final<2, RE, LIM>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2],      \
-            hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);                                 \
+            hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P, nolv);                                 \
     } while (0)
     // the flux limiters (non-default too) share one extra pair of instantiations: both flags are tested inside
     const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
@@ -2769,7 +2819,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                 prof_begin(prof, "k_trans1_fold", stream);
                 b_.nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));   // 63 new slots per wave, see fold_thread
                 if (b_.ty > 0) b_.nb = (b_.nb + 7u) & ~7u;
-                hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(FOLD_WG), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(b_.nb), dim3(FOLD_WG), 0, stream, t, b_, S.Q, S, g, cdtdx, cdtdy, cdtdz, P, nolv);
                 prof_end(prof, stream);
             }
         } else
@@ -2780,12 +2830,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                                      acc_hi[1] == t.hi[1] + 1 && acc_hi[2] == t.hi[2] + 1;
         const int assign_yz = ((flags & 2) ? 1 : 0) | (flux_out_consup ? 2 : 0);
         if (lim) {
-            KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P);
-            KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P);
+            KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P, nolv);
+            KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P, nolv);
         } else {
             struct WgGuard { unsigned keep; WgGuard() : keep(tl_wg) { if (g_final_wg > 0) tl_wg = (unsigned)g_final_wg; } ~WgGuard() { tl_wg = keep; } } wg_guard;
-            KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], assign_yz, P);
-            KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], assign_yz, P);
+            KL2_SOLV("k_final_y", K_FY, nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], assign_yz, P, nolv);
+            KL2_SOLV("k_final_z", K_FZ, nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], assign_yz, P, nolv);
         }
         XRows xr;
         for (int d = 0; d < 3; ++d) xr.lo[d] = t.lo[d];
@@ -2802,7 +2852,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 #define FXC(LIM, CLEAN, GENF, nt, rd)                                                                                        \
         hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN, GENF>), dim3(xr.nb), dim3(64u * xr.wv), 0, stream, t, xr, S.Q, S, g, Sborder,      \
                            fluxes[0], mass[0], qe[0], Snew, hdtdy, hdtdz, dt, area0, area1, area2, vol_, acc_hi[0],      \
-                           assign_yz, (flags & 1) ? 1 : 0, P, nt, rd, fluxes[1], fluxes[2])
+                           assign_yz, (flags & 1) ? 1 : 0, P, nt, rd, fluxes[1], fluxes[2], nolv)
         if (clean_ntimes > 0) {
             if (lim) FXC(true, true, 2, clean_ntimes, red);
             else if (solv == 2) FXC(false, true, 2, clean_ntimes, red);
@@ -2830,6 +2880,133 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
            P, 0, 0.0, 0.0, 0.0, (double*)nullptr);
     }
 
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---------------------------------------------------------------------------------------
+// The default path for every box of a level at once (see LevelTab): 8 launches whatever the number of boxes.
+// ---------------------------------------------------------------------------------------
+bool level_launch_supported(const DevParams& P, int flags)
+{
+    const bool tfix = P.ppm_temp_fix == 2 && P.riemann_solver != 2;
+    const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
+    return P.ppm_type == 1 && P.riemann_solver == 0 && P.hybrid_riemann != 1 && !tfix && P.reset_rhoe != 1 && !lim &&
+           g_fuse_consup == 1 && g_fold_r1 != 0 && (flags & (4 | 8)) == 0;
+}
+
+int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* table, const DevGeom& g, const DevParams& P, double dt,
+                           int flags, int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, int sb_clean)
+{
+    if (nbox < 1 || !boxes || !table) return -1;
+    std::vector<LevelBox> hb((size_t)nbox);
+    std::vector<unsigned> start((size_t)NLB * (size_t)(nbox + 1), 0u);
+    auto st = [&](int kind, int i) -> unsigned& { return start[(size_t)kind * (size_t)(nbox + 1) + (size_t)i]; };
+    for (int i = 0; i < nbox; ++i) {
+        const LevelBoxDesc& D = boxes[i];
+        LevelBox& B = hb[(size_t)i];
+        const Tile& t = D.t;
+        B.t = t; B.S = D.S; B.U = D.U; B.Unew = D.Unew;
+        for (int d = 0; d < 3; ++d) { B.fl[d] = D.fl[d]; B.mass[d] = D.mass[d]; B.qe[d] = D.qe[d]; B.acc_hi[d] = D.acc_hi[d]; }
+        const int olo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 }, ohi[3] = { t.hi[0] + 1, t.hi[1] + 1, t.hi[2] + 1 };
+        const int qlo[3] = { t.lo[0] - 4, t.lo[1] - 4, t.lo[2] - 4 }, qhi[3] = { t.hi[0] + 4, t.hi[1] + 4, t.hi[2] + 4 };
+        long n_;
+        tl_tile_rows = -1; tl_wg = 0;
+        B.b[LB_CTOPRIM] = linbox(qlo, qhi, n_);
+        B.b[LB_DIVU] = linbox2(olo, ohi, n_);
+        tl_tile_rows = g_trace_tile_rows >= 0 ? g_trace_tile_rows : -1;
+        B.b[LB_TRACE] = linbox2(olo, ohi, n_);
+        tl_tile_rows = g_fold_tile_rows >= 0 ? g_fold_tile_rows : -1;
+        B.b[LB_FOLD] = linbox2(olo, ohi, n_);
+        B.b[LB_FOLD].nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));      // 63 new slots per wave, see fold_thread
+        if (B.b[LB_FOLD].ty > 0) B.b[LB_FOLD].nb = (B.b[LB_FOLD].nb + 7u) & ~7u;
+        tl_tile_rows = -1;
+        tl_wg = g_final_wg > 0 ? (unsigned)g_final_wg : 0u;
+        for (int d = 1; d <= 2; ++d) {
+            int nlo[3] = { t.lo[0], t.lo[1], t.lo[2] }, nhi[3] = { t.hi[0], t.hi[1], t.hi[2] };
+            nhi[d] += 1;
+            B.b[d == 1 ? LB_FY : LB_FZ] = linbox2(nlo, nhi, n_);
+        }
+        tl_wg = 0;
+        XRows& xr = B.xr;
+        for (int d = 0; d < 3; ++d) xr.lo[d] = t.lo[d];
+        xr.hi0 = t.hi[0];
+        const int nx = t.hi[0] - t.lo[0] + 1;
+        xr.nslot = (nx + 1) / 2 + 1; xr.ny = t.hi[1] - t.lo[1] + 1; xr.nz = t.hi[2] - t.lo[2] + 1;
+        xr.ty = g_fused_tile_rows;
+        const long slots = (long)xr.nslot * xr.ny * xr.nz;
+        xr.wv = (unsigned)g_fused_wg / 64u;
+        xr.nb = ((unsigned)(((slots + 62) / 63 + xr.wv - 1) / xr.wv) + 7u) & ~7u;
+        // workgroup ranges: multiples of 8 wherever the kernel maps ids to XCDs (every LinBox with ty > 0 is one already)
+        const unsigned nbs[NLB] = { B.b[LB_CTOPRIM].nb, B.b[LB_DIVU].nb, B.b[LB_TRACE].nb, B.b[LB_FOLD].nb, B.b[LB_FY].nb, B.b[LB_FZ].nb,
+                                    xr.nb, (B.b[LB_TRACE].nb + 255u) / 256u };
+        for (int kind = 0; kind < NLB; ++kind) {
+            unsigned nb = nbs[kind];
+            if (kind != LB_BSTART) nb = (nb + 7u) & ~7u;
+            st(kind, i + 1) = st(kind, i) + nb;
+        }
+    }
+    // the table: boxes, then the prefix arrays; hipMemcpyAsync from pageable memory stages the bytes before it returns
+    const size_t box_bytes = sizeof(LevelBox) * (size_t)nbox, bytes = box_bytes + sizeof(unsigned) * start.size();
+    if (table->bytes < bytes) {
+        if (table->p) { hipStreamSynchronize(stream); hipFree(table->p); table->p = nullptr; table->bytes = 0; }
+        if (hipMalloc(&table->p, bytes + 4096) != hipSuccess) return -3;
+        table->bytes = bytes + 4096;
+    }
+    hipMemcpyAsync(table->p, hb.data(), box_bytes, hipMemcpyHostToDevice, stream);
+    hipMemcpyAsync((char*)table->p + box_bytes, start.data(), sizeof(unsigned) * start.size(), hipMemcpyHostToDevice, stream);
+    const LevelBox* dbox = (const LevelBox*)table->p;
+    const unsigned* dstart = (const unsigned*)((const char*)table->p + box_bytes);
+    auto lv = [&](int kind) { return LevelTab{ dbox, dstart + (size_t)kind * (size_t)(nbox + 1), nbox }; };
+    auto total = [&](int kind) { return st(kind, nbox); };
+
+    const Tile t0 = hb[0].t;
+    const DevScratch S0 = hb[0].S;
+    const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
+    const int assign = (flags & 2) ? 1 : 0;
+    const double cdtdx = dt / g.dx[0] / 3.0, cdtdy = dt / g.dx[1] / 3.0, cdtdz = dt / g.dx[2] / 3.0;
+    const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
+    const double area0 = g.dx[1] * g.dx[2], area1 = g.dx[0] * g.dx[2], area2 = g.dx[0] * g.dx[1];
+    const double vol = g.dx[0] * g.dx[1] * g.dx[2];
+
+    prof_begin(prof, sb_clean > 0 ? "k_ctoprim_clean" : "k_ctoprim", stream);
+    if (sb_clean > 0) hipLaunchKernelGGL(k_ctoprim<true>, dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
+                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM));
+    else hipLaunchKernelGGL(k_ctoprim<false>, dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
+                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_divu", stream);
+    hipLaunchKernelGGL(k_divu_pair, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
+                       1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], lv(LB_DIVU));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_trace", stream);
+    hipLaunchKernelGGL((k_trace_pair<true, 7, 0>), dim3(total(LB_TRACE)), dim3(hb[0].b[LB_TRACE].wg), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g,
+                       dt, P, none, lv(LB_TRACE));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_riemann1_blockstart", stream);
+    hipLaunchKernelGGL(k_riemann1_blockstart<0>, dim3(total(LB_BSTART)), dim3(256), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g, P, lv(LB_BSTART));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_trans1_fold", stream);
+    hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(total(LB_FOLD)), dim3(FOLD_WG), 0, stream, t0, hb[0].b[LB_FOLD], S0.Q, S0, g, cdtdx, cdtdy, cdtdz, P,
+                       lv(LB_FOLD));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_final_y", stream);
+    hipLaunchKernelGGL((k_final<1, false, false, 0>), dim3(total(LB_FY)), dim3(hb[0].b[LB_FY].wg), 0, stream, t0, hb[0].b[LB_FY], S0.Q, S0, g, hb[0].U,
+                       hb[0].fl[1], hb[0].mass[1], hb[0].qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], hb[0].acc_hi[1], assign, P, lv(LB_FY));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_final_z", stream);
+    hipLaunchKernelGGL((k_final<2, false, false, 0>), dim3(total(LB_FZ)), dim3(hb[0].b[LB_FZ].wg), 0, stream, t0, hb[0].b[LB_FZ], S0.Q, S0, g, hb[0].U,
+                       hb[0].fl[2], hb[0].mass[2], hb[0].qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], hb[0].acc_hi[2], assign, P, lv(LB_FZ));
+    prof_end(prof, stream);
+    prof_begin(prof, "k_finalx_consup", stream);
+    if (clean_ntimes > 0)
+        hipLaunchKernelGGL((k_finalx_consup<false, true, 0>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
+                           hb[0].fl[0], hb[0].mass[0], hb[0].qe[0], hb[0].Unew, hdtdy, hdtdz, dt, area0, area1, area2, vol, hb[0].acc_hi[0],
+                           assign, (flags & 1) ? 1 : 0, P, clean_ntimes, red, hb[0].fl[1], hb[0].fl[2], lv(LB_FX));
+    else
+        hipLaunchKernelGGL((k_finalx_consup<false, false, 0>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
+                           hb[0].fl[0], hb[0].mass[0], hb[0].qe[0], hb[0].Unew, hdtdy, hdtdz, dt, area0, area1, area2, vol, hb[0].acc_hi[0],
+                           assign, (flags & 1) ? 1 : 0, P, 0, (double*)nullptr, hb[0].fl[1], hb[0].fl[2], lv(LB_FX));
+    prof_end(prof, stream);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

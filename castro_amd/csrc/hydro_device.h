@@ -626,7 +626,8 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     double entho = (reo + po) * roinv * co2inv;
     double estar = reo + (pstar - po) * entho;
 
-    double cstar = fsqrt(fabs(gamco * fdiv(pstar, rstar)));      // pstar >= small_pres, small_dens <= rstar: far above 2^-767
+    // pstar >= small_pres, small_dens <= rstar: far above 2^-767
+    double cstar = kContract ? fsqrt(fabs(gamco * pstar * frcp(rstar))) : sqrt(fabs(gamco * pstar / rstar));
     cstar = amax(cstar, raux.csmall);
 
     double spout = co - sgnm * uo;

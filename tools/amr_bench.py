@@ -22,10 +22,11 @@ if nfine == 2:                                                # level-2 patch: t
 mode = sys.argv[4] if len(sys.argv) > 4 else ""                # "tags": one bounding box per level; "cluster": Berger-Rigoutsos boxes
 dynamic = mode in ("tags", "cluster")                          # the refined levels follow the tags (regrid every 2 steps)
 t_start = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0     # evolve to this time first (a developed blast wave)
+kw = dict(a.split("=") for a in sys.argv[6:])                  # bf=<blocking_factor> eff=<grid_eff> mgs=<max_grid_size>
 if dynamic:
     a = castro_amd.CastroAmr((n, n, n), refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)],
-                             regrid_int=2, n_error_buf=2, blocking_factor=16 if mode == "cluster" else 8, max_level=nfine,
-                             cluster=mode == "cluster", grid_eff=0.7, max_grid_size=128)
+                             regrid_int=2, n_error_buf=2, blocking_factor=int(kw.get("bf", 16 if mode == "cluster" else 8)), max_level=nfine,
+                             cluster=mode == "cluster", grid_eff=float(kw.get("eff", 0.7)), max_grid_size=int(kw.get("mgs", 128)))
 else:
     a = castro_amd.CastroAmr((n, n, n), patches=patches)
 a.initData("sedov")
