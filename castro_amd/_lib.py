@@ -145,6 +145,8 @@ ABI_VERSION = 4          # CASTRO_AMD_ABI_VERSION of include/castro_hydro_amd.h 
 
 def numerics_of(L):
     """"exact" / "contract" as the loaded library reports it (castro_amd_numerics)"""
+    if not hasattr(L, "castro_amd_numerics"):
+        return "exact"                                     # an A/B build of a revision before the second mode existed
     return L.castro_amd_numerics().decode()
 
 
@@ -159,13 +161,15 @@ def load(numerics=None):
             "castro_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C castro_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
     L = C.CDLL(path)
-    L.castro_amd_abi_version.restype = C.c_int
-    if L.castro_amd_abi_version() != ABI_VERSION:
-        raise ImportError("castro_amd: %s has ABI version %d, this binding expects %d: rebuild it"
-                          % (path, L.castro_amd_abi_version(), ABI_VERSION))
-    L.castro_amd_numerics.restype = C.c_char_p
-    if not os.environ.get("CASTRO_AMD_LIB") and numerics_of(L) != mode:
-        raise ImportError("castro_amd: %s is a %r build, expected %r" % (path, numerics_of(L), mode))
+    ab_build = bool(os.environ.get("CASTRO_AMD_LIB"))      # an A/B build, possibly of an older revision (tools/ab_variants.sh)
+    if hasattr(L, "castro_amd_abi_version") or not ab_build:
+        L.castro_amd_abi_version.restype = C.c_int
+        if L.castro_amd_abi_version() != ABI_VERSION:
+            raise ImportError("castro_amd: %s has ABI version %d, this binding expects %d: rebuild it"
+                              % (path, L.castro_amd_abi_version(), ABI_VERSION))
+        L.castro_amd_numerics.restype = C.c_char_p
+        if not ab_build and numerics_of(L) != mode:
+            raise ImportError("castro_amd: %s is a %r build, expected %r" % (path, numerics_of(L), mode))
     I3 = C.POINTER(C.c_int)
     PF = C.POINTER(Fab)
     L.castro_amd_version.restype = C.c_char_p
@@ -230,19 +234,20 @@ def load(numerics=None):
                                             C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
     L.castro_amd_sod_init_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Geom), C.POINTER(Params)] + \
         [C.c_double] * 6 + [C.c_int, C.c_double, C.c_void_p]
-    L.castro_amd_comm_version.restype = C.c_char_p
-    L.castro_amd_comm_unique_id.argtypes = [C.c_void_p]
-    L.castro_amd_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int]
-    L.castro_amd_comm_adopt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
-    L.castro_amd_comm_rank.argtypes = [C.c_void_p]
-    L.castro_amd_comm_size.argtypes = [C.c_void_p]
-    L.castro_amd_comm_destroy.argtypes = [C.c_void_p]
-    L.castro_amd_halo_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.POINTER(HaloRegion), C.c_int]
-    L.castro_amd_halo_plan_destroy.argtypes = [C.c_void_p]
-    L.castro_amd_halo_plan_bytes_sent.argtypes = [C.c_void_p]
-    L.castro_amd_halo_plan_bytes_sent.restype = C.c_longlong
-    L.castro_amd_fill_boundary.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
-    L.castro_amd_allreduce_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "castro_amd_comm_version"):               # absent from A/B builds of revisions before the C-level halo exchange
+        L.castro_amd_comm_version.restype = C.c_char_p
+        L.castro_amd_comm_unique_id.argtypes = [C.c_void_p]
+        L.castro_amd_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.castro_amd_comm_adopt.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.castro_amd_comm_rank.argtypes = [C.c_void_p]
+        L.castro_amd_comm_size.argtypes = [C.c_void_p]
+        L.castro_amd_comm_destroy.argtypes = [C.c_void_p]
+        L.castro_amd_halo_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.POINTER(HaloRegion), C.c_int]
+        L.castro_amd_halo_plan_destroy.argtypes = [C.c_void_p]
+        L.castro_amd_halo_plan_bytes_sent.argtypes = [C.c_void_p]
+        L.castro_amd_halo_plan_bytes_sent.restype = C.c_longlong
+        L.castro_amd_fill_boundary.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
+        L.castro_amd_allreduce_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.castro_amd_ctx_profile.argtypes = [C.c_void_p, C.c_int]
     L.castro_amd_ctx_profile_count.argtypes = [C.c_void_p]
     L.castro_amd_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int,

@@ -48,6 +48,18 @@
 #endif
 namespace cad {
 
+// A/B (round 4): delay every other group of workgroups at the start of the two VALU-heavy kernels, so that the two waves a
+// SIMD hosts (they belong to two workgroups running the same program) do not walk through their load and compute phases in
+// lockstep (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  -DSTAGGER_SLEEP=<1..127> (units of 64 cycles), -DSTAGGER_SHIFT.
+#ifdef STAGGER_SLEEP
+#ifndef STAGGER_SHIFT
+#define STAGGER_SHIFT 8
+#endif
+#define STAGGER_START() do { if ((blockIdx.x >> STAGGER_SHIFT) & 1u) __builtin_amdgcn_s_sleep(STAGGER_SLEEP); } while (0)
+#else
+#define STAGGER_START() do { } while (0)
+#endif
+
 // Host-free stepping: DevParams::dtp points at castro_amd_step_control's vector; once a step has been rejected
 // (ctl[CASTRO_AMD_CTL_STATUS] != 0) the launches that follow in the same batch must leave the caller's arrays alone --
 // the host retries from the old state of the rejected step.
@@ -195,13 +207,13 @@ __device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
 // CLEAN: Castro::clean_state applied `clean_n` times to the zone first, in place (castro_amd_hydro_opts.sborder_clean_ntimes):
 // the clean_state(S_old) of initialize_advance and the clean_state(Sborder) after FillPatch inside the pass that reads the
 // state anyway.  Plain stores: k_final / k_finalx_consup read the cleaned zones again.
-template <bool CLEAN>
+template <bool CLEAN, bool LV = false>
 __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
                                                  SkipBox skip, int clean_n, LevelTab lv)
 {
     RETURN_IF_BATCH_FAILED();
     unsigned vb = blockIdx.x;
-    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
     int i, j, k;
     if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     if (in_skip(skip, i, j, k)) return;
@@ -382,11 +394,12 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
 
 // the same for two x-adjacent nodes per thread (no shock flag): per velocity plane and row one 16-byte load of the
 // zones (i, i+1) and one 8-byte load of zone i-1 instead of four 8-byte loads
+template <bool LV = false>
 __global__ void __launch_bounds__(256) k_divu_pair(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
                                                    double dxinv, double dyinv, double dzinv, LevelTab lv)
 {
     unsigned vb = blockIdx.x;
-    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_DIVU]; Q = B.S.Q; DIV = B.S.DIV; }
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_DIVU]; Q = B.S.Q; DIV = B.S.DIV; }
     int i, j, k;
     if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     const bool v1 = i + 1 <= b.hi0;
@@ -1575,14 +1588,15 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 // device-resident time step (DevParams::dtp): cdtdx = dt/dx/3 as launch_ctu_hydro computes it on the host
 #define DT_THIRDS_FROM_DEVICE()                                                                          \
     if (P.dtp) { const double dt_ = P.dtp[6]; cdtdx = dt_ / g.dx[0] / 3.0; cdtdy = dt_ / g.dx[1] / 3.0; cdtdz = dt_ / g.dx[2] / 3.0; }
-template <bool XRIEM, int DMASK = 7, int GEN = 2>
+template <bool XRIEM, int DMASK = 7, int GEN = 2, bool LV = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : 2)))
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P, SkipBox skip, LevelTab lv)
 {
+    STAGGER_START();
     if (P.dtp) dt = P.dtp[6];
     unsigned vb = blockIdx.x;
-    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
     int i, j, k;
     bool valid = box_thread_at(b, vb, threadIdx.x, i, j, k);           // no early exit when XRIEM: the block synchronises below
     if (!valid) { i = b.lo[0]; j = b.lo[1]; k = b.lo[2]; }
@@ -1723,12 +1737,12 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
 }
 
 // the x-faces k_trace_pair leaves out: face i of the first thread of every workgroup of that launch
-template <int GEN = 2>
+template <int GEN = 2, bool LV = false>
 __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
                                                              DevGeom g, DevParams P, LevelTab lv)
 {
     unsigned vb = blockIdx.x;
-    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
     const unsigned blk = vb * blockDim.x + threadIdx.x;      // workgroup index of the k_trace_pair launch
     if (blk >= b.nb) return;
     int i, j, k;
@@ -2140,14 +2154,15 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
     }
 }
 
-template <int GEN>
+template <int GEN, bool LV = false>
 __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                          double cdtdx, double cdtdy, double cdtdz, DevParams P, LevelTab lv)
 {
     __shared__ double park[2 * 2 * NF1 * FOLD_WG];
+    STAGGER_START();
     DT_THIRDS_FROM_DEVICE();
     unsigned vb = blockIdx.x;
-    if (lv.box) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_FOLD]; S = B.S; Q = B.S.Q; }
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_FOLD]; S = B.S; Q = B.S.Q; }
     int ijk[3];
     bool owner;
     fold_thread<FOLD_WG / 64>(b, vb, ijk[0], ijk[1], ijk[2], owner);
@@ -2288,7 +2303,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
 
 // One launch per normal direction.  (All three in one launch, which fetches Sborder and div(u) once instead of
 // three times, measured slower: 5.0 vs 4.6 ms at 256^3 -- ~150 concurrent streams per workgroup.)
-template <int N, bool RE, bool LIM, int GEN = 2>
+template <int N, bool RE, bool LIM, int GEN = 2, bool LV = false>
 __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                DFab U, DFab fluxes, DFab mass, DFab qe,
                                                double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
@@ -2296,7 +2311,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, co
 {
     RETURN_IF_BATCH_FAILED();
     unsigned vb = blockIdx.x;
-    if (lv.box) {
+    if (LV) {
         const LevelBox& B = level_box(lv, vb);
         t = B.t; b = B.b[N == 1 ? LB_FY : LB_FZ]; S = B.S; Q = B.S.Q; U = B.U; fluxes = B.fl[N]; mass = B.mass[N]; qe = B.qe[N]; acc_hi = B.acc_hi[N];
     }
@@ -2408,7 +2423,7 @@ __global__ void __launch_bounds__(256) k_consup(Tile t, LinBox b, DevScratch S, 
 //   k_final<1>, k_final<2> have written before this launch.  Saves, per zone and step: FL[0] written and read (18
 //   plane passes), Sborder read once instead of twice, one launch.
 // ---------------------------------------------------------------------------------------
-template <bool LIM, bool CLEAN, int GEN = 2>
+template <bool LIM, bool CLEAN, int GEN = 2, bool LV = false>
 __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                        DFab U, DFab fluxes, DFab mass, DFab qe, DFab Unew,
                                                        double hdtdy, double hdtdz, double dt,
@@ -2419,7 +2434,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
     RETURN_IF_BATCH_FAILED();
     if (P.dtp) { dt = P.dtp[6]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
     unsigned bid = blockIdx.x;
-    if (lv.box) {
+    if (LV) {
         const LevelBox& B = level_box(lv, bid);
         t = B.t; b = B.xr; S = B.S; Q = B.S.Q; U = B.U; fluxes = B.fl[0]; mass = B.mass[0]; qe = B.qe[0]; Unew = B.Unew; acc_hi = B.acc_hi[0];
         fluxes_y = B.fl[1]; fluxes_z = B.fl[2];
@@ -2735,12 +2750,12 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             hipStream_t main_stream = stream;
             hipStream_t stream = aux.side;      // KL2 launches on `stream`
             (void)main_stream;
-            KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], nolv);
+            KL2("k_divu", k_divu_pair<false>, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], nolv);
         }
         hipEventRecord(aux.ev_join, aux.side);
         divu_forked = true;
     }
-    else { KL2("k_divu", k_divu_pair, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], nolv); }
+    else { KL2("k_divu", k_divu_pair<false>, olo, ohi, S.Q, S.DIV, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], nolv); }
     // the join must precede the first reader of DIV (and every return path after this point)
     auto join_divu = [&]() { if (divu_forked) { hipStreamWaitEvent(stream, aux.ev_join, 0); divu_forked = false; } };
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
@@ -2969,41 +2984,41 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
     const double vol = g.dx[0] * g.dx[1] * g.dx[2];
 
     prof_begin(prof, sb_clean > 0 ? "k_ctoprim_clean" : "k_ctoprim", stream);
-    if (sb_clean > 0) hipLaunchKernelGGL(k_ctoprim<true>, dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
+    if (sb_clean > 0) hipLaunchKernelGGL((k_ctoprim<true, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
                                          hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM));
-    else hipLaunchKernelGGL(k_ctoprim<false>, dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
+    else hipLaunchKernelGGL((k_ctoprim<false, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
                             hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM));
     prof_end(prof, stream);
     prof_begin(prof, "k_divu", stream);
-    hipLaunchKernelGGL(k_divu_pair, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
+    hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
                        1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], lv(LB_DIVU));
     prof_end(prof, stream);
     prof_begin(prof, "k_trace", stream);
-    hipLaunchKernelGGL((k_trace_pair<true, 7, 0>), dim3(total(LB_TRACE)), dim3(hb[0].b[LB_TRACE].wg), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g,
+    hipLaunchKernelGGL((k_trace_pair<true, 7, 0, true>), dim3(total(LB_TRACE)), dim3(hb[0].b[LB_TRACE].wg), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g,
                        dt, P, none, lv(LB_TRACE));
     prof_end(prof, stream);
     prof_begin(prof, "k_riemann1_blockstart", stream);
-    hipLaunchKernelGGL(k_riemann1_blockstart<0>, dim3(total(LB_BSTART)), dim3(256), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g, P, lv(LB_BSTART));
+    hipLaunchKernelGGL((k_riemann1_blockstart<0, true>), dim3(total(LB_BSTART)), dim3(256), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g, P, lv(LB_BSTART));
     prof_end(prof, stream);
     prof_begin(prof, "k_trans1_fold", stream);
-    hipLaunchKernelGGL(k_trans1_fold_lds<0>, dim3(total(LB_FOLD)), dim3(FOLD_WG), 0, stream, t0, hb[0].b[LB_FOLD], S0.Q, S0, g, cdtdx, cdtdy, cdtdz, P,
+    hipLaunchKernelGGL((k_trans1_fold_lds<0, true>), dim3(total(LB_FOLD)), dim3(FOLD_WG), 0, stream, t0, hb[0].b[LB_FOLD], S0.Q, S0, g, cdtdx, cdtdy, cdtdz, P,
                        lv(LB_FOLD));
     prof_end(prof, stream);
     prof_begin(prof, "k_final_y", stream);
-    hipLaunchKernelGGL((k_final<1, false, false, 0>), dim3(total(LB_FY)), dim3(hb[0].b[LB_FY].wg), 0, stream, t0, hb[0].b[LB_FY], S0.Q, S0, g, hb[0].U,
+    hipLaunchKernelGGL((k_final<1, false, false, 0, true>), dim3(total(LB_FY)), dim3(hb[0].b[LB_FY].wg), 0, stream, t0, hb[0].b[LB_FY], S0.Q, S0, g, hb[0].U,
                        hb[0].fl[1], hb[0].mass[1], hb[0].qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], hb[0].acc_hi[1], assign, P, lv(LB_FY));
     prof_end(prof, stream);
     prof_begin(prof, "k_final_z", stream);
-    hipLaunchKernelGGL((k_final<2, false, false, 0>), dim3(total(LB_FZ)), dim3(hb[0].b[LB_FZ].wg), 0, stream, t0, hb[0].b[LB_FZ], S0.Q, S0, g, hb[0].U,
+    hipLaunchKernelGGL((k_final<2, false, false, 0, true>), dim3(total(LB_FZ)), dim3(hb[0].b[LB_FZ].wg), 0, stream, t0, hb[0].b[LB_FZ], S0.Q, S0, g, hb[0].U,
                        hb[0].fl[2], hb[0].mass[2], hb[0].qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], hb[0].acc_hi[2], assign, P, lv(LB_FZ));
     prof_end(prof, stream);
     prof_begin(prof, "k_finalx_consup", stream);
     if (clean_ntimes > 0)
-        hipLaunchKernelGGL((k_finalx_consup<false, true, 0>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
+        hipLaunchKernelGGL((k_finalx_consup<false, true, 0, true>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
                            hb[0].fl[0], hb[0].mass[0], hb[0].qe[0], hb[0].Unew, hdtdy, hdtdz, dt, area0, area1, area2, vol, hb[0].acc_hi[0],
                            assign, (flags & 1) ? 1 : 0, P, clean_ntimes, red, hb[0].fl[1], hb[0].fl[2], lv(LB_FX));
     else
-        hipLaunchKernelGGL((k_finalx_consup<false, false, 0>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
+        hipLaunchKernelGGL((k_finalx_consup<false, false, 0, true>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
                            hb[0].fl[0], hb[0].mass[0], hb[0].qe[0], hb[0].Unew, hdtdy, hdtdz, dt, area0, area1, area2, vol, hb[0].acc_hi[0],
                            assign, (flags & 1) ? 1 : 0, P, 0, (double*)nullptr, hb[0].fl[1], hb[0].fl[2], lv(LB_FX));
     prof_end(prof, stream);

@@ -10,7 +10,7 @@ cd $REPO
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python3 bench.py --reference-contract --no-cpu-baseline > $OUT/${TAG}_bench_reference_contract.json 2>/dev/null
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_samebox_stats -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_samebox_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_samebox_stats -- python3 $REPO/bench.py --no-cpu-baseline --no-extras --no-contract-leg > $OUT/${TAG}_samebox_stats.log 2>&1
 cd $REPO
 find $OUT/${TAG}_samebox_stats -type f -size +8M -delete 2>/dev/null
 python3 - <<PY
