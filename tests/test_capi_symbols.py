@@ -30,6 +30,31 @@ def test_header_symbols_are_exported(lib):
         assert getattr(lib, name) is not None, name
 
 
+def test_both_numerics_builds_export_the_abi_and_name_themselves():
+    """The `exact` and the `contract` build (castro_amd/csrc/Makefile) are one ABI: every declared symbol in both, the ABI
+    version of the header, and castro_amd_numerics() naming the build; RCCL is bound at run time, so loading neither needs it."""
+    from castro_amd import _lib
+    for p in (_lib.lib_path("exact"), _lib.lib_path("contract")):
+        if not os.path.exists(p):
+            import __graft_entry__ as g
+            g.build()
+    hdr = open(os.path.join(ROOT, "include", "castro_hydro_amd.h")).read()
+    version = int(re.search(r"#define CASTRO_AMD_ABI_VERSION (\d+)", hdr).group(1))
+    assert version == _lib.ABI_VERSION
+    for mode in _lib.NUMERICS_MODES:
+        L = _lib.load(mode)
+        assert _lib.numerics_of(L) == mode and L.castro_amd_abi_version() == version
+        assert ("numerics=%s" % mode).encode() in L.castro_amd_version()
+        for name in _lib.EXPORTED_SYMBOLS:
+            assert getattr(L, name) is not None, (mode, name)
+    assert _lib.load("exact") is not _lib.load("contract")
+    with pytest.raises(ValueError):
+        _lib.lib_path("fast")
+    import subprocess
+    out = subprocess.run(["readelf", "-d", _lib.lib_path("exact")], capture_output=True, text=True).stdout
+    assert "rccl" not in out.lower(), "librccl must stay a run-time (dlopen) dependency"
+
+
 def test_struct_layouts_match_header():
     from castro_amd import _lib
     # sizes implied by the header (LP64): fab = 8 + 12 + 12 + 4 (+4 pad) = 40
@@ -37,6 +62,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Geom) == 3 * 24 + 4 * 12 + 4 + 4
     assert C.sizeof(_lib.Params) == 14 * 4 + 16 * 8 + 2 * 4 + 8 + 4 + 4      # + source_term_predictor (+ tail padding)
     assert C.sizeof(_lib.Rotation) == 6 * 8 + 4 * 4           # castro_amd_rotation
+    assert C.sizeof(_lib.HaloRegion) == 4 + 4 * 12 + 2 * 4    # castro_amd_halo_region
 
 
 def test_default_params_agree_with_oracle(lib, oracle):

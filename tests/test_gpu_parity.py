@@ -2442,3 +2442,22 @@ def test_randomised_driver_runs_match_the_oracle_level_driver():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatching 0" in r.stdout
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts its two ranks itself (a child
+    torch.distributed.run, before torch is imported) and relays rank 0's line: n_gpus == 2 == ranks_seen.  On a one-GPU box
+    the ranks share the device over gloo (CASTRO_AMD_BENCH_BACKEND=gloo: a functional check, the timing means nothing)."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, CASTRO_AMD_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ncell", "64", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["rank_grid"] == "1x1x2"
+    assert d["config"]["backend"] == "gloo" and d["value"] > 0.0
