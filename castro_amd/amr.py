@@ -632,8 +632,9 @@ class CastroAmr:
         if l not in pools:
             from .hydro import HipHydro
             dev = self._hydro_for(l).device
-            pools[l] = [(self._hydro_for(l) if k == 0 else HipHydro(dev.index), torch.cuda.Stream(device=dev))
-                        for k in range(self.box_streams)]
+            # the other contexts of a level run the same build of the kernel library as its first one
+            pools[l] = [(self._hydro_for(l) if k == 0 else HipHydro(dev.index, numerics=getattr(self._hydro_for(l), "numerics", None)),
+                         torch.cuda.Stream(device=dev)) for k in range(self.box_streams)]
         return pools[l]
 
     def all_hydros(self):

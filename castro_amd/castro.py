@@ -82,11 +82,37 @@ class DistComm:
         if not _use_c_halo(self.device_side) or not self.device_side:
             return None
         if self._ccomm is None:
-            box = [hydro.comm_unique_id() if self.rank == 0 else None]
+            # every rank takes part in every step below whatever happens on it, and the ranks agree on the outcome: either all
+            # of them use the C path or none does (a rank on its own in ncclCommInitRank would hang the others)
+            try:
+                uid = hydro.comm_unique_id() if self.rank == 0 else None
+            except Exception as e:                      # librccl could not be bound
+                uid, err = None, e
+            box = [uid]
             self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                             group=self.group)
-            self._ccomm = hydro.comm_create(self.size, self.rank, box[0])
-        return self._ccomm
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            cc = None
+            if box[0] is None:
+                ok.zero_()
+            else:
+                try:
+                    cc = hydro.comm_create(self.size, self.rank, box[0])
+                except Exception as e:
+                    ok.zero_()
+                    err = e
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 1:
+                self._ccomm = cc
+            else:
+                if cc is not None:
+                    hydro.comm_destroy(cc)
+                if self.rank == 0:
+                    import sys
+                    print("castro_amd: the C-level halo exchange is not available on every rank (%s); using torch.distributed"
+                          % (locals().get("err", "another rank failed"),), file=sys.stderr)
+                self._ccomm = False
+        return self._ccomm or None
 
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer_rank, tag, tensor).  Grouped point-to-point."""

@@ -209,8 +209,9 @@ __device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
 // state anyway.  Plain stores: k_final / k_finalx_consup read the cleaned zones again.
 template <bool CLEAN, bool LV = false>
 __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                 SkipBox skip, int clean_n, LevelTab lv)
+                                                 SkipBox skip, int clean_n, LevelTab lv, int lean_q)
 {
+    // lean_q (gamma_law_edges, default-solver path of the `contract` build): nobody downstream reads Q's (rho e) and X planes
     RETURN_IF_BATCH_FAILED();
     unsigned vb = blockIdx.x;
     if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
@@ -273,8 +274,10 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     stg(Q + PV * NC, c, v);
     stg(Q + PW * NC, c, w);
     stg(Q + PP * NC, c, p);
-    stg(Q + PRE * NC, c, e * rho);
-    stg(Q + PX * NC, c, X);
+    if (!lean_q) {
+        stg(Q + PRE * NC, c, e * rho);
+        stg(Q + PX * NC, c, X);
+    }
     stg(Q + PC * NC, c, cs);
 }
 
@@ -703,7 +706,31 @@ __device__ __forceinline__ void ppm_waves(const double s[5], double flat, double
 }
 
 // characteristic projection of trace_ppm.cpp:382-561 with zero source integrals
-template <int D>
+// GL (the `contract` build's default-solver path): gamma-law shortcut.  With (rho e) = p / (gamma - 1) in every zone -- what
+// ctoprim hands over for this EOS -- the parabolas of (rho e) are those of p divided by (gamma - 1) (the limiters are invariant
+// under a positive scaling), h_g_ref / csq_ref = 1 / (gamma - 1), alpha0e_g vanishes identically and the traced (rho e) is the
+// traced p over (gamma - 1).  So the (rho e) stencils are neither loaded nor reconstructed and the edge state's (rho e) is not
+// stored: every reader of QM / QP takes it from p (load_edge_2<NOPRE>).  Exact in real arithmetic away from the small_pres
+// floor; a rounding away from the reference's expression, hence `contract` only.
+//
+// The same switch elides the species.  This build has ONE species (NumSpec = 1), and for one species the
+// reference's own last word on the species flux is normalize_species_fluxes (advection_util.cpp:577-613): F[UFS] = F[UFS] *
+// (F[URHO] / F[UFS]) = F[URHO], whatever the traced, transversally corrected and upwinded X was (unless the interface X is
+// below 2e-16, which normalize_species excludes for a cleaned state).  X is passive -- nothing else reads it -- so every
+// operation on it from the PPM parabola to the Riemann upwinding is dead with respect to the outputs: the GEN == 0 kernels of the
+// `contract` build neither trace, store, load nor correct X (edge states: 5 planes instead of 7; state-form records: 6
+// instead of 7; FL: 8 instead of 9) and set F[UFS] = F[URHO] where the reference normalises.  One rounding away from the
+// reference (its F[UFS] is F[URHO] (1 +- 2 ulp)).
+__host__ __device__ constexpr bool gamma_law_edges(int GEN)
+{
+#ifdef CAD_NUMERICS_CONTRACT
+    return GEN == 0;
+#else
+    return (void)GEN, false;
+#endif
+}
+
+template <int D, bool GL = false>
 __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double cc, const DevParams& P,
                                              double qp[NEDGE], double qm[NEDGE])
 {
@@ -716,7 +743,7 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         double rho_ref = w.Im_rho[0];
         double un_ref = w.Im_un[0];
         double p_ref = w.Im_p[0];
-        double rhoe_g_ref = w.Im_re[0];
+        double rhoe_g_ref = GL ? 0.0 : w.Im_re[0];
 
         // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
         rho_ref = amax(rho_ref, P.small_dens);
@@ -733,7 +760,7 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 
         double drho = rho_ref - w.Im_rho[1];
         double dptot = p_ref - w.Im_p[1];
-        double drhoe_g = rhoe_g_ref - w.Im_re[1];
+        double drhoe_g = GL ? 0.0 : rhoe_g_ref - w.Im_re[1];
 
         double dup = un_ref - w.Im_un[2];
         double dptotp = p_ref - w.Im_p[2];
@@ -757,8 +784,8 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 
         qp[PRHO] = amax_hw(P.small_dens, rho_ref + alphap + alpham + alpha0r);      // positive parameter first (hydro_device.h)
         qp[QUN] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
-        qp[PRE] = amax_hw(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
         qp[PP] = amax_hw(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        qp[PRE] = GL ? qp[PP] * (1.0 / (gam - 1.0)) : amax_hw(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
         qp[QUT] = w.Im_ut[1];
         qp[QUTT] = w.Im_utt[1];
         qp[PX] = w.Im_X[1];
@@ -768,7 +795,7 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         double rho_ref = w.Ip_rho[2];
         double un_ref = w.Ip_un[2];
         double p_ref = w.Ip_p[2];
-        double rhoe_g_ref = w.Ip_re[2];
+        double rhoe_g_ref = GL ? 0.0 : w.Ip_re[2];
 
         // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
         rho_ref = amax(rho_ref, P.small_dens);
@@ -785,7 +812,7 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 
         double drho = rho_ref - w.Ip_rho[1];
         double dptot = p_ref - w.Ip_p[1];
-        double drhoe_g = rhoe_g_ref - w.Ip_re[1];
+        double drhoe_g = GL ? 0.0 : rhoe_g_ref - w.Ip_re[1];
 
         double dup = un_ref - w.Ip_un[2];
         double dptotp = p_ref - w.Ip_p[2];
@@ -809,25 +836,26 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 
         qm[PRHO] = amax_hw(P.small_dens, rho_ref + alphap + alpham + alpha0r);
         qm[QUN] = un_ref + (alphap - alpham) * cc_ref * rho_ref_inv;
-        qm[PRE] = amax_hw(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
         qm[PP] = amax_hw(P.small_pres, p_ref + (alphap + alpham) * csq_ref);
+        qm[PRE] = GL ? qm[PP] * (1.0 / (gam - 1.0)) : amax_hw(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g);
         qm[QUT] = w.Ip_ut[1];
         qm[QUTT] = w.Ip_utt[1];
         qm[PX] = w.Ip_X[1];
     }
 }
 
+template <bool NOPRE = false>          // NOPRE: the (rho e) and X planes are not stored (gamma_law_edges)
 __device__ __forceinline__ void store_edge_2(double* __restrict__ E, long NC, unsigned c, const double q[2][NEDGE], bool m0, bool m1)
 {
     if (m0 && m1) {
 #pragma unroll
-        for (int n = 0; n < NEDGE; ++n) stg2(E + (long)n * NC, c, q[0][n], q[1][n]);
+        for (int n = 0; n < NEDGE; ++n) { if (NOPRE && (n == PRE || n == PX)) continue; stg2(E + (long)n * NC, c, q[0][n], q[1][n]); }
     } else if (m0) {
 #pragma unroll
-        for (int n = 0; n < NEDGE; ++n) stg(E + (long)n * NC, c, q[0][n]);
+        for (int n = 0; n < NEDGE; ++n) { if (NOPRE && (n == PRE || n == PX)) continue; stg(E + (long)n * NC, c, q[0][n]); }
     } else if (m1) {
 #pragma unroll
-        for (int n = 0; n < NEDGE; ++n) stg(E + (long)n * NC, c + 8u, q[1][n]);
+        for (int n = 0; n < NEDGE; ++n) { if (NOPRE && (n == PRE || n == PX)) continue; stg(E + (long)n * NC, c + 8u, q[1][n]); }
     }
 }
 
@@ -886,7 +914,9 @@ __device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, uns
 // aA/aB enter holding the stencils of the normal velocity, bA/bB those of the density; with NEXT >= 0 they leave
 // holding the density (a) and normal-velocity (b) stencils of direction NEXT (stride sdn), requested before the
 // characteristic projection and the stores of this direction.
-template <int D, int NEXT>
+// GL (gamma_law_edges): the (rho e) and X variables are skipped (the two stencil buffers still change roles an odd number of
+// times: the routine leaves with a = density, b = normal velocity of direction NEXT like the full form).
+template <int D, int NEXT, bool GL = false>
 __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __restrict__ Q, unsigned c, unsigned sd, unsigned sdn,
                                                const double flat[2], double dtdx, const DevParams& P,
                                                const bool do_plus[2], const bool do_minus[2],
@@ -913,6 +943,29 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
     ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
 
+    if (GL) {
+        load_stencil_2<D>(Q + (long)QUT * NC, c, sd, bA, bB, xl);
+        ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
+        ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
+
+        load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, aA, aB, xl);
+        ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
+        ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
+
+        // no parabola for X either (see gamma_law_edges): two variables fewer, the buffers leave in the usual roles
+        if (NEXT >= 0) load_stencil_2<(NEXT >= 0 ? NEXT : 0)>(Q + (long)(NEXT == 1 ? PV : PW) * NC, c, sdn, bA, bB);
+        ppm_waves<1>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
+        ppm_waves<1>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
+        if (NEXT >= 0) load_stencil_2<(NEXT >= 0 ? NEXT : 0)>(Q + (long)PRHO * NC, c, sdn, aA, aB);
+        w[0].Ip_X[1] = w[0].Im_X[1] = w[1].Ip_X[1] = w[1].Im_X[1] = 1.0;
+
+        trace_finish<D, true>(w[0], un[0], cc[0], P, qp[0], qm[0]);
+        trace_finish<D, true>(w[1], un[1], cc[1], P, qp[1], qm[1]);
+
+        store_edge_2<true>(QPd, NC, c, qp, do_plus[0], do_plus[1]);
+        store_edge_2<true>(QMd, NC, c + sd, qm, do_minus[0], do_minus[1]);
+        return;
+    }
     load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB, xl);
     ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
     ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
@@ -1206,7 +1259,7 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
 // ---------------------------------------------------------------------------------------
 // helpers shared by the Riemann stages
 // ---------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool NOPRE = false>
 __device__ __forceinline__ void load_rstate(const double* __restrict__ E, long NC, unsigned c, double gamc,
                                             RState& q, double& X)
 {
@@ -1215,9 +1268,9 @@ __device__ __forceinline__ void load_rstate(const double* __restrict__ E, long N
     q.ut = ldg(E + (PU + RDir<D>::t) * NC, c);
     q.utt = ldg(E + (PU + RDir<D>::tt) * NC, c);
     q.p = ldg(E + PP * NC, c);
-    q.rhoe = ldg(E + PRE * NC, c);
+    q.rhoe = NOPRE ? q.p * (1.0 / (gamc - 1.0)) : ldg(E + PRE * NC, c);       // gamma_law_edges: gamc is eos_gamma
     q.gamc = gamc;
-    X = ldg(E + PX * NC, c);
+    X = NOPRE ? 1.0 : ldg(E + PX * NC, c);
 }
 
 template <int D>
@@ -1306,7 +1359,7 @@ __device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsign
         stg(F + QUTT * NC, c, f.utt);
         stg(F + QPG * NC, c, f.pgd);
         stg(F + QREG * NC, c, f.rhoe_g);
-        stg(F + QXG * NC, c, f.X_g);
+        if (!gamma_law_edges(0)) stg(F + QXG * NC, c, f.X_g);         // state form implies GEN == 0
         return;
     }
     if (FEI) stg(FEI, c, f.eint);
@@ -1341,7 +1394,10 @@ __device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC,
     if (QI) {
         double q[2][NQI];
 #pragma unroll
-        for (int n = 0; n < NQI; ++n) { const D2 v = ldg2(F + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b; }
+        for (int n = 0; n < NQI; ++n) {
+            if (gamma_law_edges(0) && n == QXG) { q[0][n] = q[1][n] = 1.0; continue; }     // species elided (gamma_law_edges)
+            const D2 v = ldg2(F + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b;
+        }
 #pragma unroll
         for (int w = 0; w < 2; ++w)
             qstate_to_rec<D>(q[w][QRHO], q[w][QUN], q[w][QUT], q[w][QUTT], q[w][QPG], q[w][QREG], q[w][QXG], r[w]);
@@ -1351,10 +1407,12 @@ __device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC,
     for (int n = 0; n < NF1; ++n) { const D2 v = ldg2(F + (long)n * NC, c); r[0][n] = v.a; r[1][n] = v.b; }
 }
 
-__device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long NC, unsigned c, double q[2][NEDGE])
+template <bool NOPRE = false>          // NOPRE (gamma_law_edges): no (rho e) plane; (rho e) = p * g1inv, g1inv = 1 / (gamma - 1)
+__device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long NC, unsigned c, double q[2][NEDGE], double g1inv = 0.0)
 {
 #pragma unroll
     for (int n = 0; n < NEDGE; ++n) {
+        if (NOPRE && (n == PRE || n == PX)) continue;
 #ifdef EXPERIMENT_NT_EDGE_LOADS     // an edge state is read by one thread of a kernel only
         const d2u w = __builtin_nontemporal_load(reinterpret_cast<const d2u*>(reinterpret_cast<const char*>(E + (long)n * NC) + c));
         q[0][n] = w.x; q[1][n] = w.y;
@@ -1362,6 +1420,7 @@ __device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long N
         const D2 v = ldg2(E + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b;
 #endif
     }
+    if (NOPRE) { q[0][PRE] = q[0][PP] * g1inv; q[1][PRE] = q[1][PP] * g1inv; q[0][PX] = q[1][PX] = 1.0; }
 }
 
 template <int D, bool QI = false>
@@ -1376,7 +1435,7 @@ __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsi
             stg2(F + QUTT * NC, c, f[0].utt, f[1].utt);
             stg2(F + QPG * NC, c, f[0].pgd, f[1].pgd);
             stg2(F + QREG * NC, c, f[0].rhoe_g, f[1].rhoe_g);
-            stg2(F + QXG * NC, c, f[0].X_g, f[1].X_g);
+            if (!gamma_law_edges(0)) stg2(F + QXG * NC, c, f[0].X_g, f[1].X_g);
         } else if (m0) {
             store_f1<D, true>(F, NC, c, f[0]);
         } else if (m1) {
@@ -1423,8 +1482,8 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
     const unsigned sd = dstr(gstr(t), D);
 
     double qm[2][NEDGE], qp[2][NEDGE];
-    load_edge_2(S.QM[D], t.NC, c, qm);
-    load_edge_2(S.QP[D], t.NC, c, qp);
+    load_edge_2<gamma_law_edges(GEN)>(S.QM[D], t.NC, c, qm, 1.0 / (P.gamma - 1.0));
+    load_edge_2<gamma_law_edges(GEN)>(S.QP[D], t.NC, c, qp, 1.0 / (P.gamma - 1.0));
     if (TFIX) {
 #pragma unroll
         for (int w = 0; w < 2; ++w) { temp_fix_edge(qm[w], P); temp_fix_edge(qp[w], P); }
@@ -1450,7 +1509,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
 // viscosity, species normalisation, record for consup, scaling and accumulation
 //   (Castro_ctu_hydro.cpp:1192-1243, 1322-1433; apply_av advection_util.cpp:482-528;
 //    normalize_species_fluxes :577-613; scale_flux :616-641)
-template <int N, bool LIM>
+template <int N, bool LIM, bool NOX = false>      // NOX: the species flux is the mass flux (gamma_law_edges)
 __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch& S, const IFlux f[2], unsigned c,
                                                 unsigned s1, unsigned s2, const DFab& U, unsigned cu, unsigned un_,
                                                 const DFab& fluxes, const DFab& mass, const DFab& qe,
@@ -1509,11 +1568,15 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
+        if (NOX) {
+            F[w][UFS] = F[w][URHO];               // what normalize_species_fluxes makes of it for one species
+        } else {
         double sum = 0.0;
         sum += F[w][UFS];
         double fac = 1.0;
         if (fabs(sum) > 2.220446049250313e-16 * fabs(F[w][URHO])) fac = F[w][URHO] / sum;
         F[w][UFS] = F[w][UFS] * fac;
+        }
 
         // record for consup (stored by the caller, two faces per store)
         R[w][GRHO] = F[w][URHO]; R[w][GMX] = F[w][UMX]; R[w][GMY] = F[w][UMY]; R[w][GMZ] = F[w][UMZ];
@@ -1593,6 +1656,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P, SkipBox skip, LevelTab lv)
 {
+    constexpr bool GL = gamma_law_edges(GEN) && DMASK == 7;
     STAGGER_START();
     if (P.dtp) dt = P.dtp[6];
     unsigned vb = blockIdx.x;
@@ -1675,7 +1739,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     if (DMASK & 1) {
         load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1], xl);
         load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1], xl);
-        trace_pair_dir<0, (DMASK & 2) ? 1 : -1>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1], xl);
+        trace_pair_dir<0, (DMASK & 2) ? 1 : -1, GL>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1], xl);
     }
 
     if (XRIEM && (DMASK & 1))
@@ -1724,7 +1788,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             load_stencil_2<1>(Q + (long)PRHO * NC, c, s.y, sa[0], sa[1]);
         }
         const bool a = j >= t.lo[1], z = j <= t.hi[1]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
-        trace_pair_dir<1, (DMASK & 4) ? 2 : -1>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sb[0], sb[1], sa[0], sa[1]);
+        trace_pair_dir<1, (DMASK & 4) ? 2 : -1, GL>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sb[0], sb[1], sa[0], sa[1]);
     }
     if (DMASK & 4) {
         if (!(DMASK & 2)) {
@@ -1732,7 +1796,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             load_stencil_2<2>(Q + (long)PRHO * NC, c, s.z, sb[0], sb[1]);
         }
         const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
-        trace_pair_dir<2, -1>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+        trace_pair_dir<2, -1, GL>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
     }
 }
 
@@ -1751,8 +1815,8 @@ __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, c
     const unsigned c = goff(t, i, j, k);
     RState ql, qr;
     double Xl, Xr;
-    load_rstate<0>(S.QM[0], t.NC, c, P.gamma, ql, Xl);
-    load_rstate<0>(S.QP[0], t.NC, c, P.gamma, qr, Xr);
+    load_rstate<0, gamma_law_edges(GEN)>(S.QM[0], t.NC, c, P.gamma, ql, Xl);
+    load_rstate<0, gamma_law_edges(GEN)>(S.QP[0], t.NC, c, P.gamma, qr, Xr);
     const double cl = ldg(Q + PC * t.NC, c - 8u);
     const double cr = ldg(Q + PC * t.NC, c);
     IFlux f;
@@ -1885,8 +1949,8 @@ __device__ __forceinline__ void trans1_body(const Tile& t, const int ijk[3], boo
         qp[w][PRHO] = 1.1 + e; qp[w][PU] = 0.2; qp[w][PV] = 0.1 + e; qp[w][PW] = 0.2; qp[w][PP] = 1.1 + e; qp[w][PRE] = 2.75; qp[w][PX] = 1.0;
     }
 #else
-    load_edge_2(S.QM[N], t.NC, c, qm);
-    load_edge_2(S.QP[N], t.NC, c, qp);
+    load_edge_2<gamma_law_edges(GEN)>(S.QM[N], t.NC, c, qm, 1.0 / (P.gamma - 1.0));
+    load_edge_2<gamma_law_edges(GEN)>(S.QP[N], t.NC, c, qp, 1.0 / (P.gamma - 1.0));
     const D2 cl = ldg2(Q + PC * t.NC, c - sn);
     const D2 cr = ldg2(Q + PC * t.NC, c);
 #endif
@@ -1964,8 +2028,8 @@ __device__ __forceinline__ void f1_at_2(const Tile& t, const double* __restrict_
                                         const DevParams& P, unsigned cf, int idx, double r[2][NF1])
 {
     double qm[2][NEDGE], qp[2][NEDGE];
-    load_edge_2(S.QM[D], t.NC, cf, qm);
-    load_edge_2(S.QP[D], t.NC, cf, qp);
+    load_edge_2<gamma_law_edges(GEN)>(S.QM[D], t.NC, cf, qm, 1.0 / (P.gamma - 1.0));
+    load_edge_2<gamma_law_edges(GEN)>(S.QP[D], t.NC, cf, qp, 1.0 / (P.gamma - 1.0));
     const unsigned sd = dstr(gstr(t), D);
     const D2 cl = ldg2(Q + PC * t.NC, cf - sd), cr = ldg2(Q + PC * t.NC, cf);
     f1_solve_2<D, GEN>(qm, qp, cl, cr, wall_fac<D>(g, idx), P, r);
@@ -1977,8 +2041,8 @@ __device__ __forceinline__ void f1_at_2c(const Tile& t, const DevScratch& S, con
                                          const D2& cl, const D2& cr, double r[2][NF1])
 {
     double qm[2][NEDGE], qp[2][NEDGE];
-    load_edge_2(S.QM[D], t.NC, cf, qm);
-    load_edge_2(S.QP[D], t.NC, cf, qp);
+    load_edge_2<gamma_law_edges(GEN)>(S.QM[D], t.NC, cf, qm, 1.0 / (P.gamma - 1.0));
+    load_edge_2<gamma_law_edges(GEN)>(S.QP[D], t.NC, cf, qp, 1.0 / (P.gamma - 1.0));
     f1_solve_2<D, GEN>(qm, qp, cl, cr, wall_fac<D>(g, idx), P, r);
 }
 
@@ -2073,8 +2137,8 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
         double A[2][NF1];
         {
             double qm[2][NEDGE], qp[2][NEDGE];
-            load_edge_2(S.QM[T], NC, c, qm);
-            load_edge_2(S.QP[T], NC, c, qp);
+            load_edge_2<gamma_law_edges(GEN)>(S.QM[T], NC, c, qm, 1.0 / (P.gamma - 1.0));
+            load_edge_2<gamma_law_edges(GEN)>(S.QP[T], NC, c, qp, 1.0 / (P.gamma - 1.0));
             const D2 cl = ldg2(Cp, c - st), cr = c0;
             f1_solve_2<T, GEN>(qm, qp, cl, cr, wall_fac<T>(g, ijk[T]), P, A);
 #pragma unroll
@@ -2112,13 +2176,13 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
         const bool m0 = tin && ijk[0] >= t.lo[0], m1 = tin && v1 && ijk[0] + 1 >= t.lo[0];
         if (m0 || m1) {
             double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
-            load_edge_2(S.QM[0], NC, c, q);
+            load_edge_2<gamma_law_edges(GEN)>(S.QM[0], NC, c, q, 1.0 / (P.gamma - 1.0));
             const int tl = th > 0 ? th - 1 : 0;    // thread 0 owns nothing
             park_get(park, 1, 1, tl, fr); park_get(park, 0, 1, tl, fl);
             trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qmo[0]);
             park_get(park, 1, 0, th, fr); park_get(park, 0, 0, th, fl);
             trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qmo[1]);
-            load_edge_2(S.QP[0], NC, c, q);
+            load_edge_2<gamma_law_edges(GEN)>(S.QP[0], NC, c, q, 1.0 / (P.gamma - 1.0));
             trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qpo[0]);
             park_get(park, 1, 1, th, fr); park_get(park, 0, 1, th, fl);
             trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qpo[1]);
@@ -2137,11 +2201,11 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
                 double B0[2][NF1], B1[2][NF1];
                 f1_at_2c<T, GEN>(t, S, g, P, c - so, ijk[T], ldg2(Cp, c - so - st), cso, B0);
                 f1_at_2c<T, GEN>(t, S, g, P, c - so + st, ijk[T] + 1, cso, ldg2(Cp, c - so + st), B1);
-                load_edge_2(S.QM[O], NC, c, q);
+                load_edge_2<gamma_law_edges(GEN)>(S.QM[O], NC, c, q, 1.0 / (P.gamma - 1.0));
 #pragma unroll
                 for (int w = 0; w < 2; ++w) trans_single<T>(q[w], B1[w], B0[w], P.gamma, cdtdt, P, qmo[w]);
             }
-            load_edge_2(S.QP[O], NC, c, q);
+            load_edge_2<gamma_law_edges(GEN)>(S.QP[O], NC, c, q, 1.0 / (P.gamma - 1.0));
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
                 park_get(park, 1, w, th, fr); park_get(park, 0, w, th, fl);
@@ -2213,7 +2277,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     const double* F21 = S.F2[f2_slot(T2, T1)];   // F^{T2|T1}: flux_t2
 
     // minus states (zones c - sn)
-    load_edge_2(S.QM[N], NC, c, q);
+    load_edge_2<gamma_law_edges(GEN)>(S.QM[N], NC, c, q, 1.0 / (P.gamma - 1.0));
     if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }   // changed by its first solve
 #ifdef DIAG_F2_REUSE      // timing diagnostic (wrong results): two record loads per face pair instead of eight
     load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c, f1l);
@@ -2240,7 +2304,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
     }
 
     // plus states (zones c)
-    load_edge_2(S.QP[N], NC, c, q);
+    load_edge_2<gamma_law_edges(GEN)>(S.QP[N], NC, c, q, 1.0 / (P.gamma - 1.0));
     if (RE && P.ppm_temp_fix == 2 && P.riemann_solver != 2) { temp_fix_edge(q[0], P); temp_fix_edge(q[1], P); }
 #ifndef DIAG_F2_REUSE
     load_f1_2<T1, (kQI && GEN == 0)>(F12, NC, c + s1, f1r);
@@ -2278,7 +2342,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
         interface_flux<N, GEN>(rl, rr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<N>(g, idxN),
                           face_shock(S, P, c + 8u * w, sn), P, f[w]);
     }
-    final_flux_tail<N, LIM>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
+    final_flux_tail<N, LIM, (gamma_law_edges(GEN) && !LIM)>(t, S, f, c, s1, s2, U, foff(U, ijk[0], ijk[1], ijk[2]), usn, fluxes, mass, qe,
                             ijk[0], ijk[1], ijk[2], dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
     if (!STORE_FL) return;
     double* FL = S.FL[N];
@@ -2289,15 +2353,16 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
         else { stg(FL + (long)GUG * NC, c + 8u, R[1][GUG]); stg(FL + (long)GPG * NC, c + 8u, R[1][GPG]); }
         return;
     }
+    constexpr bool NOX = gamma_law_edges(GEN) && !LIM;      // record GX == record GRHO: not stored, consup reads GRHO
     if (v0 && v1) {
 #pragma unroll
-        for (int n = 0; n < NFIN; ++n) stg2(FL + (long)n * NC, c, R[0][n], R[1][n]);
+        for (int n = 0; n < NFIN; ++n) { if (NOX && n == GX) continue; stg2(FL + (long)n * NC, c, R[0][n], R[1][n]); }
     } else if (v0) {
 #pragma unroll
-        for (int n = 0; n < NFIN; ++n) stg(FL + (long)n * NC, c, R[0][n]);
+        for (int n = 0; n < NFIN; ++n) { if (NOX && n == GX) continue; stg(FL + (long)n * NC, c, R[0][n]); }
     } else {
 #pragma unroll
-        for (int n = 0; n < NFIN; ++n) stg(FL + (long)n * NC, c + 8u, R[1][n]);
+        for (int n = 0; n < NFIN; ++n) { if (NOX && n == GX) continue; stg(FL + (long)n * NC, c + 8u, R[1][n]); }
     }
 }
 
@@ -2487,7 +2552,8 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
         const double* F2 = S.FL[2];
         const unsigned cn = foff(Unew, ijk[0], ijk[1], ijk[2]);
         const unsigned ci = foff(U, ijk[0], ijk[1], ijk[2]);
-        constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GX };
+        // gamma_law_edges: the species record of FL[y], FL[z] is their mass record (not stored)
+        constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, (gamma_law_edges(GEN) && !LIM) ? GRHO : GX };
         double un[2][NUM_STATE];
         // kFluxOutConsup (assign & 2): the y / z fluxes, already scaled by dt * area, from the caller's flux arrays
         const bool from_out = kFluxOutConsup && (assign & 2) != 0;
@@ -2673,7 +2739,11 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // limiters, transverse_reset_rhoe and ppm_temp_fix run kernels of the full solver set (flux-form records).
     const bool plain_path = !(P.ppm_temp_fix == 2 && P.riemann_solver != 2) && P.reset_rhoe != 1 && g_fuse_consup == 1
                             && P.limit_small_dens != 1 && P.limit_large_vel != 1;
-    const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1 || !plain_path) ? 1 : 0);
+    // gamma_law_edges (contract build): the GEN == 0 readers take (rho e) of an edge state from its p, which only the trace
+    // kernel of the no-source PPM path promises (k_trace_pair<true, 7, 0>); traces with source terms or PLM run the GEN >= 1 set
+    const bool gl_ok = !gamma_law_edges(0) || (!Src.p && P.ppm_type == 1);
+    const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1 || !plain_path || !gl_ok) ? 1 : 0);
+    const int lean_q = (gamma_law_edges(0) && solv == 0) ? 1 : 0;
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
     const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
     SkipBox valid_box, inner_box;
@@ -2713,7 +2783,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 
     if (stage_a) {
         if (splittable) {
-            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv);
+            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
             if (inner_ok) trace_with_xriemann(inner_box.lo, inner_box.hi);
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -2722,11 +2792,11 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     int slo[6][3], shi[6][3];
     if (second_half) {
         const int ns = shell_boxes(qlo, qhi, t.lo, t.hi, slo, shi);
-        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0, nolv);
+        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
     } else if (aux.sb_clean > 0) {
-        KL("k_ctoprim_clean", k_ctoprim<true>, qlo, qhi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv);
+        KL("k_ctoprim_clean", k_ctoprim<true>, qlo, qhi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q);
     } else {
-        KL("k_ctoprim", k_ctoprim<false>, qlo, qhi, Sborder, S.Q, P, d_status, none, 0, nolv);
+        KL("k_ctoprim", k_ctoprim<false>, qlo, qhi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
     }
 
     int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
@@ -2985,9 +3055,9 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
 
     prof_begin(prof, sb_clean > 0 ? "k_ctoprim_clean" : "k_ctoprim", stream);
     if (sb_clean > 0) hipLaunchKernelGGL((k_ctoprim<true, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
-                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM));
+                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM), gamma_law_edges(0) ? 1 : 0);
     else hipLaunchKernelGGL((k_ctoprim<false, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
-                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM));
+                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? 1 : 0);
     prof_end(prof, stream);
     prof_begin(prof, "k_divu", stream);
     hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,

@@ -195,3 +195,65 @@ def test_contract_sedov_256_ten_steps_against_oracle_and_to_stop_time_against_ex
     print("contract vs exact (GPU), Sedov 256^3 at t = %.4f after %d steps: max deviation %.2e (%s)" % (c.time, c.nstep, dev[worst], worst))
     bad = {k: v for k, v in dev.items() if not v <= RTOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("case", ["plm", "hllc", "hybrid", "cg", "gravity"])
+def test_contract_non_default_options_within_rtol(oracle, case):
+    """The `contract` build on the option sets that leave its default-solver path (whose edge states carry no (rho e) plane,
+    gamma_law_edges): PLM, HLLC, the hybrid solver, Colella-Glaz, and a constant-gravity source (traced source terms):
+    Sedov 32^3, 30 steps, the conserved state and dt against the oracle at the same tolerance."""
+    import torch
+    import castro_amd
+    pkw = {"plm": dict(ppm_type=0), "hllc": dict(riemann_solver=2), "hybrid": dict(hybrid_riemann=1), "cg": dict(riemann_solver=1),
+           "gravity": {}}[case]
+    n = (32, 32, 32)
+    grav = dict(do_grav=True, const_grav=-2.0) if case == "gravity" else {}
+    c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), numerics="contract", **grav)
+    c.initData("sedov", r_init=0.1, nsub=4)
+    lev = oracle.Level(n, oracle.make_geom(n), oracle.default_params(**pkw), nthreads=0)
+    if case == "gravity":
+        lev.set_gravity(-2.0)
+    lev.init_sedov(r_init=0.1, nsub=4)
+    for _ in range(30):
+        c.step(0.05)
+        lev.step(0.05)
+    torch.cuda.synchronize()
+    got, want = c.S_new().cpu().numpy(), lev.state()
+    dev = {k: np.abs(got[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-300) for k in range(8)}
+    # the momentum components of a blast centred in the box are of one size: each is held to the largest of the three
+    mom = max(np.abs(want[k]).max() for k in (1, 2, 3))
+    for k in (1, 2, 3):
+        dev[k] = np.abs(got[k] - want[k]).max() / mom
+    print("contract vs oracle, %-8s 30 steps: max deviation %.2e; dt deviation %.1e" % (case, max(dev.values()), abs(c.dt - lev.dt) / lev.dt))
+    assert all(v <= RTOL for v in dev.values()), dev
+    assert abs(c.dt - lev.dt) <= RTOL * lev.dt
+    lev.close()
+
+
+def test_contract_amr_two_refined_levels_within_rtol_of_exact():
+    """Config 4's structure (base + two refined levels, subcycled, refluxed; a level is one grid per kernel) in the `contract`
+    mode against the `exact` mode (which the AMR parity tests tie to the oracle backend bit for bit): every box of every level
+    at the tolerance after eight coarse steps, same dt."""
+    import torch
+    import castro_amd
+    from castro_amd.hydro import HipHydro
+    kw = dict(patches=[[((4, 4, 4), (11, 11, 11))], [((10, 10, 10), (15, 15, 15)), ((16, 10, 10), (19, 15, 15))]])
+    runs = {}
+    for mode in ("exact", "contract"):
+        a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1),
+                                 make_hydro=lambda m=mode: HipHydro(0, numerics=m), **kw)
+        a.initData("sedov", r_init=0.1, nsub=4)
+        dts = [a.step() for _ in range(8)]
+        torch.cuda.synchronize()
+        runs[mode] = (dts, [[b.S_new().cpu().numpy() for b in lev.boxes] for lev in a.levels], a.levels[0].boxes[0].hydro.numerics)
+    assert runs["exact"][2] == "exact" and runs["contract"][2] == "contract"
+    worst = 0.0
+    for le, lc in zip(runs["exact"][1], runs["contract"][1]):
+        for be, bc in zip(le, lc):
+            mom = max(np.abs(be[k]).max() for k in (1, 2, 3))
+            for k in range(8):
+                scale = mom if k in (1, 2, 3) else np.abs(be[k]).max()
+                worst = max(worst, np.abs(bc[k] - be[k]).max() / scale)
+    ddt = max(abs(x - y) / y for x, y in zip(runs["contract"][0], runs["exact"][0]))
+    print("contract vs exact, AMR 16^3 + 2 levels, 8 coarse steps: max deviation %.2e; dt deviation %.1e" % (worst, ddt))
+    assert 0.0 < worst <= RTOL and ddt <= RTOL

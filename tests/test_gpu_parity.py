@@ -2461,3 +2461,58 @@ def test_bench_gpus_n_launches_its_own_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["rank_grid"] == "1x1x2"
     assert d["config"]["backend"] == "gloo" and d["value"] > 0.0
+
+
+@pytest.mark.parametrize("numerics", ["exact", "contract"])
+def test_level_wide_launch_of_unequal_boxes_equals_the_per_box_calls(numerics):
+    """castro_amd_ctu_hydro_mf as ONE grid per kernel (round 4: the box table of launch_ctu_hydro_level) over seven boxes of
+    unequal and odd shapes -- a one-zone-wide one, one with more rows than a y-tile, one longer than two waves -- against
+    castro_amd_ctu_hydro_fab_ex box by box: S_new, fluxes and mass fluxes bit for bit (the arithmetic per zone is the same
+    code in both numerics modes), with the fused clean_state / reduction and in flux-assign mode."""
+    import torch
+    import castro_amd
+    h = castro_amd.HipHydro(0, numerics=numerics)
+    rng = np.random.default_rng(77)
+    P = castro_amd.default_params()
+    dx = (0.02, 0.015, 0.03)
+    shapes = [(37, 9, 11), (8, 8, 8), (1, 5, 3), (130, 4, 3), (16, 70, 2), (5, 5, 40), (24, 24, 24)]
+    G = castro_amd.make_geom((400, 400, 400), prob_hi=tuple(400 * d for d in dx))
+    dt = 6.0e-4
+    for clean, assign in ((0, False), (2, True)):
+        specs, per_box = [], []
+        red_mf = torch.full((3,), 1.e200, dtype=torch.float64, device=h.device)
+        red_pb = red_mf.clone()
+        for n, shape in enumerate(shapes):
+            lo = (3 + 17 * n, 40 - 5 * n, 7 + 11 * n)
+            hi = tuple(lo[d] + shape[d] - 1 for d in range(3))
+            sb_lo, sb_hi = tuple(x - 4 for x in lo), tuple(x + 4 for x in hi)
+            U = _to_dev(h, physical_state(rng, sb_lo, sb_hi, jump=True))
+            sl = (slice(None),) + tuple(slice(4, 4 + shape[2 - a]) for a in range(3))
+            two = []
+            for _ in range(2):
+                Sn = U[sl].clone().contiguous()
+                fl, mf, fb = [], [], []
+                for d in range(3):
+                    fhi = list(hi)
+                    fhi[d] += 1
+                    fb.append((lo, tuple(fhi)))
+                    fl.append(h.alloc(8, lo, fhi, fill=float("nan") if assign else 0.0))
+                    mf.append(h.alloc(1, lo, fhi))
+                two.append((Sn, fl, mf, fb))
+            specs.append(((lo, hi), (lo, hi), (U, (sb_lo, sb_hi)), (two[0][0], (lo, hi)), two[0][1], two[0][3], two[0][2]))
+            per_box.append(((lo, hi), U, (sb_lo, sb_hi), two[1], two[0]))
+        h.construct_ctu_hydro_source_mf(None, h.make_hydro_boxes(specs), G, P, 0.0, dt, update_from_sborder=True, flux_assign=assign,
+                                        clean_ntimes=clean, red=red_mf if clean else None)
+        for bx, U, sbb, (Sn, fl, mf, fb), _ in per_box:
+            h.construct_ctu_hydro_source(bx, U, sbb, Sn, bx, G, P, 0.0, dt, fluxes=fl, flux_boxes=fb, mass_fluxes=mf, vbx=bx,
+                                         update_from_sborder=True, flux_assign=assign, clean_ntimes=clean, red=red_pb if clean else None)
+        torch.cuda.synchronize()
+        assert h.status() == 0
+        for n, (bx, U, sbb, pb, lv) in enumerate(per_box):
+            assert torch.equal(pb[0], lv[0]), ("S_new", n, shapes[n], clean, assign)
+            for d in range(3):
+                assert torch.equal(pb[1][d], lv[1][d]), ("flux", d, n, shapes[n])
+                assert torch.equal(pb[2][d], lv[2][d]), ("mass flux", d, n, shapes[n])
+        if clean:
+            assert torch.equal(red_mf, red_pb), (red_mf, red_pb)
+    h.close()
