@@ -52,12 +52,27 @@ KERNEL_BYTES_PER_UNIT = {
 }
 
 
-def kernel_bytes_per_unit(name, contract):
+# The `contract` build with the default options (gamma-law gas, one species, default solver) does not carry (rho e) or X
+# through the edge states and X through the records (`gamma_law_edges`): its kernels have fewer planes.
+KERNEL_BYTES_PER_UNIT_LEAN = {
+    "k_ctoprim": 8 * (8 + 6),
+    "k_ctoprim_clean": 8 * (8 + 6),
+    "k_trace": 8 * (6 + 30 + 6),                          # Q without (rho e), X; 5-plane edge states; 6-plane F1[x]
+    "k_trans1_fold": 8 * (30 + 6 + 1 + 36),               # F2 in the 6-plane state form
+    "k_final_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 17),
+    "k_final_assign": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 9),  # FL without the species plane
+    "k_finalx_consup_rmw": 8 * (10 + 12 + 1 + 1 + 8 + 17 + 16 + 8),
+    "k_finalx_consup_assign": 8 * (10 + 12 + 1 + 1 + 8 + 9 + 16 + 8),
+}
+
+
+def kernel_bytes_per_unit(name, contract, lean=False):
+    tab = dict(KERNEL_BYTES_PER_UNIT, **KERNEL_BYTES_PER_UNIT_LEAN) if lean else KERNEL_BYTES_PER_UNIT
     if name in ("k_final_x", "k_final_y", "k_final_z"):
-        return KERNEL_BYTES_PER_UNIT["k_final_rmw" if contract else "k_final_assign"]
+        return tab["k_final_rmw" if contract else "k_final_assign"]
     if name == "k_finalx_consup":
-        return KERNEL_BYTES_PER_UNIT["k_finalx_consup_rmw" if contract else "k_finalx_consup_assign"]
-    return KERNEL_BYTES_PER_UNIT.get(name, 0)
+        return tab["k_finalx_consup_rmw" if contract else "k_finalx_consup_assign"]
+    return tab.get(name, 0)
 
 
 def kernel_units(name, n):
@@ -367,7 +382,7 @@ def main():
     # per-kernel HBM utilisation: compulsory bytes of a launch over its hipEvent-timed duration
     kutil = {}
     for name, (tot_ms, launches) in sorted(prof.items()):
-        bpu = kernel_bytes_per_unit(name, contract)
+        bpu = kernel_bytes_per_unit(name, contract, lean=(info["numerics"] == "contract"))
         avg_ms = tot_ms / launches
         e = {"avg_launch_ms": avg_ms, "launches_per_step": launches / ksteps, "ms_per_step": tot_ms / ksteps}
         if bpu:

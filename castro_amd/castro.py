@@ -840,11 +840,22 @@ class Castro:
         assert self._eager_done, "capture_step_graph: run at least one host-free step first (scratch is reserved lazily)"
         key = (float(stop_time), self.S_old_b.data_ptr(), self.S_new_b.data_ptr())
         if key not in self._graphs:
+            # No finaliser may run while the stream is capturing: a collected context, graph or event would call hipFree /
+            # hipGraphExecDestroy in the middle of the capture, which the runtime answers with abort().  torch.cuda.graph
+            # stopped collecting on entry (torch >= 2.9), so: collect now, and keep the cyclic collector off until the end.
+            import gc
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._step_device(stop_time)
-                self._step_device(stop_time)
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_device(stop_time)
+                    self._step_device(stop_time)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             self._graphs[key] = g
         return self._graphs[key]
 

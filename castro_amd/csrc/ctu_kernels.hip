@@ -2218,6 +2218,162 @@ __device__ __forceinline__ void trans1_fold_dir_lds(const Tile& t, const int ijk
     }
 }
 
+// ---- the same with every phase's edge states requested one phase ahead (FOLD_REQUEST_AHEAD; the `contract` build's default-solver
+// instantiation: its 5-variable edge states leave the ~40 registers a pending pair of edge states needs below the two-wave
+// limit).  A wave's loads for the next phase are in flight while it solves the current one, instead of both waves of a SIMD
+// waiting at the head of every phase.
+#ifndef FOLD_REQUEST_AHEAD
+#ifdef CAD_NUMERICS_CONTRACT
+#define FOLD_REQUEST_AHEAD 1
+#else
+#define FOLD_REQUEST_AHEAD 0
+#endif
+#endif
+struct EdgeReq { D2 m[NEDGE], p[NEDGE]; };       // requested minus / plus states of a face pair (slots PRE, PX stay untouched with NOPRE)
+
+template <bool NOPRE>
+__device__ __forceinline__ void edge_request(const double* __restrict__ EM, const double* __restrict__ EP, long NC, unsigned c, EdgeReq& r)
+{
+#pragma unroll
+    for (int n = 0; n < NEDGE; ++n) {
+        if (NOPRE && (n == PRE || n == PX)) continue;
+        r.m[n] = ldg2(EM + (long)n * NC, c);
+        r.p[n] = ldg2(EP + (long)n * NC, c);
+    }
+}
+
+template <bool NOPRE>
+__device__ __forceinline__ void edge_take(const D2 r[NEDGE], double q[2][NEDGE], double g1inv)
+{
+#pragma unroll
+    for (int n = 0; n < NEDGE; ++n) {
+        if (NOPRE && (n == PRE || n == PX)) continue;
+        q[0][n] = r[n].a; q[1][n] = r[n].b;
+    }
+    if (NOPRE) { q[0][PRE] = q[0][PP] * g1inv; q[1][PRE] = q[1][PP] * g1inv; q[0][PX] = q[1][PX] = 1.0; }
+}
+
+template <int T, int GEN, bool TX_HERE>
+__device__ __forceinline__ void trans1_fold_dir_ahead(const Tile& t, const int ijk[3], bool v1, bool owner, unsigned c,
+                                                      const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
+                                                      double cdtdt, double cdtdx, const DevParams& P, double* __restrict__ park,
+                                                      const D2& c0)
+{
+    constexpr int O = (T == 1) ? 2 : 1;
+    constexpr bool NP = gamma_law_edges(GEN);
+    const Str s = gstr(t);
+    const unsigned st = dstr(s, T), so = dstr(s, O);
+    const long NC = t.NC;
+    const double* Cp = Q + PC * NC;
+    const int th = threadIdx.x;
+    const double g1inv = 1.0 / (P.gamma - 1.0);
+
+    FOLD_SYNC();                                   // the readers of the previous direction's records are done
+    EdgeReq e0, e1;
+    edge_request<NP>(S.QM[T], S.QP[T], NC, c, e0);
+    const D2 cl = ldg2(Cp, c - st);
+    edge_request<NP>(S.QM[T], S.QP[T], NC, c + st, e1);           // ahead: the faces above
+    const D2 cst = ldg2(Cp, c + st);
+    {
+        double A[2][NF1];
+        double qm[2][NEDGE], qp[2][NEDGE];
+        edge_take<NP>(e0.m, qm, g1inv); edge_take<NP>(e0.p, qp, g1inv);
+        f1_solve_2<T, GEN>(qm, qp, cl, c0, wall_fac<T>(g, ijk[T]), P, A);
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n];
+        if (TX_HERE) {                             // the (T | x) combination on the same edge states (see trans1_fold_dir_lds)
+            bool in_t[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int ix = ijk[0] + w;
+                in_t[w] = owner && ((w == 0) || v1) && ijk[T] >= t.lo[T] && ix >= t.lo[0] && ix <= t.hi[0];
+            }
+            if (in_t[0] || in_t[1]) {
+                double bnd[2];
+                bnd[0] = bnd[1] = wall_fac<T>(g, ijk[T]);
+                trans1_pair<T, 0, false, GEN>(t, S, c, st, 8u, qm, qp, cl, c0, bnd, cdtdx, in_t[0], in_t[1], P);
+            }
+        }
+    }
+    EdgeReq x0;
+    edge_request<NP>(S.QM[0], S.QP[0], NC, c, x0);                // ahead: the x faces of the N = x phase
+    const D2 clx = ldg2(Cp, c - 8u);
+    {
+        double A[2][NF1];
+        double qm[2][NEDGE], qp[2][NEDGE];
+        edge_take<NP>(e1.m, qm, g1inv); edge_take<NP>(e1.p, qp, g1inv);
+        f1_solve_2<T, GEN>(qm, qp, c0, cst, wall_fac<T>(g, ijk[T] + 1), P, A);
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int n = 0; n < NF1; ++n) park[((1 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n];
+    }
+    FOLD_SYNC();
+
+    EdgeReq b0;
+    edge_request<NP>(S.QM[T], S.QP[T], NC, c - so, b0);           // ahead: the T faces of the zones below (N = O phase)
+    const D2 cso = ldg2(Cp, c - so), csom = ldg2(Cp, c - so - st), csop = ldg2(Cp, c - so + st);
+
+    const bool tin = owner && ijk[T] >= t.lo[T] && ijk[T] <= t.hi[T];
+    double fr[NF1], fl[NF1];
+    // ---- N = x
+    {
+        const bool m0 = tin && ijk[0] >= t.lo[0], m1 = tin && v1 && ijk[0] + 1 >= t.lo[0];
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            edge_take<NP>(x0.m, q, g1inv);
+            const int tl = th > 0 ? th - 1 : 0;    // thread 0 owns nothing
+            park_get(park, 1, 1, tl, fr); park_get(park, 0, 1, tl, fl);
+            trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qmo[0]);
+            park_get(park, 1, 0, th, fr); park_get(park, 0, 0, th, fl);
+            trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qmo[1]);
+            edge_take<NP>(x0.p, q, g1inv);
+            trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qpo[0]);
+            park_get(park, 1, 1, th, fr); park_get(park, 0, 1, th, fl);
+            trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qpo[1]);
+            double bnd[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
+            trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, clx, c0, bnd, m0, m1, P);
+        }
+    }
+    // ---- N = O
+    {
+        const bool m0 = tin && ijk[O] >= t.lo[O], m1 = m0 && v1;
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            EdgeReq b1, o0;
+            edge_request<NP>(S.QM[T], S.QP[T], NC, c - so + st, b1);      // ahead: the second pair of faces below
+            {
+                double B0[2][NF1], B1[2][NF1];
+                {
+                    double qm[2][NEDGE], qp[2][NEDGE];
+                    edge_take<NP>(b0.m, qm, g1inv); edge_take<NP>(b0.p, qp, g1inv);
+                    f1_solve_2<T, GEN>(qm, qp, csom, cso, wall_fac<T>(g, ijk[T]), P, B0);
+                }
+                edge_request<NP>(S.QM[O], S.QP[O], NC, c, o0);            // ahead: the O faces themselves
+                {
+                    double qm[2][NEDGE], qp[2][NEDGE];
+                    edge_take<NP>(b1.m, qm, g1inv); edge_take<NP>(b1.p, qp, g1inv);
+                    f1_solve_2<T, GEN>(qm, qp, cso, csop, wall_fac<T>(g, ijk[T] + 1), P, B1);
+                }
+                edge_take<NP>(o0.m, q, g1inv);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) trans_single<T>(q[w], B1[w], B0[w], P.gamma, cdtdt, P, qmo[w]);
+            }
+            edge_take<NP>(o0.p, q, g1inv);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                park_get(park, 1, w, th, fr); park_get(park, 0, w, th, fl);
+                trans_single<T>(q[w], fr, fl, P.gamma, cdtdt, P, qpo[w]);
+            }
+            double bnd[2];
+            bnd[0] = bnd[1] = wall_fac<O>(g, ijk[O]);
+            trans1_solve_store<O, T, GEN>(t, S, c, qmo, qpo, cso, c0, bnd, m0, m1, P);
+        }
+    }
+}
+
 template <int GEN, bool LV = false>
 __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                          double cdtdx, double cdtdy, double cdtdz, DevParams P, LevelTab lv)
@@ -2233,8 +2389,13 @@ __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t
     const bool v1 = ijk[0] + 1 <= b.hi0;
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     const D2 c0 = ldg2(Q + PC * t.NC, c);
-    trans1_fold_dir_lds<1, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
-    trans1_fold_dir_lds<2, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
+    if (FOLD_REQUEST_AHEAD && gamma_law_edges(GEN)) {
+        trans1_fold_dir_ahead<1, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
+        trans1_fold_dir_ahead<2, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
+    } else {
+        trans1_fold_dir_lds<1, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdy, cdtdx, P, park, c0);
+        trans1_fold_dir_lds<2, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
+    }
 }
 
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one

@@ -50,6 +50,10 @@ class HipHydro:
 
     def __del__(self):
         try:
+            # a finaliser that runs in the middle of a stream capture must not free device memory (the runtime aborts):
+            # leave the context to the end of the process instead
+            if torch.cuda.is_current_stream_capturing():
+                return
             self.close()
         except Exception:
             pass

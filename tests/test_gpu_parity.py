@@ -1841,9 +1841,15 @@ def test_hydro_call_is_hipgraph_capturable(hip):
     call(ref, red_ref)                                   # also reserves the scratch
     torch.cuda.synchronize()
     Sn, red = hip.alloc(8, bxlo, bxhi), torch.full((3,), 1e200, dtype=torch.float64, device="cuda")
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        call(Sn, red)
+    import gc
+    gc.collect()
+    gc.disable()                                         # no finaliser (hipFree, graph destruction) inside the capture
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            call(Sn, red)
+    finally:
+        gc.enable()
     torch.cuda.synchronize()
     assert float(Sn.abs().sum()) == 0.0                 # captured, not executed
     for _ in range(2):
