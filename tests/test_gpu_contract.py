@@ -257,3 +257,82 @@ def test_contract_amr_two_refined_levels_within_rtol_of_exact():
     ddt = max(abs(x - y) / y for x, y in zip(runs["contract"][0], runs["exact"][0]))
     print("contract vs exact, AMR 16^3 + 2 levels, 8 coarse steps: max deviation %.2e; dt deviation %.1e" % (worst, ddt))
     assert 0.0 < worst <= RTOL and ddt <= RTOL
+
+
+def _outputs_deviation(out):
+    """max deviation of every output array of one construct_ctu_hydro_source call from the oracle's, each component scaled by
+    the largest magnitude of its kind in the oracle's array (momenta and momentum fluxes share one scale: a component that
+    vanishes by symmetry has no scale of its own)"""
+    dev = {}
+    for name, (a, b) in out.items():
+        if name.startswith("qe"):
+            groups = [(0, 1, 2), (3,)]                              # Godunov velocities, Godunov pressure
+        elif a.shape[0] == 8:
+            groups = [(0,), (1, 2, 3), (4,), (5,), (6,), (7,)]      # rho, momenta, rho E, rho e, Temp, rho X
+        else:
+            groups = [tuple(range(a.shape[0]))]
+        worst = 0.0
+        for g in groups:
+            scale = max(np.abs(b[k]).max() for k in g)
+            d = max(np.abs(a[k] - b[k]).max() for k in g)
+            worst = max(worst, d / scale if scale > 0.0 else d)
+        dev[name] = worst
+    return dev
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_contract_single_call_every_output_array_within_rtol(oracle, tiled):
+    """Not only the plotfile: S_new, the three flux arrays, the mass fluxes and the Godunov states (qe) of ONE
+    castro_amd_ctu_hydro_fab call of the `contract` build on a noisy state, whole box and the overlapped path's seven tiles,
+    against the oracle at the tolerance; and the tiled call gives the bits of the whole-box call (same build)."""
+    import torch
+    from castro_amd.hydro import HipHydro
+    from tests.test_gpu_parity import _run_both
+    from tests.util import physical_state
+    hip = HipHydro(0, numerics="contract")
+    assert hip.numerics == "contract"
+    rng = np.random.default_rng(11)
+    bxlo, bxhi = (0, 0, 0), (19, 17, 15)
+    sb_lo, sb_hi = (-4, -4, -4), (23, 21, 19)
+    U = physical_state(rng, sb_lo, sb_hi, smooth=False, vel=2.0)
+    tiles = [((4, 4, 4), (15, 13, 11)),
+             ((0, 0, 0), (19, 17, 3)), ((0, 0, 12), (19, 17, 15)),
+             ((0, 0, 4), (19, 3, 11)), ((0, 14, 4), (19, 17, 11)),
+             ((0, 4, 4), (3, 13, 11)), ((16, 4, 4), (19, 13, 11))]
+    kw = dict(dx=(0.02, 0.02, 0.02))
+    whole = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, **kw)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 8.0e-4, tile=(1024, 8, 8), hip_tiles=tiles, **kw) if tiled else whole
+    dev = _outputs_deviation(out)
+    worst = max(dev, key=dev.get)
+    print("contract vs oracle, one call (%s): max deviation %.2e (%s)" % ("7 tiles" if tiled else "whole box", dev[worst], worst))
+    assert all(v <= RTOL for v in dev.values()), dev
+    assert any(not np.array_equal(a, b) for a, b in out.values())      # it IS the other build
+    if tiled:
+        for k in out:
+            assert np.array_equal(out[k][0], whole[k][0]), k
+    hip.close()
+
+
+def test_contract_staged_overlap_and_step_graph_equal_the_plain_contract_run():
+    """Inside one build the launch partition must not matter: the staged halo overlap (stage A on the valid zones while the
+    exchange is in flight, stage B for the rest) and the host-free, graph-replayed batch give the bits of the stepwise,
+    un-staged `contract` run."""
+    import torch
+    import castro_amd
+    n = (48, 40, 32)
+    kw = dict(lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), use_retry=False, numerics="contract")
+    plain = castro_amd.Castro(n, overlap=False, **kw)
+    staged = castro_amd.Castro(n, overlap=True, **kw)
+    batch = castro_amd.Castro(n, overlap=True, **kw)
+    for c in (plain, staged, batch):
+        c.initData("sedov", r_init=0.1, nsub=4)
+        assert c.hydro.numerics == "contract"
+    assert staged.overlap and staged._comm_stream is not None and staged.neighbors and not plain.overlap
+    for _ in range(7):
+        plain.step()
+        staged.step()
+    batch.run_steps(7)
+    torch.cuda.synchronize()
+    for c in (staged, batch):
+        assert c.time == plain.time and c.dt == plain.dt and c.nstep == plain.nstep
+        assert torch.equal(c.S_new_b, plain.S_new_b)
