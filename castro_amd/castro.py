@@ -838,7 +838,12 @@ class Castro:
         roles; captured once per (stop_time, roles) and cached.  Capturing executes nothing and leaves this object as it was."""
         self._ensure_ctl()
         assert self._eager_done, "capture_step_graph: run at least one host-free step first (scratch is reserved lazily)"
-        key = (float(stop_time), self.S_old_b.data_ptr(), self.S_new_b.data_ptr())
+        # everything the capture bakes into the launches by value belongs to the key: the parameter block and geometry, the
+        # dt limits and the flags of the driver -- a run that changes one of them between two batches gets a new graph
+        # instead of a replay of the old values
+        baked = (bytes(self.params), bytes(self.geom), self.max_dt, self.fixed_dt, bool(self.use_retry), bool(self.flux_assign),
+                 bool(self.fuse_clean), bool(self.fuse_post_clean), bool(self.fuse_sborder_clean), str(self.overlap))
+        key = (float(stop_time), self.S_old_b.data_ptr(), self.S_new_b.data_ptr(), hash(baked))
         if key not in self._graphs:
             # No finaliser may run while the stream is capturing: a collected context, graph or event would call hipFree /
             # hipGraphExecDestroy in the middle of the capture, which the runtime answers with abort().  torch.cuda.graph

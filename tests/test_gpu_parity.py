@@ -1009,6 +1009,32 @@ def test_host_free_steps_with_the_staged_halo_overlap():
     assert torch.equal(a.S_new_b, b.S_new_b)
 
 
+def test_step_graph_is_rebuilt_when_a_baked_parameter_changes():
+    """The captured pair of steps carries castro_amd_params, the dt limits and the driver's flags by value: changing one between
+    two batches must give a new graph (key of Castro.capture_step_graph), not a replay of the old values -- the batch still
+    equals the stepwise driver bit for bit after castro.cfl and castro.change_max were changed."""
+    import torch
+    import castro_amd
+    a, b = (castro_amd.Castro((24, 24, 24), use_retry=False) for _ in range(2))
+    for c in (a, b):
+        c.initData("sedov", r_init=0.1, nsub=4)
+    a.run_steps(6)
+    for _ in range(6):
+        b.step()
+    assert len(a._graphs) >= 1
+    n_before = len(a._graphs)
+    for c in (a, b):
+        c.params.cfl = 0.3
+        c.params.change_max = 1.05
+    a.run_steps(6)
+    for _ in range(6):
+        b.step()
+    torch.cuda.synchronize()
+    assert len(a._graphs) > n_before
+    assert a.time == b.time and a.dt == b.dt and a.nstep == b.nstep == 12
+    assert torch.equal(a.S_new_b, b.S_new_b)
+
+
 def test_host_free_batch_latches_a_rejected_step():
     """A step the host path rejects (timestep validity check, Castro_advance_ctu.cpp:386-392) stops a host-free batch at
     the same step: the status is latched on the device and the launches after it leave the state alone.  Without
