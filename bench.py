@@ -57,8 +57,8 @@ KERNEL_BYTES_PER_UNIT = {
 KERNEL_BYTES_PER_UNIT_LEAN = {
     "k_ctoprim": 8 * (8 + 6),
     "k_ctoprim_clean": 8 * (8 + 6),
-    "k_trace": 8 * (6 + 30 + 6),                          # Q without (rho e), X; 5-plane edge states; 6-plane F1[x]
-    "k_trans1_fold": 8 * (30 + 6 + 1 + 36),               # F2 in the 6-plane state form
+    "k_trace": 8 * (6 + 30 + 5),                          # Q without (rho e), X; 5-plane edge states; 5-plane F1[x]
+    "k_trans1_fold": 8 * (30 + 5 + 1 + 36),               # F2 in the 6-plane state form
     "k_final_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 17),
     "k_final_assign": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 9),  # FL without the species plane
     "k_finalx_consup_rmw": 8 * (10 + 12 + 1 + 1 + 8 + 17 + 16 + 8),

@@ -1349,7 +1349,10 @@ __device__ __forceinline__ void qstate_to_rec(double rho, double un, double ut, 
 
 // write a transverse-stage flux record at face offset c (global component order)
 // FEI: plane of the (rho e) flux, nullptr unless transverse_reset_rhoe = 1
-template <int D, bool QI = false>
+// NORE (first-stage records of the gamma_law_edges path): the Godunov (rho e) of a solve whose two input states have
+// (rho e) = p / (gamma - 1) is the Godunov p over (gamma - 1) -- entho = 1 / (gamma - 1), estar = pstar / (gamma - 1), and the
+// blend with the upwind state keeps the ratio (riemannus) -- so its plane is neither written nor read (load_f1_2)
+template <int D, bool QI = false, bool NORE = false>
 __device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsigned c, const IFlux& f, double* __restrict__ FEI = nullptr)
 {
     if (QI) {
@@ -1358,7 +1361,7 @@ __device__ __forceinline__ void store_f1(double* __restrict__ F, long NC, unsign
         stg(F + QUT * NC, c, f.ut);
         stg(F + QUTT * NC, c, f.utt);
         stg(F + QPG * NC, c, f.pgd);
-        stg(F + QREG * NC, c, f.rhoe_g);
+        if (!NORE) stg(F + QREG * NC, c, f.rhoe_g);
         if (!gamma_law_edges(0)) stg(F + QXG * NC, c, f.X_g);         // state form implies GEN == 0
         return;
     }
@@ -1388,16 +1391,18 @@ __device__ __forceinline__ void load_edge(const double* __restrict__ E, long NC,
 __host__ __device__ constexpr int f2_slot(int N, int T) { return N * 2 + ((T > N) ? T - 1 : T); }
 
 // pair (two x-adjacent faces) forms of the record loads / stores; D: the direction the record's face is normal to
-template <int D = 0, bool QI = false>
-__device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC, unsigned c, double r[2][NF1])
+template <int D = 0, bool QI = false, bool NORE = false>
+__device__ __forceinline__ void load_f1_2(const double* __restrict__ F, long NC, unsigned c, double r[2][NF1], double g1inv = 0.0)
 {
     if (QI) {
         double q[2][NQI];
 #pragma unroll
         for (int n = 0; n < NQI; ++n) {
             if (gamma_law_edges(0) && n == QXG) { q[0][n] = q[1][n] = 1.0; continue; }     // species elided (gamma_law_edges)
+            if (NORE && n == QREG) continue;                                                // see store_f1
             const D2 v = ldg2(F + (long)n * NC, c); q[0][n] = v.a; q[1][n] = v.b;
         }
+        if (NORE) { q[0][QREG] = q[0][QPG] * g1inv; q[1][QREG] = q[1][QPG] * g1inv; }
 #pragma unroll
         for (int w = 0; w < 2; ++w)
             qstate_to_rec<D>(q[w][QRHO], q[w][QUN], q[w][QUT], q[w][QUTT], q[w][QPG], q[w][QREG], q[w][QXG], r[w]);
@@ -1423,7 +1428,7 @@ __device__ __forceinline__ void load_edge_2(const double* __restrict__ E, long N
     if (NOPRE) { q[0][PRE] = q[0][PP] * g1inv; q[1][PRE] = q[1][PP] * g1inv; q[0][PX] = q[1][PX] = 1.0; }
 }
 
-template <int D, bool QI = false>
+template <int D, bool QI = false, bool NORE = false>
 __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsigned c, const IFlux f[2], bool m0, bool m1,
                                            double* __restrict__ FEI = nullptr)
 {
@@ -1434,12 +1439,12 @@ __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsi
             stg2(F + QUT * NC, c, f[0].ut, f[1].ut);
             stg2(F + QUTT * NC, c, f[0].utt, f[1].utt);
             stg2(F + QPG * NC, c, f[0].pgd, f[1].pgd);
-            stg2(F + QREG * NC, c, f[0].rhoe_g, f[1].rhoe_g);
+            if (!NORE) stg2(F + QREG * NC, c, f[0].rhoe_g, f[1].rhoe_g);
             if (!gamma_law_edges(0)) stg2(F + QXG * NC, c, f[0].X_g, f[1].X_g);
         } else if (m0) {
-            store_f1<D, true>(F, NC, c, f[0]);
+            store_f1<D, true, NORE>(F, NC, c, f[0]);
         } else if (m1) {
-            store_f1<D, true>(F, NC, c + 8u, f[1]);
+            store_f1<D, true, NORE>(F, NC, c + 8u, f[1]);
         }
         return;
     }
@@ -1502,7 +1507,7 @@ __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double
         interface_flux<D, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, wall_fac<D>(g, idx),
                           face_shock(S, P, c + 8u * w, sd), P, f[w]);
     }
-    store_f1_2<D, (kQI && GEN == 0)>(S.F1[D], t.NC, c, f, true, v1, S.F1E[D]);
+    store_f1_2<D, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[D], t.NC, c, f, true, v1, S.F1E[D]);
 }
 
 // shared tail of the final stage for a pair of x-adjacent faces: flux in conserved order, artificial
@@ -1778,7 +1783,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             rstate_from_edge<0>(qm[0], P.gamma, ql, Xl);
             rstate_from_edge<0>(qp[1], P.gamma, qr, Xr);
             interface_flux<0, GEN>(ql, qr, Xl, Xr, cc01.a, cc01.b, wall_fac<0>(g, i + 1), face_shock(S, P, c + 8u, 8u), P, f[1]);
-            store_f1_2<0, (kQI && GEN == 0)>(S.F1[0], NC, c, f, mA, mB, S.F1E[0]);
+            store_f1_2<0, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[0], NC, c, f, mA, mB, S.F1E[0]);
         }
     }
 
@@ -1821,7 +1826,7 @@ __global__ void __launch_bounds__(256) k_riemann1_blockstart(Tile t, LinBox b, c
     const double cr = ldg(Q + PC * t.NC, c);
     IFlux f;
     interface_flux<0, GEN>(ql, qr, Xl, Xr, cl, cr, wall_fac<0>(g, i), face_shock(S, P, c, 8u), P, f);
-    store_f1<0, (kQI && GEN == 0)>(S.F1[0], t.NC, c, f, S.F1E[0]);
+    store_f1<0, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[0], t.NC, c, f, S.F1E[0]);
 }
 
 
@@ -1836,7 +1841,7 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 
     // minus states live in zones c - sn; their T-faces are (c - sn) and (c - sn + st)
 #ifdef DIAG_F1_REUSE      // timing diagnostic (wrong results): one record load per (N,T) instead of four
-    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c, fl);
+    load_f1_2<T, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[T], t.NC, c, fl, 1.0 / (P.gamma - 1.0));
 #pragma unroll
     for (int w = 0; w < 2; ++w)
 #pragma unroll
@@ -1848,8 +1853,8 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 #pragma unroll
         for (int n = 0; n < NF1; ++n) { fr[w][n] = 1e-3 * (double)((c + n + w) & 255u); fl[w][n] = 1e-3 * (double)((c + st + n) & 255u); }
 #else
-    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c - sn + st, fr);
-    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c - sn, fl);
+    load_f1_2<T, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[T], t.NC, c - sn + st, fr, 1.0 / (P.gamma - 1.0));
+    load_f1_2<T, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[T], t.NC, c - sn, fl, 1.0 / (P.gamma - 1.0));
 #endif
 #endif
     if (RE && P.reset_rhoe == 1) {                 // transverse_reset_rhoe = 1: the (rho e) flux differences as well
@@ -1863,8 +1868,8 @@ __device__ __forceinline__ void trans1_pair(const Tile& t, const DevScratch& S, 
 
     // plus states live in zones c
 #if !defined(DIAG_F1_REUSE) && !defined(DIAG_T1_NOLOAD)
-    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c + st, fr);
-    load_f1_2<T, (kQI && GEN == 0)>(S.F1[T], t.NC, c, fl);
+    load_f1_2<T, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[T], t.NC, c + st, fr, 1.0 / (P.gamma - 1.0));
+    load_f1_2<T, (kQI && GEN == 0), gamma_law_edges(GEN)>(S.F1[T], t.NC, c, fl, 1.0 / (P.gamma - 1.0));
 #endif
     if (RE && P.reset_rhoe == 1) {
         const D2 er = ldg2(S.F1E[T], c + st), el = ldg2(S.F1E[T], c);
@@ -2107,10 +2112,14 @@ __device__ __forceinline__ void fold_thread(const LinBox& b, unsigned bid, int& 
 #define FOLD_WG 256
 #endif
 // record (face f, zone w) of thread `th`
+template <bool NOX = false>          // NOX: the species record was not parked (gamma_law_edges)
 __device__ __forceinline__ void park_get(const double* __restrict__ park, int f, int w, int th, double r[NF1])
 {
 #pragma unroll
-    for (int n = 0; n < NF1; ++n) r[n] = park[((f * 2 + w) * NF1 + n) * FOLD_WG + th];
+    for (int n = 0; n < NF1; ++n) {
+        if (NOX && n == FX) { r[n] = 0.0; continue; }
+        r[n] = park[((f * 2 + w) * NF1 + n) * FOLD_WG + th];
+    }
 }
 
 // The waves of k_trans1_fold_lds overlap by one slot each (fold_thread: 63 new slots per wave): the only foreign slot a lane
@@ -2282,7 +2291,7 @@ __device__ __forceinline__ void trans1_fold_dir_ahead(const Tile& t, const int i
 #pragma unroll
         for (int w = 0; w < 2; ++w)
 #pragma unroll
-            for (int n = 0; n < NF1; ++n) park[((0 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n];
+            for (int n = 0; n < NF1; ++n) { if (NP && n == FX) continue; park[((0 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n]; }   // no species record
         if (TX_HERE) {                             // the (T | x) combination on the same edge states (see trans1_fold_dir_lds)
             bool in_t[2];
 #pragma unroll
@@ -2308,7 +2317,7 @@ __device__ __forceinline__ void trans1_fold_dir_ahead(const Tile& t, const int i
 #pragma unroll
         for (int w = 0; w < 2; ++w)
 #pragma unroll
-            for (int n = 0; n < NF1; ++n) park[((1 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n];
+            for (int n = 0; n < NF1; ++n) { if (NP && n == FX) continue; park[((1 * 2 + w) * NF1 + n) * FOLD_WG + th] = A[w][n]; }
     }
     FOLD_SYNC();
 
@@ -2325,13 +2334,13 @@ __device__ __forceinline__ void trans1_fold_dir_ahead(const Tile& t, const int i
             double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
             edge_take<NP>(x0.m, q, g1inv);
             const int tl = th > 0 ? th - 1 : 0;    // thread 0 owns nothing
-            park_get(park, 1, 1, tl, fr); park_get(park, 0, 1, tl, fl);
+            park_get<NP>(park, 1, 1, tl, fr); park_get<NP>(park, 0, 1, tl, fl);
             trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qmo[0]);
-            park_get(park, 1, 0, th, fr); park_get(park, 0, 0, th, fl);
+            park_get<NP>(park, 1, 0, th, fr); park_get<NP>(park, 0, 0, th, fl);
             trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qmo[1]);
             edge_take<NP>(x0.p, q, g1inv);
             trans_single<T>(q[0], fr, fl, P.gamma, cdtdt, P, qpo[0]);
-            park_get(park, 1, 1, th, fr); park_get(park, 0, 1, th, fl);
+            park_get<NP>(park, 1, 1, th, fr); park_get<NP>(park, 0, 1, th, fl);
             trans_single<T>(q[1], fr, fl, P.gamma, cdtdt, P, qpo[1]);
             double bnd[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
             trans1_solve_store<0, T, GEN>(t, S, c, qmo, qpo, clx, c0, bnd, m0, m1, P);
@@ -2364,7 +2373,7 @@ __device__ __forceinline__ void trans1_fold_dir_ahead(const Tile& t, const int i
             edge_take<NP>(o0.p, q, g1inv);
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                park_get(park, 1, w, th, fr); park_get(park, 0, w, th, fl);
+                park_get<NP>(park, 1, w, th, fr); park_get<NP>(park, 0, w, th, fl);
                 trans_single<T>(q[w], fr, fl, P.gamma, cdtdt, P, qpo[w]);
             }
             double bnd[2];
