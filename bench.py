@@ -55,14 +55,14 @@ KERNEL_BYTES_PER_UNIT = {
 # The `contract` build with the default options (gamma-law gas, one species, default solver) does not carry (rho e) or X
 # through the edge states and X through the records (`gamma_law_edges`): its kernels have fewer planes.
 KERNEL_BYTES_PER_UNIT_LEAN = {
-    "k_ctoprim": 8 * (8 + 6),
-    "k_ctoprim_clean": 8 * (8 + 6),
+    "k_ctoprim": 8 * (6 + 6),                             # neither the temperature nor the species of the state is read
+    "k_ctoprim_clean": 8 * (6 + 6),
     "k_trace": 8 * (6 + 30 + 5),                          # Q without (rho e), X; 5-plane edge states; 5-plane F1[x]
     "k_trans1_fold": 8 * (30 + 5 + 1 + 36),               # F2 in the 6-plane state form
     "k_final_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 17),
     "k_final_assign": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 9),  # FL without the species plane
-    "k_finalx_consup_rmw": 8 * (10 + 12 + 1 + 1 + 8 + 17 + 16 + 8),
-    "k_finalx_consup_assign": 8 * (10 + 12 + 1 + 1 + 8 + 9 + 16 + 8),
+    "k_finalx_consup_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 17 + 16 + 8),
+    "k_finalx_consup_assign": 8 * (10 + 12 + 1 + 1 + 6 + 9 + 16 + 8),
 }
 
 

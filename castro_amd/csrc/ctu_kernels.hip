@@ -211,7 +211,8 @@ template <bool CLEAN, bool LV = false>
 __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
                                                  SkipBox skip, int clean_n, LevelTab lv, int lean_q)
 {
-    // lean_q (gamma_law_edges, default-solver path of the `contract` build): nobody downstream reads Q's (rho e) and X planes
+    // lean_q (gamma_law_edges, default-solver path of the `contract` build), bit 0: nobody downstream reads Q's (rho e) and X
+    // planes; bit 1: the update kernel has clean_state fused in and reads neither the temperature nor the species of U
     RETURN_IF_BATCH_FAILED();
     unsigned vb = blockIdx.x;
     if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
@@ -225,11 +226,14 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     double rho = ldg(U.p + URHO * U.sn, cu);
     double mx = ldg(U.p + UMX * U.sn, cu), my = ldg(U.p + UMY * U.sn, cu), mz = ldg(U.p + UMZ * U.sn, cu);
     double eden = ldg(U.p + UEDEN * U.sn, cu);
-    double rX = ldg(U.p + UFS * U.sn, cu);
+    // lean_q: with one species and a gamma-law gas nothing downstream reads the temperature or the species of this array
+    // (X is elided, the fused update recomputes both: k_finalx_consup), so they are neither loaded, cleaned nor written back
+    const bool lean_u = (lean_q & 2) != 0;
+    double rX = lean_u ? rho : ldg(U.p + UFS * U.sn, cu);
     double eint = 0.0;
     if (CLEAN) {
         eint = ldg(U.p + UEINT * U.sn, cu);
-        double temp = ldg(U.p + UTEMP * U.sn, cu);
+        double temp = lean_u ? 0.0 : ldg(U.p + UTEMP * U.sn, cu);
         const double o0 = rho, o1 = mx, o2 = my, o3 = mz, o4 = eden, o5 = eint, o6 = temp, o7 = rX;
         clean_zone(P, clean_n, rho, mx, my, mz, eden, eint, temp, rX);
         // Only components whose bits changed go back: the state arrives cleaned twice by the update that produced it, and
@@ -243,8 +247,10 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
         PUT_IF_CHANGED(UMZ, o3, mz);
         PUT_IF_CHANGED(UEDEN, o4, eden);
         PUT_IF_CHANGED(UEINT, o5, eint);
-        PUT_IF_CHANGED(UTEMP, o6, temp);
-        PUT_IF_CHANGED(UFS, o7, rX);
+        if (!lean_u) {
+            PUT_IF_CHANGED(UTEMP, o6, temp);
+            PUT_IF_CHANGED(UFS, o7, rX);
+        }
 #undef PUT_IF_CHANGED
     }
     if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
@@ -274,7 +280,7 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     stg(Q + PV * NC, c, v);
     stg(Q + PW * NC, c, w);
     stg(Q + PP * NC, c, p);
-    if (!lean_q) {
+    if (!(lean_q & 1)) {
         stg(Q + PRE * NC, c, e * rho);
         stg(Q + PX * NC, c, X);
     }
@@ -2730,8 +2736,13 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
         const unsigned cfy = from_out ? foff(fluxes_y, ijk[0], ijk[1], ijk[2]) : 0u, cfz = from_out ? foff(fluxes_z, ijk[0], ijk[1], ijk[2]) : 0u;
         const unsigned fsy = 8u * (unsigned)fluxes_y.sy, fsz = 8u * (unsigned)fluxes_z.sz;
         const double dtarea0 = dt * area0;
+        // one species, gamma-law gas, clean_state fused in (gamma_law_edges): the temperature and the species of the old state are
+        // dead -- computeTemp overwrites the one, normalize_species makes rho X = rho of the other -- and are not read
+        constexpr bool DEAD_TX = gamma_law_edges(GEN) && !LIM && CLEAN;
 #pragma unroll
         for (int m = 0; m < NUM_STATE; ++m) {
+            if (DEAD_TX && m == UTEMP) { un[0][m] = un[1][m] = 0.0; continue; }
+            if (DEAD_TX && m == UFS) { un[0][m] = un[0][URHO]; un[1][m] = un[1][URHO]; continue; }
             const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
             if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }       // zero flux
             const int r = rec[m];
@@ -2913,7 +2924,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // kernel of the no-source PPM path promises (k_trace_pair<true, 7, 0>); traces with source terms or PLM run the GEN >= 1 set
     const bool gl_ok = !gamma_law_edges(0) || (!Src.p && P.ppm_type == 1);
     const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1 || !plain_path || !gl_ok) ? 1 : 0);
-    const int lean_q = (gamma_law_edges(0) && solv == 0) ? 1 : 0;
+    const int lean_q = (gamma_law_edges(0) && solv == 0) ? (clean_ntimes > 0 ? 3 : 1) : 0;      // see k_ctoprim
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
     const SkipBox none = { { 0, 0, 0 }, { -1, -1, -1 } };
     SkipBox valid_box, inner_box;
@@ -3225,9 +3236,9 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
 
     prof_begin(prof, sb_clean > 0 ? "k_ctoprim_clean" : "k_ctoprim", stream);
     if (sb_clean > 0) hipLaunchKernelGGL((k_ctoprim<true, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
-                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM), gamma_law_edges(0) ? 1 : 0);
+                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0);
     else hipLaunchKernelGGL((k_ctoprim<false, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
-                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? 1 : 0);
+                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0);
     prof_end(prof, stream);
     prof_begin(prof, "k_divu", stream);
     hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
