@@ -222,6 +222,10 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx *ctx,
  *                         "FillPatch the uncleaned state, then clean everything" equals the reference's "clean, FillPatch,
  *                         clean".  Only for whole-box calls (bx == vbx, one tile per FAB: overlapping tiles would clean
  *                         shared ghost zones twice) without CASTRO_AMD_STAGE_A/B; Sborder is written.
+ *                         In the `contract` build (castro_amd_numerics()), on the default-solver path and together with
+ *                         clean_ntimes > 0, the temperature and species components of Sborder are neither read nor
+ *                         written back: nothing downstream depends on them (one species, gamma-law gas; the fused update
+ *                         recomputes both for S_new) -- the other six components are cleaned in place as described.
  */
 typedef struct castro_amd_hydro_opts {
     int flags;                  /* CASTRO_AMD_UPDATE_* | CASTRO_AMD_FLUX_ASSIGN | CASTRO_AMD_STAGE_* */
