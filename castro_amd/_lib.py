@@ -137,7 +137,7 @@ class FabOp(C.Structure):
                 ("side", C.c_int), ("a", C.c_double), ("b", C.c_double), ("dst", Fab), ("src", Fab), ("src2", Fab)]
 
 
-OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN = 0, 1, 2, 3, 4, 5, 6
+OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN, OP_AVGDOWN = 0, 1, 2, 3, 4, 5, 6, 7
 
 _libs = {}
 ABI_VERSION = 4          # CASTRO_AMD_ABI_VERSION of include/castro_hydro_amd.h this binding was written against

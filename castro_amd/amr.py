@@ -526,8 +526,14 @@ class _Level:
         boxes = self._cached_ops(("hydro_mf",), sp, lambda: self.hydro.make_hydro_boxes(
             [(b.bx, b.bx, (b.S_old_b, b.gbox), (b.S_new_b, b.gbox), b.fluxes, b.flux_boxes, b.mass_fluxes) for b in self.mine]))
         pool = self.amr._stream_pool(self.l) if len(self.mine) > 1 else None
+        # On the finest level nothing touches S_new between the update and post_timestep's clean_state (no reflux, no
+        # avgDown into it; FluxRegFineAdd only reads the fluxes): an attempt at the whole step takes that clean_state into the
+        # fused pass, like the single-level driver (Castro.construct_ctu_hydro_source), instead of a sweep of its own
+        post = bool(self.fuse_clean and getattr(self, "fuse_post_level", False) and getattr(self, "_whole_step", False))
+        if post:
+            self._post_clean_done = True
         self.hydro.construct_ctu_hydro_source_mf(pool, boxes, self.mine[0].geom, self.params, time, dt, update_from_sborder=True,
-                                                 flux_assign=fa[0], clean_ntimes=1 if self.fuse_clean else 0,
+                                                 flux_assign=fa[0], clean_ntimes=(2 if post else 1) if self.fuse_clean else 0,
                                                  red=self.red if self.fuse_clean else None)
         for b in self.mine:
             b._flux_clear = False
@@ -1070,8 +1076,16 @@ class CastroAmr:
     def avgDown(self, l=1):
         if self.nranks > 1:
             return self._xrun([("avgdown", p, b, lo, hi, None) for b in self.lev[l].boxes for p, (lo, hi) in b.avg_to])
-        h = self.lev[l].hydro
-        for b in self.lev[l].boxes:
+        fine = self.lev[l]
+        h = fine.hydro
+        if fine._level_calls():
+            # the whole level in one launch (CASTRO_AMD_OP_AVGDOWN): the regions are disjoint zones of the coarse level
+            pp = tuple(b.S_new_b.data_ptr() for b in fine.boxes) + tuple(p.S_new_b.data_ptr() for p in self.lev[l - 1].boxes)
+            h.fab_ops(fine._cached_ops(("avgdown",), pp, lambda: h.make_ops(
+                [(L.OP_AVGDOWN, 0, NUM_STATE, lo, hi, 0.0, 0.0, (p.S_new_b, p.gbox), (b.S_new_b, b.gbox), None)
+                 for b in fine.boxes for p, (lo, hi) in b.avg_to])), params=fine.params)
+            return
+        for b in fine.boxes:
             for p, (lo, hi) in b.avg_to:
                 h.avgdown(b.S_new_b, b.gbox, p.S_new_b, p.gbox, lo, hi, NUM_STATE)
 
@@ -1114,6 +1128,7 @@ class CastroAmr:
         h = lev.hydro
         lev.alpha = alpha
         lev._t0, lev._alpha0, lev._dt_parent = t, alpha, 2.0 * dt
+        lev.fuse_post_level = l == finest and os.environ.get("CASTRO_AMD_FUSE_POST_FINEST", "1") != "0"
         lev.advance(t, dt)
         self.level_count[l] += 1
         if l > 0:
@@ -1166,7 +1181,9 @@ class CastroAmr:
                                 h.reflux(p.S_new_b, _shift(p.gbox, csh), reg, rbox, lo, hi, d, side, NUM_STATE, vol)
             self.avgDown(l + 1)
         # Castro::post_timestep ends with clean_state(S_new) on EVERY level (Castro.cpp:1909-1916), the finest included
-        lev.clean_new()
+        # (there it may have ridden in the fused pass of the update: _hydro_level)
+        if not (l == finest and lev._post_clean_done):
+            lev.clean_new()
 
     # ---- Amr::coarseTimeStep ---------------------------------------------------------------------
     def step(self, stop_time=-1.0):

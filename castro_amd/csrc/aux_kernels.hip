@@ -806,8 +806,10 @@ __global__ void __launch_bounds__(256) k_lincomb(DFab D, DFab X, DFab Y, Box3 b,
 
 // up to FABOPS_MAX independent region operations in one launch (castro_amd_fab_ops); op r owns threads [start[r], start[r+1])
 #define FABOPS_MAX 16
-struct FabOp { DFab D, X, Y; int lo[3], n[3]; int kind, dir, ncomp, side; double a, b; };
+struct FabOp { DFab D, X, Y; int lo[3], n[3]; int kind, dir, ncomp, side; double a, b;
+               int flo[3], fhi[3]; };   // INTERP_CLEAN: lo / n enumerate the COARSE zones under the fine region [flo, fhi]
 struct FabOps { int n; long start[FABOPS_MAX + 1]; FabOp op[FABOPS_MAX]; };
+static_assert(sizeof(FabOps) + sizeof(DevParams) <= 4096, "k_fab_ops: the by-value table must fit the 4 KB of kernel arguments");
 
 __device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevParams& P);
 
@@ -841,16 +843,64 @@ __device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevP
     const long q = t / o.n[0];
     c[1] = o.lo[1] + (int)(q % o.n[1]);
     c[2] = o.lo[2] + (int)(q / o.n[1]);
-    if (o.kind == CASTRO_AMD_OP_CLEAN || o.kind == CASTRO_AMD_OP_INTERP_CLEAN) {
-        double u[NUM_STATE];
-        if (o.kind == CASTRO_AMD_OP_INTERP_CLEAN) {
-            for (int n = 0; n < NUM_STATE; ++n) u[n] = cc_interp_value(o.X, c[0], c[1], c[2], n);
-        } else {
-            for (int n = 0; n < NUM_STATE; ++n) u[n] = o.D.p[fidx(o.D, c[0], c[1], c[2], n)];
+    if (o.kind == CASTRO_AMD_OP_INTERP_CLEAN) {
+        // One thread per COARSE zone: the 27-point stencil, the three limited slopes and alpha of cc_interp_value are those of
+        // all eight fine zones under it, so they are formed once (a thread per fine zone fetched 264 values for 8 results) and
+        // evaluated at the children that lie inside the region -- the same expressions, the same bits.
+        const DFab& C = o.X;
+        double u[8][NUM_STATE];
+#pragma unroll
+        for (int n = 0; n < NUM_STATE; ++n) {
+#define CC(ii, jj, kk) C.p[fidx(C, c[0] + (ii), c[1] + (jj), c[2] + (kk), n)]
+            const double u0 = CC(0, 0, 0);
+            const double sx = mc_slope(CC(-1, 0, 0), u0, CC(1, 0, 0));
+            const double sy = mc_slope(CC(0, -1, 0), u0, CC(0, 1, 0));
+            const double sz = mc_slope(CC(0, 0, -1), u0, CC(0, 0, 1));
+            double umax = u0, umin = u0;
+            for (int kk = -1; kk <= 1; ++kk)
+            for (int jj = -1; jj <= 1; ++jj)
+            for (int ii = -1; ii <= 1; ++ii) {
+                const double v = CC(ii, jj, kk);
+                umax = amax(umax, v);
+                umin = amin(umin, v);
+            }
+#undef CC
+            const double dmax = 0.25 * (fabs(sx) + fabs(sy) + fabs(sz));
+            double alpha = 1.0;
+            if (dmax > umax - u0) alpha = amin(alpha, (umax - u0) / dmax);
+            if (dmax > u0 - umin) alpha = amin(alpha, (u0 - umin) / dmax);
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const double ox = (ch & 1) ? 0.25 : -0.25, oy = (ch & 2) ? 0.25 : -0.25, oz = (ch & 4) ? 0.25 : -0.25;
+                u[ch][n] = u0 + alpha * (sx * ox + sy * oy + sz * oz);
+            }
         }
+        const int ntimes = (int)o.a;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int fi = 2 * c[0] + (ch & 1), fj = 2 * c[1] + ((ch >> 1) & 1), fk = 2 * c[2] + ((ch >> 2) & 1);
+            if (fi < o.flo[0] || fi > o.fhi[0] || fj < o.flo[1] || fj > o.fhi[1] || fk < o.flo[2] || fk > o.fhi[2]) continue;
+            if (ntimes > 0) clean_zone(P, ntimes, u[ch][URHO], u[ch][UMX], u[ch][UMY], u[ch][UMZ], u[ch][UEDEN], u[ch][UEINT], u[ch][UTEMP], u[ch][UFS]);
+            for (int n = 0; n < NUM_STATE; ++n) o.D.p[fidx(o.D, fi, fj, fk, n)] = u[ch][n];
+        }
+        return;
+    }
+    if (o.kind == CASTRO_AMD_OP_CLEAN) {
+        double u[NUM_STATE];
+        for (int n = 0; n < NUM_STATE; ++n) u[n] = o.D.p[fidx(o.D, c[0], c[1], c[2], n)];
         const int ntimes = (int)o.a;
         if (ntimes > 0) clean_zone(P, ntimes, u[URHO], u[UMX], u[UMY], u[UMZ], u[UEDEN], u[UEINT], u[UTEMP], u[UFS]);
         for (int n = 0; n < NUM_STATE; ++n) o.D.p[fidx(o.D, c[0], c[1], c[2], n)] = u[n];
+        return;
+    }
+    if (o.kind == CASTRO_AMD_OP_AVGDOWN) {             // k_avgdown's arithmetic
+        for (int n = 0; n < o.ncomp; ++n) {
+            double s = 0.0;
+            for (int kk = 0; kk < 2; ++kk)
+            for (int jj = 0; jj < 2; ++jj)
+            for (int ii = 0; ii < 2; ++ii) s += o.X.p[fidx(o.X, 2 * c[0] + ii, 2 * c[1] + jj, 2 * c[2] + kk, n)];
+            o.D.p[fidx(o.D, c[0], c[1], c[2], n)] = 0.125 * s;
+        }
         return;
     }
     if (o.kind == CASTRO_AMD_OP_REFLUX) {
@@ -897,7 +947,15 @@ int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const 
         for (int d = 0; d < 3; ++d) { nn[d] = hi[3 * r + d] - lo[3 * r + d] + 1; n *= nn[d] > 0 ? nn[d] : 0; }
         if (n <= 0) return false;
         o.D = D[r]; o.X = X[r]; o.Y = Y[r];
-        for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * r + d]; o.n[d] = nn[d]; }
+        for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * r + d]; o.n[d] = nn[d]; o.flo[d] = lo[3 * r + d]; o.fhi[d] = hi[3 * r + d]; }
+        if (kind[r] == CASTRO_AMD_OP_INTERP_CLEAN) {         // threads enumerate the coarse zones under the region
+            n = 1;
+            for (int d = 0; d < 3; ++d) {
+                const int a_ = lo[3 * r + d], b_ = hi[3 * r + d];
+                const int cl = a_ >= 0 ? a_ / 2 : -((-a_ + 1) / 2), ch = b_ >= 0 ? b_ / 2 : -((-b_ + 1) / 2);
+                o.lo[d] = cl; o.n[d] = ch - cl + 1; n *= o.n[d];
+            }
+        }
         o.kind = kind[r]; o.dir = dir[r]; o.side = side[r]; o.ncomp = ncomp[r]; o.a = a[r]; o.b = b[r];
         return true;
     };
@@ -927,7 +985,9 @@ int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const 
         long* dstart = (long*)(base + ((bo + 255) & ~(size_t)255));
         if (hipMemcpyAsync(base, ops.data(), bo, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
         if (hipMemcpyAsync(dstart, start.data(), bs, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
-        prof_begin(prof, "k_fab_ops", stream);
+        static const char* const kind_name[8] = { "k_fab_ops_copy", "k_fab_ops_lincomb", "k_fab_ops_crse_init", "k_fab_ops_fine_add",
+                                                  "k_fab_ops_reflux", "k_fab_ops_clean", "k_fab_ops_interp_clean", "k_fab_ops_avgdown" };
+        prof_begin(prof, kind_name[ops[0].kind & 7], stream);     // tables are built per purpose: one kind each
         hipLaunchKernelGGL(k_fab_ops_mem, dim3((unsigned)((start.back() + 255) / 256)), dim3(256), 0, stream,
                            (const FabOp*)base, (const long*)dstart, (int)ops.size(), P);
         prof_end(prof, stream);

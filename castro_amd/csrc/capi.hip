@@ -635,6 +635,11 @@ static int fab_ops_impl(castro_amd_ctx* c, int nops, const castro_amd_fab_op* op
             for (int d = 0; d < 3; ++d) { clo[d] = (o.lo[d] >= 0 ? o.lo[d] / 2 : -((-o.lo[d] + 1) / 2)) - 1; chi[d] = (o.hi[d] >= 0 ? o.hi[d] / 2 : -((-o.hi[d] + 1) / 2)) + 1; }
             if (!fab_contains(&o.src, clo, chi)) return CASTRO_AMD_ERR_ARG;
             break; }
+        case CASTRO_AMD_OP_AVGDOWN: {
+            int flo[3], fhi[3];
+            for (int d = 0; d < 3; ++d) { flo[d] = 2 * o.lo[d]; fhi[d] = 2 * o.hi[d] + 1; }
+            if (!fab_contains(&o.src, flo, fhi)) return CASTRO_AMD_ERR_ARG;
+            break; }
         case CASTRO_AMD_OP_REFLUX: {
             if (o.dir < 0 || o.dir > 2 || o.side < 0 || o.side > 1 || !fab_contains(&o.src, o.lo, o.hi)) return CASTRO_AMD_ERR_ARG;
             int zlo[3] = { o.lo[0], o.lo[1], o.lo[2] }, zhi[3] = { o.hi[0], o.hi[1], o.hi[2] };

@@ -370,6 +370,7 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
  *   CASTRO_AMD_OP_FLUXREG_CRSE_INIT  castro_amd_fluxreg_crse_init_fab dst = a src
  *   CASTRO_AMD_OP_FLUXREG_FINE_ADD   castro_amd_fluxreg_fine_add_fab  dst += a (sum of the 4 fine faces of src), dir
  *   CASTRO_AMD_OP_REFLUX             castro_amd_reflux_fab            dst zones outside the faces [lo,hi] -= / += src / a
+ *   CASTRO_AMD_OP_AVGDOWN            castro_amd_avgdown_fab           dst = mean of the 8 fine zones of src (region in dst's index space)
  *                                                                      (side 0 / 1), a = zone volume */
 #define CASTRO_AMD_OP_COPY 0
 #define CASTRO_AMD_OP_LINCOMB 1
@@ -380,6 +381,8 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
 #define CASTRO_AMD_OP_INTERP_CLEAN 6    /* dst (fine, ncomp 8) = cell_cons_interp of src (coarse data under it) on the region,
                                          * then clean_state x (int)a: one slab of a FillPatch ghost shell
                                          * (castro_amd_fillpatch_shell_fab does the six slabs of one box); castro_amd_fab_ops_p */
+#define CASTRO_AMD_OP_AVGDOWN 7         /* dst (coarse) = mean of the 8 fine zones of src under each zone of the region (castro_amd_avgdown_fab):
+                                         * Castro::avgDown of a whole level in one call */
 typedef struct castro_amd_fab_op {
     int kind;
     int dir;                     /* FLUXREG_FINE_ADD, REFLUX */

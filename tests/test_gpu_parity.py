@@ -1191,6 +1191,36 @@ def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
     assert np.array_equal(got["dts"], np.array(dts)) and np.array_equal(got["S"], c.S_new().cpu().numpy())
 
 
+def test_fab_ops_avgdown_equals_the_per_box_call(hip):
+    """CASTRO_AMD_OP_AVGDOWN (Castro::avgDown of a whole level in one launch): 20 fine boxes averaged onto two coarse FABs
+    give the bits of castro_amd_avgdown_fab box by box; a region whose fine zones leave the source is refused."""
+    import torch
+    import castro_amd
+    from castro_amd import _lib as L
+    rng = np.random.default_rng(21)
+    cbox = ((-3, -2, -1), (28, 21, 18))
+    cshape = (8, 20, 24, 32)
+    one = [_to_dev(hip, rng.normal(size=cshape)) for _ in range(2)]
+    many = [t.clone() for t in one]
+    specs = []
+    for i in range(20):
+        clo = (cbox[0][0] + 1 + (i % 5) * 6, cbox[0][1] + 1 + ((i // 5) % 2) * 11, cbox[0][2] + 1 + (i // 10) * 9)
+        chi = (clo[0] + 4 + i % 2, clo[1] + 9, clo[2] + 6 + i % 3)
+        fbox = (tuple(2 * x - 2 for x in clo), tuple(2 * x + 3 for x in chi))
+        fshape = (8,) + tuple(fbox[1][d] - fbox[0][d] + 1 for d in (2, 1, 0))
+        fine = _to_dev(hip, rng.normal(size=fshape))
+        hip.avgdown(fine, fbox, one[i % 2], cbox, clo, chi, 8)
+        specs.append((L.OP_AVGDOWN, 0, 8, clo, chi, 0.0, 0.0, (many[i % 2], cbox), (fine, fbox), None))
+    hip.fab_ops(hip.make_ops(specs), params=castro_amd.default_params())
+    torch.cuda.synchronize()
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
+    bad = list(specs[0])
+    bad[4] = tuple(x + 3 for x in specs[0][4])                      # fine zones beyond the fine FAB
+    with pytest.raises(RuntimeError):
+        hip.fab_ops(hip.make_ops([tuple(bad)]), params=castro_amd.default_params())
+
+
 def test_fab_ops_equal_the_single_operations(hip):
     """castro_amd_fab_ops: 22 mixed copies, linear combinations and flux-register updates (more than one launch's worth)
     give the bits of the one-operation entry points; a region that leaves its FAB is refused."""
