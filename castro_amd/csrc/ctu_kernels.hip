@@ -39,26 +39,12 @@
 // the Colella-Glaz instantiations (GEN == 2) carry the out-of-line NaN-sign fall-back (hydro_device.h: XD), whose call
 // frame would push them past 256 VGPRs to one wave per SIMD; held at two waves the overflow is spilled around the call only
 // (Sedov 256^3, riemann_solver = 1: k_trans1 18.6 -> see DESIGN.md section 9)
-#ifdef EXPERIMENT_DEFAULT_THREE_WAVES      // A/B: the default-solver instantiations of k_trans1 / k_final / k_finalx_consup at 3 waves per SIMD
-#define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : (GEN == 0 ? 3 : 1), GEN == 2 ? 2 : (GEN == 0 ? 3 : 8))))
-#elif !defined(CG_ONE_WAVE)
+#if !defined(CG_ONE_WAVE)
 #define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : 1, GEN == 2 ? 2 : 8)))
 #else
 #define CG_TWO_WAVES
 #endif
 namespace cad {
-
-// A/B (round 4): delay every other group of workgroups at the start of the two VALU-heavy kernels, so that the two waves a
-// SIMD hosts (they belong to two workgroups running the same program) do not walk through their load and compute phases in
-// lockstep (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  -DSTAGGER_SLEEP=<1..127> (units of 64 cycles), -DSTAGGER_SHIFT.
-#ifdef STAGGER_SLEEP
-#ifndef STAGGER_SHIFT
-#define STAGGER_SHIFT 8
-#endif
-#define STAGGER_START() do { if ((blockIdx.x >> STAGGER_SHIFT) & 1u) __builtin_amdgcn_s_sleep(STAGGER_SLEEP); } while (0)
-#else
-#define STAGGER_START() do { } while (0)
-#endif
 
 // Host-free stepping: DevParams::dtp points at castro_amd_step_control's vector; once a step has been rejected
 // (ctl[CASTRO_AMD_CTL_STATUS] != 0) the launches that follow in the same batch must leave the caller's arrays alone --
@@ -865,49 +851,11 @@ __device__ __forceinline__ void store_edge_2(double* __restrict__ E, long NC, un
     }
 }
 
-// x-direction stencils from lanes (k_trace_pair): consecutive lanes of a wave hold consecutive zone pairs of a row, so the
-// pairs to the left and right of a lane's own are its neighbours' -- one DPP wave shift each instead of a load.  Only
-// the lanes at a wave boundary (0, 63) or at a row end have no such neighbour; they fetch the missing pair in ONE masked
-// load (left pair for `nl` lanes, right pair for `nr` lanes; a lane that is both -- a row of one pair -- loads twice).
-// Every lane of the wave must be active (the default trace launch has no early exit).
-struct XLane { bool nl, nr; };
-__device__ __forceinline__ double lane_shr1(double v)      // value of lane - 1
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_shl1(double v)      // value of lane + 1
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void lane_pairs(const double* __restrict__ a, unsigned c, const XLane& xl, D2& l, const D2& m, D2& r)
-{
-    l.a = lane_shr1(m.a); l.b = lane_shr1(m.b);
-    r.a = lane_shl1(m.a); r.b = lane_shl1(m.b);
-    if (xl.nl || xl.nr) {
-        const D2 f = ldg2(a, xl.nl ? c - 16u : c + 16u);
-        if (xl.nl) l = f; else r = f;
-        if (xl.nl && xl.nr) r = ldg2(a, c + 16u);
-    }
-}
-
 // five-point stencils of two x-adjacent zones along direction D
 template <int D>
-__device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, unsigned c, unsigned sd, double sA[5], double sB[5],
-                                               const XLane* xl = nullptr)
+__device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, unsigned c, unsigned sd, double sA[5], double sB[5])
 {
-    if (D == 0 && xl) {
-        const D2 m = ldg2(a, c);
-        D2 l, r;
-        lane_pairs(a, c, *xl, l, m, r);
-        sA[0] = l.a; sA[1] = l.b; sA[2] = m.a; sA[3] = m.b; sA[4] = r.a;
-        sB[0] = l.b; sB[1] = m.a; sB[2] = m.b; sB[3] = r.a; sB[4] = r.b;
-    } else if (D == 0) {
+    if (D == 0) {
         const D2 l = ldg2(a, c - 16u), m = ldg2(a, c), r = ldg2(a, c + 16u);
         sA[0] = l.a; sA[1] = l.b; sA[2] = m.a; sA[3] = m.b; sA[4] = r.a;
         sB[0] = l.b; sB[1] = m.a; sB[2] = m.b; sB[3] = r.a; sB[4] = r.b;
@@ -928,7 +876,7 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
                                                const bool do_plus[2], const bool do_minus[2],
                                                double* __restrict__ QMd, double* __restrict__ QPd,
                                                double qp[2][NEDGE], double qm[2][NEDGE],
-                                               double aA[5], double aB[5], double bA[5], double bB[5], const XLane* xl = nullptr)
+                                               double aA[5], double aB[5], double bA[5], double bB[5])
 {
     constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
     constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
@@ -945,16 +893,16 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     ppm_waves<2>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_un, w[0].Im_un);
     ppm_waves<2>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
 
-    load_stencil_2<D>(Q + (long)PP * NC, c, sd, aA, aB, xl);
+    load_stencil_2<D>(Q + (long)PP * NC, c, sd, aA, aB);
     ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
     ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
 
     if (GL) {
-        load_stencil_2<D>(Q + (long)QUT * NC, c, sd, bA, bB, xl);
+        load_stencil_2<D>(Q + (long)QUT * NC, c, sd, bA, bB);
         ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
         ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
 
-        load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, aA, aB, xl);
+        load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, aA, aB);
         ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
         ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
 
@@ -972,19 +920,19 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
         store_edge_2<true>(QMd, NC, c + sd, qm, do_minus[0], do_minus[1]);
         return;
     }
-    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB, xl);
+    load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB);
     ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
     ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
 
-    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, aA, aB, xl);
+    load_stencil_2<D>(Q + (long)QUT * NC, c, sd, aA, aB);
     ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_re, w[0].Im_re);
     ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_re, w[1].Im_re);
 
-    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, bA, bB, xl);
+    load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, bA, bB);
     ppm_waves<1>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
     ppm_waves<1>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
 
-    load_stencil_2<D>(Q + (long)PX * NC, c, sd, aA, aB, xl);
+    load_stencil_2<D>(Q + (long)PX * NC, c, sd, aA, aB);
     ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
     ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
 
@@ -1319,18 +1267,6 @@ constexpr bool kQI = false;
 constexpr bool kQI = true;
 #endif
 constexpr int QRHO = 0, QUN = 1, QUT = 2, QUTT = 3, QPG = 4, QREG = 5, QXG = 6, NQI = 7;
-
-// The y and z flux records consup_hydro needs (FL[1], FL[2]: 7 fluxes + Godunov un, p per face) are, up to the factor
-// dt * area of scale_flux, what k_final<y>, k_final<z> have just written to the caller's fluxes[1], fluxes[2] in assign mode.
-// -DCAD_FLUX_OUT_CONSUP (contract builds only: F = fluxes / (dt * area) is one rounding away from the stored flux) lets
-// k_finalx_consup read those instead and k_final<y,z> store only the two Godunov planes: 14 plane passes less per step
-// (1.9 GB at 256^3).  Measured (profiles/r04d_*): k_final<y>, <z> -0.03 ms each, k_finalx_consup +0.2 ms -- the face-box rows of
-// the caller's arrays do not line up with the scratch rows the rest of that kernel streams.  Off.
-#if defined(CAD_NUMERICS_CONTRACT) && defined(CAD_FLUX_OUT_CONSUP)
-constexpr bool kFluxOutConsup = true;
-#else
-constexpr bool kFluxOutConsup = false;
-#endif
 
 template <int D>
 __device__ __forceinline__ void qstate_to_rec(double rho, double un, double ut, double utt, double p, double rhoe, double Xg,
@@ -1668,7 +1604,6 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
                                                     double dt, DevParams P, SkipBox skip, LevelTab lv)
 {
     constexpr bool GL = gamma_law_edges(GEN) && DMASK == 7;
-    STAGGER_START();
     if (P.dtp) dt = P.dtp[6];
     unsigned vb = blockIdx.x;
     if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_TRACE]; S = B.S; Q = B.S.Q; }
@@ -1686,17 +1621,6 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const long NC = t.NC;
-#ifdef TRACE_X_LANES            // A/B (round 4): x stencils from the neighbouring lanes by DPP instead of three 16-byte loads per
-                                // variable.  Bit-exact, 16 fewer full loads per wave -- and slower: 2.61 vs 2.49 ms (contract build),
-                                // the neighbours' lines are L1 hits, the DPP moves, selects and masked loads are not free
-                                // (profiles/r04c_*).  Off by default.
-    XLane xlane;
-    xlane.nl = (threadIdx.x & 63u) == 0u || i == b.lo[0];
-    xlane.nr = (threadIdx.x & 63u) == 63u || i + 2 > b.hi0;
-    const XLane* const xl = XRIEM ? &xlane : nullptr;
-#else
-    const XLane* const xl = nullptr;
-#endif
 
     // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
     double flat[2];
@@ -1706,21 +1630,7 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
         // all three directions' stencils are requested before the first coefficient is evaluated
         const double* Pp = Q + PP * NC;
         double pxA[7], pxB[7], uxA[5], uxB[5], pyA[7], pyB[7], uyA[5], uyB[5], pzA[7], pzB[7], uzA[5], uzB[5];
-        if (xl) {
-            // p(i-3 .. i+4) from the own pair, the neighbours' pairs and one value of the next lanes but one
-            const D2 m = ldg2(Pp, c);
-            D2 l, r;
-            lane_pairs(Pp, c, *xl, l, m, r);
-            double pm3 = lane_shr1(l.b), pp4 = lane_shl1(r.a);      // valid where the neighbour's pair is the adjacent one
-            if (xl->nl || xl->nr) {
-                const double f = ldg(Pp, xl->nl ? c - 24u : c + 32u);
-                if (xl->nl) pm3 = f; else pp4 = f;
-                if (xl->nl && xl->nr) pp4 = ldg(Pp, c + 32u);
-            }
-            pxA[0] = pm3; pxA[1] = l.a; pxA[2] = l.b; pxA[3] = m.a; pxA[4] = m.b; pxA[5] = r.a; pxA[6] = r.b;
-            pxB[0] = l.a; pxB[1] = l.b; pxB[2] = m.a; pxB[3] = m.b; pxB[4] = r.a; pxB[5] = r.b; pxB[6] = pp4;
-            load_stencil_2<0>(Q + PU * NC, c, s.x, uxA, uxB, xl);
-        } else {
+        {
             const D2 p0 = ldg2(Pp, c - 24u), p1 = ldg2(Pp, c - 8u), p2 = ldg2(Pp, c + 8u), p3 = ldg2(Pp, c + 24u);
             pxA[0] = p0.a; pxA[1] = p0.b; pxA[2] = p1.a; pxA[3] = p1.b; pxA[4] = p2.a; pxA[5] = p2.b; pxA[6] = p3.a;
             pxB[0] = p0.b; pxB[1] = p1.a; pxB[2] = p1.b; pxB[3] = p2.a; pxB[4] = p2.b; pxB[5] = p3.a; pxB[6] = p3.b;
@@ -1748,9 +1658,9 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
     double sa[2][5], sb[2][5];
     if (DMASK & 1) {
-        load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1], xl);
-        load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1], xl);
-        trace_pair_dir<0, (DMASK & 2) ? 1 : -1, GL>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1], xl);
+        load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1]);
+        load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1]);
+        trace_pair_dir<0, (DMASK & 2) ? 1 : -1, GL>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1]);
     }
 
     if (XRIEM && (DMASK & 1))
@@ -2394,7 +2304,6 @@ __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t
                                                          double cdtdx, double cdtdy, double cdtdz, DevParams P, LevelTab lv)
 {
     __shared__ double park[2 * 2 * NF1 * FOLD_WG];
-    STAGGER_START();
     DT_THIRDS_FROM_DEVICE();
     unsigned vb = blockIdx.x;
     if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_FOLD]; S = B.S; Q = B.S.Q; }
@@ -2438,7 +2347,7 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
                                            const double* __restrict__ Q, const DevScratch& S, const DevGeom& g,
                                            const DFab& U, const DFab& fluxes, const DFab& mass, const DFab& qe,
                                            double hdtdx_t1, double hdtdx_t2, double dt, double area, double dxn,
-                                           int acc_hi, int assign, const DevParams& P, double R[2][NFIN], bool fl_godunov_only = false)
+                                           int acc_hi, int assign, const DevParams& P, double R[2][NFIN])
 {
     constexpr int T1 = (N == 0) ? 1 : 0;
     constexpr int T2 = (N == 2) ? 1 : 2;
@@ -2522,13 +2431,6 @@ __device__ __forceinline__ void final_body(const Tile& t, const int ijk[3], bool
                             ijk[0], ijk[1], ijk[2], dt, area, dxn, g.dx[0] * g.dx[1] * g.dx[2], acc_hi, assign != 0, v0, v1, P, R);
     if (!STORE_FL) return;
     double* FL = S.FL[N];
-    if (kFluxOutConsup && fl_godunov_only) {
-        // the fluxes themselves reach consup through fluxes[N] (see kFluxOutConsup)
-        if (v0 && v1) { stg2(FL + (long)GUG * NC, c, R[0][GUG], R[1][GUG]); stg2(FL + (long)GPG * NC, c, R[0][GPG], R[1][GPG]); }
-        else if (v0) { stg(FL + (long)GUG * NC, c, R[0][GUG]); stg(FL + (long)GPG * NC, c, R[0][GPG]); }
-        else { stg(FL + (long)GUG * NC, c + 8u, R[1][GUG]); stg(FL + (long)GPG * NC, c + 8u, R[1][GPG]); }
-        return;
-    }
     constexpr bool NOX = gamma_law_edges(GEN) && !LIM;      // record GX == record GRHO: not stored, consup reads GRHO
     if (v0 && v1) {
 #pragma unroll
@@ -2567,9 +2469,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_final(Tile t, LinBox b, co
     const bool v1 = ijk[0] + 1 <= b.hi0;          // second face of the pair inside the box
     const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
     double R[2][NFIN];
-    // assign & 2: consup will take this direction's fluxes from fluxes[N] (kFluxOutConsup): only the Godunov planes of FL[N]
-    final_body<N, RE, LIM, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R,
-                                      (assign & 2) != 0);
+    final_body<N, RE, LIM, true, GEN>(t, ijk, true, v1, c, Q, S, g, U, fluxes, mass, qe, hdtdx_t1, hdtdx_t2, dt, area, dxn, acc_hi, assign, P, R);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2670,7 +2570,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
                                                        double hdtdy, double hdtdz, double dt,
                                                        double area0, double area1, double area2, double vol,
                                                        int acc_hi, int assign, int from_sborder, DevParams P, int ntimes,
-                                                       double* red, DFab fluxes_y, DFab fluxes_z, LevelTab lv)
+                                                       double* red, LevelTab lv)
 {
     RETURN_IF_BATCH_FAILED();
     if (P.dtp) { dt = P.dtp[6]; hdtdy = 0.5 * dt / g.dx[1]; hdtdz = 0.5 * dt / g.dx[2]; }
@@ -2678,7 +2578,6 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
     if (LV) {
         const LevelBox& B = level_box(lv, bid);
         t = B.t; b = B.xr; S = B.S; Q = B.S.Q; U = B.U; fluxes = B.fl[0]; mass = B.mass[0]; qe = B.qe[0]; Unew = B.Unew; acc_hi = B.acc_hi[0];
-        fluxes_y = B.fl[1]; fluxes_z = B.fl[2];
     }
     bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
     const int lane = threadIdx.x & 63;
@@ -2731,11 +2630,6 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
         // gamma_law_edges: the species record of FL[y], FL[z] is their mass record (not stored)
         constexpr int rec[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, (gamma_law_edges(GEN) && !LIM) ? GRHO : GX };
         double un[2][NUM_STATE];
-        // kFluxOutConsup (assign & 2): the y / z fluxes, already scaled by dt * area, from the caller's flux arrays
-        const bool from_out = kFluxOutConsup && (assign & 2) != 0;
-        const unsigned cfy = from_out ? foff(fluxes_y, ijk[0], ijk[1], ijk[2]) : 0u, cfz = from_out ? foff(fluxes_z, ijk[0], ijk[1], ijk[2]) : 0u;
-        const unsigned fsy = 8u * (unsigned)fluxes_y.sy, fsz = 8u * (unsigned)fluxes_z.sz;
-        const double dtarea0 = dt * area0;
         // one species, gamma-law gas, clean_state fused in (gamma_law_edges): the temperature and the species of the old state are
         // dead -- computeTemp overwrites the one, normalize_species makes rho X = rho of the other -- and are not read
         constexpr bool DEAD_TX = gamma_law_edges(GEN) && !LIM && CLEAN;
@@ -2746,17 +2640,10 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
             const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
             if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }       // zero flux
             const int r = rec[m];
-            if (from_out) {
-                const D2 y0 = ldg2(fluxes_y.p + m * fluxes_y.sn, cfy), y1 = ldg2(fluxes_y.p + m * fluxes_y.sn, cfy + fsy);
-                const D2 z0 = ldg2(fluxes_z.p + m * fluxes_z.sn, cfz), z1 = ldg2(fluxes_z.p + m * fluxes_z.sn, cfz + fsz);
-                un[0][m] = u0.a + (dtarea0 * (R[0][r] - R[1][r]) + (y0.a - y1.a) + (z0.a - z1.a)) * volinv;
-                un[1][m] = u0.b + (dtarea0 * (R[1][r] - Rn[r]) + (y0.b - y1.b) + (z0.b - z1.b)) * volinv;
-            } else {
             const D2 y0 = ldg2(F1 + (long)r * NC, c), y1 = ldg2(F1 + (long)r * NC, c + sy);
             const D2 z0 = ldg2(F2 + (long)r * NC, c), z1 = ldg2(F2 + (long)r * NC, c + sz);
             un[0][m] = u0.a + dt * (R[0][r] * area0 - R[1][r] * area0 + y0.a * area1 - y1.a * area1 + z0.a * area2 - z1.a * area2) * volinv;
             un[1][m] = u0.b + dt * (R[1][r] * area0 - Rn[r] * area0 + y0.b * area1 - y1.b * area1 + z0.b * area2 - z1.b * area2) * volinv;
-            }
             if (m == UEINT) {
                 const D2 py0 = ldg2(F1 + GPG * NC, c), py1 = ldg2(F1 + GPG * NC, c + sy);
                 const D2 uy0 = ldg2(F1 + GUG * NC, c), uy1 = ldg2(F1 + GUG * NC, c + sy);
@@ -3090,11 +2977,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             }
         } else
         KL2_SOLV("k_trans1", K_T1, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
-        // kFluxOutConsup: whole-box calls in assign mode with both flux arrays present (a tile whose high y / z faces belong
-        // to its neighbour would read fluxes another launch writes)
-        const bool flux_out_consup = kFluxOutConsup && (flags & 2) && !lim && fluxes[1].p && fluxes[2].p &&
-                                     acc_hi[1] == t.hi[1] + 1 && acc_hi[2] == t.hi[2] + 1;
-        const int assign_yz = ((flags & 2) ? 1 : 0) | (flux_out_consup ? 2 : 0);
+        const int assign_yz = (flags & 2) ? 1 : 0;
         if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P, nolv);
             KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P, nolv);
@@ -3118,7 +3001,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 #define FXC(LIM, CLEAN, GENF, nt, rd)                                                                                        \
         hipLaunchKernelGGL((k_finalx_consup<LIM, CLEAN, GENF>), dim3(xr.nb), dim3(64u * xr.wv), 0, stream, t, xr, S.Q, S, g, Sborder,      \
                            fluxes[0], mass[0], qe[0], Snew, hdtdy, hdtdz, dt, area0, area1, area2, vol_, acc_hi[0],      \
-                           assign_yz, (flags & 1) ? 1 : 0, P, nt, rd, fluxes[1], fluxes[2], nolv)
+                           assign_yz, (flags & 1) ? 1 : 0, P, nt, rd, nolv)
         if (clean_ntimes > 0) {
             if (lim) FXC(true, true, 2, clean_ntimes, red);
             else if (solv == 2) FXC(false, true, 2, clean_ntimes, red);
@@ -3267,11 +3150,11 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
     if (clean_ntimes > 0)
         hipLaunchKernelGGL((k_finalx_consup<false, true, 0, true>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
                            hb[0].fl[0], hb[0].mass[0], hb[0].qe[0], hb[0].Unew, hdtdy, hdtdz, dt, area0, area1, area2, vol, hb[0].acc_hi[0],
-                           assign, (flags & 1) ? 1 : 0, P, clean_ntimes, red, hb[0].fl[1], hb[0].fl[2], lv(LB_FX));
+                           assign, (flags & 1) ? 1 : 0, P, clean_ntimes, red, lv(LB_FX));
     else
         hipLaunchKernelGGL((k_finalx_consup<false, false, 0, true>), dim3(total(LB_FX)), dim3(64u * hb[0].xr.wv), 0, stream, t0, hb[0].xr, S0.Q, S0, g, hb[0].U,
                            hb[0].fl[0], hb[0].mass[0], hb[0].qe[0], hb[0].Unew, hdtdy, hdtdz, dt, area0, area1, area2, vol, hb[0].acc_hi[0],
-                           assign, (flags & 1) ? 1 : 0, P, 0, (double*)nullptr, hb[0].fl[1], hb[0].fl[2], lv(LB_FX));
+                           assign, (flags & 1) ? 1 : 0, P, 0, (double*)nullptr, lv(LB_FX));
     prof_end(prof, stream);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
