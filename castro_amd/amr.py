@@ -464,6 +464,7 @@ class _Level:
         if self._pending_cleans > 0:           # see Castro.do_advance_ctu
             self._clean_boxes("S_old_b", self._pending_cleans)
         self._pending_cleans = 0
+        self._cached_est = None
         self.red.fill_(1.e200)
         self.fill("S_old_b")
         if self.have_sources:
@@ -477,7 +478,12 @@ class _Level:
             for b in self.mine:
                 self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
         self.amr.comm.allreduce_min(self.red)                 # the level's minima over the ranks that hold its boxes
-        _, rho_min, est = self.red.tolist()           # [2]: the estimate after the first clean_state (the only one here)
+        est_last, rho_min, est = self.red.tolist()    # [2]: the estimate after the first clean_state (the only one here
+                                                      # unless post_timestep's rode along: then [0] is the one after it)
+        if self._post_clean_done:
+            # the state leaves this advance as post_timestep will leave it (finest level, whole-step attempt): its CFL
+            # estimate is what estTimeStep would reduce again from the same zones (Castro.step: _next_est)
+            self._cached_est = est_last
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)
@@ -486,6 +492,8 @@ class _Level:
         return True, "", new_dt
 
     def estTimeStep(self):
+        if getattr(self, "_cached_est", None) is not None and self._post_clean_done and self.boxes:
+            return min(self.max_dt, checked_estimate(self._cached_est) * self.params.cfl)
         self.red.fill_(1.e200)
         for b in self.mine:
             self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
