@@ -99,3 +99,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
+
+
+def test_bench_byte_tables_match_the_plane_counts_of_the_design_document():
+    """bench.py's per-kernel compulsory bytes (roofline.kernel_utilisation) are the plane counts of DESIGN.md section 4: 352 passes
+    per zone of the 256^3 box for the `exact` build's default path, 291 for the `contract` build's (the box-size factors of the
+    ghost work included)."""
+    import bench
+    names = ("k_ctoprim_clean", "k_divu", "k_trace", "k_trans1_fold", "k_final_y", "k_final_z", "k_finalx_consup")
+    n = (256, 256, 256)
+    for lean, planes in ((False, 8 + 8 + 4 + 57 + 92 + 56 + 56 + 73), (True, 6 + 6 + 4 + 41 + 72 + 47 + 47 + 63)):
+        assert sum(bench.kernel_bytes_per_unit(k, False, lean) for k in names) == 8 * planes
+        passes = sum(bench.kernel_bytes_per_unit(k, False, lean) * bench.kernel_units(k, n) for k in names) / 8.0 / 256 ** 3
+        assert abs(passes - (291 if lean else 360)) < 1.0, passes
