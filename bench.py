@@ -26,15 +26,27 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # The default bench mode elides bytes the single-level driver does not need (declared, as 8(d) requires):
 #   S_new = Sborder + ... (no S_new read) and fluxes[d] = ... instead of zero-fill + "+=" (no fluxes read):
 #   8 B x (8 + 8 + 3*8 + 3) = 344 B.  --reference-contract runs the 600-B form.
+#   The `contract` build with clean_state fused into the update (this script's default) reads neither the temperature nor the
+#   species of the old state (k_ctoprim / k_finalx_consup: `lean_q` bit 1): 8 B x (6 + 8 + 3*8 + 3) = 328 B.
+#   Only bytes that move are declared (tests/test_capi_symbols.py ties these figures to the kernels' read sets).
 PATH_BYTES_CONTRACT = 600.0
-PATH_BYTES_ASSIGN = 344.0
+STATE_PLANES_READ = {False: 8, True: 6}            # planes of the old state the path reads: all / without UTEMP, UFS (lean)
+PATH_BYTES_ASSIGN = 8.0 * (STATE_PLANES_READ[False] + 8 + 3 * 8 + 3)          # 344
+PATH_BYTES_ASSIGN_LEAN = 8.0 * (STATE_PLANES_READ[True] + 8 + 3 * 8 + 3)      # 328
+
+
+def path_bytes(reference_contract, numerics, fused_clean=True):
+    """declared bytes per cell-update of the mode that was timed"""
+    if reference_contract:
+        return PATH_BYTES_CONTRACT
+    return PATH_BYTES_ASSIGN_LEAN if (numerics == "contract" and fused_clean) else PATH_BYTES_ASSIGN
 
 # compulsory bytes per processed unit of each hot-path kernel: every input and output array element exactly once
 # (DESIGN.md "Kernels").  Unit = one zone/face of the kernel's box.  These give the per-kernel HBM utilisation
 # (roofline.kernel_utilisation); the roofline figure itself is the SURVEY 8(d) contract above.
 KERNEL_BYTES_PER_UNIT = {
-    "k_ctoprim": 8 * (8 + 8),
-    "k_ctoprim_clean": 8 * (8 + 8),                       # + the pending clean_states; only changed components of U are written back
+    "k_ctoprim": 8 * (STATE_PLANES_READ[False] + 8),
+    "k_ctoprim_clean": 8 * (STATE_PLANES_READ[False] + 8),                       # + the pending clean_states; only changed components of U are written back
     "k_divu": 8 * (3 + 1),
     "k_trace": 8 * (8 + 42 + 7),                          # + F1[x] (7-plane state form): the first x Riemann solve is fused in
     "k_riemann1": 8 * (14 + 1 + 8),
@@ -55,8 +67,8 @@ KERNEL_BYTES_PER_UNIT = {
 # The `contract` build with the default options (gamma-law gas, one species, default solver) does not carry (rho e) or X
 # through the edge states and X through the records (`gamma_law_edges`): its kernels have fewer planes.
 KERNEL_BYTES_PER_UNIT_LEAN = {
-    "k_ctoprim": 8 * (6 + 6),                             # neither the temperature nor the species of the state is read
-    "k_ctoprim_clean": 8 * (6 + 6),
+    "k_ctoprim": 8 * (STATE_PLANES_READ[True] + 6),       # neither the temperature nor the species of the state is read
+    "k_ctoprim_clean": 8 * (STATE_PLANES_READ[True] + 6),
     "k_trace": 8 * (6 + 30 + 5),                          # Q without (rho e), X; 5-plane edge states; 5-plane F1[x]
     "k_trans1_fold": 8 * (30 + 5 + 1 + 36),               # F2 in the 6-plane state form
     "k_final_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 17),
@@ -370,6 +382,7 @@ def main():
                 "halo": c.halo_stats() if hasattr(c, "halo_stats") else None, "host_free": host_free,
                 "step_graph": bool(host_free and getattr(c, "_graphs", None)), "per_step": per,
                 "numerics": c.hydro.numerics, "library": c.hydro.lib.castro_amd_version().decode()}
+        c.close()                                # the C-ABI halo plans own device buffers outside torch's allocator
         del c
         torch.cuda.empty_cache()
         return wall, prof, ksteps, info
@@ -377,7 +390,7 @@ def main():
     wall, prof, ksteps, info = run(contract, args.steps, args.warmup, True)
     total_cells = n_cell[0] * n_cell[1] * n_cell[2]
     value = total_cells * args.steps / wall
-    bytes_per_cell = PATH_BYTES_CONTRACT if contract else PATH_BYTES_ASSIGN
+    bytes_per_cell = path_bytes(contract, info["numerics"], fused_clean=not contract)
 
     # per-kernel HBM utilisation: compulsory bytes of a launch over its hipEvent-timed duration
     kutil = {}
@@ -416,8 +429,9 @@ def main():
         other = "exact" if args.numerics == "contract" else "contract"
         try:
             w_o, _, _, i_o = run(contract, args.steps, args.warmup, False, numerics=other)
+            b_o = path_bytes(contract, i_o["numerics"], fused_clean=not contract)
             other_leg = {"numerics": i_o["numerics"], "ms_per_step": w_o / args.steps * 1e3, "value": total_cells * args.steps / w_o,
-                         "frac": total_cells * args.steps / w_o * bytes_per_cell / 1e9 / HBM_PEAK_GBS}
+                         "bytes_per_cell_update": b_o, "frac": total_cells * args.steps / w_o * b_o / 1e9 / HBM_PEAK_GBS}
         except Exception as e:
             other_leg = {"numerics": other, "error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
@@ -452,7 +466,8 @@ def main():
         "config": {"workload": "Sedov 3D %dx%dx%d single level, gamma-law EOS, PPM + CGF Riemann, CTU" % n_cell,
                    "rank_grid": "%dx%dx%d" % grid, "zones_per_gpu": info["zones_per_gpu"],
                    "overlap_halo": info["overlap_halo"], "sim_time": info["sim_time"], "nstep": info["nstep"],
-                   "flux_mode": "accumulate (600 B/cell contract)" if contract else "assign (344 B/cell, declared)",
+                   "flux_mode": "accumulate (600 B/cell contract)" if contract else
+                                "assign (%d B/cell, declared%s)" % (bytes_per_cell, "; old temperature / species not read" if bytes_per_cell < PATH_BYTES_ASSIGN else ""),
                    "fused_clean_state": not contract, "halo": info["halo"],
                    "host_free_steps": info["host_free"], "step_graph": info["step_graph"],
                    "ranks_seen": ranks_seen, "backend": backend_name, "rccl_version": rccl,

@@ -50,6 +50,12 @@ class SingleComm:
             self._ccomm = hydro.comm_create(1, 0, hydro.comm_unique_id())
         return self._ccomm
 
+    def close(self, hydro=None):
+        """destroy the C-ABI communicator (after every Castro object that used it has been closed)"""
+        cc, self._ccomm = getattr(self, "_ccomm", None), None
+        if cc and hydro is not None:
+            hydro.comm_destroy(cc)
+
     def exchange(self, sends, recvs):
         assert not sends and not recvs
 
@@ -113,6 +119,12 @@ class DistComm:
                           % (locals().get("err", "another rank failed"),), file=sys.stderr)
                 self._ccomm = False
         return self._ccomm or None
+
+    def close(self, hydro=None):
+        """destroy the C-ABI communicator (collective in spirit: every rank calls it, after closing its Castro objects)"""
+        cc, self._ccomm = self._ccomm, None
+        if cc and hydro is not None:
+            hydro.comm_destroy(cc)
 
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer_rank, tag, tensor).  Grouped point-to-point."""
@@ -299,6 +311,31 @@ class Castro:
             hydro.reserve(*self.n)
 
     # ----------------------------------------------------------------------------------------
+    def close(self):
+        """Give back what lives outside torch's allocator: the C-ABI halo plans of this object (two packed device buffers
+        each).  The RCCL communicator of the C ABI belongs to the comm object (DistComm / SingleComm.close), which may serve
+        several Castro objects.  Idempotent; never called while a stream is capturing (a free inside a capture aborts)."""
+        plans, self._plans = getattr(self, "_plans", {}), {}
+        if not plans:
+            return
+        h = getattr(self, "hydro", None)
+        if h is None or not getattr(h, "h", None):
+            return                                  # the context (and its library state) is gone already
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()                # a plan is single-stream and may still be in flight
+        for plan in plans.values():
+            cp = plan.pop("cplan", None)
+            if cp is not None:
+                h.halo_plan_destroy(cp)
+
+    def __del__(self):
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
+            self.close()
+        except Exception:
+            pass
+
     def S_new(self):
         """Valid-region view of the new-time state, shape (NUM_STATE, nz, ny, nx)."""
         g = NUM_GROW

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
+namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
 
 using namespace cad;
 
@@ -223,6 +223,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (const char* e = std::getenv("CASTRO_AMD_SIDE_STREAM")) g_side_stream = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_R1")) g_fold_r1 = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE_ROWS")) g_fold_tile_rows = std::atoi(e);
+    if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE")) g_fold_tile = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_FUSED_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_fused_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_final_wg = v; }
@@ -696,31 +697,67 @@ int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, i
             castro_amd_ctx* c0 = ctxs[0];
             hipSetDevice(c0->device);
             std::vector<PreparedBox> pb((size_t)nboxes);
-            size_t need = 0;
+            std::vector<size_t> need((size_t)nboxes);
             for (int i = 0; i < nboxes; ++i) {
                 const castro_amd_hydro_box& b = boxes[i];
                 int rc = prepare_box(c0, b.bxlo, b.bxhi, b.vbxlo, b.vbxhi, &b.Sborder, &b.src, &b.S_new, b.flux, b.mass_flux, b.qe,
                                      geom, params, opts, pb[(size_t)i]);
                 if (rc != CASTRO_AMD_OK) return rc;
-                need += (size_t)pb[(size_t)i].t.NC * (size_t)kPlanes;
+                need[(size_t)i] = (size_t)pb[(size_t)i].t.NC * (size_t)kPlanes;
             }
-            if (need > c0->arena_doubles) {
-                if (c0->arena) { hipDeviceSynchronize(); hipFree(c0->arena); c0->arena = nullptr; c0->arena_doubles = 0; }
-                if (hipMalloc(&c0->arena, need * sizeof(double)) != hipSuccess) return CASTRO_AMD_ERR_NOMEM;
-                c0->arena_doubles = need;
-            }
-            std::vector<LevelBoxDesc> lb((size_t)nboxes);
-            double* p = c0->arena;
+            // Scratch of a level-wide launch: kPlanes planes (1.26 KB) per ghosted zone of EVERY box of the launch at once, where
+            // the box-by-box path needs the largest box only.  So the level goes out in chunks of consecutive boxes whose scratch
+            // fits a byte budget (CASTRO_AMD_LEVEL_SCRATCH_GB, default 32; a single box larger than that is a chunk of its own):
+            // 8 launches per chunk, the chunks one after the other on the caller's stream in the same arena.  If the arena cannot
+            // be had at all the call falls through to the box-by-box path below, which needs the largest box only.
+            static const double budget_gb = [] { const char* e = std::getenv("CASTRO_AMD_LEVEL_SCRATCH_GB"); const double v = e ? std::atof(e) : 32.0; return v > 0.0 ? v : 32.0; }();
+            const size_t budget = (size_t)(budget_gb * 1073741824.0 / sizeof(double));
+            std::vector<int> first;                       // first box of every chunk
+            size_t cur = 0, largest = 0;
             for (int i = 0; i < nboxes; ++i) {
-                const PreparedBox& B = pb[(size_t)i];
-                LevelBoxDesc& L = lb[(size_t)i];
-                L.t = B.t;
-                p = carve_scratch(p, B.t, false, L.S);
-                L.U = B.dS; L.Unew = B.dN;
-                for (int d = 0; d < 3; ++d) { L.fl[d] = B.dF[d]; L.mass[d] = B.dM[d]; L.qe[d] = B.dQ[d]; L.acc_hi[d] = B.acc_hi[d]; }
+                if (i == 0 || cur + need[(size_t)i] > budget) {
+                    first.push_back(i);
+                    cur = 0;
+                }
+                cur += need[(size_t)i];
+                if (cur > largest) largest = cur;
             }
-            return launch_ctu_hydro_level(nboxes, lb.data(), &c0->level_arena, to_devgeom(geom), devP, dt, opts->flags, c0->d_status,
-                                          main_s, &c0->prof, opts->clean_ntimes, opts->d_out, opts->sborder_clean_ntimes);
+            first.push_back(nboxes);
+            bool have_arena = largest <= c0->arena_doubles;
+            if (!have_arena) {
+                if (c0->arena) { hipDeviceSynchronize(); hipFree(c0->arena); c0->arena = nullptr; c0->arena_doubles = 0; }
+                if (hipMalloc(&c0->arena, largest * sizeof(double)) == hipSuccess) { c0->arena_doubles = largest; have_arena = true; }
+                else { (void)hipGetLastError(); c0->arena = nullptr; }
+            }
+            if (have_arena) {
+                const DevGeom dg = to_devgeom(geom);
+                for (size_t ch = 0; ch + 1 < first.size(); ++ch) {
+                    const int i0 = first[ch], i1 = first[ch + 1];
+                    if (i1 - i0 == 1 && first.size() > 2) {
+                        // a chunk of one box: the ordinary call (its own kernels need no table), same arena, same stream
+                        const castro_amd_hydro_box& b = boxes[i0];
+                        const int rc = castro_amd_ctu_hydro_fab_ex(c0, b.bxlo, b.bxhi, b.vbxlo, b.vbxhi, &b.Sborder, &b.src, &b.S_new,
+                                                                   b.flux, b.mass_flux, b.qe, geom, params, time, dt, opts, main_s);
+                        if (rc != CASTRO_AMD_OK) return rc;
+                        continue;
+                    }
+                    std::vector<LevelBoxDesc> lb((size_t)(i1 - i0));
+                    double* p = c0->arena;
+                    for (int i = i0; i < i1; ++i) {
+                        const PreparedBox& B = pb[(size_t)i];
+                        LevelBoxDesc& L = lb[(size_t)(i - i0)];
+                        L.t = B.t;
+                        p = carve_scratch(p, B.t, false, L.S);
+                        L.U = B.dS; L.Unew = B.dN;
+                        for (int d = 0; d < 3; ++d) { L.fl[d] = B.dF[d]; L.mass[d] = B.dM[d]; L.qe[d] = B.dQ[d]; L.acc_hi[d] = B.acc_hi[d]; }
+                    }
+                    const int rc = launch_ctu_hydro_level(i1 - i0, lb.data(), &c0->level_arena, dg, devP, dt, opts->flags, c0->d_status,
+                                                          main_s, &c0->prof, opts->clean_ntimes, opts->d_out, opts->sborder_clean_ntimes);
+                    if (rc != 0) return rc;
+                }
+                return CASTRO_AMD_OK;
+            }
+            // no arena: box by box
         }
     }
     const int used = nboxes < nctx ? nboxes : nctx;

@@ -1983,6 +1983,9 @@ __device__ __forceinline__ void trans1_solve_store(const Tile& t, const DevScrat
         rstate_from_edge<N>(qpo[w], P.gamma, qr, Xr);
         interface_flux<N, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd_fac[w], false, P, f[w]);
     }
+#ifdef DIAG_T1_NOSTORE    // timing diagnostic: the stores behind a condition that never holds
+    if (f[0].rho == 1.2345e300)
+#endif
     store_f1_2<N, (kQI && GEN == 0)>(S.F2[f2_slot(N, T)], t.NC, c, f, m0, m1, nullptr);
 }
 
@@ -2321,6 +2324,309 @@ __global__ void __launch_bounds__(FOLD_WG) CG_TWO_WAVES k_trans1_fold_lds(Tile t
         trans1_fold_dir_lds<2, GEN, true>(t, ijk, v1, owner, c, Q, S, g, cdtdz, cdtdx, P, park, c0);
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// k_trans1_tile (round 5): the same stage with a (j,k) TILE of rows per workgroup, a WAVE per row.
+//   k_trans1_fold_lds shares nothing between waves: of its 14 Riemann solves per zone pair, 6 repeat first-stage solves a
+//   neighbouring row does too (the face above, and both faces of the zone below in the other transverse direction), and each
+//   repetition re-reads its edge states.  Here the RY x RZ waves of a workgroup own RY x RZ rows of ONE run of 63 x-slots (every
+//   wave load is still one contiguous 1-KB piece of a row -- the brick-shaped tile of round 4 lost on exactly that), every wave
+//   solves the low y- and z-face of its row, the (RY+1)(RZ+1) - RY RZ face rows on the rim of the tile (the faces above it, and those
+//   of the rows below it in the other direction) are dealt to the waves, and all first-stage records go through LDS in the 5-value
+//   state form (rho, un, ut, utt, p): 2 x 15 face rows x 5 KB = 150 KB for the 4 x 2 tile, one workgroup of 8 waves per CU -- the
+//   same two waves per SIMD as the fold kernel.  Per zone pair: 2 + 14/8 first-stage solves instead of 8, 6 second-stage solves as
+//   before; ~110 vector loads instead of ~180.
+//   Phases: (1) y first stage + (y|x); barrier; (2) z first stage + (z|x) + (z|y) on the z edge states it holds anyway; barrier;
+//   (3) (x|y), (x|z) on one load of the x edge states, (y|z).
+//   Slots: position p = 63 * workgroup + lane - 1 in the concatenation of the tiles' rows (a wave may straddle two tiles; all
+//   waves of a workgroup straddle alike, so `lane` identifies the x-slot in every row); lane 0 repeats the slot before (fold_thread).
+//   `contract` build, default solver set only (the 7-value records of the `exact` build do not fit the LDS of a CU).
+// ---------------------------------------------------------------------------------------
+struct TileRows { int lo[3]; int hi0; int nslot, ny, nz, ntj, ntk, band; unsigned nb; };
+constexpr int NRQ = 5;                             // parked record: interface state (rho, un, ut, utt, p)
+
+template <int RY, int RZ>
+struct TileGeo {
+    static constexpr int NW = RY * RZ, NFR = (RY + 1) * (RZ + 1), NEX = NFR - NW;
+    // slot of the y-records of face row (j0 + a, k0 + b), a in [0, RY], b in [-1, RZ - 1]; of the z-records, a in [-1, RY - 1], b in [0, RZ]
+    __host__ __device__ static constexpr int fy(int a, int b) { return (b + 1) * (RY + 1) + a; }
+    __host__ __device__ static constexpr int fz(int a, int b) { return (a + 1) * (RZ + 1) + b; }
+};
+
+__device__ __forceinline__ void rec_put(double* __restrict__ L, int fr, int w, int lane, const IFlux& f)
+{
+    double* p = L + ((fr * 2 + w) * NRQ) * 64 + lane;
+    p[0] = f.rho_g; p[64] = f.ugd; p[128] = f.ut; p[192] = f.utt; p[256] = f.pgd;
+}
+template <int T>
+__device__ __forceinline__ void rec_get(const double* __restrict__ L, int fr, int w, int lane, double g1inv, double r[NF1])
+{
+    const double* p = L + ((fr * 2 + w) * NRQ) * 64 + lane;
+    const double pg = p[256];
+    qstate_to_rec<T>(p[0], p[64], p[128], p[192], pg, pg * g1inv, 1.0, r);
+}
+
+template <int D, int GEN>
+__device__ __forceinline__ void f1_solve_2f(const double qm[2][NEDGE], const double qp[2][NEDGE], const D2& cl, const D2& cr,
+                                            double bnd, const DevParams& P, IFlux f[2])
+{
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        RState ql, qr;
+        double Xl, Xr;
+        rstate_from_edge<D>(qm[w], P.gamma, ql, Xl);
+        rstate_from_edge<D>(qp[w], P.gamma, qr, Xr);
+        interface_flux<D, GEN>(ql, qr, Xl, Xr, w ? cl.b : cl.a, w ? cr.b : cr.a, bnd, false, P, f[w]);
+#ifndef TILE_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+#ifdef CAD_NUMERICS_CONTRACT
+#ifdef TILE_DIAG_NOBARRIER      // timing diagnostics (wrong results): no workgroup barriers / no rim-row solves
+#define TILE_BARRIER() __builtin_amdgcn_wave_barrier()
+#else
+#define TILE_BARRIER() __syncthreads()
+#endif
+#ifdef TILE_DIAG_NORIM
+#define TILE_RIM(x) false
+#else
+#define TILE_RIM(x) (x)
+#endif
+template <int GEN, int RY, int RZ>
+__global__ void __launch_bounds__(64 * RY * RZ)
+k_trans1_tile(Tile t, TileRows b, const double* __restrict__ Q, DevScratch S, DevGeom g,
+              double cdtdx, double cdtdy, double cdtdz, DevParams P)
+{
+    using G = TileGeo<RY, RZ>;
+    constexpr bool NP = gamma_law_edges(GEN);
+    static_assert(NP, "k_trans1_tile parks 5-value records: gamma_law_edges instantiations only");
+    __shared__ double rec[2 * G::NFR * 2 * NRQ * 64];
+    double* const Ly = rec;
+    double* const Lz = rec + G::NFR * 2 * NRQ * 64;
+    DT_THIRDS_FROM_DEVICE();
+
+    unsigned bid = blockIdx.x;
+    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // the wave index as a scalar
+    const int jr = wave % RY, kr = wave / RY;
+    const unsigned total = (unsigned)b.nslot * (unsigned)b.ntj * (unsigned)b.ntk;
+    long pl = (long)bid * 63 + lane - 1;
+    bool owner = lane >= 1 && pl < (long)total;
+    if (pl < 0) pl = 0;
+    if (pl >= (long)total) pl = (long)total - 1;
+    const unsigned pos = (unsigned)pl;
+    const unsigned tile = pos / (unsigned)b.nslot;
+    const int xs = (int)(pos - tile * (unsigned)b.nslot);
+    // tiles band by band in j (b.band tiles), k-plane by k-plane inside a band: the rows an XCD works on at one time are neighbours
+    const unsigned per_band = (unsigned)b.band * (unsigned)b.ntk;
+    const unsigned bd = tile / per_band;
+    const unsigned rem = tile - bd * per_band;
+    const unsigned left = (unsigned)b.ntj - bd * (unsigned)b.band;
+    const unsigned bw = left < (unsigned)b.band ? left : (unsigned)b.band;
+    const unsigned tk = rem / bw;
+    const unsigned tj = bd * (unsigned)b.band + (rem - tk * bw);
+    const int j0 = b.lo[1] + (int)tj * RY, k0 = b.lo[2] + (int)tk * RZ;
+    const int hj = b.lo[1] + b.ny - 1, hk = b.lo[2] + b.nz - 1;          // last rows of the launch box
+    int ijk[3];
+    ijk[0] = b.lo[0] + 2 * xs;
+    ijk[1] = j0 + jr;
+    ijk[2] = k0 + kr;
+    if (ijk[1] > hj || ijk[2] > hk) owner = false;                     // a tile may reach past the box: such a row repeats the last one
+    if (ijk[1] > hj) ijk[1] = hj;
+    if (ijk[2] > hk) ijk[2] = hk;
+    const bool v1 = ijk[0] + 1 <= b.hi0;
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    const Str s = gstr(t);
+    const long NC = t.NC;
+    const double* Cp = Q + PC * NC;
+    const double g1inv = 1.0 / (P.gamma - 1.0);
+    const D2 c0 = ldg2(Cp, c);
+    const bool tin_y = owner && ijk[1] >= t.lo[1] && ijk[1] <= t.hi[1];
+    const bool tin_z = owner && ijk[2] >= t.lo[2] && ijk[2] <= t.hi[2];
+    double fr[NF1], fl[NF1];
+
+    // ---- phase 1: first y solves (own low face, one rim face row per wave), (y|x)
+    {
+        EdgeReq e0, e1;
+        edge_request<NP>(S.QM[1], S.QP[1], NC, c, e0);
+        const D2 cl = ldg2(Cp, c - s.y);
+        const int ex = wave;                                          // rim rows 0 .. NEX-1 go to waves 0 .. NEX-1
+        const bool has_ex = TILE_RIM(ex < G::NEX);
+        const int ea = ex < RZ ? RY : ex - RZ, eb = ex < RZ ? ex : -1;
+        int jf = j0 + ea, kf = k0 + eb;
+        if (jf > hj + 1) jf = hj + 1;
+        if (kf > hk) kf = hk;
+        const unsigned cfe = goff(t, ijk[0], jf, kf);
+        D2 cle, cre;
+        if (has_ex) { edge_request<NP>(S.QM[1], S.QP[1], NC, cfe, e1); cle = ldg2(Cp, cfe - s.y); cre = ldg2(Cp, cfe); }
+        {
+            double qm[2][NEDGE], qp[2][NEDGE];
+            IFlux f[2];
+            edge_take<NP>(e0.m, qm, g1inv); edge_take<NP>(e0.p, qp, g1inv);
+            f1_solve_2f<1, GEN>(qm, qp, cl, c0, wall_fac<1>(g, ijk[1]), P, f);
+            rec_put(Ly, G::fy(jr, kr), 0, lane, f[0]);
+            rec_put(Ly, G::fy(jr, kr), 1, lane, f[1]);
+            bool in_t[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int ix = ijk[0] + w;
+                in_t[w] = owner && ((w == 0) || v1) && ijk[1] >= t.lo[1] && ix >= t.lo[0] && ix <= t.hi[0];
+            }
+            if (in_t[0] || in_t[1]) {
+                double bnd[2];
+                bnd[0] = bnd[1] = wall_fac<1>(g, ijk[1]);
+                trans1_pair<1, 0, false, GEN>(t, S, c, s.y, 8u, qm, qp, cl, c0, bnd, cdtdx, in_t[0], in_t[1], P);
+            }
+        }
+        if (has_ex) {
+            double qm[2][NEDGE], qp[2][NEDGE];
+            IFlux f[2];
+            edge_take<NP>(e1.m, qm, g1inv); edge_take<NP>(e1.p, qp, g1inv);
+            f1_solve_2f<1, GEN>(qm, qp, cle, cre, wall_fac<1>(g, jf), P, f);
+            rec_put(Ly, G::fy(ea, eb), 0, lane, f[0]);
+            rec_put(Ly, G::fy(ea, eb), 1, lane, f[1]);
+        }
+    }
+#ifndef TILE_NO_PREFETCH
+    // the first loads of a phase are requested in front of the barrier that opens it: no wave waits for memory behind a barrier
+    EdgeReq ez0;
+    edge_request<NP>(S.QM[2], S.QP[2], NC, c, ez0);
+    const D2 clz0 = ldg2(Cp, c - s.z);
+#endif
+    TILE_BARRIER();
+
+    // ---- phase 2: first z solves (own low face, rim rows from the last wave down), (z|x), (z|y)
+    EdgeReq x0;
+    D2 clx;
+    {
+#ifndef TILE_NO_PREFETCH
+        EdgeReq e1;
+        EdgeReq& e0 = ez0;
+        const D2 cl = clz0;
+#else
+        EdgeReq e0, e1;
+        edge_request<NP>(S.QM[2], S.QP[2], NC, c, e0);
+        const D2 cl = ldg2(Cp, c - s.z);
+#endif
+        const int ex = G::NW - 1 - wave;
+        const bool has_ex = TILE_RIM(ex < G::NEX);
+        const int ea = ex < RY ? ex : -1, eb = ex < RY ? RZ : ex - RY;
+        int jf = j0 + ea, kf = k0 + eb;
+        if (jf > hj) jf = hj;
+        if (kf > hk + 1) kf = hk + 1;
+        const unsigned cfe = goff(t, ijk[0], jf, kf);
+        D2 cle, cre;
+        {
+            double qm[2][NEDGE], qp[2][NEDGE];
+            IFlux f[2];
+            edge_take<NP>(e0.m, qm, g1inv); edge_take<NP>(e0.p, qp, g1inv);
+            f1_solve_2f<2, GEN>(qm, qp, cl, c0, wall_fac<2>(g, ijk[2]), P, f);
+            rec_put(Lz, G::fz(jr, kr), 0, lane, f[0]);
+            rec_put(Lz, G::fz(jr, kr), 1, lane, f[1]);
+            bool in_t[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const int ix = ijk[0] + w;
+                in_t[w] = owner && ((w == 0) || v1) && ijk[2] >= t.lo[2] && ix >= t.lo[0] && ix <= t.hi[0];
+            }
+            double bnd[2];
+            bnd[0] = bnd[1] = wall_fac<2>(g, ijk[2]);
+            if (in_t[0] || in_t[1])
+                trans1_pair<2, 0, false, GEN>(t, S, c, s.z, 8u, qm, qp, cl, c0, bnd, cdtdx, in_t[0], in_t[1], P);
+            // ahead: the rim row (requested here, not earlier: the z edge states stay live across (z|x) for (z|y))
+            if (has_ex) { edge_request<NP>(S.QM[2], S.QP[2], NC, cfe, e1); cle = ldg2(Cp, cfe - s.z); cre = ldg2(Cp, cfe); }
+            // (z|y): the z edge states corrected with the y fluxes of the zones below (minus) and of the own zones (plus)
+            const bool m0 = tin_y && ijk[2] >= t.lo[2], m1 = m0 && v1;
+            if (m0 || m1) {
+                double qmo[2][NEDGE], qpo[2][NEDGE];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    rec_get<1>(Ly, G::fy(jr + 1, kr - 1), w, lane, g1inv, fr); rec_get<1>(Ly, G::fy(jr, kr - 1), w, lane, g1inv, fl);
+                    trans_single<1>(qm[w], fr, fl, P.gamma, cdtdy, P, qmo[w]);
+                    rec_get<1>(Ly, G::fy(jr + 1, kr), w, lane, g1inv, fr); rec_get<1>(Ly, G::fy(jr, kr), w, lane, g1inv, fl);
+                    trans_single<1>(qp[w], fr, fl, P.gamma, cdtdy, P, qpo[w]);
+                }
+                trans1_solve_store<2, 1, GEN>(t, S, c, qmo, qpo, cl, c0, bnd, m0, m1, P);
+            }
+        }
+        if (has_ex) {
+            double qm[2][NEDGE], qp[2][NEDGE];
+            IFlux f[2];
+            edge_take<NP>(e1.m, qm, g1inv); edge_take<NP>(e1.p, qp, g1inv);
+#ifndef TILE_NO_PREFETCH
+            edge_request<NP>(S.QM[0], S.QP[0], NC, c, x0); clx = ldg2(Cp, c - 8u);      // ahead of the barrier, behind the rim request
+#endif
+            f1_solve_2f<2, GEN>(qm, qp, cle, cre, wall_fac<2>(g, kf), P, f);
+            rec_put(Lz, G::fz(ea, eb), 0, lane, f[0]);
+            rec_put(Lz, G::fz(ea, eb), 1, lane, f[1]);
+        }
+#ifndef TILE_NO_PREFETCH
+        if (!has_ex) { edge_request<NP>(S.QM[0], S.QP[0], NC, c, x0); clx = ldg2(Cp, c - 8u); }
+#endif
+    }
+    TILE_BARRIER();
+
+    // ---- phase 3: (x|y) and (x|z) on one load of the x edge states, then (y|z)
+    {
+        EdgeReq y0;
+#ifdef TILE_NO_PREFETCH
+        edge_request<NP>(S.QM[0], S.QP[0], NC, c, x0);
+        clx = ldg2(Cp, c - 8u);
+#endif
+        const int tl = lane > 0 ? lane - 1 : 0;                         // lane 0 owns nothing
+        const bool x0ok = ijk[0] >= t.lo[0], x1ok = v1 && ijk[0] + 1 >= t.lo[0];
+        double bndx[2] = { wall_fac<0>(g, ijk[0]), wall_fac<0>(g, ijk[0] + 1) };
+        double qxm[2][NEDGE], qxp[2][NEDGE];
+        edge_take<NP>(x0.m, qxm, g1inv); edge_take<NP>(x0.p, qxp, g1inv);
+        if (tin_y && (x0ok || x1ok)) {
+            double qmo[2][NEDGE], qpo[2][NEDGE];
+            rec_get<1>(Ly, G::fy(jr + 1, kr), 1, tl, g1inv, fr); rec_get<1>(Ly, G::fy(jr, kr), 1, tl, g1inv, fl);
+            trans_single<1>(qxm[0], fr, fl, P.gamma, cdtdy, P, qmo[0]);
+            rec_get<1>(Ly, G::fy(jr + 1, kr), 0, lane, g1inv, fr); rec_get<1>(Ly, G::fy(jr, kr), 0, lane, g1inv, fl);
+            trans_single<1>(qxm[1], fr, fl, P.gamma, cdtdy, P, qmo[1]);
+            trans_single<1>(qxp[0], fr, fl, P.gamma, cdtdy, P, qpo[0]);
+            rec_get<1>(Ly, G::fy(jr + 1, kr), 1, lane, g1inv, fr); rec_get<1>(Ly, G::fy(jr, kr), 1, lane, g1inv, fl);
+            trans_single<1>(qxp[1], fr, fl, P.gamma, cdtdy, P, qpo[1]);
+            trans1_solve_store<0, 1, GEN>(t, S, c, qmo, qpo, clx, c0, bndx, x0ok, x1ok, P);
+        }
+        edge_request<NP>(S.QM[1], S.QP[1], NC, c, y0);               // ahead: the y faces of (y|z)
+        const D2 cly = ldg2(Cp, c - s.y);
+        if (tin_z && (x0ok || x1ok)) {
+            double qmo[2][NEDGE], qpo[2][NEDGE];
+            rec_get<2>(Lz, G::fz(jr, kr + 1), 1, tl, g1inv, fr); rec_get<2>(Lz, G::fz(jr, kr), 1, tl, g1inv, fl);
+            trans_single<2>(qxm[0], fr, fl, P.gamma, cdtdz, P, qmo[0]);
+            rec_get<2>(Lz, G::fz(jr, kr + 1), 0, lane, g1inv, fr); rec_get<2>(Lz, G::fz(jr, kr), 0, lane, g1inv, fl);
+            trans_single<2>(qxm[1], fr, fl, P.gamma, cdtdz, P, qmo[1]);
+            trans_single<2>(qxp[0], fr, fl, P.gamma, cdtdz, P, qpo[0]);
+            rec_get<2>(Lz, G::fz(jr, kr + 1), 1, lane, g1inv, fr); rec_get<2>(Lz, G::fz(jr, kr), 1, lane, g1inv, fl);
+            trans_single<2>(qxp[1], fr, fl, P.gamma, cdtdz, P, qpo[1]);
+            trans1_solve_store<0, 2, GEN>(t, S, c, qmo, qpo, clx, c0, bndx, x0ok, x1ok, P);
+        }
+        // (y|z): the y edge states corrected with the z fluxes of the zones below in y (minus) and of the own zones (plus)
+        const bool m0 = tin_z && ijk[1] >= t.lo[1], m1 = m0 && v1;
+        if (m0 || m1) {
+            double q[2][NEDGE], qmo[2][NEDGE], qpo[2][NEDGE];
+            edge_take<NP>(y0.m, q, g1inv);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                rec_get<2>(Lz, G::fz(jr - 1, kr + 1), w, lane, g1inv, fr); rec_get<2>(Lz, G::fz(jr - 1, kr), w, lane, g1inv, fl);
+                trans_single<2>(q[w], fr, fl, P.gamma, cdtdz, P, qmo[w]);
+            }
+            edge_take<NP>(y0.p, q, g1inv);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                rec_get<2>(Lz, G::fz(jr, kr + 1), w, lane, g1inv, fr); rec_get<2>(Lz, G::fz(jr, kr), w, lane, g1inv, fl);
+                trans_single<2>(q[w], fr, fl, P.gamma, cdtdz, P, qpo[w]);
+            }
+            double bnd[2];
+            bnd[0] = bnd[1] = wall_fac<1>(g, ijk[1]);
+            trans1_solve_store<1, 2, GEN>(t, S, c, qmo, qpo, cly, c0, bnd, m0, m1, P);
+        }
+    }
+}
+#endif
 
 // All three normal directions in one launch over grow(bx, 1): each F1 record is then fetched from HBM by one
 // kernel instead of two (F1[T] serves the two N != T), the other reads hit in L2.
@@ -2686,6 +2992,7 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
 // host-side launcher
 // ---------------------------------------------------------------------------------------
 int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
+int g_fold_tile = 0;      // CASTRO_AMD_FOLD_TILE: 1 = k_trans1_tile<4, 2> (a 4 x 2 tile of rows per workgroup), 2 = <2, 4>; `contract` build only
 int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: != 0 = k_trans1_fold_lds (records parked in LDS;
                           // -0.35 ms per 256^3 step), 0 = two k_riemann1 launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
 int g_side_stream = 0;    // 1: k_divu runs on the context's side stream beside the trace kernel (CASTRO_AMD_SIDE_STREAM); measured: no gain,
@@ -2968,6 +3275,23 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
             struct RowsGuard2 { int keep; RowsGuard2() : keep(tl_tile_rows) { if (g_fold_tile_rows >= 0) tl_tile_rows = g_fold_tile_rows; }
                                 ~RowsGuard2() { tl_tile_rows = keep; } } rows_guard2;
             LinBox b_ = linbox2(olo, ohi, n_);
+#ifdef CAD_NUMERICS_CONTRACT
+            if (n_ > 0 && g_fold_tile) {
+                const int ry = g_fold_tile == 2 ? 2 : 4, rz = g_fold_tile == 2 ? 4 : 2;
+                TileRows tr;
+                for (int d = 0; d < 3; ++d) tr.lo[d] = olo[d];
+                tr.hi0 = ohi[0];
+                tr.nslot = b_.n[0]; tr.ny = b_.n[1]; tr.nz = b_.n[2];
+                tr.ntj = (tr.ny + ry - 1) / ry; tr.ntk = (tr.nz + rz - 1) / rz;
+                tr.band = b_.ty > 0 ? (b_.ty + ry - 1) / ry : tr.ntj;
+                const long total = (long)tr.nslot * tr.ntj * tr.ntk;
+                tr.nb = ((unsigned)((total + 62) / 63) + 7u) & ~7u;
+                prof_begin(prof, "k_trans1_fold", stream);
+                if (g_fold_tile == 2) hipLaunchKernelGGL((k_trans1_tile<0, 2, 4>), dim3(tr.nb), dim3(512), 0, stream, t, tr, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                else hipLaunchKernelGGL((k_trans1_tile<0, 4, 2>), dim3(tr.nb), dim3(512), 0, stream, t, tr, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                prof_end(prof, stream);
+            } else
+#endif
             if (n_ > 0) {
                 prof_begin(prof, "k_trans1_fold", stream);
                 b_.nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));   // 63 new slots per wave, see fold_thread

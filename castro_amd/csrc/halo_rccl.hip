@@ -261,6 +261,9 @@ int castro_amd_fill_boundary(castro_amd_ctx* ctx, castro_amd_halo_plan* p, const
                              const castro_amd_geom* geom, void* stream)
 {
     if (!ctx || !p || !state || !state->p || state->ncomp != p->ncomp) return CASTRO_AMD_ERR_ARG;
+    // the plan's buffers and the communicator live on the communicator's device; a plan is single-stream: two calls with one
+    // plan on two streams would race on its send / receive buffers (one plan per stream, like one context per stream)
+    if (hipSetDevice(p->comm->device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
     DFab f;
     {

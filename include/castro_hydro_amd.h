@@ -537,6 +537,11 @@ int castro_amd_sod_init_fab(castro_amd_ctx *ctx, const castro_amd_fab *state, co
  * (equal shapes).  send_tag / recv_tag order the messages between a pair of ranks: the recv_tag of the region that
  * receives a message must equal the send_tag of the region that sent it (e.g. tag = 1 + ox + 3 (1 + oy) + 9 (1 + oz) of the
  * direction the message TRAVELS in).  peer == own rank (a periodic wrap onto this rank) is a local copy.
+ *
+ * A plan owns its two packed buffers (device memory outside any allocator of the host) until castro_amd_halo_plan_destroy,
+ * which the owner calls once nothing of the plan is in flight; a plan is SINGLE-STREAM (two calls with one plan on two
+ * streams would race on its buffers: one plan per stream and FAB shape).  castro_amd_fill_boundary selects the
+ * communicator's device itself.
  */
 typedef struct castro_amd_comm castro_amd_comm;
 typedef struct castro_amd_halo_plan castro_amd_halo_plan;

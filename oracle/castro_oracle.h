@@ -223,6 +223,7 @@ typedef struct ora_level ora_level;
 ora_level *ora_level_create(const int n[3], const ora_geom *G, const ora_params *P, int nthreads);
 void ora_level_destroy(ora_level *L);
 double *ora_level_state(ora_level *L);          /* S_new, valid box, FAB layout, NUM_STATE comps */
+void ora_level_set_last_dt(ora_level *L, double last_dt);   /* restart: see Level.set_state of oracle_lib.py */
 double *ora_level_flux(ora_level *L, int dir);  /* fluxes[dir], nodal box, NUM_STATE comps */
 double *ora_level_mass_flux(ora_level *L, int dir);
 void ora_level_set_tile(ora_level *L, const int tile[3]);

@@ -84,6 +84,10 @@ void ora_level_destroy(ora_level *L)
 }
 
 double *ora_level_state(ora_level *L) { return L->S_new; }
+/* restart from a state handed in from outside (a checkpoint in the reference's terms, Castro_io.cpp:restart): the data have
+ * been copied into ora_level_state() by the caller as they are -- no clean_state, a checkpoint holds the state post_timestep left --
+ * and the level remembers the last time step it took (Castro.cpp:906) */
+void ora_level_set_last_dt(ora_level *L, double last_dt) { L->lastDt = last_dt; }
 double *ora_level_flux(ora_level *L, int dir) { return L->fluxes[dir]; }
 double *ora_level_mass_flux(ora_level *L, int dir) { return L->mass_fluxes[dir]; }
 void ora_level_set_tile(ora_level *L, const int tile[3]) { for (int d = 0; d < 3; ++d) L->tile[d] = tile[d]; }

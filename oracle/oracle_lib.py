@@ -140,6 +140,7 @@ def lib():
         L.ora_level_destroy.argtypes = [C.c_void_p]
         L.ora_level_state.restype = C.POINTER(C.c_double)
         L.ora_level_state.argtypes = [C.c_void_p]
+        L.ora_level_set_last_dt.argtypes = [C.c_void_p, C.c_double]
         L.ora_level_flux.restype = C.POINTER(C.c_double)
         L.ora_level_flux.argtypes = [C.c_void_p, C.c_int]
         L.ora_level_mass_flux.restype = C.POINTER(C.c_double)
@@ -305,6 +306,16 @@ class Level:
         p = lib().ora_level_state(self.h)
         nx, ny, nz = self.n
         return np.ctypeslib.as_array(p, shape=(NUM_STATE, nz, ny, nx))
+
+    def set_state(self, S, time, dt, nstep):
+        """Restart from a state taken elsewhere (e.g. a developed device state): S (NUM_STATE, nz, ny, nx) becomes S_new as it
+        is -- a checkpoint holds what post_timestep left, so no clean_state --, with the time, the last time step and the
+        step count of the run it came from; the next step() computes its dt with computeNewDt like any later step."""
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        assert S.shape == self.state().shape, (S.shape, self.state().shape)
+        self.state()[...] = S
+        self.time, self.dt, self.nstep = float(time), float(dt), int(nstep)
+        lib().ora_level_set_last_dt(self.h, float(dt))
 
     def set_gravity(self, const_grav, grav_source_type=4):
         """castro.do_grav = 1, gravity.gravity_type = ConstantGrav, gravity.const_grav (along z)."""

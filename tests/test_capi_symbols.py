@@ -112,3 +112,27 @@ def test_bench_byte_tables_match_the_plane_counts_of_the_design_document():
         assert sum(bench.kernel_bytes_per_unit(k, False, lean) for k in names) == 8 * planes
         passes = sum(bench.kernel_bytes_per_unit(k, False, lean) * bench.kernel_units(k, n) for k in names) / 8.0 / 256 ** 3
         assert abs(passes - (291 if lean else 360)) < 1.0, passes
+
+
+def test_declared_path_bytes_are_the_planes_the_kernels_read():
+    """bench.py declares 8 B x (old-state planes read + 8 S_new written + 3 x 8 fluxes + 3 mass fluxes) per cell-update in its
+    flux-assign mode: 344 B where all eight components of the old state are read, 328 B where the fused clean_state makes its
+    temperature and species dead (`contract` build, lean_q bit 1).  The plane counts are read off the kernel source: k_ctoprim is
+    the one reader of the old state's ghost-grown box, and the loads it guards with `lean_u` are the ones not declared."""
+    import bench
+    src = open(os.path.join(ROOT, "castro_amd", "csrc", "ctu_kernels.hip")).read()
+    body = src[src.index("__global__ void __launch_bounds__(256) k_ctoprim("):src.index("// Castro::src_to_prim")]
+    loads = set(re.findall(r"ldg\(U\.p \+ (U[A-Z]+) \* U\.sn", body))
+    assert loads == {"URHO", "UMX", "UMY", "UMZ", "UEDEN", "UEINT", "UTEMP", "UFS"}
+    guarded = set(re.findall(r"lean_u \? [a-z0-9.]+ : ldg\(U\.p \+ (U[A-Z]+) \* U\.sn", body))
+    assert guarded == {"UTEMP", "UFS"}
+    assert bench.STATE_PLANES_READ == {False: len(loads), True: len(loads) - len(guarded)}
+    # the update kernel (k_finalx_consup) skips the same two components under the same condition
+    upd = src[src.index("k_finalx_consup(Tile t, XRows b"):src.index("// host-side launcher")]
+    assert "DEAD_TX && m == UTEMP" in upd and "DEAD_TX && m == UFS" in upd
+    assert bench.PATH_BYTES_ASSIGN == 344.0 and bench.PATH_BYTES_ASSIGN_LEAN == 328.0
+    assert bench.path_bytes(False, "contract") == 328.0 and bench.path_bytes(False, "exact") == 344.0
+    assert bench.path_bytes(False, "contract", fused_clean=False) == 344.0      # without the fused clean the old T, X are read
+    assert bench.path_bytes(True, "contract") == bench.path_bytes(True, "exact") == 600.0
+    for lean in (False, True):
+        assert bench.kernel_bytes_per_unit("k_ctoprim_clean", False, lean) // 8 - (6 if lean else 8) == bench.STATE_PLANES_READ[lean]

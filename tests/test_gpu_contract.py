@@ -197,6 +197,46 @@ def test_contract_sedov_256_ten_steps_against_oracle_and_to_stop_time_against_ex
     assert not bad, bad
 
 
+def test_contract_sedov_256_developed_state_three_steps_against_oracle(tmp_path, oracle):
+    """The bench configuration on the developed blast wave against the ORACLE (not only against the other GPU build): 700 steps of
+    the `contract` build at 256^3, the state handed to the oracle's level driver, three more steps on both, all 33 plotfile
+    fields within rtol 1e-10."""
+    import torch
+    import castro_amd
+    n = (256, 256, 256)
+    c = castro_amd.Castro(n, numerics="contract")
+    c.initData("sedov")
+    c.evolve(0.01, max_step=700)
+    torch.cuda.synchronize()
+    assert c.nstep == 700 and c.hydro.numerics == "contract"
+    G, P = oracle.make_geom(n), oracle.default_params()
+    lev = oracle.Level(n, G, P, nthreads=0)
+    lev.set_state(c.S_new().cpu().numpy(), c.time, c.dt, c.nstep)
+    for _ in range(3):
+        c.step(0.01)
+        lev.step(0.01)
+    torch.cuda.synchronize()
+    _check(c, lev, oracle, G, P, tmp_path, "sedov256_developed", 1.0 / 256)
+    lev.close()
+    del c
+    torch.cuda.empty_cache()
+
+
+def test_contract_one_256_cubed_box_of_the_512_cubed_decomposition_within_rtol(oracle):
+    """Config 3's per-rank box with its neighbours' ghost data on a developed state (tests/test_gpu_parity.py has the `exact`
+    twin): every output array of one `contract` call on the 256^3 corner box of a 512^3 Sedov run against the oracle."""
+    from castro_amd.hydro import HipHydro
+    from tests.test_gpu_parity import _run_both, _corner_box_of_512
+    U, dt, t = _corner_box_of_512("contract", 300)
+    hip = HipHydro(0, numerics="contract")
+    out = _run_both(hip, oracle, (0, 0, 0), (255, 255, 255), U, (-4, -4, -4), (259, 259, 259), dt, dx=(1.0 / 512,) * 3)
+    dev = _outputs_deviation(out)
+    worst = max(dev, key=dev.get)
+    print("contract vs oracle, 256^3 corner box of 512^3 at t = %.3e: max deviation %.2e (%s)" % (t, dev[worst], worst))
+    assert all(v <= RTOL for v in dev.values()), dev
+    hip.close()
+
+
 @pytest.mark.parametrize("case", ["plm", "hllc", "hybrid", "cg", "gravity"])
 def test_contract_non_default_options_within_rtol(oracle, case):
     """The `contract` build on the option sets that leave its default-solver path (whose edge states carry no (rho e) plane,

@@ -876,6 +876,69 @@ def test_256_cubed_against_oracle(oracle):
     torch.cuda.empty_cache()
 
 
+def test_256_cubed_developed_state_against_oracle(oracle):
+    """The bench configuration on the DEVELOPED blast wave, not only on the quiet start: the device runs Sedov 256^3 to step 700
+    (t close to the stop time 0.01; the shock has swept most of the box), hands S_new, time, dt and the step count to the oracle's
+    level driver (Level.set_state), and both take three more steps: time steps equal, S_new and the x flux register bit for bit."""
+    import torch
+    import castro_amd
+    n = (256, 256, 256)
+    c = castro_amd.Castro(n)
+    c.initData("sedov")
+    c.evolve(0.01, max_step=700)
+    torch.cuda.synchronize()
+    assert c.nstep == 700 and 0.005 < c.time < 0.01
+    S0 = c.S_new().cpu().numpy()
+    assert S0[0].max() > 3.0 and np.count_nonzero(np.abs(S0[1]) > 1e-3) > 0.2 * S0[1].size      # a developed blast wave
+    lev = oracle.Level(n, oracle.make_geom(n), oracle.default_params(), nthreads=min(64, os.cpu_count() or 8))
+    lev.set_state(S0, c.time, c.dt, c.nstep)
+    del S0
+    for _ in range(3):
+        c.step(0.01)
+        lev.step(0.01)
+        assert c.dt == lev.dt and c.time == lev.time
+    torch.cuda.synchronize()
+    assert c.hydro.status() == 0
+    _assert_exact({"S_new": (c.S_new().cpu().numpy(), lev.state()), "flux0": (c.fluxes[0].cpu().numpy(), lev.flux(0))},
+                  "256^3, steps 701-703")
+    lev.close()
+    del c
+    torch.cuda.empty_cache()
+
+
+def _corner_box_of_512(numerics, nsteps):
+    """Config 3's per-rank shape: Sedov 512^3 on the device for `nsteps` steps, then the ghosted state (Sborder) of the 256^3 box
+    [0, 255]^3 of the 2 x 2 x 2 decomposition -- the blast centre sits on its high corner, its high-side ghost zones are the
+    NEIGHBOURS' valid zones, its low-side ones the physical outflow fill.  Returns (Sborder on the host, dt of the next step)."""
+    import torch
+    import castro_amd
+    from castro_amd._lib import NUM_GROW
+    n = (512, 512, 512)
+    c = castro_amd.Castro(n, numerics=numerics)
+    c.initData("sedov")
+    c.run_steps(nsteps)
+    dt = c.computeNewDt(c.dt, 0.01)
+    S = c.S_new_b
+    c.expand_state(S)                         # FillPatch of the whole level: physical boundaries
+    torch.cuda.synchronize()
+    g = NUM_GROW
+    U = S[:, 0:256 + 2 * g, 0:256 + 2 * g, 0:256 + 2 * g].contiguous().cpu().numpy()
+    t = c.time
+    del c, S
+    torch.cuda.empty_cache()
+    return U, dt, t
+
+
+def test_one_256_cubed_box_of_the_512_cubed_decomposition_against_oracle(hip, oracle):
+    """One rank's box of config 3 (512^3 over 2 x 2 x 2 ranks) with its neighbours' ghost data, on a developed state: one
+    construct_ctu_hydro_source call on the 256^3 corner box against the oracle, every output array bit for bit."""
+    U, dt, t = _corner_box_of_512("exact", 300)
+    assert U[0].max() > 2.0                   # the shock is inside this box
+    bxlo, bxhi = (0, 0, 0), (255, 255, 255)
+    out = _run_both(hip, oracle, bxlo, bxhi, U, (-4, -4, -4), (259, 259, 259), dt, dx=(1.0 / 512,) * 3)
+    _assert_exact(out, "256^3 corner box of 512^3 at t = %.3e" % t)
+
+
 def test_320_cubed_against_oracle_where_mirror_symmetry_is_inexact(oracle):
     """What stands behind the relaxed mirror-symmetry bound of test_full_size_512_cubed_properties: at 320^3 (r_init = 3.2
     zones) the reference's expression order is no longer mirror symmetric in the last bit -- the ORACLE's density field

@@ -218,3 +218,23 @@ def test_sedov_against_reference_analytic_table(sedov32):
     err = (np.abs(prof - ref) * wgt).sum() / (ref * wgt).sum()
     assert err < 0.12, err
     assert 1.3 < prof.max() < 6.0           # analytic peak is (gamma+1)/(gamma-1) = 6 at infinite resolution
+
+
+def test_level_restart_from_a_handed_over_state_continues_bit_for_bit(oracle):
+    """Level.set_state (the hook the developed-state GPU parity tests use): a level restarted from the state, time, last dt and
+    step count of another run continues exactly like the run it came from."""
+    n = (16, 16, 16)
+    a = oracle.Level(n, oracle.make_geom(n), oracle.default_params(), nthreads=2)
+    a.init_sedov()
+    for _ in range(6):
+        a.step(0.01)
+    b = oracle.Level(n, oracle.make_geom(n), oracle.default_params(), nthreads=2)
+    b.set_state(np.array(a.state()), a.time, a.dt, a.nstep)
+    for _ in range(4):
+        a.step(0.01)
+        b.step(0.01)
+        assert a.dt == b.dt and a.time == b.time
+    assert np.array_equal(a.state(), b.state())
+    assert np.array_equal(a.flux(0), b.flux(0))
+    a.close()
+    b.close()

@@ -1,12 +1,14 @@
 #!/bin/bash
 # extra PMC passes (each in its own rocprofv3 run with --kernel-trace only)
 set -u
-TAG=${1:-pmc}
+# NUMERICS (environment, default contract): the build of the kernel library that is profiled; pinned on every bench.py line and part of the tag
+NUMERICS=${NUMERICS:-contract}
+TAG=${1:-pmc}_$NUMERICS
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-contract-leg --no-extras"
+ARGS="--numerics $NUMERICS --steps 3 --warmup 2 --no-cpu-baseline --no-contract-leg --no-extras"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" \

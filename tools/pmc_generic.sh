@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: pmc_generic.sh <tag> "<counter set 1>" "<counter set 2>" ...   (each set = one rocprofv3 pass)
-TAG=$1; shift
+NUMERICS=${NUMERICS:-exact}     # the build that is profiled (environment; pinned on the bench.py line, part of the tag)
+TAG=$1_$NUMERICS; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
@@ -8,7 +9,7 @@ cd /tmp
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_p$i -- python3 $REPO/bench.py --numerics exact --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-contract-leg > $OUT/${TAG}_p$i.log 2>&1 || tail -3 $OUT/${TAG}_p$i.log
+  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/${TAG}_p$i -- python3 $REPO/bench.py --numerics $NUMERICS --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-contract-leg > $OUT/${TAG}_p$i.log 2>&1 || tail -3 $OUT/${TAG}_p$i.log
 done
 cd $REPO
 python3 - <<PY

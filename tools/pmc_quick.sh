@@ -1,12 +1,14 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of every kernel for the current environment, one line per kernel (GB per launch, x2 applied to
 # FETCH_SIZE): usage tools/pmc_quick.sh <tag>
-TAG=${1:-q}
+# NUMERICS (environment, default contract): the build of the kernel library that is profiled; pinned on every bench.py line and part of the tag
+NUMERICS=${NUMERICS:-contract}
+TAG=${1:-q}_$NUMERICS
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-contract-leg --no-extras"
+ARGS="--numerics $NUMERICS --steps 3 --warmup 1 --no-cpu-baseline --no-contract-leg --no-extras"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python3 $REPO/bench.py $ARGS > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python3 $REPO/bench.py $ARGS > /dev/null 2>&1
 cd $REPO
@@ -28,6 +30,6 @@ for k in sorted(v, key=lambda k: -sum(v[k].values())):
     if k.startswith("k_") and "init" not in k and "estdt" not in k:
         print("%-44s R %6.2f W %6.2f GB" % (k[:44], v[k].get("FETCH_SIZE", 0), v[k].get("WRITE_SIZE", 0)))
         tot += sum(v[k].values())
-print("sum over hot kernels (one launch each): %.1f GB" % tot)
+print("numerics = $NUMERICS; sum over hot kernels (one launch each): %.1f GB" % tot)
 PY
 rm -rf $OUT/${TAG}_fetch $OUT/${TAG}_write

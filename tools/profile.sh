@@ -2,12 +2,14 @@
 # Profiling recipe used for profiles/ (run on the GPU box through gpurun).
 # usage: tools/profile.sh <tag>   -> writes gpurun_out/<tag>_{stats,fetch,write}/ and summaries
 set -u
-TAG=${1:-r01}
+# NUMERICS (environment, default contract): the build of the kernel library that is profiled; pinned on every bench.py line and part of the tag
+NUMERICS=${NUMERICS:-contract}
+TAG=${1:-r01}_$NUMERICS
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-contract-leg --no-extras"
+ARGS="--numerics $NUMERICS --steps 5 --warmup 2 --no-cpu-baseline --no-contract-leg --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1

@@ -2,15 +2,17 @@
 # bench.py and the rocprofv3 --kernel-trace --stats summary of the same command on the same box (the kernel times
 # of two boxes differ by up to ~8 %): writes gpurun_out/<tag>_bench.json and gpurun_out/<tag>_samebox_stats/
 set -u
-TAG=${1:-r01}
+# NUMERICS (environment, default contract): the build of the kernel library that is profiled; pinned on every bench.py line and part of the tag
+NUMERICS=${NUMERICS:-contract}
+TAG=${1:-r01}_$NUMERICS
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 export TMPDIR=/tmp
 cd $REPO
-python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python3 bench.py --reference-contract --no-cpu-baseline > $OUT/${TAG}_bench_reference_contract.json 2>/dev/null
+python3 bench.py --numerics $NUMERICS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 bench.py --numerics $NUMERICS --reference-contract --no-cpu-baseline > $OUT/${TAG}_bench_reference_contract.json 2>/dev/null
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_samebox_stats -- python3 $REPO/bench.py --no-cpu-baseline --no-extras --no-contract-leg > $OUT/${TAG}_samebox_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_samebox_stats -- python3 $REPO/bench.py --numerics $NUMERICS --no-cpu-baseline --no-extras --no-contract-leg > $OUT/${TAG}_samebox_stats.log 2>&1
 cd $REPO
 find $OUT/${TAG}_samebox_stats -type f -size +8M -delete 2>/dev/null
 python3 - <<PY
