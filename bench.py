@@ -75,6 +75,10 @@ KERNEL_BYTES_PER_UNIT_LEAN = {
     "k_final_assign": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 9),  # FL without the species plane
     "k_finalx_consup_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 17 + 16 + 8),
     "k_finalx_consup_assign": 8 * (10 + 12 + 1 + 1 + 6 + 9 + 16 + 8),
+    # the whole final stage in one zone-centred launch (k_final_tile): edge states and F2 records of all three directions, the sound
+    # speed, div(u) and Sborder once; the three flux arrays (+ mass fluxes) and S_new out; no FL
+    "k_final_tile_rmw": 8 * (30 + 36 + 1 + 1 + 6 + 3 * 17 + 8),
+    "k_final_tile_assign": 8 * (30 + 36 + 1 + 1 + 6 + 3 * 9 + 8),
 }
 
 
@@ -84,6 +88,8 @@ def kernel_bytes_per_unit(name, contract, lean=False):
         return tab["k_final_rmw" if contract else "k_final_assign"]
     if name == "k_finalx_consup":
         return tab["k_finalx_consup_rmw" if contract else "k_finalx_consup_assign"]
+    if name == "k_final_tile":
+        return tab.get("k_final_tile_rmw" if contract else "k_final_tile_assign", 0)
     return tab.get(name, 0)
 
 
@@ -256,7 +262,11 @@ def main():
                          "division, rsq sqrt; rtol 1e-10 against the oracle on every plotfile field: tests/test_gpu_contract.py) "
                          "or `exact` (bit-identical to the oracle: tests/test_gpu_parity.py); the other one is timed as a leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (developed Sedov state, noisy state, "
-                    "per-step medians) of the default single-GPU run")
+                    "per-step medians, rank proxies) of the default single-GPU run")
+    ap.add_argument("--proxy-rank-of", type=int, nargs="*", default=None, metavar="N",
+                    help="untimed extra (single GPU): ms/step of ONE rank's box of the N-rank strong-scaling run of this workload "
+                         "with a full 26-region halo exchange through RCCL self-send (default with extras: 2 4 8); a PROJECTION, "
+                         "reported in config.rank_proxies, never in value")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD torch.distributed.run (never an exec, and
@@ -341,8 +351,8 @@ def main():
         host_free = (not stepwise) and c.host_free_ok()
         if host_free:
             c.run_steps(warmup)
-            if world == 1 and warmup >= 2:
-                c.capture_step_graph()           # untimed: the graph for the roles the state buffers have now
+            if warmup >= 2:
+                c.prepare_step_graph()           # untimed: the graph for the roles the state buffers have now (per rank with RCCL)
         else:
             for _ in range(warmup):
                 c.step()
@@ -457,6 +467,53 @@ def main():
                 extras[st + "_error"] = "%s: %s" % (type(e).__name__, e)
                 torch.cuda.synchronize()
 
+    # Projection of the strong-scaling curve from ONE GPU (clearly not a measurement of N GPUs): the box one rank of the N-rank run
+    # owns (z, then y, then x halved), periodic in every direction so that all 26 neighbour regions exist, every region packed,
+    # sent to and received from this same rank through ncclSend / ncclRecv of the kernel library's communicator
+    # (CASTRO_AMD_HALO_SELF_SEND), unpacked, with the staged overlap exactly as a rank of that size would run it and the step
+    # graph of the RCCL form.  What it leaves out: xGMI instead of a loopback copy, and the waiting for the slowest rank.
+    proxies = None
+    want = args.proxy_rank_of if args.proxy_rank_of is not None else ([2, 4, 8] if (world == 1 and not args.no_extras and not contract) else [])
+    if world == 1 and want:
+        proxies = {"note": "PROJECTED from one GPU: one rank's box of the N-rank strong-scaling run, 26-region exchange through RCCL self-send; "
+                           "projected_value = N x zones of the box / time, an upper bound of what N GPUs can reach"}
+        saved = {k: os.environ.get(k) for k in ("CASTRO_AMD_C_HALO", "CASTRO_AMD_HALO_SELF_SEND")}
+        os.environ["CASTRO_AMD_C_HALO"], os.environ["CASTRO_AMD_HALO_SELF_SEND"] = "1", "1"
+        try:
+            for N in want:
+                gN = castro_amd.default_grid(N)
+                nb = tuple(n_cell[d] // gN[d] for d in range(3))
+                try:
+                    c = castro_amd.Castro(nb, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), overlap=overlap, numerics=args.numerics, proxy_ranks=N)
+                    c.initData("sedov", r_init=0.01 * 256.0 / max(n_cell))
+                    ks = max(10, min(args.steps, 30))
+                    c.run_steps(6)
+                    c.prepare_step_graph()
+                    sync()
+                    t0 = time.perf_counter()
+                    c.run_steps(ks)
+                    sync()
+                    ms = (time.perf_counter() - t0) / ks * 1e3
+                    hs = c.halo_stats()
+                    proxies[str(N)] = {"box": list(nb), "ms_per_step": ms, "projected_value": N * nb[0] * nb[1] * nb[2] / ms * 1e3,
+                                       "projected_efficiency_vs_1gpu": (N * nb[0] * nb[1] * nb[2] / ms * 1e3) / (N * value),
+                                       "overlap_halo": bool(c.overlap and c._comm_stream is not None and c.neighbors),
+                                       "step_graph": bool(getattr(c, "_graphs", None)), "regions": hs["regions"],
+                                       "bytes_exchanged_per_step": sum(nbr["sbuf"].numel() * 8 for nbr in c.neighbors),
+                                       "fillboundary_ms": hs["fillboundary_ms"], "issued_by": hs["issued_by"]}
+                    c.close()
+                    del c
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    proxies[str(N)] = {"box": list(nb), "error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.synchronize()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     out = {
         "metric": "cell-updates/sec, Sedov 3D 256\u00b3 single-level at 1/2/4/8 MI355X; % HBM roofline",
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -474,7 +531,7 @@ def main():
                    "numerics": info["numerics"], "library": info["library"],
                    "numerics_parity": {"contract": "rtol 1e-10 on all 33 plotfile fields vs the CPU oracle (tests/test_gpu_contract.py)",
                                        "exact": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}[info["numerics"]],
-                   "other_numerics_leg": other_leg, "other_states": extras},
+                   "other_numerics_leg": other_leg, "other_states": extras, "rank_proxies": proxies},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -110,6 +110,7 @@ class DistComm:
             self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
             if int(ok.item()) == 1:
                 self._ccomm = cc
+                self._chydro = hydro
             else:
                 if cc is not None:
                     hydro.comm_destroy(cc)
@@ -148,6 +149,11 @@ class DistComm:
                 req.wait()
 
     def allreduce_min(self, t):
+        if t.is_cuda and self._ccomm and os.environ.get("CASTRO_AMD_C_ALLREDUCE", "1") != "0":
+            # the library's own RCCL communicator, on the current stream: ncclAllReduce(MIN) behind the kernels that produced t,
+            # capturable into the step graph together with the grouped ncclSend / ncclRecv of castro_amd_fill_boundary
+            self._chydro.allreduce_min_c(self._ccomm, t)
+            return t
         if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
             h = t.cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.MIN, group=self.group)
@@ -193,13 +199,18 @@ class AdvanceFailure(RuntimeError):
     pass
 
 
+# smallest box side from which the staged halo overlap is on by default (measured on one GPU through the RCCL self-send path:
+# tools/overlap_cost.sh, profiles/r05*_overlap_threshold.txt)
+OVERLAP_MIN_ZONES = 192
+
+
 # --------------------------------------------------------------------------------------------
 class Castro:
     def __init__(self, n_cell, prob_lo=(0., 0., 0.), prob_hi=(1., 1., 1.), lo_bc=(2, 2, 2), hi_bc=(2, 2, 2),
                  params=None, hydro=None, comm=None, grid=None, overlap=None, make_params=None, fuse_clean=True, flux_assign=True,
                  use_retry=True, retry_subcycle_factor=0.5, max_subcycles=10, dt_cutoff=1.e-12,
                  do_grav=False, const_grav=0.0, grav_source_type=4, box=None, rotation=None, fixed_dt=-1.0, initial_dt=-1.0, max_dt=1.e200,
-                 alloc=True, numerics=None):
+                 alloc=True, numerics=None, proxy_ranks=1):
         """numerics: "exact" | "contract" for the HipHydro this object creates (castro_amd/_lib.py).  alloc=False: the geometry and bookkeeping of a box another rank owns (castro_amd/amr.py), no device memory."""
         self.n_cell = tuple(int(x) for x in n_cell)
         self.owned = bool(alloc)
@@ -265,8 +276,10 @@ class Castro:
         # Measured on one GPU with periodic self-neighbours (tools/overlap_cost.sh): the staged form costs +4 % at
         # 256^3 per rank and +16 % at 128^3 (about twenty extra small launches), the exchange itself 1-5 % of a
         # step; so by default it is used only for boxes of at least 192 zones a side.
+        # proxy_ranks > 1 (bench.py --proxy-rank-of): this single-rank object stands for one rank of such a run -- the defaults
+        # that depend on the communicator size are taken as that rank would take them
         if overlap is None:
-            overlap = self.comm.size > 1 and min(self.n) >= 192
+            overlap = max(self.comm.size, int(proxy_ranks)) > 1 and min(self.n) >= OVERLAP_MIN_ZONES
         self.overlap = overlap                                                   # True | "tiles" | False
         self.fuse_clean = bool(fuse_clean)
         self.fuse_post_clean = True        # post_timestep's clean_state may ride in the fused pass (a level of CastroAmr: no)
@@ -901,11 +914,59 @@ class Castro:
             self._graphs[key] = g
         return self._graphs[key]
 
+    def _rank_graph_ok(self):
+        """A distributed run replays a per-rank hipGraph of a pair of steps -- pack, the grouped ncclSend / ncclRecv, unpack, BC
+        fill, the hydro kernels, ncclAllReduce(MIN), k_step_control -- when every collective of the step is issued by the kernel
+        library on its own RCCL communicator (castro_amd_fill_boundary / castro_amd_allreduce_min on the capturing stream) and
+        no rank has failed a capture before.  CASTRO_AMD_STEP_GRAPH_RCCL=0 keeps the stream form."""
+        if os.environ.get("CASTRO_AMD_STEP_GRAPH_RCCL", "1") == "0" or getattr(self, "_rank_graph_failed", False):
+            return False
+        plan = self._plans.get(id(self.neighbors))
+        have_c = bool(getattr(self.comm, "_ccomm", None)) and os.environ.get("CASTRO_AMD_C_ALLREDUCE", "1") != "0"
+        return bool(getattr(self.comm, "device_side", False) and have_c and (not self.neighbors or (plan is not None and "cplan" in plan)))
+
+    def _capture_rank_graph(self, stop_time):
+        """capture_step_graph on every rank, then one all-reduce (torch.distributed, outside any capture) to agree on the
+        outcome: the graph is used only if EVERY rank has one (a rank replaying a graph while another issues the stream form would
+        still match call for call, but a rank whose runtime refused the capture should not be the only one on the slow path
+        unnoticed).  Returns the graph or None (stream form from now on)."""
+        g, ok = None, 1
+        try:
+            g = self.capture_step_graph(stop_time)
+        except Exception as e:                      # the runtime or RCCL refused the capture
+            ok = 0
+            self._rank_graph_error = "%s: %s" % (type(e).__name__, e)
+            torch.cuda.synchronize()
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.red.device)
+        self.comm.dist.all_reduce(flag, op=self.comm.dist.ReduceOp.MIN, group=self.comm.group)
+        if int(flag.item()) != 1:
+            self._rank_graph_failed = True
+            self._graphs = {}
+            if self.comm.rank == 0:
+                import sys
+                print("castro_amd: per-rank step graph not available on every rank (%s); stream-ordered steps instead"
+                      % getattr(self, "_rank_graph_error", "another rank failed"), file=sys.stderr)
+            return None
+        return g
+
+    def prepare_step_graph(self, stop_time=-1.0):
+        """Capture (untimed) the step graph run_steps would use for the buffers' current roles: one rank, or RCCL ranks
+        (_rank_graph_ok; collective: every rank calls it).  Returns True if a graph is in place."""
+        if os.environ.get("CASTRO_AMD_STEP_GRAPH", "1") == "0" or not self.host_free_ok():
+            return False
+        self._ensure_ctl()
+        if not self._eager_done:
+            return False
+        if isinstance(self.comm, SingleComm):
+            return self.capture_step_graph(stop_time) is not None
+        return self._rank_graph_ok() and self._capture_rank_graph(stop_time) is not None
+
     def run_steps(self, nsteps, stop_time=-1.0, graph=None):
         """`nsteps` coarse steps with ONE host synchronisation at the end instead of one per step: the time step lives in a
         device vector (castro_amd_step_control), the kernels read it from there, a rejected step latches a status that
-        is raised here.  With graph (default: a single rank and at least 6 steps) a pair of steps -- the two roles of the
-        ping-pong state buffers -- is captured in a hipGraph once and replayed.  Falls back to step() when host_free_ok()
+        is raised here.  With graph (default: at least 4 steps; a single rank, or RCCL ranks whose collectives the kernel library
+        issues itself: _rank_graph_ok) a pair of steps -- the two roles of the ping-pong state buffers -- is captured in a
+        hipGraph once, per rank, and replayed.  Falls back to step() when host_free_ok()
         is false.  Bit-identical to step(): the same kernels with the same dt, computed by the same expressions."""
         if nsteps <= 0:
             return
@@ -923,16 +984,16 @@ class Castro:
         self.red.fill_(1.e200)
         n0 = self.nstep
         if graph is None:
-            # no capture across ranks: the collectives of a distributed run stay ordinary stream-ordered RCCL calls
-            graph = isinstance(self.comm, SingleComm) and nsteps >= 4 and os.environ.get("CASTRO_AMD_STEP_GRAPH", "1") != "0"
+            graph = nsteps >= 4 and os.environ.get("CASTRO_AMD_STEP_GRAPH", "1") != "0" and (
+                isinstance(self.comm, SingleComm) or self._rank_graph_ok())
         left = nsteps
         if graph:
             if not self._eager_done:
                 self._step_device(stop_time)            # two eager steps first: every lazy allocation happens outside a capture
                 self._step_device(stop_time)
                 left -= 2
-            g = self.capture_step_graph(stop_time)
-            while left >= 2:
+            g = self.capture_step_graph(stop_time) if isinstance(self.comm, SingleComm) else self._capture_rank_graph(stop_time)
+            while g is not None and left >= 2:
                 g.replay()
                 left -= 2
         for _ in range(left):

@@ -278,8 +278,9 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
 // sources -> primitive sources (CTU, source_term_predictor = 0: srcU = old_source)
 // ---------------------------------------------------------------------------------------
 // CORR (p != nullptr with source_term_predictor = 1): Castro::source_corrector, dt/2 of it time-centres the momentum sources
+// lean (gamma_law_edges): Q carries no (rho e) plane -- it is p / (gamma - 1) -- and nobody reads the (rho e) source plane
 __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const double* __restrict__ Q, DFab SRC,
-                                                     double* __restrict__ SQ, DevParams P, DFab CORR, double dt)
+                                                     double* __restrict__ SQ, DevParams P, DFab CORR, double dt, int lean)
 {
     int i, j, k;
     if (!box_thread(b, i, j, k)) return;
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const dou
 
     const double rho = ldg(Q + PRHO * NC, c);
     const double rhoinv = 1.0 / rho;
-    const double qre = ldg(Q + PRE * NC, c);
+    const double qre = lean ? ldg(Q + PP * NC, c) * (1.0 / (P.gamma - 1.0)) : ldg(Q + PRE * NC, c);
     const double e = qre * rhoinv;
     const double dpde = (P.gamma - 1.0) * rho;
     const double dpdr_e = (P.gamma - 1.0) * e;
@@ -313,7 +314,7 @@ __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const dou
     stg(SQ + PU * NC, c, (s_mx - ldg(Q + PU * NC, c) * q_rho) * rhoinv);
     stg(SQ + PV * NC, c, (s_my - ldg(Q + PV * NC, c) * q_rho) * rhoinv);
     stg(SQ + PW * NC, c, (s_mz - ldg(Q + PW * NC, c) * q_rho) * rhoinv);
-    stg(SQ + PRE * NC, c, s_ei);
+    if (!lean) stg(SQ + PRE * NC, c, s_ei);
     stg(SQ + PP * NC, c, dpde * (s_ei - qre * q_rho * rhoinv) * rhoinv + dpdr_e * q_rho);
 }
 
@@ -465,7 +466,11 @@ __device__ __forceinline__ void trace_source(const double* __restrict__ a, unsig
     }
 }
 
-template <int D, bool SRC>
+// GL (gamma_law_edges, see trace_finish): the (rho e) and X variables are neither loaded, traced nor stored.  With source terms
+// the identity still holds: for a gamma-law gas src_to_prim's p source is (gamma - 1) times its (rho e) source
+// (dpde (s_e - e s_rho) / rho ... + dpdr_e s_rho = (gamma - 1) s_e, Castro_ctu.cpp:525-540), so the traced (rho e) -- parabola
+// integrals plus dt/2 times the source integrals, all linear -- is the traced p over (gamma - 1); X has no source.
+template <int D, bool SRC, bool GL = false>
 __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restrict__ Q, const double* __restrict__ SQ,
                                           unsigned c, unsigned sd,
                                           double flat, double dtdx, double hdt, const DevParams& P,
@@ -513,13 +518,15 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
     ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip_p2, Im_p2);
 
     // rho e: three waves
-    double Ip_re0, Im_re0, Ip_re1, Im_re1, Ip_re2, Im_re2;
+    double Ip_re0 = 0.0, Im_re0 = 0.0, Ip_re1 = 0.0, Im_re1 = 0.0, Ip_re2 = 0.0, Im_re2 = 0.0;
+    if (!GL) {
     LOAD5(PRE);
     ppm_reconstruct(s, flat, sm, sp);
     s6 = 6.0 * s[2] - 3.0 * (sm + sp);
     ppm_int_wave(sm, sp, s6, un - cc, dtdx, Ip_re0, Im_re0);
     ppm_int_wave(sm, sp, s6, un, dtdx, Ip_re1, Im_re1);
     ppm_int_wave(sm, sp, s6, un + cc, dtdx, Ip_re2, Im_re2);
+    }
 
     // transverse velocities and the passive: contact wave only
     double Ip_ut, Im_ut, Ip_utt, Im_utt, Ip_X, Im_X;
@@ -533,10 +540,12 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
     s6 = 6.0 * s[2] - 3.0 * (sm + sp);
     ppm_int_wave(sm, sp, s6, un, dtdx, Ip_utt, Im_utt);
 
+    if (!GL) {
     LOAD5(PX);
     ppm_reconstruct(s, flat, sm, sp);
     s6 = 6.0 * s[2] - 3.0 * (sm + sp);
     ppm_int_wave(sm, sp, s6, un, dtdx, Ip_X, Im_X);
+    } else { Ip_X = Im_X = 1.0; }
 #undef LOAD5
 
     // source terms (trace_ppm.cpp:226-330); SQ planes are indexed like the primitive components
@@ -546,7 +555,8 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         trace_source<3>(SQ + PRHO * NC, c, sd, flat, un, cc, dtdx, Ips_rho, Ims_rho);
         trace_source<2>(SQ + (long)QUN * NC, c, sd, flat, un, cc, dtdx, Ips_un, Ims_un);
         trace_source<3>(SQ + PP * NC, c, sd, flat, un, cc, dtdx, Ips_p, Ims_p);
-        trace_source<3>(SQ + PRE * NC, c, sd, flat, un, cc, dtdx, Ips_re, Ims_re);
+        if (!GL) trace_source<3>(SQ + PRE * NC, c, sd, flat, un, cc, dtdx, Ips_re, Ims_re);
+        else { Ips_re[0] = Ips_re[1] = Ips_re[2] = Ims_re[0] = Ims_re[1] = Ims_re[2] = 0.0; }
         trace_source<1>(SQ + (long)QUT * NC, c, sd, flat, un, cc, dtdx, Ips_ut, Ims_ut);
         trace_source<1>(SQ + (long)QUTT * NC, c, sd, flat, un, cc, dtdx, Ips_utt, Ims_utt);
     }
@@ -604,11 +614,11 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
 
         stg(QPd + PRHO * NC, c, amax(P.small_dens, rho_ref + alphap + alpham + alpha0r));
         stg(QPd + QUN * NC, c, un_ref + (alphap - alpham) * cc_ref * rho_ref_inv);
-        stg(QPd + PRE * NC, c, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
+        if (!GL) stg(QPd + PRE * NC, c, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
         stg(QPd + PP * NC, c, amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref));
         stg(QPd + QUT * NC, c, SADD(Im_ut, Ims_ut[1]));
         stg(QPd + QUTT * NC, c, SADD(Im_utt, Ims_utt[1]));
-        stg(QPd + PX * NC, c, Im_X);
+        if (!GL) stg(QPd + PX * NC, c, Im_X);
     }
 
     if (do_minus) {
@@ -658,11 +668,11 @@ __device__ __forceinline__ void trace_dir(const Tile& t, const double* __restric
         const unsigned cp = c + sd;
         stg(QMd + PRHO * NC, cp, amax(P.small_dens, rho_ref + alphap + alpham + alpha0r));
         stg(QMd + QUN * NC, cp, un_ref + (alphap - alpham) * cc_ref * rho_ref_inv);
-        stg(QMd + PRE * NC, cp, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
+        if (!GL) stg(QMd + PRE * NC, cp, amax(P.small_dens_ener, rhoe_g_ref + (alphap + alpham) * h_g_ref + alpha0e_g));
         stg(QMd + PP * NC, cp, amax(P.small_pres, p_ref + (alphap + alpham) * csq_ref));
         stg(QMd + QUT * NC, cp, SADD(Ip_ut, Ips_ut[1]));
         stg(QMd + QUTT * NC, cp, SADD(Ip_utt, Ips_utt[1]));
-        stg(QMd + PX * NC, cp, Ip_X);
+        if (!GL) stg(QMd + PX * NC, cp, Ip_X);
     }
 #undef SADD
 #undef SSUB
@@ -1153,7 +1163,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
     }
 }
 
-template <bool SRC, bool PLM>
+template <bool SRC, bool PLM, bool GL = false>
 __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                double dt, DevParams P)
 {
@@ -1204,9 +1214,9 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
         trace_plm_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, k, g, flat, dt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
     } else {
         const double hdt = 0.5 * dt;
-        trace_dir<0, SRC>(t, Q, S.SRCQ, c, s.x, flat, dt / g.dx[0], hdt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
-        trace_dir<1, SRC>(t, Q, S.SRCQ, c, s.y, flat, dt / g.dx[1], hdt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
-        trace_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, flat, dt / g.dx[2], hdt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+        trace_dir<0, SRC, GL>(t, Q, S.SRCQ, c, s.x, flat, dt / g.dx[0], hdt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+        trace_dir<1, SRC, GL>(t, Q, S.SRCQ, c, s.y, flat, dt / g.dx[1], hdt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+        trace_dir<2, SRC, GL>(t, Q, S.SRCQ, c, s.z, flat, dt / g.dx[2], hdt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
     }
 }
 
@@ -2989,10 +2999,207 @@ __global__ void __launch_bounds__(256) CG_TWO_WAVES k_finalx_consup(Tile t, XRow
 }
 
 // ---------------------------------------------------------------------------------------
+// k_final_tile (round 5): the WHOLE final stage in one zone-centred launch -- trans_final, the final Riemann solves and the
+// flux tail (apply_av, species flux, scaling, fluxes / mass_fluxes / qe) for x, y and z, consup_hydro and the fused
+// clean_state / CFL reduction -- so that no final flux ever goes through HBM on its way to the update: FL[y], FL[z] (16 planes
+// written, 16 read), two of the three reads of Sborder, div(u) and the sound speed (14 planes) leave the step, 48 of 291 passes.
+//   A workgroup owns RY x RZ rows of zones of one run of 63 x-slots, a wave per row (wave loads stay 1-KB pieces of one row).
+//   Every wave solves the low y-face and the low z-face of its row; a zone's HIGH y / z fluxes are the low ones of the rows above:
+//   handed over through LDS (8-value records: six fluxes, Godunov u_n and p), the faces on top of the tile (RY + RZ face rows) are
+//   dealt to the waves and solved a second time (they belong to the tiles above; only the box's last faces are stored from here).
+//   One barrier; then the x faces (the high one from the next lane, as in k_finalx_consup) and the update.  Own low z
+//   contribution rides in registers (16 doubles), own low y records in LDS: 18 rows x 8 KB = 144 KB, one workgroup of 8 waves per CU.
+//   `contract` build, default solver set, no flux limiters.  Sum order of consup_hydro as in the reference (Castro_ctu.cpp:40-70).
+// ---------------------------------------------------------------------------------------
+struct FinalOut { DFab fl[3], mass[3], qe[3]; int acc_hi[3]; };
+constexpr int NRF = 8;                             // handed-over record: GRHO GMX GMY GMZ GE GEI, then GUG, GPG
+
+__device__ __forceinline__ void frec_put(double* __restrict__ L, int row, int w, int lane, const double R[NFIN])
+{
+    double* p = L + ((row * 2 + w) * NRF) * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) p[n * 64] = R[n];
+    p[6 * 64] = R[GUG]; p[7 * 64] = R[GPG];
+}
+__device__ __forceinline__ void frec_get(const double* __restrict__ L, int row, int w, int lane, double R[NRF])
+{
+    const double* p = L + ((row * 2 + w) * NRF) * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < NRF; ++n) R[n] = p[n * 64];
+}
+
+#ifdef CAD_NUMERICS_CONTRACT
+template <bool CLEAN, int GEN, int RY, int RZ>
+__global__ void __launch_bounds__(64 * RY * RZ)
+k_final_tile(Tile t, TileRows b, const double* __restrict__ Q, DevScratch S, DevGeom g, DFab U, FinalOut O, DFab Unew,
+             double dt, double area0, double area1, double area2, double vol, int assign, int from_sborder, DevParams P,
+             int ntimes, double* red)
+{
+    static_assert(gamma_law_edges(GEN), "k_final_tile: gamma_law_edges instantiations only");
+    static_assert(GRHO == 0 && GEI == 5, "record order");
+    RETURN_IF_BATCH_FAILED();
+    if (P.dtp) dt = P.dtp[6];
+    const double hdtdx = 0.5 * dt / g.dx[0], hdtdy = 0.5 * dt / g.dx[1], hdtdz = 0.5 * dt / g.dx[2];
+    constexpr int ROWD = 2 * NRF * 64;              // doubles per face row
+    __shared__ double rec[((RY + 1) * RZ + RY * RZ) * ROWD];
+    double* const Ly = rec;                         // y records of face rows a = 0 .. RY of every kr: row kr (RY + 1) + a
+    double* const Lz = rec + (RY + 1) * RZ * ROWD;  // z records of face rows b = 1 .. RZ of every jr: row (b - 1) RY + jr
+
+    unsigned bid = blockIdx.x;
+    bid = (bid & 7u) * (b.nb >> 3) + (bid >> 3);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int jr = wave % RY, kr = wave / RY;
+    const unsigned total = (unsigned)b.nslot * (unsigned)b.ntj * (unsigned)b.ntk;
+    unsigned pos = bid * 63u + (unsigned)lane;
+    const bool live = pos < total;
+    if (!live) pos = total - 1u;
+    const bool owner = live && lane < 63;            // lane 63 repeats the first slot of the next run: it only hands its x record over
+    const unsigned tile = pos / (unsigned)b.nslot;
+    const int xs = (int)(pos - tile * (unsigned)b.nslot);
+    const unsigned per_band = (unsigned)b.band * (unsigned)b.ntk;
+    const unsigned bd = tile / per_band;
+    const unsigned rem = tile - bd * per_band;
+    const unsigned left = (unsigned)b.ntj - bd * (unsigned)b.band;
+    const unsigned bw = left < (unsigned)b.band ? left : (unsigned)b.band;
+    const unsigned tk = rem / bw;
+    const unsigned tj = bd * (unsigned)b.band + (rem - tk * bw);
+    const int j0 = b.lo[1] + (int)tj * RY, k0 = b.lo[2] + (int)tk * RZ;
+    const int hj = b.lo[1] + b.ny - 1, hk = b.lo[2] + b.nz - 1;            // last rows of zones
+    const int i = b.lo[0] + 2 * xs;
+    const int j = j0 + jr, k = k0 + kr;
+    const bool zrow = j <= hj && k <= hk;
+    const bool f0 = i <= b.hi0 + 1, f1 = i + 1 <= b.hi0 + 1;               // faces of nodal(bx, x)
+    const bool iA = i <= b.hi0, iB = i + 1 <= b.hi0;                      // zones of bx
+    const bool zA = owner && zrow && iA, zB = owner && zrow && iB;
+    const Str s = gstr(t);
+    const long NC = t.NC;
+
+    // ---- own low z-faces (face row k of the zones (j, k)): flux arrays, the record for the row below, the own contribution
+    double accz[2][6], pz[2], uz[2];
+    {
+        const bool ok = owner && j <= hj && k <= hk + 1;
+        int ijk[3] = { i, j <= hj ? j : hj, k <= hk + 1 ? k : hk + 1 };
+        double R[2][NFIN];
+        final_body<2, false, false, false, GEN>(t, ijk, ok && iA, ok && iB, goff(t, ijk[0], ijk[1], ijk[2]), Q, S, g, U, O.fl[2], O.mass[2], O.qe[2],
+                                                hdtdx, hdtdy, dt, area2, g.dx[2], O.acc_hi[2], assign, P, R);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) accz[w][m] = R[w][m];
+            pz[w] = R[w][GPG]; uz[w] = R[w][GUG];
+            if (kr >= 1) frec_put(Lz, (kr - 1) * RY + jr, w, lane, R[w]);
+        }
+    }
+    // ---- own low y-faces
+    {
+        const bool ok = owner && j <= hj + 1 && k <= hk;
+        int ijk[3] = { i, j <= hj + 1 ? j : hj + 1, k <= hk ? k : hk };
+        double R[2][NFIN];
+        final_body<1, false, false, false, GEN>(t, ijk, ok && iA, ok && iB, goff(t, ijk[0], ijk[1], ijk[2]), Q, S, g, U, O.fl[1], O.mass[1], O.qe[1],
+                                                hdtdx, hdtdz, dt, area1, g.dx[1], O.acc_hi[1], assign, P, R);
+        frec_put(Ly, kr * (RY + 1) + jr, 0, lane, R[0]);
+        frec_put(Ly, kr * (RY + 1) + jr, 1, lane, R[1]);
+    }
+    // ---- the face rows on top of the tile: they are the low faces of the tiles above (solved there too); stored from here only
+    //      where they are the last faces of the box
+    if (wave < RZ) {
+        const int jf = j0 + RY, kf = k0 + wave;
+        const bool ok = owner && jf == hj + 1 && kf <= hk;
+        int ijk[3] = { i, jf <= hj + 1 ? jf : hj + 1, kf <= hk ? kf : hk };
+        double R[2][NFIN];
+        final_body<1, false, false, false, GEN>(t, ijk, ok && iA, ok && iB, goff(t, ijk[0], ijk[1], ijk[2]), Q, S, g, U, O.fl[1], O.mass[1], O.qe[1],
+                                                hdtdx, hdtdz, dt, area1, g.dx[1], O.acc_hi[1], assign, P, R);
+        frec_put(Ly, wave * (RY + 1) + RY, 0, lane, R[0]);
+        frec_put(Ly, wave * (RY + 1) + RY, 1, lane, R[1]);
+    } else if (wave < RZ + RY) {
+        const int jf = j0 + (wave - RZ), kf = k0 + RZ;
+        const bool ok = owner && kf == hk + 1 && jf <= hj;
+        int ijk[3] = { i, jf <= hj ? jf : hj, kf <= hk + 1 ? kf : hk + 1 };
+        double R[2][NFIN];
+        final_body<2, false, false, false, GEN>(t, ijk, ok && iA, ok && iB, goff(t, ijk[0], ijk[1], ijk[2]), Q, S, g, U, O.fl[2], O.mass[2], O.qe[2],
+                                                hdtdx, hdtdy, dt, area2, g.dx[2], O.acc_hi[2], assign, P, R);
+        frec_put(Lz, (RZ - 1) * RY + (wave - RZ), 0, lane, R[0]);
+        frec_put(Lz, (RZ - 1) * RY + (wave - RZ), 1, lane, R[1]);
+    }
+    __syncthreads();
+
+    // ---- the x faces of the row and Castro::consup_hydro (Castro_ctu.cpp:11-86) for the zones i and i+1
+    int ijk[3] = { i, j <= hj ? j : hj, k <= hk ? k : hk };
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    double R[2][NFIN];
+    final_body<0, false, false, false, GEN>(t, ijk, owner && zrow && f0, owner && zrow && f1, c, Q, S, g, U, O.fl[0], O.mass[0], O.qe[0],
+                                            hdtdy, hdtdz, dt, area0, g.dx[0], O.acc_hi[0], assign, P, R);
+    double Rn[NFIN];                                   // face i+2
+#pragma unroll
+    for (int m = 0; m < NFIN; ++m) Rn[m] = __shfl_down(R[0][m], 1, 64);
+
+    double dtmin = 1.e200, rmin_raw = 1.e300, dtmin1 = 1.e200;
+    if (zA) {
+        const double volinv = 1.0 / vol;
+        const unsigned cn = foff(Unew, ijk[0], ijk[1], ijk[2]);
+        const unsigned ci = foff(U, ijk[0], ijk[1], ijk[2]);
+        double y0[2][NRF], y1[2][NRF], z1[2][NRF];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            frec_get(Ly, kr * (RY + 1) + jr, w, lane, y0[w]);
+            frec_get(Ly, kr * (RY + 1) + jr + 1, w, lane, y1[w]);
+            frec_get(Lz, kr * RY + jr, w, lane, z1[w]);
+        }
+        constexpr int rec_of[NUM_STATE] = { GRHO, GMX, GMY, GMZ, GE, GEI, -1, GRHO };       // the species flux is the mass flux
+        constexpr bool DEAD_TX = CLEAN;              // the temperature and the species of the old state are dead (see k_finalx_consup)
+        double un[2][NUM_STATE];
+#pragma unroll
+        for (int m = 0; m < NUM_STATE; ++m) {
+            if (DEAD_TX && m == UTEMP) { un[0][m] = un[1][m] = 0.0; continue; }
+            if (DEAD_TX && m == UFS) { un[0][m] = un[0][URHO]; un[1][m] = un[1][URHO]; continue; }
+            const D2 u0 = from_sborder ? ldg2(U.p + m * U.sn, ci) : ldg2(Unew.p + m * Unew.sn, cn);
+            if (m == UTEMP) { un[0][m] = u0.a; un[1][m] = u0.b; continue; }       // zero flux
+            const int r = rec_of[m];
+            un[0][m] = u0.a + dt * (R[0][r] * area0 - R[1][r] * area0 + y0[0][r] * area1 - y1[0][r] * area1 + accz[0][r] * area2 - z1[0][r] * area2) * volinv;
+            un[1][m] = u0.b + dt * (R[1][r] * area0 - Rn[r] * area0 + y0[1][r] * area1 - y1[1][r] * area1 + accz[1][r] * area2 - z1[1][r] * area2) * volinv;
+            if (m == UEINT) {
+                double pdu = (R[1][GPG] + R[0][GPG]) * (R[1][GUG] * area0 - R[0][GUG] * area0);
+                pdu += (y1[0][7] + y0[0][7]) * (y1[0][6] * area1 - y0[0][6] * area1);
+                pdu += (z1[0][7] + pz[0]) * (z1[0][6] * area2 - uz[0] * area2);
+                pdu = 0.5 * pdu * volinv;
+                un[0][m] = un[0][m] - dt * pdu;
+                pdu = (Rn[GPG] + R[1][GPG]) * (Rn[GUG] * area0 - R[1][GUG] * area0);
+                pdu += (y1[1][7] + y0[1][7]) * (y1[1][6] * area1 - y0[1][6] * area1);
+                pdu += (z1[1][7] + pz[1]) * (z1[1][6] * area2 - uz[1] * area2);
+                pdu = 0.5 * pdu * volinv;
+                un[1][m] = un[1][m] - dt * pdu;
+            }
+        }
+        if (CLEAN) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                if (w == 1 && !zB) continue;
+                rmin_raw = fmin(rmin_raw, nan_guard(un[w][URHO]));
+                double d1, d2;
+                clean_zone_dt(P, ntimes, g.dx[0], g.dx[1], g.dx[2], un[w][URHO], un[w][UMX], un[w][UMY], un[w][UMZ], un[w][UEDEN], un[w][UEINT], un[w][UTEMP], un[w][UFS], d1, d2);
+                dtmin1 = fmin(dtmin1, d1);
+                dtmin = fmin(dtmin, d2);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NUM_STATE; ++m) {
+            if (m == UTEMP && !CLEAN && !from_sborder) continue;     // unchanged in place
+            if (zB) stg2(Unew.p + m * Unew.sn, cn, un[0][m], un[1][m]);
+            else stg(Unew.p + m * Unew.sn, cn, un[0][m]);
+        }
+    }
+    if (CLEAN && red) wave_min3_atomic(dtmin, rmin_raw, dtmin1, red);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------
 int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
-int g_fold_tile = 0;      // CASTRO_AMD_FOLD_TILE: 1 = k_trans1_tile<4, 2> (a 4 x 2 tile of rows per workgroup), 2 = <2, 4>; `contract` build only
+int g_final_tile = 0;     // CASTRO_AMD_FINAL_TILE: 1 = the final stage as ONE zone-centred launch (k_final_tile<4, 2>); `contract` build only
+int g_fold_tile = -1;     // CASTRO_AMD_FOLD_TILE: 1 = k_trans1_tile<4, 2> (a 4 x 2 tile of rows per workgroup), 2 = <2, 4>, 0 = k_trans1_fold_lds;
+                          // -1 (default): <4, 2> for boxes of at least 96 rows in y and z (128^3: equal, 64^3: the fold kernel is faster;
+                          // profiles/r05c_ab_fold_tile_kernel.txt); `contract` build only
 int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: != 0 = k_trans1_fold_lds (records parked in LDS;
                           // -0.35 ms per 256^3 step), 0 = two k_riemann1 launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
 int g_side_stream = 0;    // 1: k_divu runs on the context's side stream beside the trace kernel (CASTRO_AMD_SIDE_STREAM); measured: no gain,
@@ -3116,7 +3323,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                             && P.limit_small_dens != 1 && P.limit_large_vel != 1;
     // gamma_law_edges (contract build): the GEN == 0 readers take (rho e) of an edge state from its p, which only the trace
     // kernel of the no-source PPM path promises (k_trace_pair<true, 7, 0>); traces with source terms or PLM run the GEN >= 1 set
-    const bool gl_ok = !gamma_law_edges(0) || (!Src.p && P.ppm_type == 1);
+    // (round 5: traced source terms keep the identity -- trace_dir<D, SRC, GL> -- so only PLM is left out)
+    const bool gl_ok = !gamma_law_edges(0) || P.ppm_type == 1;
     const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1 || !plain_path || !gl_ok) ? 1 : 0);
     const int lean_q = (gamma_law_edges(0) && solv == 0) ? (clean_ntimes > 0 ? 3 : 1) : 0;      // see k_ctoprim
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
@@ -3207,8 +3415,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
-        KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P, SrcCorr, dt);
+        KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P, SrcCorr, dt, lean_q & 1);
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P); }
+        else if (lean_q & 1) { KL("k_trace", (k_trace<true, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P); }
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
@@ -3276,8 +3485,9 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                                 ~RowsGuard2() { tl_tile_rows = keep; } } rows_guard2;
             LinBox b_ = linbox2(olo, ohi, n_);
 #ifdef CAD_NUMERICS_CONTRACT
-            if (n_ > 0 && g_fold_tile) {
-                const int ry = g_fold_tile == 2 ? 2 : 4, rz = g_fold_tile == 2 ? 4 : 2;
+            const int fold_tile = g_fold_tile >= 0 ? g_fold_tile : ((b_.n[1] >= 96 && b_.n[2] >= 96 && b_.n[0] >= 48) ? 1 : 0);
+            if (n_ > 0 && fold_tile) {
+                const int ry = fold_tile == 2 ? 2 : 4, rz = fold_tile == 2 ? 4 : 2;
                 TileRows tr;
                 for (int d = 0; d < 3; ++d) tr.lo[d] = olo[d];
                 tr.hi0 = ohi[0];
@@ -3287,7 +3497,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                 const long total = (long)tr.nslot * tr.ntj * tr.ntk;
                 tr.nb = ((unsigned)((total + 62) / 63) + 7u) & ~7u;
                 prof_begin(prof, "k_trans1_fold", stream);
-                if (g_fold_tile == 2) hipLaunchKernelGGL((k_trans1_tile<0, 2, 4>), dim3(tr.nb), dim3(512), 0, stream, t, tr, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
+                if (fold_tile == 2) hipLaunchKernelGGL((k_trans1_tile<0, 2, 4>), dim3(tr.nb), dim3(512), 0, stream, t, tr, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
                 else hipLaunchKernelGGL((k_trans1_tile<0, 4, 2>), dim3(tr.nb), dim3(512), 0, stream, t, tr, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
                 prof_end(prof, stream);
             } else
@@ -3302,6 +3512,32 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         } else
         KL2_SOLV("k_trans1", K_T1, olo, ohi, S.Q, S, g, cdtdx, cdtdy, cdtdz, P);
         const int assign_yz = (flags & 2) ? 1 : 0;
+#ifdef CAD_NUMERICS_CONTRACT
+        if (g_final_tile && solv == 0 && !lim) {
+            constexpr int ry = 4, rz = 2;
+            TileRows tr;
+            for (int d = 0; d < 3; ++d) tr.lo[d] = t.lo[d];
+            tr.hi0 = t.hi[0];
+            const int nx = t.hi[0] - t.lo[0] + 1;
+            tr.nslot = (nx + 1) / 2 + 1; tr.ny = t.hi[1] - t.lo[1] + 1; tr.nz = t.hi[2] - t.lo[2] + 1;
+            tr.ntj = (tr.ny + ry - 1) / ry; tr.ntk = (tr.nz + rz - 1) / rz;
+            tr.band = g_fused_tile_rows > 0 ? (g_fused_tile_rows + ry - 1) / ry : tr.ntj;
+            const long total = (long)tr.nslot * tr.ntj * tr.ntk;
+            tr.nb = ((unsigned)((total + 62) / 63) + 7u) & ~7u;
+            FinalOut fo;
+            for (int d = 0; d < 3; ++d) { fo.fl[d] = fluxes[d]; fo.mass[d] = mass[d]; fo.qe[d] = qe[d]; fo.acc_hi[d] = acc_hi[d]; }
+            const double vol_ = g.dx[0] * g.dx[1] * g.dx[2];
+            prof_begin(prof, "k_final_tile", stream);
+            if (clean_ntimes > 0)
+                hipLaunchKernelGGL((k_final_tile<true, 0, ry, rz>), dim3(tr.nb), dim3(64 * ry * rz), 0, stream, t, tr, S.Q, S, g, Sborder, fo, Snew, dt,
+                                   area0, area1, area2, vol_, assign_yz, (flags & 1) ? 1 : 0, P, clean_ntimes, red);
+            else
+                hipLaunchKernelGGL((k_final_tile<false, 0, ry, rz>), dim3(tr.nb), dim3(64 * ry * rz), 0, stream, t, tr, S.Q, S, g, Sborder, fo, Snew, dt,
+                                   area0, area1, area2, vol_, assign_yz, (flags & 1) ? 1 : 0, P, 0, (double*)nullptr);
+            prof_end(prof, stream);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
+#endif
         if (lim) {
             KL2("k_final_y", (k_final<1, false, true>), nlo[1], nhi[1], S.Q, S, g, Sborder, fluxes[1], mass[1], qe[1], hdtdx, hdtdz, dt, area1, g.dx[1], acc_hi[1], (flags & 2) ? 1 : 0, P, nolv);
             KL2("k_final_z", (k_final<2, false, true>), nlo[2], nhi[2], S.Q, S, g, Sborder, fluxes[2], mass[2], qe[2], hdtdx, hdtdy, dt, area2, g.dx[2], acc_hi[2], (flags & 2) ? 1 : 0, P, nolv);

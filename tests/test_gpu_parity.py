@@ -889,7 +889,7 @@ def test_256_cubed_developed_state_against_oracle(oracle):
     torch.cuda.synchronize()
     assert c.nstep == 700 and 0.005 < c.time < 0.01
     S0 = c.S_new().cpu().numpy()
-    assert S0[0].max() > 3.0 and np.count_nonzero(np.abs(S0[1]) > 1e-3) > 0.2 * S0[1].size      # a developed blast wave
+    assert S0[0].max() > 3.0 and np.count_nonzero(np.abs(S0[1]) > 1e-3) > 0.01 * S0[1].size     # a developed blast wave: > 10^5 zones in motion
     lev = oracle.Level(n, oracle.make_geom(n), oracle.default_params(), nthreads=min(64, os.cpu_count() or 8))
     lev.set_state(S0, c.time, c.dt, c.nstep)
     del S0
@@ -1222,12 +1222,13 @@ def _rccl_worker(rank, world, port, out_path):
         assert torch.equal(ra, a) and torch.equal(rb, b)
         plan = c._plans.get(id(c.neighbors))
         np.savez(out_path, S=c.S_new().cpu().numpy(), dts=np.array(dts),
-                 halo_path="c_abi" if plan is not None and "cplan" in plan else "torch")
+                 halo_path="c_abi" if plan is not None and "cplan" in plan else "torch",
+                 graphed=bool(getattr(c, "_graphs", None)), graph_error=str(getattr(c, "_rank_graph_error", "")))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("halo", ["c_abi", "c_abi_self_send", "torch"])
+@pytest.mark.parametrize("halo", ["c_abi", "c_abi_self_send", "c_abi_self_send_stream_form", "torch"])
 def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
     """halo: who issues the exchange -- castro_amd_fill_boundary of the C ABI (round 4: ncclSend / ncclRecv from the kernel
     library on its own communicator; `self_send`: the periodic wraps onto this rank travel through RCCL as well, so the
@@ -1242,11 +1243,16 @@ def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
     from tests.test_driver_cpu import _free_port
     out = str(tmp_path / "rccl.npz")
     monkeypatch.setenv("CASTRO_AMD_C_HALO", "0" if halo == "torch" else "1")
-    monkeypatch.setenv("CASTRO_AMD_HALO_SELF_SEND", "1" if halo == "c_abi_self_send" else "0")
+    monkeypatch.setenv("CASTRO_AMD_HALO_SELF_SEND", "1" if halo.startswith("c_abi_self_send") else "0")
+    monkeypatch.setenv("CASTRO_AMD_STEP_GRAPH_RCCL", "0" if halo.endswith("stream_form") else "1")
     mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     monkeypatch.setenv("CASTRO_AMD_C_HALO", "0")
     got = np.load(out)
     assert str(got["halo_path"]) == ("torch" if halo == "torch" else "c_abi")
+    # round 5: with the collectives issued by the kernel library (halo exchange AND all-reduce on its own RCCL communicator) the
+    # host-free batch is a per-rank hipGraph of a pair of steps that CONTAINS the ncclSend / ncclRecv group and the
+    # ncclAllReduce -- with self-send the point-to-point calls really are inside the captured graph; same bits as the stream form
+    assert bool(got["graphed"]) == (halo in ("c_abi", "c_abi_self_send")), str(got["graph_error"])
     c = castro_amd.Castro((24, 16, 32), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
     c.initData("sedov", r_init=0.1, nsub=4)
     dts = [c.step(0.01) for _ in range(7)]

@@ -1,13 +1,16 @@
 #!/bin/bash
 # NUMERICS (environment, default contract): the build of the kernel library, pinned on every bench.py line
-# per-rank cost of the tiled/overlapped path, emulated on one GPU with periodic self-neighbours
-for n in 128 256; do
-for mode in "--periodic --no-overlap" "--periodic --force-overlap" "--periodic --overlap-tiles"; do
-  python bench.py --numerics ${NUMERICS:-contract} --ncell $n --steps 10 --warmup 3 --no-cpu-baseline --no-contract-leg $mode > gpurun_out/ov.json 2> gpurun_out/ov.err || tail -3 gpurun_out/ov.err
-  python - <<PY
-import json
-d=json.load(open("gpurun_out/ov.json"))
-k={a: b["ms_per_step"] for a, b in d["roofline"]["kernel_utilisation"].items()}
-print("n=$n $mode: ms/step %.3f  kernels %.3f  pack %.3f unpack %.3f" % (d["ms_per_step"], sum(k.values()), k.get("k_pack",0), k.get("k_unpack",0)), d["config"]["overlap_halo"])
-PY
-done; done
+# Per-rank cost of the halo exchange and of the staged overlap, sized on ONE GPU: the box one rank of the 2-, 4- and 8-rank
+# strong-scaling run of the 256^3 problem owns (256x256x128, 256x128x128, 128^3) and the 256^3 box of the weak run, periodic in
+# every direction, all 26 regions through ncclSend / ncclRecv to the own rank (bench.py --proxy-rank-of), without and with the
+# staged overlap.  Sets castro_amd/castro.py: OVERLAP_MIN_ZONES.
+N=${NUMERICS:-contract}
+for mode in "--no-overlap" "--force-overlap"; do
+  python bench.py --numerics $N --steps 20 --warmup 3 --no-cpu-baseline --no-contract-leg --no-extras --proxy-rank-of 1 2 4 8 $mode 2> gpurun_out/ov.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); p=d['config']['rank_proxies']
+for k in ('1','2','4','8'):
+    e=p[k]
+    print('[$N] $mode N=%s box %s: %.3f ms/step (graph %s, overlap %s, fillboundary alone %.3f ms, %.1f MB exchanged)' % (k, e['box'], e['ms_per_step'], e.get('step_graph'), e.get('overlap_halo'), e.get('fillboundary_ms', 0), e.get('bytes_exchanged_per_step', 0)/1e6) if 'error' not in e else (k, e))
+" || tail -3 gpurun_out/ov.err
+done
