@@ -274,6 +274,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
 
+    # ONE JSON line on stdout and nothing else: libraries that chat on file descriptor 1 (RCCL prints a version banner there when
+    # a communicator is created) are sent to stderr for the whole run; the line goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import castro_amd
 
@@ -323,21 +329,21 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    def run(contract_mode, steps, warmup, kernel_pass, stepwise=None, state="sedov", per_step=False, numerics=None):
+    def run(contract_mode, steps, warmup, kernel_pass, stepwise=None, state="sedov", per_step=False, numerics=None, overlap_=None):
         """W untimed warm-up steps, K timed steps (no profiling events in the timed region), then -- untimed -- a second
         pass of min(K, 5) steps with hipEvents around every kernel on its launch stream for the per-kernel table."""
         if stepwise is None and (args.stepwise or world > 1):
             stepwise = bool(args.stepwise)
         if stepwise is None:
             try:
-                return run(contract_mode, steps, warmup, kernel_pass, stepwise=False, state=state, per_step=per_step, numerics=numerics)
+                return run(contract_mode, steps, warmup, kernel_pass, stepwise=False, state=state, per_step=per_step, numerics=numerics, overlap_=overlap_)
             except castro_amd.AdvanceFailure:
                 raise
             except Exception as e:          # a box whose runtime refuses the graph capture: the stepwise form measures the same kernels
                 print("bench.py: host-free batch failed (%s: %s); falling back to --stepwise" % (type(e).__name__, e), file=sys.stderr)
                 torch.cuda.synchronize()
-                return run(contract_mode, steps, warmup, kernel_pass, stepwise=True, state=state, per_step=per_step, numerics=numerics)
-        c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc, overlap=overlap,
+                return run(contract_mode, steps, warmup, kernel_pass, stepwise=True, state=state, per_step=per_step, numerics=numerics, overlap_=overlap_)
+        c = castro_amd.Castro(n_cell, comm=comm, grid=grid, lo_bc=bc, hi_bc=bc, overlap=overlap if overlap_ is None else overlap_,
                               fuse_clean=not contract_mode, flux_assign=not contract_mode, numerics=numerics or args.numerics)
         if state == "noise":
             c.set_state(noise_state(torch, n_cell, torch.device("cuda", local_rank)))
@@ -445,6 +451,17 @@ def main():
         except Exception as e:
             other_leg = {"numerics": other, "error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
+    # a multi-GPU run: the same workload with the staged halo overlap forced on (off by default at these box sizes: castro.py
+    # OVERLAP_MIN_ZONES was set from one GPU; this leg is the measurement on real links), untimed extra
+    overlap_leg = None
+    if world > 1 and not args.no_extras and overlap is None and not info["overlap_halo"]:
+        try:
+            w_v, _, _, i_v = run(contract, args.steps, args.warmup, False, overlap_=True)
+            overlap_leg = {"ms_per_step": w_v / args.steps * 1e3, "value": total_cells * args.steps / w_v, "overlap_halo": i_v["overlap_halo"],
+                           "host_free": i_v["host_free"], "step_graph": i_v["step_graph"]}
+        except Exception as e:
+            overlap_leg = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
     extras = None
     if world == 1 and not contract and not args.no_extras:
         # untimed extras (the headline above is unchanged): the same step on states that are not
@@ -531,7 +548,7 @@ def main():
                    "numerics": info["numerics"], "library": info["library"],
                    "numerics_parity": {"contract": "rtol 1e-10 on all 33 plotfile fields vs the CPU oracle (tests/test_gpu_contract.py)",
                                        "exact": "bit-identical to the CPU oracle (tests/test_gpu_parity.py)"}[info["numerics"]],
-                   "other_numerics_leg": other_leg, "other_states": extras, "rank_proxies": proxies},
+                   "other_numerics_leg": other_leg, "other_states": extras, "rank_proxies": proxies, "overlap_leg": overlap_leg},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -539,7 +556,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.dist.destroy_process_group()
 

@@ -491,6 +491,12 @@ class _Level:
             return False, "timestep validity check failed", None
         return True, "", new_dt
 
+    def invalidate_estimate(self):
+        """S_new of this level has been written outside its own advance (avgDown from a finer level, reflux, initData, a
+        regrid that filled it, a user's edit of b.S_new()): the CFL estimate cached from the fused post-update pass no longer
+        describes it and estTimeStep reduces over the zones again, as the reference always does (Castro.cpp:1507-1626)."""
+        self._cached_est = None
+
     def estTimeStep(self):
         if getattr(self, "_cached_est", None) is not None and self._post_clean_done and self.boxes:
             return min(self.max_dt, checked_estimate(self._cached_est) * self.params.cfl)
@@ -1042,6 +1048,7 @@ class CastroAmr:
 
     # ---- Amr::init (bldFineLevels: one new level per pass) / Castro::post_init ---------------------------
     def initData(self, problem="sedov", **kw):
+        self.invalidate_estimates()                     # also on an existing hierarchy: no estimate survives new data
         for b in self.lev[0].mine:
             b.initData(problem, **kw)
         if self.refine is not None:
@@ -1081,7 +1088,13 @@ class CastroAmr:
         self.level_count = [0] * 16
 
     # ---- Castro::avgDown (Castro.cpp:3096-3113): level l onto level l-1 ------------------------------
+    def invalidate_estimates(self):
+        """call after writing any level's S_new from outside (user edits between coarse steps): see _Level.invalidate_estimate"""
+        for lev in self.lev:
+            lev.invalidate_estimate()
+
     def avgDown(self, l=1):
+        self.lev[l - 1].invalidate_estimate()           # the coarser level's S_new is overwritten under the fine boxes
         if self.nranks > 1:
             return self._xrun([("avgdown", p, b, lo, hi, None) for b in self.lev[l].boxes for p, (lo, hi) in b.avg_to])
         fine = self.lev[l]
@@ -1187,6 +1200,7 @@ class CastroAmr:
                             reg, rbox = b.regs[(d, side)]
                             for p, (lo, hi), csh in b.reflux_to[(d, side)]:
                                 h.reflux(p.S_new_b, _shift(p.gbox, csh), reg, rbox, lo, hi, d, side, NUM_STATE, vol)
+            lev.invalidate_estimate()                   # reflux has corrected this level's S_new
             self.avgDown(l + 1)
         # Castro::post_timestep ends with clean_state(S_new) on EVERY level (Castro.cpp:1909-1916), the finest included
         # (there it may have ridden in the fused pass of the update: _hydro_level)

@@ -199,9 +199,12 @@ class AdvanceFailure(RuntimeError):
     pass
 
 
-# smallest box side from which the staged halo overlap is on by default (measured on one GPU through the RCCL self-send path:
-# tools/overlap_cost.sh, profiles/r05*_overlap_threshold.txt)
-OVERLAP_MIN_ZONES = 192
+# smallest box side from which the staged halo overlap is on by default.  Round 5, measured on one GPU with all 26 regions through
+# the RCCL self-send path and the `contract` kernels (tools/overlap_cost.sh, profiles/r05f_overlap_threshold_and_rank_proxies.txt): the
+# staged form costs 0.76 ms at 256^3 per rank (8 %; 0.42 ms at 256x256x128, 0.18 ms at 128^3) -- the split launches and the loss of the
+# host-free graph form -- against 0.2-0.3 ms of exchange it could hide: off for every box of the headline configurations (192 in
+# rounds 2-4, measured with the round-2 kernels).  overlap=True / bench.py --force-overlap turn it on.
+OVERLAP_MIN_ZONES = 384
 
 
 # --------------------------------------------------------------------------------------------
@@ -273,9 +276,7 @@ class Castro:
         # tracing of the zones >= 3 from the box faces while the exchange is in flight, then the rest -- no
         # redundant work.  The older interior-tile + six-slab split ("tiles") re-does ctoprim/trace on 3x the
         # slab volume (+18 % at 256^3, +44 % at 128^3 per rank, tools/overlap_cost.sh).
-        # Measured on one GPU with periodic self-neighbours (tools/overlap_cost.sh): the staged form costs +4 % at
-        # 256^3 per rank and +16 % at 128^3 (about twenty extra small launches), the exchange itself 1-5 % of a
-        # step; so by default it is used only for boxes of at least 192 zones a side.
+        # Default: OVERLAP_MIN_ZONES above (measured: the staged form costs more than the exchange it hides at 256^3 per rank).
         # proxy_ranks > 1 (bench.py --proxy-rank-of): this single-rank object stands for one rank of such a run -- the defaults
         # that depend on the communicator size are taken as that rank would take them
         if overlap is None:

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_final_tile; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
+namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_final_tile; extern int g_gl_sources; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; }
 
 using namespace cad;
 
@@ -225,6 +225,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE_ROWS")) g_fold_tile_rows = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE")) g_fold_tile = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_TILE")) g_final_tile = std::atoi(e);
+    if (const char* e = std::getenv("CASTRO_AMD_GL_SOURCES")) g_gl_sources = std::atoi(e);
     if (const char* e = std::getenv("CASTRO_AMD_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_FUSED_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_fused_wg = v; }
     if (const char* e = std::getenv("CASTRO_AMD_FINAL_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_final_wg = v; }

@@ -353,6 +353,43 @@ def test_contract_single_call_every_output_array_within_rtol(oracle, tiled):
     hip.close()
 
 
+@pytest.mark.parametrize("shape", [(37, 23, 19), (16, 12, 10), (130, 9, 11), (12, 8, 64)])
+@pytest.mark.parametrize("form", ["fold_tile_4x2", "fold_tile_2x4", "fold_and_final_tile", "final_tile_only"])
+def test_contract_tile_kernels_on_ragged_boxes(oracle, shape, form):
+    """The tile forms of round 5 -- k_trans1_tile (a 4 x 2 / 2 x 4 tile of rows per workgroup, first-stage records through LDS;
+    the default of large boxes) and k_final_tile (the final stage in one zone-centred launch; a variant) -- on boxes whose row
+    counts are no multiples of the tile (partial tiles, waves that straddle two tiles, rows shorter than a wave): every output
+    array of one call against the oracle at the tolerance, and against the row-form kernels of the same build (k_trans1_fold_lds,
+    k_final<y,z> + k_finalx_consup) at a rounding level."""
+    from castro_amd.hydro import HipHydro
+    from tests.test_gpu_parity import _run_both
+    from tests.util import physical_state
+    env = {"fold_tile_4x2": ("1", "0"), "fold_tile_2x4": ("2", "0"), "fold_and_final_tile": ("1", "1"), "final_tile_only": ("0", "1")}[form]
+    rng = np.random.default_rng(5)
+    bxlo = (2, -3, 1)
+    bxhi = tuple(bxlo[d] + shape[d] - 1 for d in range(3))
+    sb_lo, sb_hi = tuple(x - 4 for x in bxlo), tuple(x + 4 for x in bxhi)
+    U = physical_state(rng, sb_lo, sb_hi, smooth=False, vel=1.5)
+    kw = dict(dx=(0.02, 0.017, 0.023))
+    outs = {}
+    try:
+        for name, (ft, fin) in (("rows", ("0", "0")), ("tile", env)):
+            os.environ["CASTRO_AMD_FOLD_TILE"], os.environ["CASTRO_AMD_FINAL_TILE"] = ft, fin
+            hip = HipHydro(0, numerics="contract")          # the knobs are read when a context is created
+            outs[name] = _run_both(hip, oracle, bxlo, bxhi, U, sb_lo, sb_hi, 6.0e-4, **kw)
+            hip.close()
+    finally:
+        os.environ["CASTRO_AMD_FOLD_TILE"], os.environ["CASTRO_AMD_FINAL_TILE"] = "-1", "0"
+        HipHydro(0, numerics="contract").close()           # back to the defaults for the tests that follow
+        del os.environ["CASTRO_AMD_FOLD_TILE"], os.environ["CASTRO_AMD_FINAL_TILE"]
+    dev = _outputs_deviation(outs["tile"])
+    worst = max(dev, key=dev.get)
+    print("contract %s vs oracle, box %s: max deviation %.2e (%s)" % (form, shape, dev[worst], worst))
+    assert all(v <= RTOL for v in dev.values()), dev
+    same = _outputs_deviation({k: (outs["tile"][k][0], outs["rows"][k][0]) for k in outs["tile"]})
+    assert all(v <= 1e-13 for v in same.values()), same
+
+
 def test_contract_staged_overlap_and_step_graph_equal_the_plain_contract_run():
     """Inside one build the launch partition must not matter: the staged halo overlap (stage A on the valid zones while the
     exchange is in flight, stage B for the rest) and the host-free, graph-replayed batch give the bits of the stepwise,

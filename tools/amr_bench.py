@@ -22,13 +22,14 @@ if nfine == 2:                                                # level-2 patch: t
 mode = sys.argv[4] if len(sys.argv) > 4 else ""                # "tags": one bounding box per level; "cluster": Berger-Rigoutsos boxes
 dynamic = mode in ("tags", "cluster")                          # the refined levels follow the tags (regrid every 2 steps)
 t_start = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0     # evolve to this time first (a developed blast wave)
-kw = dict(a.split("=") for a in sys.argv[6:])                  # bf=<blocking_factor> eff=<grid_eff> mgs=<max_grid_size>
+kw = dict(a.split("=") for a in sys.argv[6:])                  # bf=<blocking_factor> eff=<grid_eff> mgs=<max_grid_size> grav=<const_grav>; the build: CASTRO_AMD_NUMERICS
+grav = dict(do_grav=True, const_grav=float(kw["grav"])) if "grav" in kw else {}
 if dynamic:
     a = castro_amd.CastroAmr((n, n, n), refine=[("density", "gradient", 0.05), ("rho_E", "relative_gradient", 0.5)],
                              regrid_int=2, n_error_buf=2, blocking_factor=int(kw.get("bf", 16 if mode == "cluster" else 8)), max_level=nfine,
-                             cluster=mode == "cluster", grid_eff=float(kw.get("eff", 0.7)), max_grid_size=int(kw.get("mgs", 128)))
+                             cluster=mode == "cluster", grid_eff=float(kw.get("eff", 0.7)), max_grid_size=int(kw.get("mgs", 128)), **grav)
 else:
-    a = castro_amd.CastroAmr((n, n, n), patches=patches)
+    a = castro_amd.CastroAmr((n, n, n), patches=patches, **grav)
 a.initData("sedov")
 if t_start > 0.0:
     a.evolve(t_start)

@@ -8,7 +8,7 @@ N=${NUMERICS:-contract}
 for mode in "--no-overlap" "--force-overlap"; do
   python bench.py --numerics $N --steps 20 --warmup 3 --no-cpu-baseline --no-contract-leg --no-extras --proxy-rank-of 1 2 4 8 $mode 2> gpurun_out/ov.err | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); p=d['config']['rank_proxies']
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{') and 'metric' in l][-1]); p=d['config']['rank_proxies']
 for k in ('1','2','4','8'):
     e=p[k]
     print('[$N] $mode N=%s box %s: %.3f ms/step (graph %s, overlap %s, fillboundary alone %.3f ms, %.1f MB exchanged)' % (k, e['box'], e['ms_per_step'], e.get('step_graph'), e.get('overlap_halo'), e.get('fillboundary_ms', 0), e.get('bytes_exchanged_per_step', 0)/1e6) if 'error' not in e else (k, e))
