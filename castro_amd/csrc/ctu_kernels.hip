@@ -849,6 +849,9 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
 template <bool NOPRE = false>          // NOPRE: the (rho e) and X planes are not stored (gamma_law_edges)
 __device__ __forceinline__ void store_edge_2(double* __restrict__ E, long NC, unsigned c, const double q[2][NEDGE], bool m0, bool m1)
 {
+#ifdef TRACE_DIAG_NOSTORE     // timing diagnostic (wrong results): the edge-state stores behind a condition that never holds
+    if (q[0][PRHO] != 1.2345e300) return;
+#endif
     if (m0 && m1) {
 #pragma unroll
         for (int n = 0; n < NEDGE; ++n) { if (NOPRE && (n == PRE || n == PX)) continue; stg2(E + (long)n * NC, c, q[0][n], q[1][n]); }
@@ -886,8 +889,7 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
                                                const bool do_plus[2], const bool do_minus[2],
                                                double* __restrict__ QMd, double* __restrict__ QPd,
                                                double qp[2][NEDGE], double qm[2][NEDGE],
-                                               double aA[5], double aB[5], double bA[5], double bB[5],
-                                               double* cA = nullptr, double* cB = nullptr)
+                                               double aA[5], double aB[5], double bA[5], double bB[5])
 {
     constexpr int QUN = (D == 0) ? PU : (D == 1) ? PV : PW;
     constexpr int QUT = (D == 0) ? PV : (D == 1) ? PW : PU;
@@ -905,41 +907,9 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
     ppm_waves<2>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_un, w[1].Im_un);
 
     load_stencil_2<D>(Q + (long)PP * NC, c, sd, aA, aB);
-#ifdef TRACE_PREFETCH2
-    if (!(GL && cA)) {
-#endif
     ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
     ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
-#ifdef TRACE_PREFETCH2
-    }
-#endif
 
-#ifdef TRACE_PREFETCH2
-    // two stencil requests in flight instead of one (a third buffer cA / cB; GL only): the parabola of a variable is evaluated
-    // while the stencils of the next TWO variables are on their way.  Enters with a = normal velocity, b = density (as the
-    // one-deep form), c = spare; with NEXT >= 0 it leaves with a = normal velocity and c = density of direction NEXT (b spare).
-    if (GL && cA) {
-        // p was requested into a by the line above; the one-deep form's buffer roles are kept for the first three variables
-        load_stencil_2<D>(Q + (long)QUT * NC, c, sd, cA, cB);                     // in flight: p (a), ut (c)
-        ppm_waves<3>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_rho, w[0].Im_rho);
-        ppm_waves<3>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_rho, w[1].Im_rho);
-        load_stencil_2<D>(Q + (long)QUTT * NC, c, sd, bA, bB);                    // in flight: ut (c), utt (b)
-        ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
-        ppm_waves<3>(aB, flat[1], un[1], cc[1], dtdx, w[1].Ip_p, w[1].Im_p);
-        if (NEXT >= 0) load_stencil_2<(NEXT >= 0 ? NEXT : 0)>(Q + (long)(NEXT == 1 ? PV : PW) * NC, c, sdn, aA, aB);     // utt (b), next un (a)
-        ppm_waves<1>(cA, flat[0], un[0], cc[0], dtdx, w[0].Ip_ut, w[0].Im_ut);
-        ppm_waves<1>(cB, flat[1], un[1], cc[1], dtdx, w[1].Ip_ut, w[1].Im_ut);
-        if (NEXT >= 0) load_stencil_2<(NEXT >= 0 ? NEXT : 0)>(Q + (long)PRHO * NC, c, sdn, cA, cB);                       // next un (a), next rho (c)
-        ppm_waves<1>(bA, flat[0], un[0], cc[0], dtdx, w[0].Ip_utt, w[0].Im_utt);
-        ppm_waves<1>(bB, flat[1], un[1], cc[1], dtdx, w[1].Ip_utt, w[1].Im_utt);
-        w[0].Ip_X[1] = w[0].Im_X[1] = w[1].Ip_X[1] = w[1].Im_X[1] = 1.0;
-        trace_finish<D, true>(w[0], un[0], cc[0], P, qp[0], qm[0]);
-        trace_finish<D, true>(w[1], un[1], cc[1], P, qp[1], qm[1]);
-        store_edge_2<true>(QPd, NC, c, qp, do_plus[0], do_plus[1]);
-        store_edge_2<true>(QMd, NC, c + sd, qm, do_minus[0], do_minus[1]);
-        return;
-    }
-#endif
     if (GL) {
         load_stencil_2<D>(Q + (long)QUT * NC, c, sd, bA, bB);
         ppm_waves<3>(aA, flat[0], un[0], cc[0], dtdx, w[0].Ip_p, w[0].Im_p);
@@ -1667,6 +1637,11 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
 
     // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
     double flat[2];
+#ifdef TRACE_DIAG_NOFLAT      // timing diagnostic (wrong results): no flattening stencils
+    if (P.first_order_hydro != 2) {
+        flat[0] = flat[1] = 1.0;
+    } else
+#endif
     if (P.first_order_hydro == 1) {
         flat[0] = flat[1] = 0.0;
     } else if (P.use_flattening == 1) {
@@ -1700,16 +1675,9 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     dp[0] = valid && i >= t.lo[0]; dp[1] = v1 && i + 1 >= t.lo[0];
     dm[0] = valid && i <= t.hi[0]; dm[1] = v1 && i + 1 <= t.hi[0];
     double sa[2][5], sb[2][5];
-#ifdef TRACE_PREFETCH2
-    double sc[2][5];
-#endif
     if (DMASK & 1) {
         load_stencil_2<0>(Q + (long)PU * NC, c, s.x, sa[0], sa[1]);
         load_stencil_2<0>(Q + (long)PRHO * NC, c, s.x, sb[0], sb[1]);
-#ifdef TRACE_PREFETCH2
-        if (GL) trace_pair_dir<0, (DMASK & 2) ? 1 : -1, GL>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]);
-        else
-#endif
         trace_pair_dir<0, (DMASK & 2) ? 1 : -1, GL>(t, Q, c, s.x, s.y, flat, dt / g.dx[0], P, dp, dm, S.QM[0], S.QP[0], qp, qm, sa[0], sa[1], sb[0], sb[1]);
     }
 
@@ -1759,11 +1727,6 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             load_stencil_2<1>(Q + (long)PRHO * NC, c, s.y, sa[0], sa[1]);
         }
         const bool a = j >= t.lo[1], z = j <= t.hi[1]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
-#ifdef TRACE_PREFETCH2
-        // x left the normal velocity in a (sa) and the density in c (sc); spare: sb
-        if (GL) trace_pair_dir<1, (DMASK & 4) ? 2 : -1, GL>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sa[0], sa[1], sc[0], sc[1], sb[0], sb[1]);
-        else
-#endif
         trace_pair_dir<1, (DMASK & 4) ? 2 : -1, GL>(t, Q, c, s.y, s.z, flat, dt / g.dx[1], P, dp, dm, S.QM[1], S.QP[1], qp, qm, sb[0], sb[1], sa[0], sa[1]);
     }
     if (DMASK & 4) {
@@ -1772,11 +1735,6 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
             load_stencil_2<2>(Q + (long)PRHO * NC, c, s.z, sb[0], sb[1]);
         }
         const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
-#ifdef TRACE_PREFETCH2
-        // y (entered with a = sa, b = sc, c = sb) left the normal velocity in its a (sa) and the density in its c (sb); spare: sc
-        if (GL) trace_pair_dir<2, -1, GL>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]);
-        else
-#endif
         trace_pair_dir<2, -1, GL>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
     }
 }
