@@ -28,7 +28,7 @@ def prof(sub):
         if sub in r["Name"]:
             tot += float(r["TotalDurationNs"]); n += int(r["Calls"])
     return (tot / n / 1e6, n) if n else (float("nan"), 0)
-for label, sub in (("k_trans1", "k_trans1<"), ("k_trans1_fold", "k_trans1_fold"), ("k_trace", "k_trace_pair"), ("k_finalx_consup", "k_finalx_consup"),
+for label, sub in (("k_trans1", "k_trans1<"), ("k_trans1_fold", "k_trans1_tile" if any("k_trans1_tile" in r["Name"] for r in rows) else "k_trans1_fold"), ("k_trace", "k_trace_pair"), ("k_finalx_consup", "k_finalx_consup"),
                    ("k_final_y", "k_final<1"), ("k_final_z", "k_final<2")):
     if label in ku:
         a, n = prof(sub)

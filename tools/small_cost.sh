@@ -1,7 +1,7 @@
 #!/bin/bash
 # NUMERICS (environment, default contract): the build of the kernel library, pinned on every bench.py line
 for n in 64 128 256; do
-  python bench.py --numerics ${NUMERICS:-contract} --ncell $n --steps 20 --warmup 5 --no-cpu-baseline --no-contract-leg > gpurun_out/sm.json 2> gpurun_out/sm.err || tail -3 gpurun_out/sm.err
+  python bench.py --numerics ${NUMERICS:-contract} --ncell $n --steps 20 --warmup 5 --no-cpu-baseline --no-contract-leg --no-extras > gpurun_out/sm.json 2> gpurun_out/sm.err || tail -3 gpurun_out/sm.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/sm.json"))
