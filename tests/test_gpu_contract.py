@@ -353,6 +353,72 @@ def test_contract_single_call_every_output_array_within_rtol(oracle, tiled):
     hip.close()
 
 
+@pytest.mark.parametrize("case", ["rotation_rst4", "rotation_rst1", "predictor"])
+def test_contract_traced_sources_on_the_five_variable_path_within_rtol(oracle, case):
+    """Round 5: with traced source terms the `contract` build keeps its gamma-law identities (k_trace<SRC, PLM, GL>: the p source of
+    a gamma-law gas is (gamma - 1) times its (rho e) source, so the traced (rho e) is still the traced p over (gamma - 1)).  The
+    gravity case of test_contract_non_default_options_within_rtol has no (rho e) source at all; these do: rotation (two energy forms,
+    implicit Coriolis update) with gravity on a perturbed state, and castro.source_term_predictor = 1 on a stratified atmosphere with
+    random velocities -- conserved state and dt against the oracle at the tolerance."""
+    import torch
+    import castro_amd
+    if case == "predictor":
+        from tests.test_driver_cpu import _hse_atmosphere
+        n = (8, 8, 32)
+        bc = dict(lo_bc=(4, 2, 3), hi_bc=(4, 2, 3))
+        prob_hi = (0.25, 0.25, 1.0)
+        S0 = _hse_atmosphere(n)
+        rng = np.random.default_rng(8)
+        for d in (1, 2, 3):
+            S0[d] = S0[0] * 0.1 * rng.uniform(-1, 1, size=S0[0].shape)
+        S0[4] += 0.5 * (S0[1] ** 2 + S0[2] ** 2 + S0[3] ** 2) / S0[0]
+        pkw = dict(source_term_predictor=1, init_shrink=1.0, change_max=1.05)
+        c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), do_grav=True, const_grav=-20.0, prob_hi=prob_hi,
+                              numerics="contract", **bc)
+        lev = oracle.Level(n, oracle.make_geom(n, probhi=prob_hi, **bc), oracle.default_params(**pkw), nthreads=0)
+        lev.set_gravity(-20.0, 4)
+        nsteps, stop = 10, 1.0
+    else:
+        rst = 4 if case == "rotation_rst4" else 1
+        n = (12, 10, 8)
+        pkw = dict(cfl=0.5, init_shrink=1.0, change_max=1.1)
+        rng = np.random.default_rng(8)
+        S0 = np.zeros((8,) + n[::-1])
+        S0[0] = 1.0 + 0.1 * rng.uniform(-1, 1, size=S0[0].shape)
+        S0[7] = S0[0]
+        S0[6] = 1.0
+        for d in (1, 2, 3):
+            S0[d] = S0[0] * 0.05 * rng.uniform(-1, 1, size=S0[0].shape)
+        S0[5] = 2.5
+        S0[4] = S0[5] + 0.5 * (S0[1] ** 2 + S0[2] ** 2 + S0[3] ** 2) / S0[0]
+        bc = dict(lo_bc=(2, 4, 3), hi_bc=(2, 4, 2))
+        rkw = dict(center=(0.4, 0.5, 0.6), rot_source_type=rst, implicit_rotation_update=1)
+        c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), rotation=castro_amd.make_rotation(5.0, 2, **rkw),
+                              do_grav=True, const_grav=-0.5, numerics="contract", **bc)
+        lev = oracle.Level(n, oracle.make_geom(n, **bc), oracle.default_params(**pkw), nthreads=0)
+        lev.set_rotation(oracle.make_rotation(5.0, 2, **rkw))
+        lev.set_gravity(-0.5)
+        nsteps, stop = 6, 2.0
+    assert c.hydro.numerics == "contract"
+    c.set_state(S0.copy())
+    lev.state()[...] = S0
+    oracle.lib().ora_level_post_init(lev.h)
+    for _ in range(nsteps):
+        c.step(stop)
+        lev.step(stop)
+    torch.cuda.synchronize()
+    got, want = c.S_new().cpu().numpy(), lev.state()
+    dev = {k: np.abs(got[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-300) for k in range(8)}
+    mom = max(np.abs(want[k]).max() for k in (1, 2, 3))
+    for k in (1, 2, 3):
+        dev[k] = np.abs(got[k] - want[k]).max() / mom
+    print("contract vs oracle, %-14s %2d steps: max deviation %.2e; dt deviation %.1e" % (case, nsteps, max(dev.values()), abs(c.dt - lev.dt) / lev.dt))
+    assert all(v <= RTOL for v in dev.values()), dev
+    assert abs(c.dt - lev.dt) <= RTOL * lev.dt
+    assert not np.array_equal(got, want)               # it IS the other build
+    lev.close()
+
+
 @pytest.mark.parametrize("shape", [(37, 23, 19), (16, 12, 10), (130, 9, 11), (12, 8, 64)])
 @pytest.mark.parametrize("form", ["fold_tile_4x2", "fold_tile_2x4", "fold_and_final_tile", "final_tile_only"])
 def test_contract_tile_kernels_on_ragged_boxes(oracle, shape, form):
