@@ -136,3 +136,21 @@ def test_declared_path_bytes_are_the_planes_the_kernels_read():
     assert bench.path_bytes(True, "contract") == bench.path_bytes(True, "exact") == 600.0
     for lean in (False, True):
         assert bench.kernel_bytes_per_unit("k_ctoprim_clean", False, lean) // 8 - (6 if lean else 8) == bench.STATE_PLANES_READ[lean]
+
+
+def test_amrex_adapter_compiles_against_the_api_mock():
+    """include/castro_hydro_amd_amrex.H cannot be compiled against AMReX here (not in the image).  A compiler sees it all the
+    same: tests/mock_amrex/ declares the AMReX API subset the adapter uses (MultiFab / MFIter / Box / BoxArray::RefID / Geometry /
+    Periodicity / BCRec / Gpu::gpuStream / ParallelDescriptor / ExecOnFinalize -- declarations only, clearly a MOCK) and
+    adapter_tu.cpp calls every entry point once: syntax, types and overload resolution of the header are checked, against the
+    C ABI header of this revision.  What it cannot show: that the mock's signatures are AMReX's."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = subprocess.run([hipcc, "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-command-line-argument",
+                        "-x", "hip", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "tests", "mock_amrex"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "mock_amrex", "adapter_tu.cpp")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
