@@ -873,8 +873,15 @@ __device__ __forceinline__ void load_stencil_2(const double* __restrict__ a, uns
         sA[0] = l.a; sA[1] = l.b; sA[2] = m.a; sA[3] = m.b; sA[4] = r.a;
         sB[0] = l.b; sB[1] = m.a; sB[2] = m.b; sB[3] = r.a; sB[4] = r.b;
     } else {
+#ifdef TRACE_DIAG_CENTER_ONLY      // timing diagnostic (wrong results): one load per y / z stencil instead of five
+        const D2 v = ldg2(a, c);
+#pragma unroll
+        for (int m = -2; m <= 2; ++m) { sA[m + 2] = v.a * (1.0 + 0.01 * m); sB[m + 2] = v.b * (1.0 - 0.01 * m); }
+        (void)sd;
+#else
 #pragma unroll
         for (int m = -2; m <= 2; ++m) { const D2 v = ldg2(a, c + m * sd); sA[m + 2] = v.a; sB[m + 2] = v.b; }
+#endif
     }
 }
 
@@ -929,8 +936,13 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
         trace_finish<D, true>(w[0], un[0], cc[0], P, qp[0], qm[0]);
         trace_finish<D, true>(w[1], un[1], cc[1], P, qp[1], qm[1]);
 
+#ifdef TRACE_DIAG_STORES_AT_END       // timing diagnostic (wrong results): the x and y edge states are not stored where they are computed ...
+        if (D == 2)
+#endif
+        {
         store_edge_2<true>(QPd, NC, c, qp, do_plus[0], do_plus[1]);
         store_edge_2<true>(QMd, NC, c + sd, qm, do_minus[0], do_minus[1]);
+        }
         return;
     }
     load_stencil_2<D>(Q + (long)PRE * NC, c, sd, bA, bB);
@@ -1736,6 +1748,14 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
         }
         const bool a = k >= t.lo[2], z = k <= t.hi[2]; dp[0] = valid && a; dp[1] = v1 && a; dm[0] = valid && z; dm[1] = v1 && z;
         trace_pair_dir<2, -1, GL>(t, Q, c, s.z, 0u, flat, dt / g.dx[2], P, dp, dm, S.QM[2], S.QP[2], qp, qm, sa[0], sa[1], sb[0], sb[1]);
+#ifdef TRACE_DIAG_STORES_AT_END       // ... but as twenty more stores (of the z values) behind the z stores: same bytes, same instructions, all at the end
+        if (GL) {
+            store_edge_2<true>(S.QP[0], NC, c, qp, dp[0], dp[1]);
+            store_edge_2<true>(S.QM[0], NC, c + s.x, qm, dm[0], dm[1]);
+            store_edge_2<true>(S.QP[1], NC, c, qp, dp[0], dp[1]);
+            store_edge_2<true>(S.QM[1], NC, c + s.y, qm, dm[0], dm[1]);
+        }
+#endif
     }
 }
 
