@@ -330,7 +330,7 @@ class Castro:
         each).  The RCCL communicator of the C ABI belongs to the comm object (DistComm / SingleComm.close), which may serve
         several Castro objects.  Idempotent; never called while a stream is capturing (a free inside a capture aborts)."""
         plans, self._plans = getattr(self, "_plans", {}), {}
-        if not plans:
+        if not any("cplan" in plan for plan in plans.values()):
             return
         h = getattr(self, "hydro", None)
         if h is None or not getattr(h, "h", None):
