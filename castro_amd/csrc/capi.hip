@@ -712,7 +712,7 @@ int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, i
             // fits a byte budget (CASTRO_AMD_LEVEL_SCRATCH_GB, default 32; a single box larger than that is a chunk of its own):
             // 8 launches per chunk, the chunks one after the other on the caller's stream in the same arena.  If the arena cannot
             // be had at all the call falls through to the box-by-box path below, which needs the largest box only.
-            static const double budget_gb = [] { const char* e = std::getenv("CASTRO_AMD_LEVEL_SCRATCH_GB"); const double v = e ? std::atof(e) : 32.0; return v > 0.0 ? v : 32.0; }();
+            const double budget_gb = [] { const char* e = std::getenv("CASTRO_AMD_LEVEL_SCRATCH_GB"); const double v = e ? std::atof(e) : 32.0; return v > 0.0 ? v : 32.0; }();   // read per call: a host may change it between levels
             const size_t budget = (size_t)(budget_gb * 1073741824.0 / sizeof(double));
             std::vector<int> first;                       // first box of every chunk
             size_t cur = 0, largest = 0;

@@ -2604,14 +2604,19 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert d["config"]["backend"] == "gloo" and d["value"] > 0.0
 
 
-@pytest.mark.parametrize("numerics", ["exact", "contract"])
-def test_level_wide_launch_of_unequal_boxes_equals_the_per_box_calls(numerics):
+@pytest.mark.parametrize("numerics,scratch_gb", [("exact", None), ("contract", None), ("exact", "0.06"), ("exact", "0.001")])
+def test_level_wide_launch_of_unequal_boxes_equals_the_per_box_calls(numerics, scratch_gb, monkeypatch):
     """castro_amd_ctu_hydro_mf as ONE grid per kernel (round 4: the box table of launch_ctu_hydro_level) over seven boxes of
     unequal and odd shapes -- a one-zone-wide one, one with more rows than a y-tile, one longer than two waves -- against
     castro_amd_ctu_hydro_fab_ex box by box: S_new, fluxes and mass fluxes bit for bit (the arithmetic per zone is the same
-    code in both numerics modes), with the fused clean_state / reduction and in flux-assign mode."""
+    code in both numerics modes), with the fused clean_state / reduction and in flux-assign mode.
+    scratch_gb (round 5, CASTRO_AMD_LEVEL_SCRATCH_GB): the level goes out in chunks of consecutive boxes whose scratch fits the
+    budget -- 0.06 GB: several chunks, some of them a single box (which takes the ordinary per-box call inside the library);
+    0.001 GB: every box a chunk of its own -- same bits."""
     import torch
     import castro_amd
+    if scratch_gb is not None:
+        monkeypatch.setenv("CASTRO_AMD_LEVEL_SCRATCH_GB", scratch_gb)
     h = castro_amd.HipHydro(0, numerics=numerics)
     rng = np.random.default_rng(77)
     P = castro_amd.default_params()
