@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--force-overlap", action="store_true", help="staged overlap (ghost-free part of the update while the halo "
                     "exchange runs on the communication stream), as every rank of a multi-GPU run does")
     ap.add_argument("--overlap-tiles", action="store_true", help="the older interior tile + 6 boundary slabs form of the overlap")
+    ap.add_argument("--overlap-staged", action="store_true", help="the round-2 staged form of the overlap (ctoprim + tracing of the "
+                    "inner zones beside the exchange, split trace launches); --force-overlap is the light split of round 6")
     ap.add_argument("--no-contract-leg", action="store_true", help="skip the 600-B contract leg of the default run")
     ap.add_argument("--stepwise", action="store_true", help="one host round trip per step (Castro.step) instead of the "
                     "host-free batch (Castro.run_steps)")
@@ -321,7 +323,8 @@ def main():
 
     contract = args.reference_contract
     bc = (0, 0, 0) if args.periodic else (2, 2, 2)
-    overlap = (False if args.no_overlap else ("tiles" if args.overlap_tiles else (True if args.force_overlap else None)))
+    overlap = (False if args.no_overlap else ("tiles" if args.overlap_tiles else ("staged" if args.overlap_staged else
+                                                                                   (True if args.force_overlap else None))))
 
     def sync():
         torch.cuda.synchronize()
@@ -394,7 +397,7 @@ def main():
             prof = c.hydro.profile_report()
             c.hydro.profile(False)
         info = {"zones_per_gpu": c.n[0] * c.n[1] * c.n[2], "sim_time": c.time, "nstep": c.nstep, "n": c.n,
-                "overlap_halo": ("tiles" if c.overlap == "tiles" else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
+                "overlap_halo": (c.overlap if c.overlap in ("tiles", "staged") else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
                 "halo": c.halo_stats() if hasattr(c, "halo_stats") else None, "host_free": host_free,
                 "step_graph": bool(host_free and getattr(c, "_graphs", None)), "per_step": per,
                 "numerics": c.hydro.numerics, "library": c.hydro.lib.castro_amd_version().decode()}
@@ -451,12 +454,13 @@ def main():
         except Exception as e:
             other_leg = {"numerics": other, "error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
-    # a multi-GPU run: the same workload with the staged halo overlap forced on (off by default at these box sizes: castro.py
-    # OVERLAP_MIN_ZONES was set from one GPU; this leg is the measurement on real links), untimed extra
+    # a multi-GPU run: the same workload with the halo overlap switched the other way (castro.py OVERLAP_MIN_ZONES was set from
+    # one GPU; this leg is the measurement on real links), untimed extra
     overlap_leg = None
-    if world > 1 and not args.no_extras and overlap is None and not info["overlap_halo"]:
+    if world > 1 and not args.no_extras and overlap is None:
         try:
-            w_v, _, _, i_v = run(contract, args.steps, args.warmup, False, overlap_=True)
+            # the other setting of the halo overlap (default since round 6: the light split, on) on the same links
+            w_v, _, _, i_v = run(contract, args.steps, args.warmup, False, overlap_=not info["overlap_halo"])
             overlap_leg = {"ms_per_step": w_v / args.steps * 1e3, "value": total_cells * args.steps / w_v, "overlap_halo": i_v["overlap_halo"],
                            "host_free": i_v["host_free"], "step_graph": i_v["step_graph"]}
         except Exception as e:
@@ -514,11 +518,12 @@ def main():
                     hs = c.halo_stats()
                     proxies[str(N)] = {"box": list(nb), "ms_per_step": ms, "projected_value": N * nb[0] * nb[1] * nb[2] / ms * 1e3,
                                        "projected_efficiency_vs_1gpu": (N * nb[0] * nb[1] * nb[2] / ms * 1e3) / (N * value),
-                                       "overlap_halo": bool(c.overlap and c._comm_stream is not None and c.neighbors),
+                                       "overlap_halo": (c.overlap if c.overlap in ("tiles", "staged") else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
                                        "step_graph": bool(getattr(c, "_graphs", None)), "regions": hs["regions"],
                                        "bytes_exchanged_per_step": sum(nbr["sbuf"].numel() * 8 for nbr in c.neighbors),
                                        "fillboundary_ms": hs["fillboundary_ms"], "issued_by": hs["issued_by"]}
                     c.close()
+                    c.comm.close(c.hydro)          # the proxy's own one-rank RCCL communicator
                     del c
                     torch.cuda.empty_cache()
                 except Exception as e:
@@ -559,6 +564,13 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if comm is not None:
+        try:
+            from castro_amd.hydro import HipHydro
+            hc = HipHydro(local_rank, numerics=args.numerics)
+            comm.close(hc)                         # the kernel library's communicator, before the process group goes
+            hc.close()
+        except Exception:
+            pass
         comm.dist.destroy_process_group()
 
 

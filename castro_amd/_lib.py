@@ -34,6 +34,7 @@ URHO, UMX, UMY, UMZ, UEDEN, UEINT, UTEMP, UFS = range(8)
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
 UPDATE_ADD, UPDATE_FROM_SBORDER, FLUX_ASSIGN, STAGE_A, STAGE_B = 0, 1, 2, 4, 8
+STAGE_VALID, STAGE_REST, BC_FILL = 16, 32, 64
 # CASTRO_AMD_DER_* ids, in the order the reference registers the fields (Castro_setup.cpp:756-960)
 DERIVE_IDS = {"pressure": 0, "kineng": 1, "soundspeed": 2, "Gamma_1": 3, "MachNumber": 4, "magvort": 5, "divu": 6,
               "eint_E": 7, "eint_e": 8, "logden": 9, "X(X)": 10, "abar": 11, "x_velocity": 12, "y_velocity": 13,
@@ -57,7 +58,8 @@ EXPORTED_SYMBOLS = (
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version", "castro_amd_abi_version", "castro_amd_numerics",
     "castro_amd_comm_version", "castro_amd_comm_unique_id", "castro_amd_comm_create", "castro_amd_comm_adopt", "castro_amd_comm_rank",
     "castro_amd_comm_size", "castro_amd_comm_destroy", "castro_amd_halo_plan_create", "castro_amd_halo_plan_destroy",
-    "castro_amd_halo_plan_bytes_sent", "castro_amd_fill_boundary", "castro_amd_allreduce_min",
+    "castro_amd_halo_plan_bytes_sent", "castro_amd_fill_boundary", "castro_amd_fill_boundary_ex", "castro_amd_halo_plan_wait_packed",
+    "castro_amd_allreduce_min",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
     "castro_amd_cmpflx_points", "castro_amd_ppm_points", "castro_amd_flatten_points", "castro_amd_trans_points",
@@ -140,7 +142,7 @@ class FabOp(C.Structure):
 OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN, OP_AVGDOWN = 0, 1, 2, 3, 4, 5, 6, 7
 
 _libs = {}
-ABI_VERSION = 4          # CASTRO_AMD_ABI_VERSION of include/castro_hydro_amd.h this binding was written against
+ABI_VERSION = 5          # CASTRO_AMD_ABI_VERSION of include/castro_hydro_amd.h this binding was written against
 
 
 def numerics_of(L):
@@ -247,6 +249,8 @@ def load(numerics=None):
         L.castro_amd_halo_plan_bytes_sent.argtypes = [C.c_void_p]
         L.castro_amd_halo_plan_bytes_sent.restype = C.c_longlong
         L.castro_amd_fill_boundary.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
+        L.castro_amd_fill_boundary_ex.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_int, C.c_void_p]
+        L.castro_amd_halo_plan_wait_packed.argtypes = [C.c_void_p, C.c_void_p]
         L.castro_amd_allreduce_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.castro_amd_ctx_profile.argtypes = [C.c_void_p, C.c_int]
     L.castro_amd_ctx_profile_count.argtypes = [C.c_void_p]

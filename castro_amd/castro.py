@@ -37,6 +37,13 @@ def _use_c_halo(default):
     return default if v is None else v not in ("0", "")
 
 
+def _drop_graphs_of(users):
+    """the step graphs of the Castro objects that captured collectives of a communicator that is about to go"""
+    for u in list(users or ()):
+        if getattr(u, "_graphs", None):
+            u._graphs = {}
+
+
 class SingleComm:
     rank, size = 0, 1
     device_side = True          # no collective ever touches the host
@@ -53,6 +60,7 @@ class SingleComm:
     def close(self, hydro=None):
         """destroy the C-ABI communicator (after every Castro object that used it has been closed)"""
         cc, self._ccomm = getattr(self, "_ccomm", None), None
+        _drop_graphs_of(getattr(self, "_users", None))
         if cc and hydro is not None:
             hydro.comm_destroy(cc)
 
@@ -124,6 +132,7 @@ class DistComm:
     def close(self, hydro=None):
         """destroy the C-ABI communicator (collective in spirit: every rank calls it, after closing its Castro objects)"""
         cc, self._ccomm = self._ccomm, None
+        _drop_graphs_of(getattr(self, "_users", None))
         if cc and hydro is not None:
             hydro.comm_destroy(cc)
 
@@ -199,12 +208,14 @@ class AdvanceFailure(RuntimeError):
     pass
 
 
-# smallest box side from which the staged halo overlap is on by default.  Round 5, measured on one GPU with all 26 regions through
-# the RCCL self-send path and the `contract` kernels (tools/overlap_cost.sh, profiles/r05f_overlap_threshold_and_rank_proxies.txt): the
-# staged form costs 0.76 ms at 256^3 per rank (8 %; 0.42 ms at 256x256x128, 0.18 ms at 128^3) -- the split launches and the loss of the
-# host-free graph form -- against 0.2-0.3 ms of exchange it could hide: off for every box of the headline configurations (192 in
-# rounds 2-4, measured with the round-2 kernels).  overlap=True / bench.py --force-overlap turn it on.
-OVERLAP_MIN_ZONES = 384
+# smallest box side from which the halo overlap is on by default in a multi-rank run.  Round 6: the LIGHT split (ctoprim with the
+# pending cleans on the valid zones beside the exchange, the ghost shell as one launch, everything downstream un-split) is host-free
+# under castro.use_retry and lives inside the per-rank step graph, so it is compared graph against graph: with all 26 regions
+# through RCCL self-send on one GPU it costs +0.13 / -0.03 / -0.01 / +0.02 ms at 256^3 / 256x256x128 / 256x128x128 / 128^3 per rank
+# (profiles/r06b_overlap_light_split.txt: the loop-back copy and ctoprim compete for the same HBM; the kernel trace shows both
+# running side by side) and it can hide up to the 0.05-0.31 ms of that ctoprim behind real links: on for every box.  (Round 5 had
+# 384 here: the round-2 staged form -- split trace launches, not host-free under use_retry -- cost 0.2-0.8 ms; overlap="staged".)
+OVERLAP_MIN_ZONES = 0
 
 
 # --------------------------------------------------------------------------------------------
@@ -218,6 +229,13 @@ class Castro:
         self.n_cell = tuple(int(x) for x in n_cell)
         self.owned = bool(alloc)
         self.comm = comm if comm is not None else SingleComm()
+        try:
+            import weakref
+            if getattr(self.comm, "_users", None) is None:
+                self.comm._users = weakref.WeakSet()
+            self.comm._users.add(self)              # comm.close() drops the step graphs that captured its collectives
+        except (AttributeError, TypeError):
+            pass
         if hydro is None:
             from .hydro import HipHydro
             dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
@@ -281,7 +299,14 @@ class Castro:
         # that depend on the communicator size are taken as that rank would take them
         if overlap is None:
             overlap = max(self.comm.size, int(proxy_ranks)) > 1 and min(self.n) >= OVERLAP_MIN_ZONES
-        self.overlap = overlap                                                   # True | "tiles" | False
+        # True: the light split of round 6 (ctoprim + the pending cleans on the valid zones beside the exchange, then the ghost
+        # shell in one launch and the un-split update); "staged": the round-2 split (ctoprim + tracing of the inner zones beside
+        # the exchange, split trace launches after it); "tiles": interior tile + six slabs
+        self.overlap = overlap                                                   # True | "staged" | "tiles" | False
+        # the hydro call fills the physical-boundary zones of Sborder itself (CASTRO_AMD_BC_FILL: k_ctoprim_bc instead of
+        # k_bc_fill + the k_ctoprim pass over those zones); needs the image of a mirrored ghost layer inside the box
+        self.bc_in_hydro = (hasattr(self.hydro, "lib") and box is None and alloc and min(self.n) >= NUM_GROW
+                            and os.environ.get("CASTRO_AMD_BC_IN_HYDRO", "1") != "0")
         self.fuse_clean = bool(fuse_clean)
         self.fuse_post_clean = True        # post_timestep's clean_state may ride in the fused pass (a level of CastroAmr: no)
         # the clean_state sweeps in front of the hydro update ride inside k_ctoprim (castro_amd_ctu_hydro_fab_ex) when the
@@ -329,15 +354,22 @@ class Castro:
         """Give back what lives outside torch's allocator: the C-ABI halo plans of this object (two packed device buffers
         each).  The RCCL communicator of the C ABI belongs to the comm object (DistComm / SingleComm.close), which may serve
         several Castro objects.  Idempotent; never called while a stream is capturing (a free inside a capture aborts)."""
-        plans, self._plans = getattr(self, "_plans", {}), {}
+        plans = getattr(self, "_plans", {})
+        # a captured step graph holds the plans' buffers (and the communicator's collectives) by address: never replay one
+        # after they are gone -- the next run_steps captures afresh (or runs stream-ordered)
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
+        self._eager_done = False
         if not any("cplan" in plan for plan in plans.values()):
             return
         h = getattr(self, "hydro", None)
         if h is None or not getattr(h, "h", None):
+            for plan in plans.values():
+                plan.pop("cplan", None)
             return                                  # the context (and its library state) is gone already
         if torch.cuda.is_available():
             torch.cuda.synchronize()                # a plan is single-stream and may still be in flight
-        for plan in plans.values():
+        for plan in plans.values():                 # the torch-side tables stay: expand_state keeps its one-launch pack / unpack
             cp = plan.pop("cplan", None)
             if cp is not None:
                 h.halo_plan_destroy(cp)
@@ -426,17 +458,32 @@ class Castro:
         return out
 
     # ---- AmrLevel::FillPatch at a single level: same-level copy + physical BCs ----
-    def expand_state(self, S, box=None, neighbors=None):
-        """box / neighbors default to the state's (NUM_GROW ghosts); the Source_Type FillPatch passes its own."""
+    def expand_state(self, S, box=None, neighbors=None, bc=True, mark_packed=False):
+        """box / neighbors default to the state's (NUM_GROW ghosts); the Source_Type FillPatch passes its own.
+        bc=False: the same-level exchange only (the hydro call that follows fills the physical-boundary zones itself:
+        CASTRO_AMD_BC_FILL).  mark_packed: an event is recorded behind the pack -- the last read of the valid zones -- for
+        _wait_packed() on the stream that goes on to write them (the light overlap)."""
         h = self.hydro
         box = self.gbox if box is None else box
         neighbors = self.neighbors if neighbors is None else neighbors
         plan = self._plans.get(id(neighbors))
         if plan is not None and "cplan" in plan:
-            h.fill_boundary(plan["cplan"], S, box, self.geom)
+            if mark_packed:
+                h.fill_boundary_ex(plan["cplan"], S, box, self.geom if bc else None)
+                self._packed = ("c", plan["cplan"])
+            else:
+                h.fill_boundary(plan["cplan"], S, box, self.geom if bc else None)
             return
+
+        def packed():
+            if mark_packed:
+                if getattr(self, "_ev_packed", None) is None:
+                    self._ev_packed = torch.cuda.Event()
+                self._ev_packed.record()
+                self._packed = ("t", self._ev_packed)
         if plan is not None:
             h.pack_regions(S, box, plan["pack"], plan["sall"])
+            packed()
             sends = [(nb["peer"], nb["send_tag"], nb["sbuf"]) for nb in neighbors if nb["peer"] != self.comm.rank]
             recvs = [(nb["peer"], nb["recv_tag"], nb["rbuf"]) for nb in neighbors if nb["peer"] != self.comm.rank]
             self.comm.exchange(sends, recvs)
@@ -444,11 +491,13 @@ class Castro:
                 h.unpack_regions(S, box, plan["unpack_local"], plan["sall"])
             if plan["unpack_remote"] is not None:
                 h.unpack_regions(S, box, plan["unpack_remote"], plan["rall"])
-            h.bc_fill(S, box, self.geom)
+            if bc:
+                h.bc_fill(S, box, self.geom)
             return
         sends, recvs, local = [], [], []
         for nb in neighbors:
             h.pack(S, box, nb["sbox"][0], nb["sbox"][1], nb["sbuf"])
+        packed()
         for nb in neighbors:
             if nb["peer"] == self.comm.rank:
                 local.append(nb)
@@ -462,7 +511,21 @@ class Castro:
         self.comm.exchange(sends, recvs)
         for nb in neighbors:
             h.unpack(S, box, nb["rbox"][0], nb["rbox"][1], nb["rbuf"])
-        h.bc_fill(S, box, self.geom)
+        if bc:
+            h.bc_fill(S, box, self.geom)
+
+    def _wait_packed(self):
+        """the current stream waits for the pack of the last expand_state(mark_packed=True)"""
+        kind, what = self._packed
+        if kind == "c":
+            self.hydro.halo_plan_wait_packed(what)
+        else:
+            torch.cuda.current_stream().wait_event(what)
+
+    def _light_overlap(self):
+        """the light split can carry the pending cleans inside its two ctoprim launches: overlap is True and the hydro call fills
+        the physical-boundary zones itself (a boundary fill between the two stages would hand clean zones to a pass that cleans)"""
+        return self.overlap is True and self.bc_in_hydro and not self.have_sources
 
     def halo_stats(self, repeats=5):
         """What one FillBoundary of the state costs this rank: bytes sent to other ranks per step, the number of
@@ -543,7 +606,7 @@ class Castro:
 
     # ---- Castro::construct_ctu_hydro_source over this rank's box ------------------------------
     def construct_ctu_hydro_source(self, time, dt, tiles=None, fuse_clean=False, src=None, stage=None, sborder_clean=0,
-                                   d_dt=None):
+                                   d_dt=None, bc_fill=False):
         """fuse_clean: no new-time source follows the hydro update, so S_new.min(URHO), clean_state(S_new)
         and the CFL estimate run inside the update pass (castro_amd_ctu_hydro_clean_fab) and reduce into
         self.red, which the caller has initialised.  When the attempt covers the whole step of a single level,
@@ -553,7 +616,7 @@ class Castro:
         check of do_advance_ctu sees) and after the last (red[0]: what estTimeStep of the next coarse step sees); the
         density check uses the raw update (red[1])."""
         h = self.hydro
-        post_clean = fuse_clean and self.fuse_post_clean and getattr(self, "_whole_step", False) and stage != "A"
+        post_clean = fuse_clean and self.fuse_post_clean and getattr(self, "_whole_step", False) and stage not in ("A", "valid")
         if post_clean:
             self._post_clean_done = True
         for bx in (tiles or [self.bx]):
@@ -564,7 +627,8 @@ class Castro:
                                          clean_ntimes=(2 if post_clean else 1) if fuse_clean else 0, red=self.red if fuse_clean else None,
                                          flux_assign=self.flux_assign and self._flux_clear, stage=stage,
                                          **({"sborder_clean": sborder_clean} if sborder_clean else {}),
-                                         **({"d_dt": d_dt} if d_dt is not None else {}))
+                                         **({"d_dt": d_dt} if d_dt is not None else {}),
+                                         **({"bc_fill": True} if bc_fill else {}))
 
     def _shell_tiles(self):
         """interior box (needs no ghost data) + 6 boundary slabs of thickness NUM_GROW."""
@@ -601,9 +665,11 @@ class Castro:
         # sweep of their own (castro_amd_hydro_opts.sborder_clean_ntimes): FillPatch copies the uncleaned zones and the
         # hydro call cleans valid and ghost zones alike -- the same zone-local function of the same values.
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
+        light = self._light_overlap()
+        bc_h = self.bc_in_hydro and not self.have_sources        # the hydro call fills the physical-boundary zones
         sb_clean = 0
         if self._pending_cleans > 0:
-            if self.fuse_sborder_clean and not self.have_sources and not use_overlap:
+            if self.fuse_sborder_clean and not self.have_sources and (not use_overlap or light):
                 sb_clean = self._pending_cleans
             else:
                 self.clean_state(S, self._pending_cleans)
@@ -628,19 +694,21 @@ class Castro:
                 self.construct_ctu_hydro_source(time, dt, tiles=[interior], fuse_clean=fuse)   # overlapped: needs no ghost data
             cur.wait_stream(self._comm_stream)
             self.construct_ctu_hydro_source(time, dt, tiles=shells, fuse_clean=fuse)
-        elif use_overlap:
+        elif use_overlap and self.overlap == "staged":
             # halo exchange + BC fill on the communication stream while the compute stream runs the part of the
             # update that reads no ghost zone (ctoprim on the valid zones, PPM tracing 3 zones inside the box)
             cur = torch.cuda.current_stream()
             self._comm_stream.wait_stream(cur)
+            self.expand_state(S)                    # the exchange on the issuing stream, stage A on the side stream (see _advance_light_overlap)
             with torch.cuda.stream(self._comm_stream):
-                self.expand_state(S)
-            self.construct_ctu_hydro_source(time, dt, stage="A")
+                self.construct_ctu_hydro_source(time, dt, stage="A")
             cur.wait_stream(self._comm_stream)
             self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, stage="B")
+        elif use_overlap:
+            self._advance_light_overlap(S, time, dt, fuse, sb_clean, bc_h)
         else:
-            self.expand_state(S)
-            self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, sborder_clean=sb_clean)
+            self.expand_state(S, bc=not bc_h)
+            self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, sborder_clean=sb_clean, bc_fill=bc_h)
         self._flux_clear = False
 
         if not fuse:
@@ -658,6 +726,23 @@ class Castro:
             return False, "timestep validity check failed", None
         new_dt = self.fixed_dt if self.fixed_dt > 0.0 else min(self.max_dt, est * self.params.cfl)
         return True, "", new_dt
+
+    def _advance_light_overlap(self, S, time, dt, fuse, sb_clean, bc_h, d_dt=None):
+        """The light split (round 6).  Issuing stream: pack -> grouped send / recv -> unpack (-> BC fill when the hydro call does
+        not do it).  Side stream, once the pack has read the valid zones: ctoprim with the pending clean_states on the valid
+        zones (it writes them in place, and no ghost zone).  Then, both joined: the ghost shell in one launch (+ the
+        physical-boundary zones) and the whole un-split update."""
+        # The exchange stays on the stream the step is issued on and the ghost-free compute goes to the side stream: RCCL 2.26
+        # captured on a stream that was forked INTO a capture takes the process down at hipStreamEndCapture (measured,
+        # profiles/r06a_*); on the capture's origin stream its group is captured like any other node.
+        cur = torch.cuda.current_stream()
+        self.expand_state(S, bc=not bc_h, mark_packed=True)
+        kw = {} if d_dt is None else {"d_dt": d_dt}
+        with torch.cuda.stream(self._comm_stream):
+            self._wait_packed()                     # joins the side stream to everything up to and including the pack
+            self.construct_ctu_hydro_source(time, dt, stage="valid", sborder_clean=sb_clean, **kw)
+        cur.wait_stream(self._comm_stream)
+        self.construct_ctu_hydro_source(time, dt, fuse_clean=fuse, stage="rest", sborder_clean=sb_clean, bc_fill=bc_h, **kw)
 
     def _do_advance_with_sources(self, time, dt, S):
         """do_advance_ctu with old- and new-time gravity / rotation sources (Castro_advance_ctu.cpp:94-143, 156-274;
@@ -846,7 +931,7 @@ class Castro:
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
         # with castro.use_retry a rejected step is redone by the host from its old state (run_steps): every write to the
         # caller's arrays must then sit in a kernel that checks the latched status, i.e. the cleans ride in k_ctoprim
-        retry_ok = (not self.use_retry) or (self.fuse_sborder_clean and not use_overlap)
+        retry_ok = (not self.use_retry) or (self.fuse_sborder_clean and (not use_overlap or self._light_overlap()))
         return (self.fuse_clean and self.fuse_post_clean and not self.have_sources and retry_ok
                 and hasattr(self.hydro, "step_control") and getattr(self.comm, "device_side", False)
                 and self.overlap != "tiles")
@@ -859,20 +944,23 @@ class Castro:
         self._post_clean_done, self._whole_step, self._in_retry = True, True, False
         S = self.S_old_b
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
-        sb_clean = 2 if (self.fuse_sborder_clean and not use_overlap) else 0
+        light, bc_h = self._light_overlap(), self.bc_in_hydro
+        sb_clean = 2 if (self.fuse_sborder_clean and (not use_overlap or light)) else 0
         if not sb_clean:
             self.clean_state(S, 2)                  # clean_state(S_old) + clean_state(Sborder), see do_advance_ctu
-        if use_overlap:
+        if use_overlap and self.overlap == "staged":
             cur = torch.cuda.current_stream()
             self._comm_stream.wait_stream(cur)
+            self.expand_state(S)
             with torch.cuda.stream(self._comm_stream):
-                self.expand_state(S)
-            self.construct_ctu_hydro_source(0.0, 0.0, stage="A", d_dt=self._ctl)
+                self.construct_ctu_hydro_source(0.0, 0.0, stage="A", d_dt=self._ctl)
             cur.wait_stream(self._comm_stream)
             self.construct_ctu_hydro_source(0.0, 0.0, fuse_clean=True, stage="B", d_dt=self._ctl)
+        elif use_overlap:
+            self._advance_light_overlap(S, 0.0, 0.0, True, sb_clean, bc_h, d_dt=self._ctl)
         else:
-            self.expand_state(S)
-            self.construct_ctu_hydro_source(0.0, 0.0, fuse_clean=True, sborder_clean=sb_clean, d_dt=self._ctl)
+            self.expand_state(S, bc=not bc_h)
+            self.construct_ctu_hydro_source(0.0, 0.0, fuse_clean=True, sborder_clean=sb_clean, d_dt=self._ctl, bc_fill=bc_h)
         self._flux_clear = False
         self.comm.allreduce_min(self.red)
         self.hydro.step_control(self.red, self._ctl, self.params, self.max_dt, self.fixed_dt, stop_time, use_retry=self.use_retry)
@@ -904,11 +992,18 @@ class Castro:
             gc.collect()
             gc_was_on = gc.isenabled()
             gc.disable()
+            keep = self._host_step_state()
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
+                    if os.environ.get("CASTRO_AMD_TEST_FAIL_CAPTURE") == "1":       # tests: a runtime that refuses the capture half way
+                        self._step_device(stop_time)
+                        raise RuntimeError("capture refused (CASTRO_AMD_TEST_FAIL_CAPTURE)")
                     self._step_device(stop_time)
                     self._step_device(stop_time)
+            except BaseException:
+                self._restore_host_step_state(keep)        # nothing was executed: the host-side roles go back too
+                raise
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -926,17 +1021,31 @@ class Castro:
         have_c = bool(getattr(self.comm, "_ccomm", None)) and os.environ.get("CASTRO_AMD_C_ALLREDUCE", "1") != "0"
         return bool(getattr(self.comm, "device_side", False) and have_c and (not self.neighbors or (plan is not None and "cplan" in plan)))
 
+    _HOST_STEP_STATE = ("S_old_b", "S_new_b", "_flux_clear", "_post_clean_done", "_whole_step", "_in_retry", "_pending_cleans")
+
+    def _host_step_state(self):
+        return {k: getattr(self, k) for k in self._HOST_STEP_STATE}
+
+    def _restore_host_step_state(self, keep):
+        for k, v in keep.items():
+            setattr(self, k, v)
+
     def _capture_rank_graph(self, stop_time):
         """capture_step_graph on every rank, then one all-reduce (torch.distributed, outside any capture) to agree on the
         outcome: the graph is used only if EVERY rank has one (a rank replaying a graph while another issues the stream form would
         still match call for call, but a rank whose runtime refused the capture should not be the only one on the slow path
         unnoticed).  Returns the graph or None (stream form from now on)."""
         g, ok = None, 1
+        # _step_device changes host-side state while it captures (the roles of the two state buffers, the flux-assign and
+        # post-clean flags): a capture that dies half way has executed nothing on the device, so the object must be put back
+        # exactly as it was or the stream-ordered steps that follow would start from the wrong buffer
+        keep = self._host_step_state()
         try:
             g = self.capture_step_graph(stop_time)
         except Exception as e:                      # the runtime or RCCL refused the capture
             ok = 0
             self._rank_graph_error = "%s: %s" % (type(e).__name__, e)
+            self._restore_host_step_state(keep)
             torch.cuda.synchronize()
         flag = torch.tensor([ok], dtype=torch.int32, device=self.red.device)
         self.comm.dist.all_reduce(flag, op=self.comm.dist.ReduceOp.MIN, group=self.comm.group)
@@ -993,7 +1102,17 @@ class Castro:
                 self._step_device(stop_time)            # two eager steps first: every lazy allocation happens outside a capture
                 self._step_device(stop_time)
                 left -= 2
-            g = self.capture_step_graph(stop_time) if isinstance(self.comm, SingleComm) else self._capture_rank_graph(stop_time)
+            if isinstance(self.comm, SingleComm):
+                try:
+                    g = self.capture_step_graph(stop_time)
+                except AdvanceFailure:
+                    raise
+                except Exception as e:              # the runtime refused the capture: the object is as it was (capture_step_graph
+                    g = None                        # restores the host-side roles), the steps go out stream-ordered
+                    self._graph_error = "%s: %s" % (type(e).__name__, e)
+                    torch.cuda.synchronize()
+            else:
+                g = self._capture_rank_graph(stop_time)
             while g is not None and left >= 2:
                 g.replay()
                 left -= 2

@@ -164,6 +164,11 @@ __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, doubl
 __global__ void k_step_control(double* red, double* ctl, double cfl, double change_max, double small_dens, double max_dt,
                                double fixed_dt, double stop_time, int retry_form)
 {
+    // the host's expressions in the host's order in BOTH builds: with the `contract` build's -fassociative-math the single
+    // subcycle (time + dt) - time below was folded to dt, one ulp away from what Castro.subcycle_advance_ctu (and the
+    // reference, Castro_advance_ctu.cpp:463-471) computes every now and then -- a graph-replayed batch then left the bits of
+    // the stepwise driver (round 6, profiles/r06a_*)
+#pragma clang fp reassociate(off) contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double est = red[0], rho_min = red[1], est1 = red[2];
     red[0] = 1.e200; red[1] = 1.e200; red[2] = 1.e200;

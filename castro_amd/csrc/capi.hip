@@ -336,11 +336,17 @@ static int prepare_box(castro_amd_ctx* c, const int bxlo[3], const int bxhi[3], 
     if (!opts) return CASTRO_AMD_ERR_ARG;
     const int flags = opts->flags, clean_ntimes = opts->clean_ntimes, sb_clean = opts->sborder_clean_ntimes;
     if (clean_ntimes < 0 || sb_clean < 0) return CASTRO_AMD_ERR_ARG;
-    if (sb_clean > 0) {
-        // in-place cleaning of Sborder: whole-box calls only, never staged (see the header)
-        if (flags & (CASTRO_AMD_STAGE_A | CASTRO_AMD_STAGE_B)) return CASTRO_AMD_ERR_ARG;
+    const int light = flags & (CASTRO_AMD_STAGE_VALID | CASTRO_AMD_STAGE_REST);
+    if (light == (CASTRO_AMD_STAGE_VALID | CASTRO_AMD_STAGE_REST)) return CASTRO_AMD_ERR_ARG;
+    if ((light || (flags & CASTRO_AMD_BC_FILL)) && (flags & (CASTRO_AMD_STAGE_A | CASTRO_AMD_STAGE_B))) return CASTRO_AMD_ERR_ARG;
+    if (sb_clean > 0 || light || (flags & CASTRO_AMD_BC_FILL)) {
+        // in-place cleaning of Sborder, the valid / rest split and the fused boundary fill: whole-box calls only, never with the
+        // round-2 staging (see the header)
+        if (sb_clean > 0 && (flags & (CASTRO_AMD_STAGE_A | CASTRO_AMD_STAGE_B))) return CASTRO_AMD_ERR_ARG;
         if (vbxlo && vbxhi)
             for (int d = 0; d < 3; ++d) if (vbxlo[d] != bxlo[d] || vbxhi[d] != bxhi[d]) return CASTRO_AMD_ERR_ARG;
+        // cleaned valid zones + a separate k_bc_fill + cleaning the shell would clean the boundary zones twice over
+        if (sb_clean > 0 && (flags & CASTRO_AMD_STAGE_REST) && !(flags & CASTRO_AMD_BC_FILL)) return CASTRO_AMD_ERR_ARG;
     }
     if (!c || !bxlo || !bxhi || !Sborder || !Sborder->p || !S_new || !S_new->p || !geom || !params)
         return CASTRO_AMD_ERR_ARG;
@@ -454,6 +460,7 @@ int castro_amd_ctu_hydro_fab_ex(castro_amd_ctx* c, const int bxlo[3], const int 
     LaunchAux aux;
     aux.sb_clean = opts->sborder_clean_ntimes;
     aux.side = c->side; aux.ev_fork = c->ev_fork; aux.ev_join = c->ev_join;
+    for (int d = 0; d < 3; ++d) { aux.bc_lo[d] = geom->lo_bc[d]; aux.bc_hi[d] = geom->hi_bc[d]; }
     DevParams devP = to_devparams(params);
     devP.dtp = opts->d_dt;
     return launch_ctu_hydro(B.t, S, B.dS, B.dSrc, B.dN, B.dF, B.dM, B.dQ, to_devgeom(geom), devP, dt, opts->flags,

@@ -67,6 +67,7 @@ struct LaunchAux {
     int sb_clean = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int bc_lo[3] = { 0, 0, 0 }, bc_hi[3] = { 0, 0, 0 };     // castro_amd_geom::lo_bc / hi_bc (CASTRO_AMD_BC_FILL)
 };
 
 int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, const DFab& Src, const DFab& Snew,

@@ -193,18 +193,13 @@ __device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
 // CLEAN: Castro::clean_state applied `clean_n` times to the zone first, in place (castro_amd_hydro_opts.sborder_clean_ntimes):
 // the clean_state(S_old) of initialize_advance and the clean_state(Sborder) after FillPatch inside the pass that reads the
 // state anyway.  Plain stores: k_final / k_finalx_consup read the cleaned zones again.
-template <bool CLEAN, bool LV = false>
-__global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                 SkipBox skip, int clean_n, LevelTab lv, int lean_q)
+// one zone of k_ctoprim / k_ctoprim_shell
+template <bool CLEAN>
+__device__ __forceinline__ void ctoprim_zone(const Tile& t, const DFab& U, double* __restrict__ Q, const DevParams& P, int* status,
+                                             int clean_n, int lean_q, int i, int j, int k)
 {
     // lean_q (gamma_law_edges, default-solver path of the `contract` build), bit 0: nobody downstream reads Q's (rho e) and X
     // planes; bit 1: the update kernel has clean_state fused in and reads neither the temperature nor the species of U
-    RETURN_IF_BATCH_FAILED();
-    unsigned vb = blockIdx.x;
-    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
-    int i, j, k;
-    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
-    if (in_skip(skip, i, j, k)) return;
     const unsigned c = goff(t, i, j, k);
     const unsigned cu = foff(U, i, j, k);
     const long NC = t.NC;
@@ -261,6 +256,121 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
     const double p = (P.gamma - 1.0) * rho * e;
     const double cs = kContract ? fsqrt(P.gamma * p * rhoinv) : sqrt(P.gamma * p / rho);
 
+    stg(Q + PRHO * NC, c, rho);
+    stg(Q + PU * NC, c, u);
+    stg(Q + PV * NC, c, v);
+    stg(Q + PW * NC, c, w);
+    stg(Q + PP * NC, c, p);
+    if (!(lean_q & 1)) {
+        stg(Q + PRE * NC, c, e * rho);
+        stg(Q + PX * NC, c, X);
+    }
+    stg(Q + PC * NC, c, cs);
+}
+
+template <bool CLEAN, bool LV = false>
+__global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
+                                                 SkipBox skip, int clean_n, LevelTab lv, int lean_q)
+{
+    RETURN_IF_BATCH_FAILED();
+    unsigned vb = blockIdx.x;
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
+    int i, j, k;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
+    if (in_skip(skip, i, j, k)) return;
+    ctoprim_zone<CLEAN>(t, U, Q, P, status, clean_n, lean_q, i, j, k);
+}
+
+// Up to six boxes in one launch, x fastest inside each (the ghost shell of a box as z, y and x slabs): thread -> zone
+struct ShellBoxes { int lo[6][3], nn[6][3]; unsigned start[7]; };
+__device__ __forceinline__ bool shell_thread(const ShellBoxes& S, int& i, int& j, int& k)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= S.start[6]) return false;
+    int r = 0;
+    while (tid >= S.start[r + 1]) ++r;
+    const unsigned q = tid - S.start[r];
+    const unsigned n0 = (unsigned)S.nn[r][0], n1 = (unsigned)S.nn[r][1];
+    i = S.lo[r][0] + (int)(q % n0);
+    const unsigned rr = q / n0;
+    j = S.lo[r][1] + (int)(rr % n1);
+    k = S.lo[r][2] + (int)(rr / n1);
+    return true;
+}
+
+// k_ctoprim on the ghost shell of a box whose valid zones an earlier launch has done (CASTRO_AMD_STAGE_REST): ONE launch
+// for the six slabs
+template <bool CLEAN>
+__global__ void __launch_bounds__(256) k_ctoprim_shell(Tile t, ShellBoxes S, DFab U, double* __restrict__ Q, DevParams P, int* status,
+                                                       int clean_n, int lean_q)
+{
+    RETURN_IF_BATCH_FAILED();
+    int i, j, k;
+    if (!shell_thread(S, i, j, k)) return;
+    ctoprim_zone<CLEAN>(t, U, Q, P, status, clean_n, lean_q, i, j, k);
+}
+
+// The physical-boundary part of FillPatch (Source/problems/Castro_bc_fill_nd.cpp:11-125; BC tables Castro_setup.cpp:40-53)
+// fused with ctoprim for the ghost zones of Sborder outside the problem domain in a non-periodic direction
+// (CASTRO_AMD_BC_FILL): the zone takes the state of the in-domain zone the per-direction index map names -- clamp to the
+// nearest interior zone (FOEXTRAP: outflow, inflow) or mirror about the boundary with the normal momentum negated (REFLECT_ODD:
+// symmetry and walls) -- which the launches before this one have cleaned already (clean_state commutes with the copy and with
+// the mirror image: it is zone-local and even in the momenta), stores it into Sborder (the artificial viscosity of the final
+// stage reads one ghost layer of it) and writes its primitive record like k_ctoprim<false>.  Replaces k_bc_fill + the
+// k_ctoprim pass over those zones.
+struct BcKinds { int lo[3], hi[3]; int kind_lo[3], kind_hi[3]; };   // domain extent; kind 0 leave (interior / periodic), 1 extrapolate, 2 mirror
+__global__ void __launch_bounds__(256) k_ctoprim_bc(Tile t, ShellBoxes S, DFab U, double* __restrict__ Q, DevParams P, int* status,
+                                                    BcKinds M, int lean_q)
+{
+    RETURN_IF_BATCH_FAILED();
+    int ijk[3];
+    if (!shell_thread(S, ijk[0], ijk[1], ijk[2])) return;
+    int s[3];
+    bool flip[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        s[d] = ijk[d];
+        flip[d] = false;
+        if (ijk[d] < M.lo[d] && M.kind_lo[d] != 0) {
+            if (M.kind_lo[d] == 1) s[d] = M.lo[d];
+            else { s[d] = 2 * M.lo[d] - ijk[d] - 1; flip[d] = true; }
+        } else if (ijk[d] > M.hi[d] && M.kind_hi[d] != 0) {
+            if (M.kind_hi[d] == 1) s[d] = M.hi[d];
+            else { s[d] = 2 * M.hi[d] - ijk[d] + 1; flip[d] = true; }
+        }
+    }
+    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
+    const unsigned cd = foff(U, ijk[0], ijk[1], ijk[2]);
+    const unsigned cs_ = foff(U, s[0], s[1], s[2]);
+    const long NC = t.NC;
+    const double rho = ldg(U.p + URHO * U.sn, cs_);
+    double mx = ldg(U.p + UMX * U.sn, cs_), my = ldg(U.p + UMY * U.sn, cs_), mz = ldg(U.p + UMZ * U.sn, cs_);
+    const double eden = ldg(U.p + UEDEN * U.sn, cs_), eint = ldg(U.p + UEINT * U.sn, cs_);
+    const double temp = ldg(U.p + UTEMP * U.sn, cs_), rXs = ldg(U.p + UFS * U.sn, cs_);
+    if (flip[0]) mx = -mx;                          // norm_vel_bc: REFLECT_ODD
+    if (flip[1]) my = -my;
+    if (flip[2]) mz = -mz;
+    double* up = U.p;
+#define PUT(comp, v) *reinterpret_cast<double*>(reinterpret_cast<char*>(up + (comp) * U.sn) + cd) = (v)
+    PUT(URHO, rho); PUT(UMX, mx); PUT(UMY, my); PUT(UMZ, mz); PUT(UEDEN, eden); PUT(UEINT, eint); PUT(UTEMP, temp); PUT(UFS, rXs);
+#undef PUT
+    if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
+    // from here on the statements of ctoprim_zone<false>
+    const double rX = (lean_q & 2) ? rho : rXs;
+    const double rhoinv = frcp(rho);
+    const double u = mx * rhoinv;
+    const double v = my * rhoinv;
+    const double w = mz * rhoinv;
+    const double kineng = 0.5 * rho * (u * u + v * v + w * w);
+    double e;
+    if ((eden - kineng) > P.eta1 * eden) {
+        e = (eden - kineng) * rhoinv;
+    } else {
+        e = eint * rhoinv;
+    }
+    const double X = rX * rhoinv;
+    const double p = (P.gamma - 1.0) * rho * e;
+    const double cs = kContract ? fsqrt(P.gamma * p * rhoinv) : sqrt(P.gamma * p / rho);
     stg(Q + PRHO * NC, c, rho);
     stg(Q + PU * NC, c, u);
     stg(Q + PV * NC, c, v);
@@ -3400,15 +3510,77 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
+    // The light split (round 6: CASTRO_AMD_STAGE_VALID / _REST): ctoprim -- with the pending clean_states -- on the valid zones
+    // is all that runs beside the halo exchange; the ghost shell follows as ONE launch, everything downstream is un-split.
+    // CASTRO_AMD_BC_FILL: the zones of grow(bx, 4) outside the problem domain in a non-periodic direction are filled here
+    // (k_ctoprim_bc) from in-domain zones that the launches in front of it have cleaned, instead of by a k_bc_fill before the call.
+    const bool light_a = (flags & 16) != 0, light_b = (flags & 32) != 0, fill_bc = (flags & 64) != 0;
+    if ((light_a || light_b || fill_bc) && staged) return -1;
+    if (light_a && light_b) return -1;
+    int ilo[3], ihi[3];                                  // the zones of grow(bx, 4) that hold data when the call starts
+    BcKinds M;
+    bool have_bc = false;
+    for (int d = 0; d < 3; ++d) {
+        ilo[d] = qlo[d]; ihi[d] = qhi[d];
+        M.lo[d] = g.domlo[d]; M.hi[d] = g.domhi[d];
+        M.kind_lo[d] = aux.bc_lo[d] == 0 ? 0 : (aux.bc_lo[d] >= 3 ? 2 : 1);      // Symmetry, SlipWall, NoSlipWall mirror
+        M.kind_hi[d] = aux.bc_hi[d] == 0 ? 0 : (aux.bc_hi[d] >= 3 ? 2 : 1);
+        if (!fill_bc) continue;
+        if (M.kind_lo[d] != 0 && qlo[d] < g.domlo[d]) { ilo[d] = g.domlo[d]; have_bc = true; }
+        if (M.kind_hi[d] != 0 && qhi[d] > g.domhi[d]) { ihi[d] = g.domhi[d]; have_bc = true; }
+        // the tile lies inside the domain, and a mirrored ghost layer finds its image among the in-domain zones of this FAB
+        if (t.lo[d] < ilo[d] || t.hi[d] > ihi[d]) return -1;
+        if (M.kind_lo[d] == 2 && 2 * g.domlo[d] - qlo[d] - 1 > ihi[d]) return -2;
+        if (M.kind_hi[d] == 2 && 2 * g.domhi[d] - qhi[d] + 1 < ilo[d]) return -2;
+    }
+    auto shell_launch_boxes = [&](const int olo_[3], const int ohi_[3], const int nlo_[3], const int nhi_[3], ShellBoxes& sb) {
+        int lo6[6][3], hi6[6][3];
+        const int ns = shell_boxes(olo_, ohi_, nlo_, nhi_, lo6, hi6);
+        sb.start[0] = 0;
+        for (int r = 0; r < 6; ++r) {
+            unsigned n = 0;
+            if (r < ns) {
+                n = 1;
+                for (int d = 0; d < 3; ++d) { sb.lo[r][d] = lo6[r][d]; sb.nn[r][d] = hi6[r][d] - lo6[r][d] + 1; n *= (unsigned)sb.nn[r][d]; }
+            } else {
+                for (int d = 0; d < 3; ++d) { sb.lo[r][d] = 0; sb.nn[r][d] = 1; }
+            }
+            sb.start[r + 1] = sb.start[r] + n;
+        }
+        return sb.start[6];
+    };
+    if (light_a) {
+        if (aux.sb_clean > 0) KL("k_ctoprim_clean", k_ctoprim<true>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q);
+        else KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     const bool second_half = stage_b && splittable;     // stage A has run on this tile
     int slo[6][3], shi[6][3];
-    if (second_half) {
+    if (light_b) {
+        ShellBoxes sb;
+        const unsigned nz_ = shell_launch_boxes(ilo, ihi, t.lo, t.hi, sb);
+        if (nz_ > 0) {
+            prof_begin(prof, "k_ctoprim_shell", stream);
+            if (aux.sb_clean > 0) hipLaunchKernelGGL(k_ctoprim_shell<true>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, sb, Sborder, S.Q, P, d_status, aux.sb_clean, lean_q);
+            else hipLaunchKernelGGL(k_ctoprim_shell<false>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, sb, Sborder, S.Q, P, d_status, 0, lean_q);
+            prof_end(prof, stream);
+        }
+    } else if (second_half) {
         const int ns = shell_boxes(qlo, qhi, t.lo, t.hi, slo, shi);
         for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
     } else if (aux.sb_clean > 0) {
-        KL("k_ctoprim_clean", k_ctoprim<true>, qlo, qhi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q);
+        KL("k_ctoprim_clean", k_ctoprim<true>, ilo, ihi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q);
     } else {
-        KL("k_ctoprim", k_ctoprim<false>, qlo, qhi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+        KL("k_ctoprim", k_ctoprim<false>, ilo, ihi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+    }
+    if (have_bc) {
+        ShellBoxes sb;
+        const unsigned nz_ = shell_launch_boxes(qlo, qhi, ilo, ihi, sb);
+        if (nz_ > 0) {
+            prof_begin(prof, "k_ctoprim_bc", stream);
+            hipLaunchKernelGGL(k_ctoprim_bc, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, sb, Sborder, S.Q, P, d_status, M, lean_q);
+            prof_end(prof, stream);
+        }
     }
 
     int flo[3][3], fhi[3][3], nlo[3][3], nhi[3][3];
@@ -3629,7 +3801,7 @@ bool level_launch_supported(const DevParams& P, int flags)
     const bool tfix = P.ppm_temp_fix == 2 && P.riemann_solver != 2;
     const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
     return P.ppm_type == 1 && P.riemann_solver == 0 && P.hybrid_riemann != 1 && !tfix && P.reset_rhoe != 1 && !lim &&
-           g_fuse_consup == 1 && g_fold_r1 != 0 && (flags & (4 | 8)) == 0;
+           g_fuse_consup == 1 && g_fold_r1 != 0 && (flags & (4 | 8 | 16 | 32 | 64)) == 0;
 }
 
 int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* table, const DevGeom& g, const DevParams& P, double dt,

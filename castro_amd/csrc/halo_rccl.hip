@@ -110,6 +110,8 @@ struct castro_amd_halo_plan {
     double* rbuf = nullptr;
     long long total = 0;
     int self_send = 0;          // test mode: periodic wraps go through ncclSend / ncclRecv to this rank as well
+    hipEvent_t ev_packed = nullptr;   // castro_amd_fill_boundary_ex: recorded behind the pack launch
+    bool packed_recorded = false;
 };
 
 extern "C" {
@@ -236,6 +238,11 @@ int castro_amd_halo_plan_create(castro_amd_halo_plan** out, castro_amd_comm* com
         delete p;
         return CASTRO_AMD_ERR_NOMEM;
     }
+    if (hipEventCreateWithFlags(&p->ev_packed, hipEventDisableTiming) != hipSuccess) {
+        hipFree(p->sbuf); hipFree(p->rbuf);
+        delete p;
+        return CASTRO_AMD_ERR_HIP;
+    }
     *out = p;
     return CASTRO_AMD_OK;
 }
@@ -245,6 +252,7 @@ int castro_amd_halo_plan_destroy(castro_amd_halo_plan* p)
     if (!p) return CASTRO_AMD_OK;
     if (p->sbuf) hipFree(p->sbuf);
     if (p->rbuf) hipFree(p->rbuf);
+    if (p->ev_packed) hipEventDestroy(p->ev_packed);
     delete p;
     return CASTRO_AMD_OK;
 }
@@ -257,8 +265,32 @@ long long castro_amd_halo_plan_bytes_sent(const castro_amd_halo_plan* p)
     return n;
 }
 
+static int fill_boundary_impl(castro_amd_ctx* ctx, castro_amd_halo_plan* p, const castro_amd_fab* state,
+                              const castro_amd_geom* geom, void* stream, bool mark_packed);
+
 int castro_amd_fill_boundary(castro_amd_ctx* ctx, castro_amd_halo_plan* p, const castro_amd_fab* state,
                              const castro_amd_geom* geom, void* stream)
+{
+    return fill_boundary_impl(ctx, p, state, geom, stream, false);
+}
+
+int castro_amd_fill_boundary_ex(castro_amd_ctx* ctx, castro_amd_halo_plan* p, const castro_amd_fab* state,
+                                const castro_amd_geom* geom, int flags, void* stream)
+{
+    if (flags != 0) return CASTRO_AMD_ERR_ARG;
+    return fill_boundary_impl(ctx, p, state, geom, stream, true);
+}
+
+int castro_amd_halo_plan_wait_packed(castro_amd_halo_plan* p, void* other_stream)
+{
+    if (!p || !p->ev_packed) return CASTRO_AMD_ERR_ARG;
+    if (!p->packed_recorded) return CASTRO_AMD_ERR_ARG;          // no castro_amd_fill_boundary_ex has been issued with this plan
+    if (hipSetDevice(p->comm->device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+    return hipStreamWaitEvent((hipStream_t)other_stream, p->ev_packed, 0) == hipSuccess ? CASTRO_AMD_OK : CASTRO_AMD_ERR_HIP;
+}
+
+static int fill_boundary_impl(castro_amd_ctx* ctx, castro_amd_halo_plan* p, const castro_amd_fab* state,
+                              const castro_amd_geom* geom, void* stream, bool mark_packed)
 {
     if (!ctx || !p || !state || !state->p || state->ncomp != p->ncomp) return CASTRO_AMD_ERR_ARG;
     // the plan's buffers and the communicator live on the communicator's device; a plan is single-stream: two calls with one
@@ -280,6 +312,10 @@ int castro_amd_fill_boundary(castro_amd_ctx* ctx, castro_amd_halo_plan* p, const
     if (p->nreg > 0) {
         rc = launch_pack_regions(f, p->nreg, p->slo.data(), p->shi.data(), p->off.data(), p->ncomp, p->sbuf, 0, s, nullptr);
         if (rc != CASTRO_AMD_OK) return rc;
+    }
+    if (mark_packed) {
+        if (hipEventRecord(p->ev_packed, s) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+        p->packed_recorded = true;
     }
     if (!p->remote.empty()) {
         const Rccl* R = rccl();

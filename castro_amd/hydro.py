@@ -123,7 +123,7 @@ class HipHydro:
     def construct_ctu_hydro_source(self, bx, Sborder, sb_box, S_new, snew_box, geom, params, time, dt,
                                    fluxes=None, flux_boxes=None, mass_fluxes=None, qe=None, vbx=None,
                                    update_from_sborder=False, src=None, src_box=None, stream=None,
-                                   clean_ntimes=0, red=None, flux_assign=False, stage=None, sborder_clean=0, d_dt=None):
+                                   clean_ntimes=0, red=None, flux_assign=False, stage=None, sborder_clean=0, d_dt=None, bc_fill=False):
         """clean_ntimes > 0 selects castro_amd_ctu_hydro_clean_fab: the update is followed, in the same
         pass, by S_new.min(URHO), clean_state x clean_ntimes and the CFL estimate, reduced into `red`.
         sborder_clean > 0 (castro_amd_ctu_hydro_fab_ex): clean_state that many times on every zone of Sborder, in place,
@@ -147,8 +147,11 @@ class HipHydro:
         flags = L.UPDATE_FROM_SBORDER if update_from_sborder else L.UPDATE_ADD
         if flux_assign:
             flags |= L.FLUX_ASSIGN
-        if stage is not None:         # "A": the ghost-free part (overlaps the halo exchange); "B": the rest
-            flags |= {"A": L.STAGE_A, "B": L.STAGE_B}[stage]
+        if stage is not None:         # "A": the ghost-free part (overlaps the halo exchange); "B": the rest -- the round-2 split;
+            #                           "valid": ctoprim (+ the cleans) on the valid zones only; "rest": everything else (round 6)
+            flags |= {"A": L.STAGE_A, "B": L.STAGE_B, "valid": L.STAGE_VALID, "rest": L.STAGE_REST}[stage]
+        if bc_fill:                   # the call fills the physical-boundary zones of Sborder itself (CASTRO_AMD_BC_FILL)
+            flags |= L.BC_FILL
         if sborder_clean > 0 or d_dt is not None:
             o = L.HydroOpts(flags, int(clean_ntimes), red.data_ptr() if red is not None else None, int(sborder_clean),
                             d_dt.data_ptr() if d_dt is not None else None)
@@ -437,6 +440,15 @@ class HipHydro:
         """pack -> grouped ncclSend / ncclRecv -> unpack -> physical BC fill, enqueued on the stream"""
         L.check(self.lib.castro_amd_fill_boundary(self.h, plan, C.byref(L.fab_of(state, *box)),
                                                   C.byref(geom) if geom is not None else None, _stream_ptr(stream)), "fill_boundary")
+
+    def fill_boundary_ex(self, plan, state, box, geom=None, stream=None):
+        """fill_boundary + the plan's "packed" event recorded behind the pack launch (the last read of the valid zones)"""
+        L.check(self.lib.castro_amd_fill_boundary_ex(self.h, plan, C.byref(L.fab_of(state, *box)),
+                                                     C.byref(geom) if geom is not None else None, 0, _stream_ptr(stream)), "fill_boundary_ex")
+
+    def halo_plan_wait_packed(self, plan, stream=None):
+        """`stream` (default: the current one) waits until the last fill_boundary_ex of `plan` has packed"""
+        L.check(self.lib.castro_amd_halo_plan_wait_packed(plan, _stream_ptr(stream)), "halo_plan_wait_packed")
 
     def allreduce_min_c(self, comm, t, stream=None):
         L.check(self.lib.castro_amd_allreduce_min(comm, C.c_void_p(t.data_ptr()), int(t.numel()), _stream_ptr(stream)), "allreduce_min")

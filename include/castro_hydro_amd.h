@@ -50,10 +50,12 @@ extern "C" {
  *   3: reduction vectors (`d_out`) are THREE device doubles (0.2 had two): castro_amd_ctu_hydro_clean_fab,
  *      castro_amd_ctu_hydro_fab_ex / _mf (opts.d_out), castro_amd_clean_state_reduce_fab.
  *   4: castro_amd_numerics(), castro_amd_fill_boundary*(), castro_amd_abi_version().
+ *   5: CASTRO_AMD_STAGE_VALID / _REST / CASTRO_AMD_BC_FILL, castro_amd_fill_boundary_ex, castro_amd_halo_plan_wait_packed;
+ *      castro_amd_hydro_opts.sborder_clean_ntimes is accepted by the staged calls.
  * A caller checks `castro_amd_abi_version() == CASTRO_AMD_ABI_VERSION` once after loading the library; a mismatch means
  * the library was built from another revision of this header (a 0.2 caller with 2-double vectors would be written 8 bytes
  * out of bounds by a 0.3 library). */
-#define CASTRO_AMD_ABI_VERSION 4
+#define CASTRO_AMD_ABI_VERSION 5
 
 #define CASTRO_AMD_NUM_STATE 8
 #define CASTRO_AMD_NGDNV 4
@@ -152,6 +154,26 @@ int castro_amd_ctx_poison_scratch(castro_amd_ctx *ctx, void *stream);
 #define CASTRO_AMD_STAGE_A 4             /* only the part that reads no ghost zone of Sborder (ctoprim on bx, tracing on
                                           * grow(bx,-3)): may run while the halo exchange fills the ghost zones */
 #define CASTRO_AMD_STAGE_B 8             /* the rest, after CASTRO_AMD_STAGE_A on the same context, tile and arguments */
+/* The light split for the overlap of the halo exchange (round 6; not together with CASTRO_AMD_STAGE_A / _B):
+ *   CASTRO_AMD_STAGE_VALID  only ctoprim -- with the sborder_clean_ntimes applications of clean_state -- on the zones of bx:
+ *                           reads and writes NO ghost zone of Sborder, so it may run on one stream while the exchange fills
+ *                           the ghost zones on another (after the exchange has packed: castro_amd_halo_plan_wait_packed);
+ *   CASTRO_AMD_STAGE_REST   the rest, after CASTRO_AMD_STAGE_VALID on the same context, tile and arguments: ctoprim (+ the
+ *                           cleans) on the ghost shell in ONE launch, then the whole un-split update;
+ *   CASTRO_AMD_BC_FILL      the call fills the zones of grow(bx, 4) outside the problem domain in a non-periodic direction
+ *                           itself (what castro_amd_bc_fill_fab does: FOEXTRAP / REFLECT_ODD per geom->lo_bc / hi_bc), from
+ *                           in-domain zones it has cleaned already, and writes their primitive record in the same pass:
+ *                           the caller passes Sborder with its same-level ghost zones exchanged and NO physical-boundary
+ *                           fill.  clean_state is zone-local and even in the momenta, so "fill, then clean" (the
+ *                           reference: Castro_advance.cpp:186) equals "clean, then fill"; every zone is cleaned
+ *                           sborder_clean_ntimes times exactly.  Whole-box calls only.  CASTRO_AMD_ERR_UNSUPPORTED when a
+ *                           mirrored ghost layer reaches past the in-domain zones of this FAB (a box thinner than its ghost
+ *                           depth at a wall: fill with castro_amd_bc_fill_fab instead).
+ * CASTRO_AMD_STAGE_REST with sborder_clean_ntimes > 0 needs CASTRO_AMD_BC_FILL (a boundary fill between the two stages
+ * would copy zones that are clean already into zones the shell pass cleans again). */
+#define CASTRO_AMD_STAGE_VALID 16
+#define CASTRO_AMD_STAGE_REST 32
+#define CASTRO_AMD_BC_FILL 64
 #define CASTRO_AMD_FLUX_ASSIGN 2         /* flux_out[d] = 0 + dt*area*flux instead of +=: for callers that would zero
                                           * fluxes[d] just before this (one) hydro call of the step
                                           * (Castro_advance.cpp:391-394); elides that fill and the read of the RMW */
@@ -221,14 +243,16 @@ int castro_amd_ctu_hydro_clean_fab(castro_amd_ctx *ctx,
  *                         the ghost zones of a single level are copies (or mirror images) of valid zones, so
  *                         "FillPatch the uncleaned state, then clean everything" equals the reference's "clean, FillPatch,
  *                         clean".  Only for whole-box calls (bx == vbx, one tile per FAB: overlapping tiles would clean
- *                         shared ghost zones twice) without CASTRO_AMD_STAGE_A/B; Sborder is written.
+ *                         shared ghost zones twice) without CASTRO_AMD_STAGE_A/B; Sborder is written.  With
+ *                         CASTRO_AMD_STAGE_VALID the zones of bx are cleaned, with CASTRO_AMD_STAGE_REST the ghost shell
+ *                         (pass the same count to both calls).
  *                         In the `contract` build (castro_amd_numerics()), on the default-solver path and together with
  *                         clean_ntimes > 0, the temperature and species components of Sborder are neither read nor
  *                         written back: nothing downstream depends on them (one species, gamma-law gas; the fused update
  *                         recomputes both for S_new) -- the other six components are cleaned in place as described.
  */
 typedef struct castro_amd_hydro_opts {
-    int flags;                  /* CASTRO_AMD_UPDATE_* | CASTRO_AMD_FLUX_ASSIGN | CASTRO_AMD_STAGE_* */
+    int flags;                  /* CASTRO_AMD_UPDATE_* | CASTRO_AMD_FLUX_ASSIGN | CASTRO_AMD_STAGE_* | CASTRO_AMD_BC_FILL */
     int clean_ntimes;           /* as in castro_amd_ctu_hydro_clean_fab */
     double *d_out;              /* as in castro_amd_ctu_hydro_clean_fab (device, THREE doubles) or NULL */
     int sborder_clean_ntimes;   /* see above; 0 = Sborder is read only */
@@ -566,6 +590,14 @@ long long castro_amd_halo_plan_bytes_sent(const castro_amd_halo_plan *plan);   /
 /* geom == NULL: no physical-boundary fill (interior boxes of a level, or a caller that fills them itself) */
 int castro_amd_fill_boundary(castro_amd_ctx *ctx, castro_amd_halo_plan *plan, const castro_amd_fab *state,
                              const castro_amd_geom *geom, void *stream);
+/* castro_amd_fill_boundary for a caller that overlaps the exchange with work on another stream: the plan's "packed" event is
+ * recorded on `stream` right behind the pack launch -- the LAST read of the valid zones of `state` by this call; everything after
+ * it touches ghost zones only.  castro_amd_halo_plan_wait_packed makes `other_stream` wait for that event, after which work that
+ * WRITES valid zones of `state` (CASTRO_AMD_STAGE_VALID with sborder_clean_ntimes > 0) may run on it beside the exchange.  Both
+ * calls are capturable (the event becomes a dependency between the two streams of the graph).  flags: reserved, 0. */
+int castro_amd_fill_boundary_ex(castro_amd_ctx *ctx, castro_amd_halo_plan *plan, const castro_amd_fab *state,
+                                const castro_amd_geom *geom, int flags, void *stream);
+int castro_amd_halo_plan_wait_packed(castro_amd_halo_plan *plan, void *other_stream);
 /* ncclAllReduce(MIN) in place on n device doubles: the [dt estimate, min density, ...] reduction of a step */
 int castro_amd_allreduce_min(castro_amd_comm *comm, double *d_buf, int n, void *stream);
 

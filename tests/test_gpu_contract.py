@@ -456,26 +456,34 @@ def test_contract_tile_kernels_on_ragged_boxes(oracle, shape, form):
     assert all(v <= 1e-13 for v in same.values()), same
 
 
-def test_contract_staged_overlap_and_step_graph_equal_the_plain_contract_run():
+@pytest.mark.parametrize("use_retry", [False, True])
+def test_contract_staged_overlap_and_step_graph_equal_the_plain_contract_run(use_retry):
     """Inside one build the launch partition must not matter: the staged halo overlap (stage A on the valid zones while the
     exchange is in flight, stage B for the rest) and the host-free, graph-replayed batch give the bits of the stepwise,
     un-staged `contract` run."""
     import torch
     import castro_amd
     n = (48, 40, 32)
-    kw = dict(lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), use_retry=False, numerics="contract")
+    # use_retry: the device-side step control has to form the single subcycle (time + dt) - time like the host does -- the
+    # `contract` build's reassociation folded it to dt until round 6 (k_step_control)
+    kw = dict(lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), use_retry=use_retry, numerics="contract")
     plain = castro_amd.Castro(n, overlap=False, **kw)
-    staged = castro_amd.Castro(n, overlap=True, **kw)
-    batch = castro_amd.Castro(n, overlap=True, **kw)
-    for c in (plain, staged, batch):
+    staged = castro_amd.Castro(n, overlap="staged", **kw)
+    batch = castro_amd.Castro(n, overlap="staged", **kw)
+    light = castro_amd.Castro(n, overlap=True, **kw)            # round 6: the light split (valid zones / rest)
+    light_batch = castro_amd.Castro(n, overlap=True, **kw)
+    for c in (plain, staged, batch, light, light_batch):
         c.initData("sedov", r_init=0.1, nsub=4)
         assert c.hydro.numerics == "contract"
     assert staged.overlap and staged._comm_stream is not None and staged.neighbors and not plain.overlap
+    assert light._light_overlap() and light_batch.host_free_ok() and (batch.host_free_ok() or use_retry)
     for _ in range(7):
         plain.step()
         staged.step()
+        light.step()
     batch.run_steps(7)
+    light_batch.run_steps(7)
     torch.cuda.synchronize()
-    for c in (staged, batch):
+    for c in (staged, batch, light, light_batch):
         assert c.time == plain.time and c.dt == plain.dt and c.nstep == plain.nstep
         assert torch.equal(c.S_new_b, plain.S_new_b)

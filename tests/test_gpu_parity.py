@@ -720,7 +720,7 @@ def test_staged_call_equals_one_call(hip, oracle, pkw):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("mode", [True, "tiles"])
+@pytest.mark.parametrize("mode", [True, "staged", "tiles"])
 def test_overlapped_driver_equals_plain_driver_periodic(mode):
     """Periodic box on one GPU: the 26 self-neighbour halo regions go through pack/exchange/unpack on the
     communication stream while the compute stream runs the ghost-free stage (or the interior tile)."""
@@ -1062,15 +1062,19 @@ def test_evolve_in_host_free_batches_equals_stepwise_evolve():
     assert torch.equal(a.S_new_b, b.S_new_b)
 
 
-def test_host_free_steps_with_the_staged_halo_overlap():
-    """run_steps through the staged-overlap branch (periodic self-neighbours on one GPU stand in for the ranks of a
-    decomposed run: halo exchange and BC fill on the communication stream while stage A runs, castro_amd_hydro_opts.d_dt in
-    both stages), captured as a hipGraph with its second stream: bit for bit the stepwise driver."""
+@pytest.mark.parametrize("overlap,use_retry,bc", [(True, False, (0, 0, 0)), (True, True, (0, 0, 0)), (True, True, (0, 2, 4)),
+                                                  ("staged", False, (0, 0, 0))])
+def test_host_free_steps_with_the_halo_overlap(overlap, use_retry, bc):
+    """run_steps through the overlap branches (periodic self-neighbours on one GPU stand in for the ranks of a decomposed run):
+    the light split of round 6 -- exchange on the communication stream while ctoprim with the pending cleans runs on the valid
+    zones, then the ghost shell and the un-split update; host-free also under castro.use_retry, because every write sits in a
+    kernel that checks the failure latch -- and the round-2 staged form, castro_amd_hydro_opts.d_dt in both stages, captured as a
+    hipGraph with its second stream: bit for bit the stepwise, un-overlapped driver."""
     import torch
     import castro_amd
     n = (48, 40, 32)
-    kw = dict(lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), overlap=True, use_retry=False)
-    a, b = castro_amd.Castro(n, **kw), castro_amd.Castro(n, **kw)
+    kw = dict(lo_bc=bc, hi_bc=bc, use_retry=use_retry)
+    a, b = castro_amd.Castro(n, overlap=overlap, **kw), castro_amd.Castro(n, overlap=False, **kw)
     for c in (a, b):
         c.initData("sedov", r_init=0.1, nsub=4)
     assert a.overlap and a._comm_stream is not None and a.neighbors and a.host_free_ok()
@@ -1078,8 +1082,93 @@ def test_host_free_steps_with_the_staged_halo_overlap():
         b.step()
     a.run_steps(7)
     torch.cuda.synchronize()
+    assert a._graphs, getattr(a, "_graph_error", None)
     assert a.time == b.time and a.dt == b.dt and a.nstep == b.nstep
     assert torch.equal(a.S_new_b, b.S_new_b)
+
+
+def test_a_refused_graph_capture_leaves_the_object_as_it_was(monkeypatch):
+    """A capture that dies half way (CASTRO_AMD_TEST_FAIL_CAPTURE: after one captured step) has executed nothing, but
+    _step_device has swapped the roles of the state buffers on the host: they must go back, and the batch continues
+    stream-ordered with the bits of the stepwise driver."""
+    import torch
+    import castro_amd
+    n = (32, 24, 16)
+    a, b = castro_amd.Castro(n), castro_amd.Castro(n)
+    for c in (a, b):
+        c.initData("sedov", r_init=0.1, nsub=4)
+    monkeypatch.setenv("CASTRO_AMD_TEST_FAIL_CAPTURE", "1")
+    a.run_steps(7)
+    monkeypatch.delenv("CASTRO_AMD_TEST_FAIL_CAPTURE")
+    for _ in range(7):
+        b.step()
+    torch.cuda.synchronize()
+    assert not a._graphs and "capture refused" in a._graph_error
+    assert a.time == b.time and a.dt == b.dt and a.nstep == b.nstep == 7
+    assert torch.equal(a.S_new_b, b.S_new_b)
+    a.run_steps(6)                                  # and the next batch captures
+    for _ in range(6):
+        b.step()
+    torch.cuda.synchronize()
+    assert a._graphs and torch.equal(a.S_new_b, b.S_new_b)
+
+
+@pytest.mark.parametrize("bc", [((2, 2, 2), (2, 2, 2)), ((3, 4, 2), (5, 2, 3)), ((0, 3, 2), (0, 2, 4))])
+@pytest.mark.parametrize("sb_clean", [0, 2])
+def test_boundary_fill_inside_the_hydro_call(hip, bc, sb_clean):
+    """CASTRO_AMD_BC_FILL / CASTRO_AMD_STAGE_VALID + _REST: a call that fills the physical-boundary zones of Sborder itself
+    (k_ctoprim_bc: outflow clamps and wall mirror images of zones it has cleaned already) gives the bits of castro_amd_bc_fill_fab
+    followed by the plain call -- every output array and Sborder itself -- whole and split into the valid / rest stages (the
+    bc_fill + call form is what the oracle comparisons of this file pin)."""
+    import torch
+    import castro_amd
+    from castro_amd import _lib as L
+    from tests.util import physical_state
+    rng = np.random.default_rng(11)
+    n = (20, 12, 9)
+    lo_bc, hi_bc = bc
+    G = castro_amd.make_geom(n, (0., 0., 0.), (1., 0.6, 0.45), lo_bc, hi_bc)
+    bxlo, bxhi = (0, 0, 0), tuple(x - 1 for x in n)
+    sb_lo, sb_hi = tuple(x - 4 for x in bxlo), tuple(x + 4 for x in bxhi)
+    U = physical_state(rng, sb_lo, sb_hi, smooth=False, vel=1.2)
+    U[7] = U[0] * rng.uniform(0.9, 1.0, size=U[0].shape)            # clean_state has something to do
+    P = castro_amd.default_params(small_dens=0.5) if sb_clean else castro_amd.default_params()     # clean_state has to floor densities
+    res = {}
+    for form in ("bc_fill_then_call", "call_fills", "valid_then_rest"):
+        Ud = _to_dev(hip, U)
+        Sn = hip.alloc(8, bxlo, bxhi)
+        fl, ms, fboxes = [], [], []
+        for d in range(3):
+            fhi = list(bxhi); fhi[d] += 1
+            fboxes.append((bxlo, tuple(fhi)))
+            fl.append(hip.alloc(8, bxlo, fhi)); ms.append(hip.alloc(1, bxlo, fhi))
+        red = torch.full((3,), 1.e200, dtype=torch.float64, device=Ud.device)
+        kw = dict(fluxes=fl, flux_boxes=fboxes, mass_fluxes=ms, update_from_sborder=True, flux_assign=True, clean_ntimes=1, red=red)
+        args = ((bxlo, bxhi), Ud, (sb_lo, sb_hi), Sn, (bxlo, bxhi), G, P, 0.0, 6e-4)
+        if form == "bc_fill_then_call":
+            hip.bc_fill(Ud, (sb_lo, sb_hi), G)
+            hip.construct_ctu_hydro_source(*args, sborder_clean=sb_clean, **kw)
+        elif form == "call_fills":
+            hip.construct_ctu_hydro_source(*args, sborder_clean=sb_clean, bc_fill=True, **kw)
+        else:
+            hip.construct_ctu_hydro_source(*args, sborder_clean=sb_clean, stage="valid", **kw)
+            hip.construct_ctu_hydro_source(*args, sborder_clean=sb_clean, stage="rest", bc_fill=True, **kw)
+        torch.cuda.synchronize()
+        assert hip.status() == 0
+        res[form] = [Sn.cpu().numpy(), Ud.cpu().numpy(), red.cpu().numpy()] + [f.cpu().numpy() for f in fl + ms]
+    for form in ("call_fills", "valid_then_rest"):
+        for a, b in zip(res["bc_fill_then_call"], res[form]):
+            assert np.array_equal(a, b), form
+    # a mirrored ghost layer deeper than the box: refused, not mis-filled
+    if any(k >= 3 for k in lo_bc + hi_bc):
+        thin = (3, 12, 9) if (lo_bc[0] >= 3 or hi_bc[0] >= 3) else ((20, 3, 9) if (lo_bc[1] >= 3 or hi_bc[1] >= 3) else (20, 12, 3))
+        Gt = castro_amd.make_geom(thin, (0., 0., 0.), (1., 1., 1.), lo_bc, hi_bc)
+        tlo, thi = (0, 0, 0), tuple(x - 1 for x in thin)
+        glo, ghi = tuple(x - 4 for x in tlo), tuple(x + 4 for x in thi)
+        Ut, St = _to_dev(hip, physical_state(rng, glo, ghi)), hip.alloc(8, tlo, thi)
+        with pytest.raises(RuntimeError):
+            hip.construct_ctu_hydro_source((tlo, thi), Ut, (glo, ghi), St, (tlo, thi), Gt, P, 0.0, 1e-4, bc_fill=True,
+                                           update_from_sborder=True)
 
 
 def test_step_graph_is_rebuilt_when_a_baked_parameter_changes():
@@ -1214,7 +1303,8 @@ def _rccl_worker(rank, world, port, out_path):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     try:
-        c = castro_amd.Castro((24, 16, 32), comm=castro_amd.DistComm(), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
+        c = castro_amd.Castro((24, 16, 32), comm=castro_amd.DistComm(), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2),
+                              overlap=os.environ.get("CASTRO_AMD_TEST_OVERLAP") == "1")
         c.initData("sedov", r_init=0.1, nsub=4)
         dts = [c.step(0.01) for _ in range(3)]
         # host-free steps with the RCCL communicator: the all_reduce(MIN) is enqueued on the device, no host read per step
@@ -1238,7 +1328,7 @@ def _rccl_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("halo", ["c_abi", "c_abi_self_send", "c_abi_self_send_stream_form", "torch"])
+@pytest.mark.parametrize("halo", ["c_abi", "c_abi_self_send", "c_abi_self_send_overlap", "c_abi_self_send_stream_form", "torch", "torch_overlap"])
 def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
     """halo: who issues the exchange -- castro_amd_fill_boundary of the C ABI (round 4: ncclSend / ncclRecv from the kernel
     library on its own communicator; `self_send`: the periodic wraps onto this rank travel through RCCL as well, so the
@@ -1252,17 +1342,20 @@ def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
     import castro_amd
     from tests.test_driver_cpu import _free_port
     out = str(tmp_path / "rccl.npz")
-    monkeypatch.setenv("CASTRO_AMD_C_HALO", "0" if halo == "torch" else "1")
+    monkeypatch.setenv("CASTRO_AMD_C_HALO", "0" if halo.startswith("torch") else "1")
     monkeypatch.setenv("CASTRO_AMD_HALO_SELF_SEND", "1" if halo.startswith("c_abi_self_send") else "0")
     monkeypatch.setenv("CASTRO_AMD_STEP_GRAPH_RCCL", "0" if halo.endswith("stream_form") else "1")
+    # `overlap`: the light split of round 6 -- the exchange on the communication stream beside ctoprim on the valid zones -- inside
+    # the per-rank graph (two streams, the plan's "packed" event and the RCCL group captured together)
+    monkeypatch.setenv("CASTRO_AMD_TEST_OVERLAP", "1" if halo.endswith("overlap") else "0")
     mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
     monkeypatch.setenv("CASTRO_AMD_C_HALO", "0")
     got = np.load(out)
-    assert str(got["halo_path"]) == ("torch" if halo == "torch" else "c_abi")
+    assert str(got["halo_path"]) == ("torch" if halo.startswith("torch") else "c_abi")
     # round 5: with the collectives issued by the kernel library (halo exchange AND all-reduce on its own RCCL communicator) the
     # host-free batch is a per-rank hipGraph of a pair of steps that CONTAINS the ncclSend / ncclRecv group and the
     # ncclAllReduce -- with self-send the point-to-point calls really are inside the captured graph; same bits as the stream form
-    assert bool(got["graphed"]) == (halo in ("c_abi", "c_abi_self_send")), str(got["graph_error"])
+    assert bool(got["graphed"]) == (halo in ("c_abi", "c_abi_self_send", "c_abi_self_send_overlap")), str(got["graph_error"])
     c = castro_amd.Castro((24, 16, 32), lo_bc=(0, 2, 2), hi_bc=(0, 2, 2), overlap=False)
     c.initData("sedov", r_init=0.1, nsub=4)
     dts = [c.step(0.01) for _ in range(7)]
@@ -1454,7 +1547,7 @@ def _two_rank_gpu_worker(rank, world, port, n, nsteps, out_path, overlap, bc=(0,
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap,bc", [(2, False, (0, 2, 2)), (2, True, (0, 2, 2)), (8, False, (0, 2, 2)),
+@pytest.mark.parametrize("world,overlap,bc", [(2, False, (0, 2, 2)), (2, True, (0, 2, 2)), (2, "staged", (0, 2, 2)), (4, True, (2, 2, 2)), (8, False, (0, 2, 2)),
                                               (2, False, (2, 2, 2)), (4, False, (2, 2, 2)), (8, False, (2, 2, 2)), (8, True, (2, 4, 3))])
 def test_two_ranks_sharing_one_gpu_equal_one_rank(tmp_path, world, overlap, bc):
     """The N > 1 device path end to end (device pack -> inter-process exchange -> device unpack -> BC fill -> hydro,
