@@ -124,6 +124,9 @@ class _Level:
         self.fuse_clean = b0.fuse_clean
         self.nsubcycles, self.nretries, self.last_failure = 0, 0, ""
         self.time, self.nstep = 0.0, 0
+        # castro.source_term_predictor: Castro::lastDt of this level (1e200 in every constructor, Castro.cpp:906 -- a level made
+        # by a regrid starts with it again) and the in_retry flag of subcycle_advance_ctu
+        self.lastDt, self._in_retry = 1.e200, False
 
     def __getattr__(self, name):
         # a level of one box answers for its box (S_new(), lo, hi, n, gbox, S_new_b, ...)
@@ -357,9 +360,28 @@ class _Level:
             h.copy(b.new_source_g, b.sbox, b.new_source, b.bx, b.lo, b.hi)
         self.fill_source("new_source_g")
 
+    def create_source_corrector(self):
+        """Castro::create_source_corrector on a level of boxes (Castro.cpp:3780-3818): AmrLevel::FillPatch(Source_Type at its old
+        time -- after the swap that is the new-time corrector of the LAST advance --, components UMX .. UMZ, NUM_GROW_SRC ghost
+        zones): the valid zones of every box from its own data, ghost zones from the other boxes of the level, from the coarser
+        level's Source_Type data interpolated in time and space (the FillPatch of fill_source) and from the physical boundaries;
+        then x 2 / lastDt.  The factor dt / 2 is applied in src_to_prim (Castro_ctu.cpp:493-497)."""
+        g = 3                                   # NUM_GROW_SRC
+        for b in self.mine:
+            c, n = b.source_corrector, b.n
+            c.zero_()
+            c[1:4, g:g + n[2], g:g + n[1], g:g + n[0]] = b.new_source[1:4]
+        self.fill_source("source_corrector")
+        for b in self.mine:
+            c = b.source_corrector
+            c[0].zero_()                        # the FillPatch of the reference moves the three momentum components only
+            c[4:].zero_()
+            c.mul_(2.0 / self.lastDt)
+
     def _advance_with_sources(self, time, dt):
-        if self.params.source_term_predictor == 1:
-            raise NotImplementedError("castro.source_term_predictor = 1 is built for single-level runs (castro_amd.Castro)")
+        if self.params.source_term_predictor == 1 and not self._in_retry:
+            # not on the attempt that follows a rejected one: the data it is made from are gone by then (Castro_advance_ctu.cpp:60-62)
+            self.create_source_corrector()
         return self._advance_with_sources_impl(time, dt)
 
     def _advance_with_sources_impl(self, time, dt):
@@ -381,8 +403,16 @@ class _Level:
                 h.saxpy(b.S_new_b, b.gbox, dt, b.old_source, b.sbox, NSRC, lo, hi)
                 h.clean_state(b.S_new_b, b.gbox, lo, hi, b.params, ntimes=1)
         self.fill_source("old_source")
+        predictor = self.params.source_term_predictor == 1
         def hydro(b):
-            b.construct_ctu_hydro_source(time, dt, src=b.old_source)
+            # b.hydro is the context this box's call runs on (one of the stream pool's, _hydro_calls)
+            if predictor:
+                b.hydro.set_source_corrector(b.source_corrector, b.sbox)
+            try:
+                b.construct_ctu_hydro_source(time, dt, src=b.old_source)
+            finally:
+                if predictor:
+                    b.hydro.set_source_corrector(None, None)      # the context must not keep a pointer into this box's tensor
             b._flux_clear = False
         self._hydro_calls(hydro)
         for b in self.mine:

@@ -215,20 +215,24 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     if (hipMalloc(&c->d_status, sizeof(int)) != hipSuccess) { delete c; return CASTRO_AMD_ERR_NOMEM; }
     hipMemset(c->d_status, 0, sizeof(int));
     if (hipHostMalloc(&c->h_status, sizeof(int)) != hipSuccess) { hipFree(c->d_status); delete c; return CASTRO_AMD_ERR_NOMEM; }
-    if (const char* e = std::getenv("CASTRO_AMD_TILE_ROWS")) g_tile_rows = std::atoi(e);   // tuning knob, see ctu_kernels.hip
-    if (const char* e = std::getenv("CASTRO_AMD_FUSED_TILE_ROWS")) g_fused_tile_rows = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_FUSE_CONSUP")) g_fuse_consup = std::atoi(e);   // 0: k_final<x> + k_consup
-    if (const char* e = std::getenv("CASTRO_AMD_TRACE_TILE_ROWS")) g_trace_tile_rows = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_XPAD")) g_xpad = std::atoi(e);             // unused columns in front of every scratch row
-    if (const char* e = std::getenv("CASTRO_AMD_SIDE_STREAM")) g_side_stream = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_FOLD_R1")) g_fold_r1 = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE_ROWS")) g_fold_tile_rows = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_FOLD_TILE")) g_fold_tile = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_FINAL_TILE")) g_final_tile = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_GL_SOURCES")) g_gl_sources = std::atoi(e);
-    if (const char* e = std::getenv("CASTRO_AMD_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_wg = v; }
-    if (const char* e = std::getenv("CASTRO_AMD_FUSED_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_fused_wg = v; }
-    if (const char* e = std::getenv("CASTRO_AMD_FINAL_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) g_final_wg = v; }
+    // tuning knobs (ctu_kernels.hip), process-wide, read afresh by every context creation: a variable that is not set puts its
+    // knob back to the default (until round 6 a knob kept the last value it had been given, so "unset" did not undo "set")
+    auto knob = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    auto wg_knob = [&](const char* name, int dflt) { const int v = knob(name, dflt); return (v == 64 || v == 128 || v == 256) ? v : dflt; };
+    g_tile_rows = knob("CASTRO_AMD_TILE_ROWS", 32);
+    g_fused_tile_rows = knob("CASTRO_AMD_FUSED_TILE_ROWS", 16);
+    g_fuse_consup = knob("CASTRO_AMD_FUSE_CONSUP", 1);                 // 0: k_final<x> + k_consup
+    g_trace_tile_rows = knob("CASTRO_AMD_TRACE_TILE_ROWS", 64);
+    g_xpad = knob("CASTRO_AMD_XPAD", 0);                               // unused columns in front of every scratch row
+    g_side_stream = knob("CASTRO_AMD_SIDE_STREAM", 0);
+    g_fold_r1 = knob("CASTRO_AMD_FOLD_R1", 2);
+    g_fold_tile_rows = knob("CASTRO_AMD_FOLD_TILE_ROWS", -1);
+    g_fold_tile = knob("CASTRO_AMD_FOLD_TILE", -1);
+    g_final_tile = knob("CASTRO_AMD_FINAL_TILE", 0);
+    g_gl_sources = knob("CASTRO_AMD_GL_SOURCES", 1);
+    g_wg = wg_knob("CASTRO_AMD_WG", 256);
+    g_fused_wg = wg_knob("CASTRO_AMD_FUSED_WG", 128);
+    g_final_wg = wg_knob("CASTRO_AMD_FINAL_WG", 0);
     if (g_side_stream) {
         if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||

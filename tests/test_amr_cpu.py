@@ -449,6 +449,42 @@ def test_source_fillpatch_of_a_refined_level(oracle):
             assert np.abs(got[n] - want).max() <= 1e-13 * np.abs(want).max()
 
 
+def test_source_term_predictor_on_refined_levels(oracle):
+    """castro.source_term_predictor = 1 with AMR (round 6; Castro::create_source_corrector, Castro.cpp:3780-3818, on every level:
+    the FillPatch of the last advance's new-time momentum sources x 2 / lastDt).  Level 1 in one box or in two gives the same
+    bits (the corrector's ghost zones then come from the neighbour box and from both parents), the predictor changes the
+    solution, and a single-level CastroAmr equals castro_amd.Castro with the predictor."""
+    import castro_amd
+    kw = dict(make_hydro=OracleBackend, do_grav=True, const_grav=-3.0, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0))
+    P = lambda pred: oracle.default_params(init_shrink=0.1, source_term_predictor=pred)
+    l2 = ((12, 12, 12), (19, 19, 19))
+    one = castro_amd.CastroAmr((16, 16, 16), params=P(1), patches=[((4, 4, 4), (11, 11, 11)), l2], **kw)
+    two = castro_amd.CastroAmr((16, 16, 16), params=P(1), patches=[[((4, 4, 4), (11, 7, 11)), ((4, 8, 4), (11, 11, 11))], l2], **kw)
+    off = castro_amd.CastroAmr((16, 16, 16), params=P(0), patches=[((4, 4, 4), (11, 11, 11)), l2], **kw)
+    for a in (one, two, off):
+        a.initData("sedov", r_init=0.08, nsub=4)
+    for _ in range(5):
+        dt = one.step(0.05)
+        assert dt == two.step(0.05)
+        off.step(0.05)
+    assert np.array_equal(two.crse.S_new().numpy(), one.crse.S_new().numpy())
+    assert np.array_equal(_assemble(two.levels[1], (8, 8, 8), (16, 16, 16)), one.levels[1].S_new().numpy())
+    assert np.array_equal(two.levels[2].S_new().numpy(), one.levels[2].S_new().numpy())
+    for l in range(3):
+        assert one.levels[l].lastDt < 1.0                                   # Castro::lastDt of every level is the last advance's dt
+        c = one.levels[l].boxes[0].source_corrector.numpy()
+        assert np.abs(c[3]).max() > 0.0 and not c[0].any() and not c[4:].any()      # momentum components only
+    assert not np.array_equal(one.levels[2].S_new().numpy(), off.levels[2].S_new().numpy())
+    # one level: the AMR driver with the predictor is the single-level driver with the predictor
+    flat = castro_amd.CastroAmr((16, 16, 16), params=P(1), patches=[], **kw)
+    ref = castro_amd.Castro((16, 16, 16), params=P(1), hydro=OracleBackend(), do_grav=True, const_grav=-3.0, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0))
+    for a in (flat, ref):
+        a.initData("sedov", r_init=0.08, nsub=4)
+    for _ in range(5):
+        assert flat.step(0.05) == ref.step(0.05)
+    assert np.array_equal(flat.crse.S_new().numpy(), ref.S_new().numpy())
+
+
 def test_gravity_and_rotation_on_refined_levels(oracle):
     """Constant gravity and rotation on three levels: level 1 in one box or in two (the Source_Type ghost zones of a box
     then come from its neighbour and from both parents) -- bit for bit the same; mass is conserved, the momentum gained
@@ -741,10 +777,11 @@ def test_base_level_cut_into_boxes_is_bitwise_identical(oracle, case):
             assert np.array_equal(x.S_new().numpy(), y.S_new().numpy()), (l, x.bx)
 
 
-def _mr_grav_run(comm, nsteps, base_grid):
+def _mr_grav_run(comm, nsteps, base_grid, predictor=0):
     import castro_amd
     from oracle import oracle_lib as O
-    a = castro_amd.CastroAmr((16, 16, 16), patches=_MR_PATCHES, params=O.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+    a = castro_amd.CastroAmr((16, 16, 16), patches=_MR_PATCHES, params=O.default_params(init_shrink=0.1, source_term_predictor=predictor),
+                             make_hydro=OracleBackend,
                              do_grav=True, const_grav=-2.0, lo_bc=(2, 2, 4), hi_bc=(2, 2, 4), comm=comm, base_grid=base_grid,
                              rotation=castro_amd.make_rotation(3.0, rot_axis=3, center=(0.5, 0.5, 0.5)))
     a.initData("sedov", r_init=0.1, nsub=4)
@@ -752,7 +789,7 @@ def _mr_grav_run(comm, nsteps, base_grid):
     return a, dts
 
 
-def _mr_grav_worker(rank, world, port, nsteps, base_grid, out_path):
+def _mr_grav_worker(rank, world, port, nsteps, base_grid, out_path, predictor=0):
     import pickle
     import torch.distributed as dist
     import castro_amd
@@ -761,7 +798,7 @@ def _mr_grav_worker(rank, world, port, nsteps, base_grid, out_path):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        a, dts = _mr_grav_run(castro_amd.DistComm(), nsteps, base_grid)
+        a, dts = _mr_grav_run(castro_amd.DistComm(), nsteps, base_grid, predictor)
         levels = [a.gather_level(l) for l in range(len(a.lev))]
         if rank == 0:
             pickle.dump(dict(dts=dts, data=[[(bx, arr) for bx, arr in lv] for lv in levels]), open(out_path, "wb"))
@@ -769,17 +806,18 @@ def _mr_grav_worker(rank, world, port, nsteps, base_grid, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,base_grid", [(2, None), (3, (2, 2, 2))])
-def test_amr_with_sources_and_boxes_spread_over_ranks_gloo(tmp_path, oracle, world, base_grid):
+@pytest.mark.parametrize("world,base_grid,predictor", [(2, None, 0), (3, (2, 2, 2), 0), (3, (2, 2, 2), 1)])
+def test_amr_with_sources_and_boxes_spread_over_ranks_gloo(tmp_path, oracle, world, base_grid, predictor):
     """Constant gravity and rotation on three levels with the boxes (and, with base_grid, level 0 too) dealt over ranks:
     the Source_Type FillPatch of a refined level -- coarse sources interpolated in time and space, the siblings' sources --
-    goes through the staged transfers like the state.  dt sequence and every box equal the one-rank run bit for bit."""
+    goes through the staged transfers like the state (predictor = 1: so does the FillPatch of Castro::source_corrector).  dt
+    sequence and every box equal the one-rank run bit for bit."""
     import pickle
     nsteps = 4
     out = str(tmp_path / "amr_grav_ranks.pkl")
-    mp.spawn(_mr_grav_worker, args=(world, _free_port(), nsteps, base_grid, out), nprocs=world, join=True)
+    mp.spawn(_mr_grav_worker, args=(world, _free_port(), nsteps, base_grid, out, predictor), nprocs=world, join=True)
     got = pickle.load(open(out, "rb"))
-    a, dts = _mr_grav_run(None, nsteps, base_grid)
+    a, dts = _mr_grav_run(None, nsteps, base_grid, predictor)
     assert got["dts"] == dts
     for l, lev in enumerate(a.lev):
         assert [bx for bx, _ in got["data"][l]] == [b.bx for b in lev.boxes]

@@ -1860,10 +1860,11 @@ def test_amr_with_gravity_and_rotation_on_the_device_matches_oracle_backend(orac
     from tests.oracle_backend import OracleBackend
     kw = dict(patches=[[((4, 4, 0), (11, 7, 7)), ((4, 8, 0), (11, 11, 7)), ((4, 4, 12), (11, 11, 15))], ((12, 10, 4), (19, 19, 11))],
               lo_bc=(2, 4, 0), hi_bc=(3, 2, 0), do_grav=True, const_grav=-3.0)
-    for gst, rst in ((4, 4), (2, 1)):
-        a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1), grav_source_type=gst,
+    # the third case: castro.source_term_predictor = 1 on every level (round 6: create_source_corrector of a level of boxes)
+    for gst, rst, pred in ((4, 4, 0), (2, 1, 0), (4, 4, 1)):
+        a = castro_amd.CastroAmr((16, 16, 16), params=castro_amd.default_params(init_shrink=0.1, source_term_predictor=pred), grav_source_type=gst,
                                  rotation=castro_amd.make_rotation(20.0, 3, rot_source_type=rst), **kw)
-        b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1), make_hydro=OracleBackend,
+        b = castro_amd.CastroAmr((16, 16, 16), params=oracle.default_params(init_shrink=0.1, source_term_predictor=pred), make_hydro=OracleBackend,
                                  grav_source_type=gst, rotation=oracle.make_rotation(20.0, 3, rot_source_type=rst), **kw)
         for x in (a, b):
             x.initData("sedov", r_init=0.12, nsub=4)
@@ -1874,8 +1875,11 @@ def test_amr_with_gravity_and_rotation_on_the_device_matches_oracle_backend(orac
         for l in range(3):
             for i, (x, y) in enumerate(zip(a.levels[l].boxes, b.levels[l].boxes)):
                 pairs["L%d box %d" % (l, i)] = (x.S_new().cpu().numpy(), y.S_new().numpy())
-        _assert_exact(pairs, "AMR with sources (grav_source_type %d, rot_source_type %d)" % (gst, rst))
+        _assert_exact(pairs, "AMR with sources (grav_source_type %d, rot_source_type %d, predictor %d)" % (gst, rst, pred))
         assert np.abs(pairs["L2 box 0"][0][3]).max() > 1e-6
+        if pred:
+            assert all(torch.equal(x.source_corrector.cpu(), y.source_corrector) and x.source_corrector[3].abs().max() > 0
+                       for l in range(3) for x, y in zip(a.levels[l].boxes, b.levels[l].boxes))
 
 
 def test_three_level_amr_on_the_device_matches_oracle_backend(oracle):
