@@ -59,6 +59,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_comm_version", "castro_amd_comm_unique_id", "castro_amd_comm_create", "castro_amd_comm_adopt", "castro_amd_comm_rank",
     "castro_amd_comm_size", "castro_amd_comm_destroy", "castro_amd_halo_plan_create", "castro_amd_halo_plan_destroy",
     "castro_amd_halo_plan_bytes_sent", "castro_amd_fill_boundary", "castro_amd_fill_boundary_ex", "castro_amd_halo_plan_wait_packed",
+    "castro_amd_halo_group_create", "castro_amd_halo_group_destroy", "castro_amd_halo_group_bytes_sent", "castro_amd_fill_boundary_group",
     "castro_amd_allreduce_min",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
@@ -79,6 +80,11 @@ class HaloRegion(C.Structure):
     """castro_amd_halo_region"""
     _fields_ = [("peer", C.c_int), ("sbox_lo", C.c_int * 3), ("sbox_hi", C.c_int * 3), ("rbox_lo", C.c_int * 3),
                 ("rbox_hi", C.c_int * 3), ("send_tag", C.c_int), ("recv_tag", C.c_int)]
+
+
+class HaloMsg(C.Structure):
+    """castro_amd_halo_msg: one send or one receive of a many-box exchange (castro_amd_halo_group_create)"""
+    _fields_ = [("fab", C.c_int), ("peer", C.c_int), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("tag", C.c_int)]
 
 
 class HydroOpts(C.Structure):
@@ -251,6 +257,12 @@ def load(numerics=None):
         L.castro_amd_fill_boundary.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_void_p]
         L.castro_amd_fill_boundary_ex.argtypes = [C.c_void_p, C.c_void_p, PF, C.POINTER(Geom), C.c_int, C.c_void_p]
         L.castro_amd_halo_plan_wait_packed.argtypes = [C.c_void_p, C.c_void_p]
+        L.castro_amd_halo_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.POINTER(HaloMsg), C.c_int,
+                                                   C.POINTER(HaloMsg), C.c_int]
+        L.castro_amd_halo_group_destroy.argtypes = [C.c_void_p]
+        L.castro_amd_halo_group_bytes_sent.argtypes = [C.c_void_p]
+        L.castro_amd_halo_group_bytes_sent.restype = C.c_longlong
+        L.castro_amd_fill_boundary_group.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Fab), C.POINTER(Geom), C.c_void_p]
         L.castro_amd_allreduce_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.castro_amd_ctx_profile.argtypes = [C.c_void_p, C.c_int]
     L.castro_amd_ctx_profile_count.argtypes = [C.c_void_p]

@@ -354,4 +354,190 @@ static int fill_boundary_impl(castro_amd_ctx* ctx, castro_amd_halo_plan* p, cons
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Many boxes per rank (round 6): one grouped exchange for SEVERAL FABs of a level -- an AMR level, or two boxes per GPU.  Sends and
+// receives are separate lists (with boxes of unequal size the zones a box sends to a neighbour and those it receives from it
+// differ in shape); a message is identified by its tag, which both ends derive from (source box, destination box, periodic
+// shift), so the k-th send of rank A to rank B in tag order IS the k-th receive of B from A in tag order.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct castro_amd_halo_group {
+    castro_amd_comm* comm = nullptr;
+    int ncomp = 0, nfab = 0, self_send = 0;
+    struct Msg { int fab, peer, tag; int lo[3], hi[3]; long long off, count; bool local; };
+    std::vector<Msg> sends, recvs;              // off: doubles into sbuf (sends) / into rbuf -- or, local, into sbuf -- (recvs)
+    std::vector<int> send_order, recv_order;    // the remote ones by (peer, tag)
+    // per FAB, in chunks of <= CASTRO_AMD_MAX_REGIONS regions: pack, unpack from sbuf (local), unpack from rbuf (remote)
+    struct Chunk { int fab; std::vector<int> lo, hi; std::vector<long long> off; };
+    std::vector<Chunk> pack, unpack_local, unpack_remote;
+    double* sbuf = nullptr;
+    double* rbuf = nullptr;
+    long long stotal = 0, rtotal = 0;
+};
+
+static void group_chunks(const std::vector<castro_amd_halo_group::Msg>& msgs, int nfab, bool want_local, bool any,
+                         std::vector<castro_amd_halo_group::Chunk>& out)
+{
+    for (int f = 0; f < nfab; ++f) {
+        castro_amd_halo_group::Chunk c;
+        c.fab = f;
+        auto flush = [&]() { if (!c.off.empty()) { out.push_back(c); c.lo.clear(); c.hi.clear(); c.off.clear(); } };
+        for (const auto& m : msgs) {
+            if (m.fab != f || (!any && m.local != want_local)) continue;
+            for (int d = 0; d < 3; ++d) { c.lo.push_back(m.lo[d]); c.hi.push_back(m.hi[d]); }
+            c.off.push_back(m.off);
+            if ((int)c.off.size() == CASTRO_AMD_MAX_REGIONS) flush();
+        }
+        flush();
+    }
+}
+
+int castro_amd_halo_group_create(castro_amd_halo_group** out, castro_amd_comm* comm, int nfabs, int nsends, const castro_amd_halo_msg* sends,
+                                 int nrecvs, const castro_amd_halo_msg* recvs, int ncomp)
+{
+    if (!out || !comm || nfabs < 1 || nsends < 0 || nrecvs < 0 || (nsends > 0 && !sends) || (nrecvs > 0 && !recvs) || ncomp < 1) return CASTRO_AMD_ERR_ARG;
+    castro_amd_halo_group* g = new (std::nothrow) castro_amd_halo_group();
+    if (!g) return CASTRO_AMD_ERR_NOMEM;
+    g->comm = comm; g->ncomp = ncomp; g->nfab = nfabs;
+    if (const char* e = std::getenv("CASTRO_AMD_HALO_SELF_SEND")) g->self_send = std::atoi(e);
+    auto take = [&](const castro_amd_halo_msg& m, castro_amd_halo_group::Msg& o) {
+        if (m.fab < 0 || m.fab >= nfabs || m.peer < 0 || m.peer >= comm->size) return false;
+        o.fab = m.fab; o.peer = m.peer; o.tag = m.tag; o.count = ncomp;
+        for (int d = 0; d < 3; ++d) {
+            if (m.hi[d] < m.lo[d]) return false;
+            o.lo[d] = m.lo[d]; o.hi[d] = m.hi[d];
+            o.count *= m.hi[d] - m.lo[d] + 1;
+        }
+        o.local = m.peer == comm->rank && !g->self_send;
+        o.off = 0;
+        return true;
+    };
+    long long off = 0;
+    for (int i = 0; i < nsends; ++i) {
+        castro_amd_halo_group::Msg m;
+        if (!take(sends[i], m)) { delete g; return CASTRO_AMD_ERR_ARG; }
+        m.off = off; off += m.count;
+        g->sends.push_back(m);
+    }
+    g->stotal = off;
+    off = 0;
+    for (int i = 0; i < nrecvs; ++i) {
+        castro_amd_halo_group::Msg m;
+        if (!take(recvs[i], m)) { delete g; return CASTRO_AMD_ERR_ARG; }
+        if (m.local) {
+            // a copy between two boxes of this rank (or a periodic wrap onto the same box): read from where the matching send was packed
+            int src = -1;
+            for (int q = 0; q < (int)g->sends.size(); ++q) if (g->sends[q].local && g->sends[q].tag == m.tag) { src = q; break; }
+            if (src < 0 || g->sends[src].count != m.count) { delete g; return CASTRO_AMD_ERR_ARG; }
+            m.off = g->sends[src].off;
+        } else {
+            m.off = off; off += m.count;
+        }
+        g->recvs.push_back(m);
+    }
+    g->rtotal = off;
+    for (int i = 0; i < (int)g->sends.size(); ++i) if (!g->sends[i].local) g->send_order.push_back(i);
+    for (int i = 0; i < (int)g->recvs.size(); ++i) if (!g->recvs[i].local) g->recv_order.push_back(i);
+    std::sort(g->send_order.begin(), g->send_order.end(), [&](int a, int b) {
+        return g->sends[a].peer != g->sends[b].peer ? g->sends[a].peer < g->sends[b].peer : g->sends[a].tag < g->sends[b].tag; });
+    std::sort(g->recv_order.begin(), g->recv_order.end(), [&](int a, int b) {
+        return g->recvs[a].peer != g->recvs[b].peer ? g->recvs[a].peer < g->recvs[b].peer : g->recvs[a].tag < g->recvs[b].tag; });
+    // two messages of one pair of ranks with one tag would be matched arbitrarily: refuse
+    for (size_t i = 1; i < g->send_order.size(); ++i) {
+        const auto &a = g->sends[g->send_order[i - 1]], &b = g->sends[g->send_order[i]];
+        if (a.peer == b.peer && a.tag == b.tag) { delete g; return CASTRO_AMD_ERR_ARG; }
+    }
+    for (size_t i = 1; i < g->recv_order.size(); ++i) {
+        const auto &a = g->recvs[g->recv_order[i - 1]], &b = g->recvs[g->recv_order[i]];
+        if (a.peer == b.peer && a.tag == b.tag) { delete g; return CASTRO_AMD_ERR_ARG; }
+    }
+    group_chunks(g->sends, nfabs, false, true, g->pack);
+    group_chunks(g->recvs, nfabs, true, false, g->unpack_local);
+    group_chunks(g->recvs, nfabs, false, false, g->unpack_remote);
+    if (hipSetDevice(comm->device) != hipSuccess) { delete g; return CASTRO_AMD_ERR_HIP; }
+    if (hipMalloc(&g->sbuf, (size_t)std::max<long long>(g->stotal, 1) * sizeof(double)) != hipSuccess ||
+        hipMalloc(&g->rbuf, (size_t)std::max<long long>(g->rtotal, 1) * sizeof(double)) != hipSuccess) {
+        if (g->sbuf) hipFree(g->sbuf);
+        delete g;
+        return CASTRO_AMD_ERR_NOMEM;
+    }
+    *out = g;
+    return CASTRO_AMD_OK;
+}
+
+int castro_amd_halo_group_destroy(castro_amd_halo_group* g)
+{
+    if (!g) return CASTRO_AMD_OK;
+    if (g->sbuf) hipFree(g->sbuf);
+    if (g->rbuf) hipFree(g->rbuf);
+    delete g;
+    return CASTRO_AMD_OK;
+}
+
+long long castro_amd_halo_group_bytes_sent(const castro_amd_halo_group* g)
+{
+    if (!g) return 0;
+    long long n = 0;
+    for (int i : g->send_order) n += g->sends[i].count * (long long)sizeof(double);
+    return n;
+}
+
+int castro_amd_fill_boundary_group(castro_amd_ctx* ctx, castro_amd_halo_group* g, const castro_amd_fab* states,
+                                   const castro_amd_geom* geom, void* stream)
+{
+    if (!ctx || !g || !states) return CASTRO_AMD_ERR_ARG;
+    if (hipSetDevice(g->comm->device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<DFab> f((size_t)g->nfab);
+    for (int i = 0; i < g->nfab; ++i) {
+        const castro_amd_fab& st = states[i];
+        if (!st.p || st.ncomp != g->ncomp) return CASTRO_AMD_ERR_ARG;
+        const long nx = st.hi[0] - st.lo[0] + 1, ny = st.hi[1] - st.lo[1] + 1, nz = st.hi[2] - st.lo[2] + 1;
+        f[(size_t)i].p = st.p;
+        for (int d = 0; d < 3; ++d) f[(size_t)i].lo[d] = st.lo[d];
+        f[(size_t)i].sy = nx; f[(size_t)i].sz = nx * ny; f[(size_t)i].sn = nx * ny * nz;
+    }
+    auto inside = [&](const castro_amd_halo_group::Msg& m) {
+        for (int d = 0; d < 3; ++d) if (m.lo[d] < states[m.fab].lo[d] || m.hi[d] > states[m.fab].hi[d]) return false;
+        return true;
+    };
+    for (const auto& m : g->sends) if (!inside(m)) return CASTRO_AMD_ERR_ARG;
+    for (const auto& m : g->recvs) if (!inside(m)) return CASTRO_AMD_ERR_ARG;
+    int rc = CASTRO_AMD_OK;
+    for (const auto& c : g->pack) {
+        rc = launch_pack_regions(f[(size_t)c.fab], (int)c.off.size(), c.lo.data(), c.hi.data(), c.off.data(), g->ncomp, g->sbuf, 0, s, nullptr);
+        if (rc != CASTRO_AMD_OK) return rc;
+    }
+    if (!g->send_order.empty() || !g->recv_order.empty()) {
+        const Rccl* R = rccl();
+        if (!R) return CASTRO_AMD_ERR_UNSUPPORTED;
+        int e = R->GroupStart();
+        for (int i : g->recv_order)
+            if (e == ncclSuccess) e = R->Recv(g->rbuf + g->recvs[i].off, (size_t)g->recvs[i].count, ncclFloat64, g->recvs[i].peer, g->comm->comm, s);
+        for (int i : g->send_order)
+            if (e == ncclSuccess) e = R->Send(g->sbuf + g->sends[i].off, (size_t)g->sends[i].count, ncclFloat64, g->sends[i].peer, g->comm->comm, s);
+        const int e2 = R->GroupEnd();
+        if ((rc = nccl_check(R, e != ncclSuccess ? e : e2, "ncclSend/ncclRecv group")) != CASTRO_AMD_OK) return rc;
+    }
+    for (const auto& c : g->unpack_local) {
+        rc = launch_pack_regions(f[(size_t)c.fab], (int)c.off.size(), c.lo.data(), c.hi.data(), c.off.data(), g->ncomp, g->sbuf, 1, s, nullptr);
+        if (rc != CASTRO_AMD_OK) return rc;
+    }
+    for (const auto& c : g->unpack_remote) {
+        rc = launch_pack_regions(f[(size_t)c.fab], (int)c.off.size(), c.lo.data(), c.hi.data(), c.off.data(), g->ncomp, g->rbuf, 1, s, nullptr);
+        if (rc != CASTRO_AMD_OK) return rc;
+    }
+    if (geom) {
+        DevGeom G;
+        for (int d = 0; d < 3; ++d) {
+            G.dx[d] = geom->dx[d];
+            G.domlo[d] = geom->domlo[d]; G.domhi[d] = geom->domhi[d];
+            G.wall_lo[d] = (geom->lo_bc[d] >= 3) ? 1 : 0; G.wall_hi[d] = (geom->hi_bc[d] >= 3) ? 1 : 0;
+            G.sym_lo[d] = (geom->lo_bc[d] == 3) ? 1 : 0; G.sym_hi[d] = (geom->hi_bc[d] == 3) ? 1 : 0;
+        }
+        for (int i = 0; i < g->nfab && rc == CASTRO_AMD_OK; ++i)
+            rc = launch_bc_fill(f[(size_t)i], states[i].lo, states[i].hi, states[i].ncomp, G, geom->lo_bc, geom->hi_bc, s, nullptr);
+    }
+    return rc;
+}
+
 } // extern "C"

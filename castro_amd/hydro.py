@@ -450,6 +450,34 @@ class HipHydro:
         """`stream` (default: the current one) waits until the last fill_boundary_ex of `plan` has packed"""
         L.check(self.lib.castro_amd_halo_plan_wait_packed(plan, _stream_ptr(stream)), "halo_plan_wait_packed")
 
+    # ---- several boxes per rank: one grouped exchange for all local FABs of a level (castro_amd_halo_group_*) ----------------
+    def halo_group(self, comm, nfabs, sends, recvs, ncomp):
+        """sends / recvs: [(fab, peer, (lo, hi), tag)] as castro_amd.halo.level_messages derives them -> castro_amd_halo_group handle"""
+        def arr(msgs):
+            a = (L.HaloMsg * max(len(msgs), 1))()
+            for m, (fab, peer, box, tag) in zip(a, msgs):
+                m.fab, m.peer, m.tag = int(fab), int(peer), int(tag)
+                for d in range(3):
+                    m.lo[d], m.hi[d] = int(box[0][d]), int(box[1][d])
+            return a
+        h = C.c_void_p()
+        L.check(self.lib.castro_amd_halo_group_create(C.byref(h), comm, int(nfabs), len(sends), arr(sends), len(recvs), arr(recvs), int(ncomp)),
+                "halo_group_create")
+        return h
+
+    def halo_group_destroy(self, group):
+        if group:
+            self.lib.castro_amd_halo_group_destroy(group)
+
+    def halo_group_bytes_sent(self, group):
+        return int(self.lib.castro_amd_halo_group_bytes_sent(group))
+
+    def fill_boundary_group(self, group, states, boxes, geom=None, stream=None):
+        """states[f], boxes[f]: tensor and index box of local FAB f"""
+        fabs = (L.Fab * len(states))(*[L.fab_of(t, *b) for t, b in zip(states, boxes)])
+        L.check(self.lib.castro_amd_fill_boundary_group(self.h, group, fabs, C.byref(geom) if geom is not None else None,
+                                                        _stream_ptr(stream)), "fill_boundary_group")
+
     def allreduce_min_c(self, comm, t, stream=None):
         L.check(self.lib.castro_amd_allreduce_min(comm, C.c_void_p(t.data_ptr()), int(t.numel()), _stream_ptr(stream)), "allreduce_min")
 

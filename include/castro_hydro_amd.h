@@ -50,7 +50,8 @@ extern "C" {
  *   3: reduction vectors (`d_out`) are THREE device doubles (0.2 had two): castro_amd_ctu_hydro_clean_fab,
  *      castro_amd_ctu_hydro_fab_ex / _mf (opts.d_out), castro_amd_clean_state_reduce_fab.
  *   4: castro_amd_numerics(), castro_amd_fill_boundary*(), castro_amd_abi_version().
- *   5: CASTRO_AMD_STAGE_VALID / _REST / CASTRO_AMD_BC_FILL, castro_amd_fill_boundary_ex, castro_amd_halo_plan_wait_packed;
+ *   5: CASTRO_AMD_STAGE_VALID / _REST / CASTRO_AMD_BC_FILL, castro_amd_fill_boundary_ex, castro_amd_halo_plan_wait_packed,
+ *      castro_amd_halo_group_* / castro_amd_fill_boundary_group (several boxes per rank);
  *      castro_amd_hydro_opts.sborder_clean_ntimes is accepted by the staged calls.
  * A caller checks `castro_amd_abi_version() == CASTRO_AMD_ABI_VERSION` once after loading the library; a mismatch means
  * the library was built from another revision of this header (a 0.2 caller with 2-double vectors would be written 8 bytes
@@ -598,6 +599,32 @@ int castro_amd_fill_boundary(castro_amd_ctx *ctx, castro_amd_halo_plan *plan, co
 int castro_amd_fill_boundary_ex(castro_amd_ctx *ctx, castro_amd_halo_plan *plan, const castro_amd_fab *state,
                                 const castro_amd_geom *geom, int flags, void *stream);
 int castro_amd_halo_plan_wait_packed(castro_amd_halo_plan *plan, void *other_stream);
+/*
+ * Several boxes per rank (round 6): ONE grouped exchange for all FABs of a level that this rank owns -- an AMR level, or two
+ * boxes per GPU (Source/driver/Castro.cpp:4201-4209 over a BoxArray of any shape).  Sends and receives are separate lists:
+ * with boxes of unequal size the zones a box sends to a neighbour and those it receives from it differ in shape.
+ *   fab   index of the local FAB (0 .. nfabs-1) the zones [lo, hi] belong to
+ *   peer  rank of the other end (own rank: a copy between two local boxes, or a periodic wrap; no RCCL call)
+ *   tag   identifies the message between the two ranks: both ends must derive the same number for it, e.g.
+ *         (source box * nboxes + destination box) * 27 + code of the periodic shift, box = index in the level's BoxArray
+ * The k-th send to a peer in tag order is matched with the peer's k-th receive from this rank in tag order; two messages of
+ * one pair of ranks with one tag are refused.  A local receive needs a local send of the same tag and size.
+ * The group owns its two packed buffers; single-stream like a plan.  castro_amd_fill_boundary_group: states[f] is the FAB of
+ * local box f; geom == NULL: no physical-boundary fill.
+ */
+typedef struct castro_amd_halo_group castro_amd_halo_group;
+typedef struct castro_amd_halo_msg {
+    int fab;
+    int peer;
+    int lo[3], hi[3];
+    int tag;
+} castro_amd_halo_msg;
+int castro_amd_halo_group_create(castro_amd_halo_group **out, castro_amd_comm *comm, int nfabs,
+                                 int nsends, const castro_amd_halo_msg *sends, int nrecvs, const castro_amd_halo_msg *recvs, int ncomp);
+int castro_amd_halo_group_destroy(castro_amd_halo_group *group);
+long long castro_amd_halo_group_bytes_sent(const castro_amd_halo_group *group);   /* bytes to OTHER ranks per exchange */
+int castro_amd_fill_boundary_group(castro_amd_ctx *ctx, castro_amd_halo_group *group, const castro_amd_fab *states,
+                                   const castro_amd_geom *geom, void *stream);
 /* ncclAllReduce(MIN) in place on n device doubles: the [dt estimate, min density, ...] reduction of a step */
 int castro_amd_allreduce_min(castro_amd_comm *comm, double *d_buf, int n, void *stream);
 

@@ -1363,6 +1363,58 @@ def test_rccl_process_group_of_one_rank(tmp_path, halo, monkeypatch):
     assert np.array_equal(got["dts"], np.array(dts)) and np.array_equal(got["S"], c.S_new().cpu().numpy())
 
 
+@pytest.mark.parametrize("self_send", [0, 1])
+def test_many_boxes_per_rank_fill_boundary_group(hip, self_send, monkeypatch):
+    """castro_amd_halo_group / castro_amd_fill_boundary_group (round 6: the C++ twin of the many-box plan of castro_amd/amr.py):
+    FOUR boxes of unequal size on one rank, periodic in x and z, messages derived by castro_amd/halo.py (the derivation of
+    include/castro_hydro_amd_amrex.H::fill_boundary).  Every ghost zone that lies in a box of the level -- or in a periodic image
+    of one -- takes that box's valid data, bit for bit; every other zone keeps its value; with the physical-boundary fill the
+    outflow zones follow.  self_send: the copies between the local boxes travel through ncclSend / ncclRecv to the own rank."""
+    import torch
+    from castro_amd import halo
+    import castro_amd
+    monkeypatch.setenv("CASTRO_AMD_HALO_SELF_SEND", str(self_send))
+    boxes = [((0, 0, 0), (7, 15, 15)), ((8, 0, 0), (15, 7, 15)), ((8, 8, 0), (15, 15, 9)), ((8, 8, 10), (15, 15, 15))]
+    dom, periodic, ng, ncomp = ((0, 0, 0), (15, 15, 15)), (True, False, True), 4, 8
+    rng = np.random.default_rng(3)
+    comm = hip.comm_create(1, 0, hip.comm_unique_id())
+    local, sends, recvs = halo.level_messages(boxes, [0] * 4, 0, ng, dom, periodic)
+    assert local == [0, 1, 2, 3] and len(recvs) > 8
+    group = hip.halo_group(comm, 4, sends, recvs, ncomp)
+    assert hip.halo_group_bytes_sent(group) == (sum(8 * ncomp * int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for _, _, b, _ in sends)
+                                                if self_send else 0)
+    gboxes = [(tuple(x - ng for x in lo), tuple(x + ng for x in hi)) for lo, hi in boxes]
+    host = [rng.normal(size=(ncomp,) + tuple(g[1][d] - g[0][d] + 1 for d in (2, 1, 0))) for g in gboxes]
+    dev = [_to_dev(hip, a) for a in host]
+    hip.fill_boundary_group(group, dev, gboxes)
+    torch.cuda.synchronize()
+    # expectation: the level's valid data on the domain, ghost zones read from it through the periodic wrap
+    G = np.full((ncomp, 16, 16, 16), np.nan)
+    for (lo, hi), a in zip(boxes, host):
+        G[:, lo[2]:hi[2] + 1, lo[1]:hi[1] + 1, lo[0]:hi[0] + 1] = a[:, ng:-ng, ng:-ng, ng:-ng]
+    for (glo, ghi), (lo, hi), a, d in zip(gboxes, boxes, host, dev):
+        want = a.copy()
+        idx = [np.arange(glo[x], ghi[x] + 1) for x in range(3)]
+        ok = [np.ones_like(idx[x], dtype=bool) if periodic[x] else ((idx[x] >= 0) & (idx[x] <= 15)) for x in range(3)]
+        wrapped = [idx[x] % 16 for x in range(3)]
+        src = G[:, wrapped[2][:, None, None], wrapped[1][None, :, None], wrapped[0][None, None, :]]
+        inside = ok[2][:, None, None] & ok[1][None, :, None] & ok[0][None, None, :]
+        valid = np.zeros(want.shape[1:], dtype=bool)
+        valid[ng:-ng, ng:-ng, ng:-ng] = True
+        take = inside & ~valid & ~np.isnan(src[0])
+        want[:, take] = src[:, take]
+        assert np.array_equal(d.cpu().numpy(), want)
+        assert take.sum() > 0
+    # with the physical-boundary fill (outflow in y): the zones beyond the y faces copy the first / last in-domain row
+    geom = castro_amd.make_geom((16, 16, 16), lo_bc=(0, 2, 0), hi_bc=(0, 2, 0))
+    hip.fill_boundary_group(group, dev, gboxes, geom)
+    torch.cuda.synchronize()
+    low = dev[0].cpu().numpy()                   # box 0 touches y = 0: ghost rows j = -4 .. -1 equal row j = 0
+    assert np.array_equal(low[:, :, 0:ng, :], np.repeat(low[:, :, ng:ng + 1, :], ng, axis=2))
+    hip.halo_group_destroy(group)
+    hip.comm_destroy(comm)
+
+
 def test_fab_ops_avgdown_equals_the_per_box_call(hip):
     """CASTRO_AMD_OP_AVGDOWN (Castro::avgDown of a whole level in one launch): 20 fine boxes averaged onto two coarse FABs
     give the bits of castro_amd_avgdown_fab box by box; a region whose fine zones leave the source is refused."""
