@@ -60,6 +60,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_comm_size", "castro_amd_comm_destroy", "castro_amd_halo_plan_create", "castro_amd_halo_plan_destroy",
     "castro_amd_halo_plan_bytes_sent", "castro_amd_fill_boundary", "castro_amd_fill_boundary_ex", "castro_amd_halo_plan_wait_packed",
     "castro_amd_halo_group_create", "castro_amd_halo_group_destroy", "castro_amd_halo_group_bytes_sent", "castro_amd_fill_boundary_group",
+    "castro_amd_fill_boundary_group_ex", "castro_amd_halo_group_wait_packed",
     "castro_amd_allreduce_min",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
@@ -263,6 +264,8 @@ def load(numerics=None):
         L.castro_amd_halo_group_bytes_sent.argtypes = [C.c_void_p]
         L.castro_amd_halo_group_bytes_sent.restype = C.c_longlong
         L.castro_amd_fill_boundary_group.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Fab), C.POINTER(Geom), C.c_void_p]
+        L.castro_amd_fill_boundary_group_ex.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Fab), C.POINTER(Geom), C.c_int, C.c_void_p]
+        L.castro_amd_halo_group_wait_packed.argtypes = [C.c_void_p, C.c_void_p]
         L.castro_amd_allreduce_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.castro_amd_ctx_profile.argtypes = [C.c_void_p, C.c_int]
     L.castro_amd_ctx_profile_count.argtypes = [C.c_void_p]

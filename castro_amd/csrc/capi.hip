@@ -159,7 +159,7 @@ extern "C" {
 #else
 #define CAD_NUMERICS_NAME "exact"
 #endif
-const char* castro_amd_version(void) { return "castro_hydro_amd 0.4 (gfx950, round 4, numerics=" CAD_NUMERICS_NAME ")"; }
+const char* castro_amd_version(void) { return "castro_hydro_amd " CASTRO_AMD_RELEASE " (gfx950, numerics=" CAD_NUMERICS_NAME ")"; }
 int castro_amd_abi_version(void) { return CASTRO_AMD_ABI_VERSION; }
 const char* castro_amd_numerics(void) { return CAD_NUMERICS_NAME; }
 

@@ -193,35 +193,75 @@ __device__ __forceinline__ bool in_skip(const SkipBox& s, int i, int j, int k)
 // CLEAN: Castro::clean_state applied `clean_n` times to the zone first, in place (castro_amd_hydro_opts.sborder_clean_ntimes):
 // the clean_state(S_old) of initialize_advance and the clean_state(Sborder) after FillPatch inside the pass that reads the
 // state anyway.  Plain stores: k_final / k_finalx_consup read the cleaned zones again.
-// one zone of k_ctoprim / k_ctoprim_shell
+// Up to six boxes in one launch, x fastest inside each (the ghost shell of a box as z, y and x slabs): thread -> zone
+struct ShellBoxes { int lo[6][3], nn[6][3]; unsigned start[7]; };
+__device__ __forceinline__ bool shell_thread(const ShellBoxes& S, int& i, int& j, int& k)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= S.start[6]) return false;
+    int r = 0;
+    while (tid >= S.start[r + 1]) ++r;
+    const unsigned q = tid - S.start[r];
+    const unsigned n0 = (unsigned)S.nn[r][0], n1 = (unsigned)S.nn[r][1];
+    i = S.lo[r][0] + (int)(q % n0);
+    const unsigned rr = q / n0;
+    j = S.lo[r][1] + (int)(rr % n1);
+    k = S.lo[r][2] + (int)(rr / n1);
+    return true;
+}
+struct BcKinds { int lo[3], hi[3]; int kind_lo[3], kind_hi[3]; };   // domain extent; kind 0 leave (interior / periodic), 1 extrapolate, 2 mirror
+
+// One zone of k_ctoprim.  `bc`: the zone (i,j,k) lies outside the problem domain in a non-periodic direction and takes the state of
+// the in-domain zone (si,sj,sk) -- the physical-boundary part of FillPatch (Source/problems/Castro_bc_fill_nd.cpp:11-125; BC tables
+// Castro_setup.cpp:40-53: clamp to the nearest interior zone for outflow / inflow (FOEXTRAP), mirror about the boundary with the
+// normal momentum negated for symmetry and walls (REFLECT_ODD: fx, fy, fz)) fused with ctoprim: the source zone has been cleaned by
+// an earlier launch already (clean_state commutes with the copy and with the mirror image: it is zone-local and even in the
+// momenta), so the copy is stored into Sborder as it is (the artificial viscosity of the final stage reads one ghost layer of it),
+// the clean_state loop below runs zero times, and the primitive record follows from the SAME instructions as for every other
+// zone of this kernel -- boundary zones, ghost-shell zones and valid zones share one compiled copy of the arithmetic, so the
+// `contract` build (whose FMA contraction may differ between two copies of one expression) gives the bits of
+// k_bc_fill + k_ctoprim whatever the launch partition.
 template <bool CLEAN>
 __device__ __forceinline__ void ctoprim_zone(const Tile& t, const DFab& U, double* __restrict__ Q, const DevParams& P, int* status,
-                                             int clean_n, int lean_q, int i, int j, int k)
+                                             int clean_n, int lean_q, int i, int j, int k,
+                                             int si, int sj, int sk, bool fx, bool fy, bool fz, bool bc)
 {
     // lean_q (gamma_law_edges, default-solver path of the `contract` build), bit 0: nobody downstream reads Q's (rho e) and X
     // planes; bit 1: the update kernel has clean_state fused in and reads neither the temperature nor the species of U
     const unsigned c = goff(t, i, j, k);
-    const unsigned cu = foff(U, i, j, k);
+    const unsigned cd = foff(U, i, j, k);           // where the zone lives
+    const unsigned cu = foff(U, si, sj, sk);        // where its state is read from (== cd unless bc)
     const long NC = t.NC;
 
     double rho = ldg(U.p + URHO * U.sn, cu);
     double mx = ldg(U.p + UMX * U.sn, cu), my = ldg(U.p + UMY * U.sn, cu), mz = ldg(U.p + UMZ * U.sn, cu);
     double eden = ldg(U.p + UEDEN * U.sn, cu);
+    if (fx) mx = -mx;                               // norm_vel_bc: REFLECT_ODD
+    if (fy) my = -my;
+    if (fz) mz = -mz;
     // lean_q: with one species and a gamma-law gas nothing downstream reads the temperature or the species of this array
     // (X is elided, the fused update recomputes both: k_finalx_consup), so they are neither loaded, cleaned nor written back
     const bool lean_u = (lean_q & 2) != 0;
     double rX = lean_u ? rho : ldg(U.p + UFS * U.sn, cu);
     double eint = 0.0;
-    if (CLEAN) {
+    double* up = U.p;
+    if (bc) {
+        // the boundary fill proper: all eight components of the source zone, whatever this build reads of them
         eint = ldg(U.p + UEINT * U.sn, cu);
+        const double tb = ldg(U.p + UTEMP * U.sn, cu), xb = ldg(U.p + UFS * U.sn, cu);
+#define PUT(comp, v) *reinterpret_cast<double*>(reinterpret_cast<char*>(up + (comp) * U.sn) + cd) = (v)
+        PUT(URHO, rho); PUT(UMX, mx); PUT(UMY, my); PUT(UMZ, mz); PUT(UEDEN, eden); PUT(UEINT, eint); PUT(UTEMP, tb); PUT(UFS, xb);
+#undef PUT
+    }
+    if (CLEAN) {
+        if (!bc) eint = ldg(U.p + UEINT * U.sn, cu);
         double temp = lean_u ? 0.0 : ldg(U.p + UTEMP * U.sn, cu);
         const double o0 = rho, o1 = mx, o2 = my, o3 = mz, o4 = eden, o5 = eint, o6 = temp, o7 = rX;
-        clean_zone(P, clean_n, rho, mx, my, mz, eden, eint, temp, rX);
+        clean_zone(P, clean_n, rho, mx, my, mz, eden, eint, temp, rX);          // clean_n == 0 in a boundary zone
         // Only components whose bits changed go back: the state arrives cleaned twice by the update that produced it, and
         // the applications here almost always reproduce it (8 planes less to write; a plane nobody changes stays clean in L2).
-        double* up = U.p;
 #define PUT_IF_CHANGED(comp, o, v) \
-        if (__double_as_longlong(o) != __double_as_longlong(v)) *reinterpret_cast<double*>(reinterpret_cast<char*>(up + (comp) * U.sn) + cu) = (v)
+        if (__double_as_longlong(o) != __double_as_longlong(v)) *reinterpret_cast<double*>(reinterpret_cast<char*>(up + (comp) * U.sn) + cd) = (v)
         PUT_IF_CHANGED(URHO, o0, rho);
         PUT_IF_CHANGED(UMX, o1, mx);
         PUT_IF_CHANGED(UMY, o2, my);
@@ -247,7 +287,7 @@ __device__ __forceinline__ void ctoprim_zone(const Tile& t, const DFab& U, doubl
     if ((eden - kineng) > P.eta1 * eden) {
         e = (eden - kineng) * rhoinv;
     } else {
-        e = (CLEAN ? eint : ldg(U.p + UEINT * U.sn, cu)) * rhoinv;
+        e = ((CLEAN || bc) ? eint : ldg(U.p + UEINT * U.sn, cu)) * rhoinv;
     }
 
     const double X = rX * rhoinv;
@@ -268,119 +308,41 @@ __device__ __forceinline__ void ctoprim_zone(const Tile& t, const DFab& U, doubl
     stg(Q + PC * NC, c, cs);
 }
 
+// mode 0: the zones of the LinBox `b` (minus `skip`); 1: the zones of the boxes `sh` (the ghost shell of a box whose valid zones an
+// earlier launch has done: CASTRO_AMD_STAGE_REST, ONE launch for the six slabs); 2: the zones of `sh` as physical-boundary zones
+// (CASTRO_AMD_BC_FILL: source zone by the per-direction index map of M, see ctoprim_zone).  One kernel for the three, so that
+// every zone goes through the same compiled arithmetic.
 template <bool CLEAN, bool LV = false>
 __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                 SkipBox skip, int clean_n, LevelTab lv, int lean_q)
+                                                 SkipBox skip, int clean_n, LevelTab lv, int lean_q, int mode, ShellBoxes sh, BcKinds M)
 {
     RETURN_IF_BATCH_FAILED();
-    unsigned vb = blockIdx.x;
-    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
-    int i, j, k;
-    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
-    if (in_skip(skip, i, j, k)) return;
-    ctoprim_zone<CLEAN>(t, U, Q, P, status, clean_n, lean_q, i, j, k);
-}
-
-// Up to six boxes in one launch, x fastest inside each (the ghost shell of a box as z, y and x slabs): thread -> zone
-struct ShellBoxes { int lo[6][3], nn[6][3]; unsigned start[7]; };
-__device__ __forceinline__ bool shell_thread(const ShellBoxes& S, int& i, int& j, int& k)
-{
-    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= S.start[6]) return false;
-    int r = 0;
-    while (tid >= S.start[r + 1]) ++r;
-    const unsigned q = tid - S.start[r];
-    const unsigned n0 = (unsigned)S.nn[r][0], n1 = (unsigned)S.nn[r][1];
-    i = S.lo[r][0] + (int)(q % n0);
-    const unsigned rr = q / n0;
-    j = S.lo[r][1] + (int)(rr % n1);
-    k = S.lo[r][2] + (int)(rr / n1);
-    return true;
-}
-
-// k_ctoprim on the ghost shell of a box whose valid zones an earlier launch has done (CASTRO_AMD_STAGE_REST): ONE launch
-// for the six slabs
-template <bool CLEAN>
-__global__ void __launch_bounds__(256) k_ctoprim_shell(Tile t, ShellBoxes S, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                       int clean_n, int lean_q)
-{
-    RETURN_IF_BATCH_FAILED();
-    int i, j, k;
-    if (!shell_thread(S, i, j, k)) return;
-    ctoprim_zone<CLEAN>(t, U, Q, P, status, clean_n, lean_q, i, j, k);
-}
-
-// The physical-boundary part of FillPatch (Source/problems/Castro_bc_fill_nd.cpp:11-125; BC tables Castro_setup.cpp:40-53)
-// fused with ctoprim for the ghost zones of Sborder outside the problem domain in a non-periodic direction
-// (CASTRO_AMD_BC_FILL): the zone takes the state of the in-domain zone the per-direction index map names -- clamp to the
-// nearest interior zone (FOEXTRAP: outflow, inflow) or mirror about the boundary with the normal momentum negated (REFLECT_ODD:
-// symmetry and walls) -- which the launches before this one have cleaned already (clean_state commutes with the copy and with
-// the mirror image: it is zone-local and even in the momenta), stores it into Sborder (the artificial viscosity of the final
-// stage reads one ghost layer of it) and writes its primitive record like k_ctoprim<false>.  Replaces k_bc_fill + the
-// k_ctoprim pass over those zones.
-struct BcKinds { int lo[3], hi[3]; int kind_lo[3], kind_hi[3]; };   // domain extent; kind 0 leave (interior / periodic), 1 extrapolate, 2 mirror
-__global__ void __launch_bounds__(256) k_ctoprim_bc(Tile t, ShellBoxes S, DFab U, double* __restrict__ Q, DevParams P, int* status,
-                                                    BcKinds M, int lean_q)
-{
-    RETURN_IF_BATCH_FAILED();
-    int ijk[3];
-    if (!shell_thread(S, ijk[0], ijk[1], ijk[2])) return;
-    int s[3];
-    bool flip[3];
+    int ijk[3], s[3];
+    bool flip[3] = { false, false, false };
+    if (LV || mode == 0) {
+        unsigned vb = blockIdx.x;
+        if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_CTOPRIM]; U = B.U; Q = B.S.Q; }
+        if (!box_thread_at(b, vb, threadIdx.x, ijk[0], ijk[1], ijk[2])) return;
+        if (in_skip(skip, ijk[0], ijk[1], ijk[2])) return;
+    } else {
+        if (!shell_thread(sh, ijk[0], ijk[1], ijk[2])) return;
+    }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        s[d] = ijk[d];
-        flip[d] = false;
-        if (ijk[d] < M.lo[d] && M.kind_lo[d] != 0) {
-            if (M.kind_lo[d] == 1) s[d] = M.lo[d];
-            else { s[d] = 2 * M.lo[d] - ijk[d] - 1; flip[d] = true; }
-        } else if (ijk[d] > M.hi[d] && M.kind_hi[d] != 0) {
-            if (M.kind_hi[d] == 1) s[d] = M.hi[d];
-            else { s[d] = 2 * M.hi[d] - ijk[d] + 1; flip[d] = true; }
+    for (int d = 0; d < 3; ++d) s[d] = ijk[d];
+    const bool bc = !LV && mode == 2;
+    if (bc) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (ijk[d] < M.lo[d] && M.kind_lo[d] != 0) {
+                if (M.kind_lo[d] == 1) s[d] = M.lo[d];
+                else { s[d] = 2 * M.lo[d] - ijk[d] - 1; flip[d] = true; }
+            } else if (ijk[d] > M.hi[d] && M.kind_hi[d] != 0) {
+                if (M.kind_hi[d] == 1) s[d] = M.hi[d];
+                else { s[d] = 2 * M.hi[d] - ijk[d] + 1; flip[d] = true; }
+            }
         }
     }
-    const unsigned c = goff(t, ijk[0], ijk[1], ijk[2]);
-    const unsigned cd = foff(U, ijk[0], ijk[1], ijk[2]);
-    const unsigned cs_ = foff(U, s[0], s[1], s[2]);
-    const long NC = t.NC;
-    const double rho = ldg(U.p + URHO * U.sn, cs_);
-    double mx = ldg(U.p + UMX * U.sn, cs_), my = ldg(U.p + UMY * U.sn, cs_), mz = ldg(U.p + UMZ * U.sn, cs_);
-    const double eden = ldg(U.p + UEDEN * U.sn, cs_), eint = ldg(U.p + UEINT * U.sn, cs_);
-    const double temp = ldg(U.p + UTEMP * U.sn, cs_), rXs = ldg(U.p + UFS * U.sn, cs_);
-    if (flip[0]) mx = -mx;                          // norm_vel_bc: REFLECT_ODD
-    if (flip[1]) my = -my;
-    if (flip[2]) mz = -mz;
-    double* up = U.p;
-#define PUT(comp, v) *reinterpret_cast<double*>(reinterpret_cast<char*>(up + (comp) * U.sn) + cd) = (v)
-    PUT(URHO, rho); PUT(UMX, mx); PUT(UMY, my); PUT(UMZ, mz); PUT(UEDEN, eden); PUT(UEINT, eint); PUT(UTEMP, temp); PUT(UFS, rXs);
-#undef PUT
-    if (rho <= 0.0 || rho < P.small_dens) atomicOr(status, 1);
-    // from here on the statements of ctoprim_zone<false>
-    const double rX = (lean_q & 2) ? rho : rXs;
-    const double rhoinv = frcp(rho);
-    const double u = mx * rhoinv;
-    const double v = my * rhoinv;
-    const double w = mz * rhoinv;
-    const double kineng = 0.5 * rho * (u * u + v * v + w * w);
-    double e;
-    if ((eden - kineng) > P.eta1 * eden) {
-        e = (eden - kineng) * rhoinv;
-    } else {
-        e = eint * rhoinv;
-    }
-    const double X = rX * rhoinv;
-    const double p = (P.gamma - 1.0) * rho * e;
-    const double cs = kContract ? fsqrt(P.gamma * p * rhoinv) : sqrt(P.gamma * p / rho);
-    stg(Q + PRHO * NC, c, rho);
-    stg(Q + PU * NC, c, u);
-    stg(Q + PV * NC, c, v);
-    stg(Q + PW * NC, c, w);
-    stg(Q + PP * NC, c, p);
-    if (!(lean_q & 1)) {
-        stg(Q + PRE * NC, c, e * rho);
-        stg(Q + PX * NC, c, X);
-    }
-    stg(Q + PC * NC, c, cs);
+    ctoprim_zone<CLEAN>(t, U, Q, P, status, bc ? 0 : clean_n, lean_q, ijk[0], ijk[1], ijk[2], s[0], s[1], s[2], flip[0], flip[1], flip[2], bc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -3505,7 +3467,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 
     if (stage_a) {
         if (splittable) {
-            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+            KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 0, ShellBoxes{}, BcKinds{});
             if (inner_ok) trace_with_xriemann(inner_box.lo, inner_box.hi);
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -3513,12 +3475,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // The light split (round 6: CASTRO_AMD_STAGE_VALID / _REST): ctoprim -- with the pending clean_states -- on the valid zones
     // is all that runs beside the halo exchange; the ghost shell follows as ONE launch, everything downstream is un-split.
     // CASTRO_AMD_BC_FILL: the zones of grow(bx, 4) outside the problem domain in a non-periodic direction are filled here
-    // (k_ctoprim_bc) from in-domain zones that the launches in front of it have cleaned, instead of by a k_bc_fill before the call.
+    // (k_ctoprim in its boundary-zone mode) from in-domain zones that the launches in front of it have cleaned, instead of by a k_bc_fill before the call.
     const bool light_a = (flags & 16) != 0, light_b = (flags & 32) != 0, fill_bc = (flags & 64) != 0;
     if ((light_a || light_b || fill_bc) && staged) return -1;
     if (light_a && light_b) return -1;
     int ilo[3], ihi[3];                                  // the zones of grow(bx, 4) that hold data when the call starts
     BcKinds M;
+    const ShellBoxes no_shell = {};
     bool have_bc = false;
     for (int d = 0; d < 3; ++d) {
         ilo[d] = qlo[d]; ihi[d] = qhi[d];
@@ -3550,8 +3513,8 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         return sb.start[6];
     };
     if (light_a) {
-        if (aux.sb_clean > 0) KL("k_ctoprim_clean", k_ctoprim<true>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q);
-        else KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+        if (aux.sb_clean > 0) KL("k_ctoprim_clean", k_ctoprim<true>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q, 0, no_shell, M);
+        else KL("k_ctoprim", k_ctoprim<false>, t.lo, t.hi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 0, no_shell, M);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
     const bool second_half = stage_b && splittable;     // stage A has run on this tile
@@ -3561,24 +3524,28 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         const unsigned nz_ = shell_launch_boxes(ilo, ihi, t.lo, t.hi, sb);
         if (nz_ > 0) {
             prof_begin(prof, "k_ctoprim_shell", stream);
-            if (aux.sb_clean > 0) hipLaunchKernelGGL(k_ctoprim_shell<true>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, sb, Sborder, S.Q, P, d_status, aux.sb_clean, lean_q);
-            else hipLaunchKernelGGL(k_ctoprim_shell<false>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, sb, Sborder, S.Q, P, d_status, 0, lean_q);
+            LinBox nobox = {};
+            if (aux.sb_clean > 0) hipLaunchKernelGGL(k_ctoprim<true>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, nobox, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q, 1, sb, M);
+            else hipLaunchKernelGGL(k_ctoprim<false>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, nobox, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 1, sb, M);
             prof_end(prof, stream);
         }
     } else if (second_half) {
         const int ns = shell_boxes(qlo, qhi, t.lo, t.hi, slo, shi);
-        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+        for (int m = 0; m < ns; ++m) KL("k_ctoprim", k_ctoprim<false>, slo[m], shi[m], Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 0, no_shell, M);
     } else if (aux.sb_clean > 0) {
-        KL("k_ctoprim_clean", k_ctoprim<true>, ilo, ihi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q);
+        KL("k_ctoprim_clean", k_ctoprim<true>, ilo, ihi, Sborder, S.Q, P, d_status, none, aux.sb_clean, nolv, lean_q, 0, no_shell, M);
     } else {
-        KL("k_ctoprim", k_ctoprim<false>, ilo, ihi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q);
+        KL("k_ctoprim", k_ctoprim<false>, ilo, ihi, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 0, no_shell, M);
     }
     if (have_bc) {
         ShellBoxes sb;
         const unsigned nz_ = shell_launch_boxes(qlo, qhi, ilo, ihi, sb);
         if (nz_ > 0) {
+            // the instantiation that did the in-domain zones of this call: one compiled copy of the arithmetic for both
+            LinBox nobox = {};
             prof_begin(prof, "k_ctoprim_bc", stream);
-            hipLaunchKernelGGL(k_ctoprim_bc, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, sb, Sborder, S.Q, P, d_status, M, lean_q);
+            if (aux.sb_clean > 0) hipLaunchKernelGGL(k_ctoprim<true>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, nobox, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 2, sb, M);
+            else hipLaunchKernelGGL(k_ctoprim<false>, dim3((nz_ + 255u) / 256u), dim3(256), 0, stream, t, nobox, Sborder, S.Q, P, d_status, none, 0, nolv, lean_q, 2, sb, M);
             prof_end(prof, stream);
         }
     }
@@ -3880,9 +3847,9 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
 
     prof_begin(prof, sb_clean > 0 ? "k_ctoprim_clean" : "k_ctoprim", stream);
     if (sb_clean > 0) hipLaunchKernelGGL((k_ctoprim<true, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
-                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0);
+                                         hb[0].U, S0.Q, P, d_status, none, sb_clean, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0, 0, ShellBoxes{}, BcKinds{});
     else hipLaunchKernelGGL((k_ctoprim<false, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
-                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0);
+                            hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0, 0, ShellBoxes{}, BcKinds{});
     prof_end(prof, stream);
     prof_begin(prof, "k_divu", stream);
     hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,

@@ -372,6 +372,8 @@ struct castro_amd_halo_group {
     double* sbuf = nullptr;
     double* rbuf = nullptr;
     long long stotal = 0, rtotal = 0;
+    hipEvent_t ev_packed = nullptr;             // castro_amd_fill_boundary_group_ex: recorded behind the last pack launch
+    bool packed_recorded = false;
 };
 
 static void group_chunks(const std::vector<castro_amd_halo_group::Msg>& msgs, int nfab, bool want_local, bool any,
@@ -460,6 +462,11 @@ int castro_amd_halo_group_create(castro_amd_halo_group** out, castro_amd_comm* c
         delete g;
         return CASTRO_AMD_ERR_NOMEM;
     }
+    if (hipEventCreateWithFlags(&g->ev_packed, hipEventDisableTiming) != hipSuccess) {
+        hipFree(g->sbuf); hipFree(g->rbuf);
+        delete g;
+        return CASTRO_AMD_ERR_HIP;
+    }
     *out = g;
     return CASTRO_AMD_OK;
 }
@@ -469,6 +476,7 @@ int castro_amd_halo_group_destroy(castro_amd_halo_group* g)
     if (!g) return CASTRO_AMD_OK;
     if (g->sbuf) hipFree(g->sbuf);
     if (g->rbuf) hipFree(g->rbuf);
+    if (g->ev_packed) hipEventDestroy(g->ev_packed);
     delete g;
     return CASTRO_AMD_OK;
 }
@@ -481,8 +489,31 @@ long long castro_amd_halo_group_bytes_sent(const castro_amd_halo_group* g)
     return n;
 }
 
+static int fill_boundary_group_impl(castro_amd_ctx* ctx, castro_amd_halo_group* g, const castro_amd_fab* states,
+                                    const castro_amd_geom* geom, void* stream, bool mark_packed);
+
 int castro_amd_fill_boundary_group(castro_amd_ctx* ctx, castro_amd_halo_group* g, const castro_amd_fab* states,
                                    const castro_amd_geom* geom, void* stream)
+{
+    return fill_boundary_group_impl(ctx, g, states, geom, stream, false);
+}
+
+int castro_amd_fill_boundary_group_ex(castro_amd_ctx* ctx, castro_amd_halo_group* g, const castro_amd_fab* states,
+                                      const castro_amd_geom* geom, int flags, void* stream)
+{
+    if (flags != 0) return CASTRO_AMD_ERR_ARG;
+    return fill_boundary_group_impl(ctx, g, states, geom, stream, true);
+}
+
+int castro_amd_halo_group_wait_packed(castro_amd_halo_group* g, void* other_stream)
+{
+    if (!g || !g->ev_packed || !g->packed_recorded) return CASTRO_AMD_ERR_ARG;
+    if (hipSetDevice(g->comm->device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+    return hipStreamWaitEvent((hipStream_t)other_stream, g->ev_packed, 0) == hipSuccess ? CASTRO_AMD_OK : CASTRO_AMD_ERR_HIP;
+}
+
+static int fill_boundary_group_impl(castro_amd_ctx* ctx, castro_amd_halo_group* g, const castro_amd_fab* states,
+                                    const castro_amd_geom* geom, void* stream, bool mark_packed)
 {
     if (!ctx || !g || !states) return CASTRO_AMD_ERR_ARG;
     if (hipSetDevice(g->comm->device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
@@ -506,6 +537,10 @@ int castro_amd_fill_boundary_group(castro_amd_ctx* ctx, castro_amd_halo_group* g
     for (const auto& c : g->pack) {
         rc = launch_pack_regions(f[(size_t)c.fab], (int)c.off.size(), c.lo.data(), c.hi.data(), c.off.data(), g->ncomp, g->sbuf, 0, s, nullptr);
         if (rc != CASTRO_AMD_OK) return rc;
+    }
+    if (mark_packed) {
+        if (hipEventRecord(g->ev_packed, s) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+        g->packed_recorded = true;
     }
     if (!g->send_order.empty() || !g->recv_order.empty()) {
         const Rccl* R = rccl();

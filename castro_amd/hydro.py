@@ -478,6 +478,15 @@ class HipHydro:
         L.check(self.lib.castro_amd_fill_boundary_group(self.h, group, fabs, C.byref(geom) if geom is not None else None,
                                                         _stream_ptr(stream)), "fill_boundary_group")
 
+    def fill_boundary_group_ex(self, group, states, boxes, geom=None, stream=None):
+        """fill_boundary_group + the group's "packed" event recorded behind the last pack launch"""
+        fabs = (L.Fab * len(states))(*[L.fab_of(t, *b) for t, b in zip(states, boxes)])
+        L.check(self.lib.castro_amd_fill_boundary_group_ex(self.h, group, fabs, C.byref(geom) if geom is not None else None, 0,
+                                                           _stream_ptr(stream)), "fill_boundary_group_ex")
+
+    def halo_group_wait_packed(self, group, stream=None):
+        L.check(self.lib.castro_amd_halo_group_wait_packed(group, _stream_ptr(stream)), "halo_group_wait_packed")
+
     def allreduce_min_c(self, comm, t, stream=None):
         L.check(self.lib.castro_amd_allreduce_min(comm, C.c_void_p(t.data_ptr()), int(t.numel()), _stream_ptr(stream)), "allreduce_min")
 

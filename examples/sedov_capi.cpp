@@ -132,8 +132,8 @@ int main(int argc, char** argv)
                     std::fwrite(&h[(size_t)c * ng + ((size_t)(k + NG) * gx + (j + NG)) * gx + NG], sizeof(double), n, f);
         std::fclose(f);
     }
-    for (int d = 0; d < 3; ++d) { hipFree(fl[d]); hipFree(mf[d]); }
-    hipFree(A); hipFree(B); hipFree(d_red);
+    for (int d = 0; d < 3; ++d) { (void)hipFree(fl[d]); (void)hipFree(mf[d]); }
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(d_red);
     castro_amd_ctx_destroy(ctx);
     return 0;
 }

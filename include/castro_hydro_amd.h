@@ -57,6 +57,8 @@ extern "C" {
  * the library was built from another revision of this header (a 0.2 caller with 2-double vectors would be written 8 bytes
  * out of bounds by a 0.3 library). */
 #define CASTRO_AMD_ABI_VERSION 5
+/* release of the library: castro_amd_version() is "castro_hydro_amd <this> (gfx950, numerics=...)" -- the one place it is written */
+#define CASTRO_AMD_RELEASE "0.6"
 
 #define CASTRO_AMD_NUM_STATE 8
 #define CASTRO_AMD_NGDNV 4
@@ -625,6 +627,11 @@ int castro_amd_halo_group_destroy(castro_amd_halo_group *group);
 long long castro_amd_halo_group_bytes_sent(const castro_amd_halo_group *group);   /* bytes to OTHER ranks per exchange */
 int castro_amd_fill_boundary_group(castro_amd_ctx *ctx, castro_amd_halo_group *group, const castro_amd_fab *states,
                                    const castro_amd_geom *geom, void *stream);
+/* the overlap hooks of castro_amd_fill_boundary_ex / castro_amd_halo_plan_wait_packed for a group: the event is recorded behind
+ * the LAST pack launch (the valid zones of every local FAB have been read by then).  flags: reserved, 0. */
+int castro_amd_fill_boundary_group_ex(castro_amd_ctx *ctx, castro_amd_halo_group *group, const castro_amd_fab *states,
+                                      const castro_amd_geom *geom, int flags, void *stream);
+int castro_amd_halo_group_wait_packed(castro_amd_halo_group *group, void *other_stream);
 /* ncclAllReduce(MIN) in place on n device doubles: the [dt estimate, min density, ...] reduction of a step */
 int castro_amd_allreduce_min(castro_amd_comm *comm, double *d_buf, int n, void *stream);
 

@@ -6,5 +6,6 @@ void use (amrex::MultiFab& a, amrex::MultiFab& b, amrex::Vector<std::unique_ptr<
     castro_amd::construct_ctu_hydro_source(a, b, f, m, g, bc, p, 0.0, 1.0);
     castro_amd::construct_ctu_hydro_source_mf(a, b, f, m, g, bc, p, 0.0, 1.0);
     castro_amd::fill_boundary(a, g, bc);
+    castro_amd::expand_state_and_hydro(a, b, f, m, g, bc, p, 0.0, 1.0, 2);
     castro_amd::halo_plans_clear();
 }

@@ -121,8 +121,9 @@ def test_declared_path_bytes_are_the_planes_the_kernels_read():
     the one reader of the old state's ghost-grown box, and the loads it guards with `lean_u` are the ones not declared."""
     import bench
     src = open(os.path.join(ROOT, "castro_amd", "csrc", "ctu_kernels.hip")).read()
-    # the zone function of k_ctoprim / k_ctoprim_shell (k_ctoprim_bc copies whole boundary zones outside the domain: no cell update)
+    # the zone function of k_ctoprim (its boundary-zone mode copies whole zones outside the domain -- `if (bc)`: no cell update)
     body = src[src.index("void ctoprim_zone("):src.index("__global__ void __launch_bounds__(256) k_ctoprim(")]
+    body = body[:body.index("if (bc) {")] + body[body.index("if (CLEAN) {"):]
     loads = set(re.findall(r"ldg\(U\.p \+ (U[A-Z]+) \* U\.sn", body))
     assert loads == {"URHO", "UMX", "UMY", "UMZ", "UEDEN", "UEINT", "UTEMP", "UFS"}
     guarded = set(re.findall(r"lean_u \? [a-z0-9.]+ : ldg\(U\.p \+ (U[A-Z]+) \* U\.sn", body))

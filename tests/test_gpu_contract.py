@@ -74,13 +74,21 @@ def field_deviation(got, want, dx):
     return dev
 
 
-ELEM_FLOOR = 1e-6      # the elementwise bound holds on zones with |f| >= ELEM_FLOOR * scale(f)
+# Zone by zone.  The deviation of the `contract` build is an ABSOLUTE error of <= 1e-13 x scale(f) (the norm-relative figure above:
+# rounding differences of order 1e-16 x scale accumulated over the steps), so a relative bound per zone can only hold above a floor:
+#   |f_hip - f_oracle| <= 1e-10 |f_oracle|   on zones with |f_oracle| >= 1e-3 x scale(f)      (asserted)
+#   |f_hip - f_oracle| <= 1e-8  |f_oracle|   on zones with |f_oracle| >= 1e-6 x scale(f)      (asserted; measured worst 7.7e-10: a
+#       velocity of 2.6e-5 where the field reaches 10 -- Sedov 128^3 at t = 0.01, profiles/r06d_*)
+ELEM_BOUNDS = ((1e-3, RTOL), (1e-6, 1e-8))       # (floor as a fraction of scale(f), relative bound)
+ELEM_FLOOR = ELEM_BOUNDS[0][0]
 
 
 def elementwise_deviation(got, want, dx, floor=ELEM_FLOOR):
     """{field: (max over the zones with |f_oracle| >= floor * scale(f) of |f_hip - f_oracle| / |f_oracle|, zone index (k, j, i), value there)}
     -- the zone-by-zone relative error above a floor, next to the norm-relative figure of field_deviation (round 6: asserted, not
-    only printed by tools/numerics_deviation.py).  scale(f) as in the module docstring; circvel through its square."""
+    only printed by tools/numerics_deviation.py).  scale(f) as in the module docstring; circvel through its square; logden =
+    log10(rho) is measured against max(|log10 rho|, 1): next to rho = 1 the logarithm is the rounding residue of the density
+    itself (a density right to 1e-16 gives log10 rho = 1.4e-7 to 7e-10 only), so its error is that of rho, not a fraction of itself."""
     vmax = max(np.abs(want[k]).max() for k in ("x_velocity", "y_velocity", "z_velocity"))
     out = {}
     for nm, b in want.items():
@@ -94,7 +102,8 @@ def elementwise_deviation(got, want, dx, floor=ELEM_FLOOR):
         if scale == 0.0 or not mask.any():
             out[nm] = (0.0, None, 0.0)
             continue
-        rel = np.where(mask, np.abs(a - b) / np.where(mask, np.abs(b), 1.0), 0.0)
+        den = np.maximum(np.abs(b), 1.0) if nm == "logden" else np.abs(b)
+        rel = np.where(mask, np.abs(a - b) / np.where(mask, den, 1.0), 0.0)
         idx = np.unravel_index(np.argmax(rel), rel.shape)
         out[nm] = (float(rel[idx]), tuple(int(x) for x in idx), float(b[idx]))
     return out
@@ -111,13 +120,13 @@ def _check(c, lev, oracle, G, P, tmp_path, tag, dx, elementwise=False):
     assert not bad, "%s: fields beyond rtol %g: %s" % (tag, RTOL, bad)
     assert abs(c.time - lev.time) <= RTOL * lev.time
     if elementwise:
-        # zone by zone: |f_hip - f_oracle| <= RTOL * |f_oracle| wherever |f_oracle| >= ELEM_FLOOR * scale(f)
-        el = elementwise_deviation(got, want, dx)
-        w = max(el, key=lambda k: el[k][0])
-        print("    elementwise above %g x scale:      worst zone %s of %s (value %.3e): relative deviation %.2e"
-              % (ELEM_FLOOR, el[w][1], w, el[w][2], el[w][0]))
-        bad = {k: v for k, v in el.items() if not v[0] <= RTOL}
-        assert not bad, "%s: zones beyond the elementwise rtol %g: %s" % (tag, RTOL, bad)
+        for floor, bound in ELEM_BOUNDS:
+            el = elementwise_deviation(got, want, dx, floor)
+            w = max(el, key=lambda k: el[k][0])
+            print("    elementwise above %g x scale:      worst zone %s of %s (value %.3e): relative deviation %.2e (bound %g)"
+                  % (floor, el[w][1], w, el[w][2], el[w][0], bound))
+            bad = {k: v for k, v in el.items() if not v[0] <= bound}
+            assert not bad, "%s: zones above %g x scale beyond the elementwise rtol %g: %s" % (tag, floor, bound, bad)
     return dev[worst]
 
 

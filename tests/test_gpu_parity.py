@@ -1113,17 +1113,23 @@ def test_a_refused_graph_capture_leaves_the_object_as_it_was(monkeypatch):
     assert a._graphs and torch.equal(a.S_new_b, b.S_new_b)
 
 
+@pytest.mark.parametrize("numerics", ["exact", "contract"])
 @pytest.mark.parametrize("bc", [((2, 2, 2), (2, 2, 2)), ((3, 4, 2), (5, 2, 3)), ((0, 3, 2), (0, 2, 4))])
 @pytest.mark.parametrize("sb_clean", [0, 2])
-def test_boundary_fill_inside_the_hydro_call(hip, bc, sb_clean):
+def test_boundary_fill_inside_the_hydro_call(bc, sb_clean, numerics):
     """CASTRO_AMD_BC_FILL / CASTRO_AMD_STAGE_VALID + _REST: a call that fills the physical-boundary zones of Sborder itself
     (k_ctoprim_bc: outflow clamps and wall mirror images of zones it has cleaned already) gives the bits of castro_amd_bc_fill_fab
     followed by the plain call -- every output array and Sborder itself -- whole and split into the valid / rest stages (the
-    bc_fill + call form is what the oracle comparisons of this file pin)."""
+    bc_fill + call form is what the oracle comparisons of this file pin).  In BOTH builds: boundary zones, ghost-shell zones and
+    valid zones go through one compiled copy of the ctoprim arithmetic (the modes of k_ctoprim), so the `contract` build's FMA
+    contraction cannot tell the launch partitions apart -- a separate boundary kernel differed by an ulp in the primitive state,
+    which a rough state amplified to 1e-4 in a few hundred zones (profiles/r06e_*)."""
     import torch
     import castro_amd
     from castro_amd import _lib as L
+    from castro_amd.hydro import HipHydro
     from tests.util import physical_state
+    hip = HipHydro(0, numerics=numerics)
     rng = np.random.default_rng(11)
     n = (20, 12, 9)
     lo_bc, hi_bc = bc
@@ -1169,6 +1175,7 @@ def test_boundary_fill_inside_the_hydro_call(hip, bc, sb_clean):
         with pytest.raises(RuntimeError):
             hip.construct_ctu_hydro_source((tlo, thi), Ut, (glo, ghi), St, (tlo, thi), Gt, P, 0.0, 1e-4, bc_fill=True,
                                            update_from_sborder=True)
+    hip.close()
 
 
 def test_step_graph_is_rebuilt_when_a_baked_parameter_changes():
@@ -1413,6 +1420,82 @@ def test_many_boxes_per_rank_fill_boundary_group(hip, self_send, monkeypatch):
     assert np.array_equal(low[:, :, 0:ng, :], np.repeat(low[:, :, ng:ng + 1, :], ng, axis=2))
     hip.halo_group_destroy(group)
     hip.comm_destroy(comm)
+
+
+@pytest.mark.parametrize("numerics", ["exact", "contract"])
+def test_two_unequal_boxes_on_one_rank_with_the_overlapped_exchange_equal_one_box(numerics, monkeypatch):
+    """The sequence of castro_amd::expand_state_and_hydro (include/castro_hydro_amd_amrex.H, round 6) through the C ABI: a level of
+    TWO boxes of unequal size on one rank -- castro_amd_fill_boundary_group_ex on the issuing stream, CASTRO_AMD_STAGE_VALID with
+    the pending cleans of every box on a side stream once the group has packed, then CASTRO_AMD_STAGE_REST | CASTRO_AMD_BC_FILL per
+    box, one context per box -- gives, zone for zone, the update of the undivided domain (bc_fill + one whole call).  With RCCL
+    self-send, so that the copies between the two boxes go through ncclSend / ncclRecv."""
+    import torch
+    import castro_amd
+    from castro_amd import halo
+    from castro_amd.hydro import HipHydro
+    from tests.util import physical_state
+    monkeypatch.setenv("CASTRO_AMD_HALO_SELF_SEND", "1")
+    n, ng = (32, 16, 12), 4
+    lo_bc, hi_bc = (2, 3, 2), (2, 2, 4)
+    G = castro_amd.make_geom(n, (0., 0., 0.), (1., 0.5, 0.375), lo_bc, hi_bc)
+    P = castro_amd.default_params(small_dens=0.5)
+    rng = np.random.default_rng(17)
+    dom = ((0, 0, 0), tuple(x - 1 for x in n))
+    gdom = (tuple(x - ng for x in dom[0]), tuple(x + ng for x in dom[1]))
+    U = physical_state(rng, gdom[0], gdom[1], smooth=False, vel=1.0)
+    U[7] = U[0] * rng.uniform(0.9, 1.0, size=U[0].shape)
+    dt = 5e-4
+
+    def outputs(h, bx):
+        Sn = h.alloc(8, *bx)
+        fl, ms, fb = [], [], []
+        for d in range(3):
+            fhi = list(bx[1]); fhi[d] += 1
+            fb.append((bx[0], tuple(fhi)))
+            fl.append(h.alloc(8, bx[0], fhi)); ms.append(h.alloc(1, bx[0], fhi))
+        return Sn, fl, ms, fb
+
+    # the undivided domain
+    whole = HipHydro(0, numerics=numerics)
+    Ud = _to_dev(whole, U)
+    Sn, fl, ms, fb = outputs(whole, dom)
+    whole.bc_fill(Ud, gdom, G)
+    whole.construct_ctu_hydro_source(dom, Ud, gdom, Sn, dom, G, P, 0.0, dt, fluxes=fl, flux_boxes=fb, mass_fluxes=ms,
+                                     update_from_sborder=True, flux_assign=True, sborder_clean=2)
+    torch.cuda.synchronize()
+    want_S, want_fx = Sn.cpu().numpy(), fl[0].cpu().numpy()
+
+    boxes = [((0, 0, 0), (19, 15, 11)), ((20, 0, 0), (31, 15, 11))]
+    ctxs = [HipHydro(0, numerics=numerics) for _ in boxes]
+    comm = ctxs[0].comm_create(1, 0, ctxs[0].comm_unique_id())
+    local, sends, recvs = halo.level_messages(boxes, [0, 0], 0, ng, dom, (False, False, False))
+    group = ctxs[0].halo_group(comm, 2, sends, recvs, 8)
+    gb = [(tuple(x - ng for x in lo), tuple(x + ng for x in hi)) for lo, hi in boxes]
+    S = []
+    for (glo, ghi), (lo, hi) in zip(gb, boxes):
+        a = np.full((8,) + tuple(ghi[d] - glo[d] + 1 for d in (2, 1, 0)), np.nan)        # ghost zones: never read before they are filled
+        a[:, ng:-ng, ng:-ng, ng:-ng] = U[:, lo[2] + ng:hi[2] + ng + 1, lo[1] + ng:hi[1] + ng + 1, lo[0] + ng:hi[0] + ng + 1]
+        S.append(_to_dev(ctxs[0], a))
+    outs = [outputs(h, bx) for h, bx in zip(ctxs, boxes)]
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    ctxs[0].fill_boundary_group_ex(group, S, gb, None)
+    kw = lambda o: dict(fluxes=o[1], flux_boxes=o[3], mass_fluxes=o[2], update_from_sborder=True, flux_assign=True, sborder_clean=2)
+    with torch.cuda.stream(side):
+        ctxs[0].halo_group_wait_packed(group)
+        for h, bx, g_, s_, o in zip(ctxs, boxes, gb, S, outs):
+            h.construct_ctu_hydro_source(bx, s_, g_, o[0], bx, G, P, 0.0, dt, stage="valid", **kw(o))
+    main.wait_stream(side)
+    for h, bx, g_, s_, o in zip(ctxs, boxes, gb, S, outs):
+        h.construct_ctu_hydro_source(bx, s_, g_, o[0], bx, G, P, 0.0, dt, stage="rest", bc_fill=True, **kw(o))
+    torch.cuda.synchronize()
+    assert all(h.status() == 0 for h in ctxs)
+    for (lo, hi), o in zip(boxes, outs):
+        assert np.array_equal(o[0].cpu().numpy(), want_S[:, :, :, lo[0]:hi[0] + 1]), (numerics, lo)
+        assert np.array_equal(o[1][0].cpu().numpy(), want_fx[:, :, :, lo[0]:hi[0] + 2])
+    ctxs[0].halo_group_destroy(group)
+    ctxs[0].comm_destroy(comm)
+    for h in ctxs + [whole]:
+        h.close()
 
 
 def test_fab_ops_avgdown_equals_the_per_box_call(hip):

@@ -16,18 +16,18 @@ c = castro_amd.Castro((n, n, n), numerics=numerics)
 c.initData("sedov")
 dt = c.computeInitialDt(0.01)
 c._swap_state_time_levels()
-c.expand_state(c.S_old_b)
+c.expand_state(c.S_old_b, bc=not c.bc_in_hydro)
 c.red.fill_(1.e200)
 c._whole_step = True
 for _ in range(2):
     c._flux_clear = True
-    c.construct_ctu_hydro_source(0.0, dt, fuse_clean=True, sborder_clean=2)
+    c.construct_ctu_hydro_source(0.0, dt, fuse_clean=True, sborder_clean=2, bc_fill=c.bc_in_hydro)
 torch.cuda.synchronize()
 c.hydro.profile(True)
 c.hydro.profile_reset()
 for _ in range(reps):
     c._flux_clear = True
-    c.construct_ctu_hydro_source(0.0, dt, fuse_clean=True, sborder_clean=2)
+    c.construct_ctu_hydro_source(0.0, dt, fuse_clean=True, sborder_clean=2, bc_fill=c.bc_in_hydro)
 torch.cuda.synchronize()
 prof = c.hydro.profile_report()
 k = {a: round(ms / cnt, 3) for a, (ms, cnt) in sorted(prof.items())}
