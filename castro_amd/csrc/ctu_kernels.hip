@@ -40,7 +40,10 @@
 // frame would push them past 256 VGPRs to one wave per SIMD; held at two waves the overflow is spilled around the call only
 // (Sedov 256^3, riemann_solver = 1: k_trans1 18.6 -> see DESIGN.md section 9)
 #if !defined(CG_ONE_WAVE)
-#define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : 1, GEN == 2 ? 2 : 8)))
+#ifndef FINAL_MIN_WAVES         // A/B (round 6, profiles/r06f_*): 3 = the fold / final / update kernels held to 168 registers for a third wave
+#define FINAL_MIN_WAVES 1
+#endif
+#define CG_TWO_WAVES __attribute__((amdgpu_waves_per_eu(GEN == 2 ? 2 : FINAL_MIN_WAVES, GEN == 2 ? 2 : 8)))
 #else
 #define CG_TWO_WAVES
 #endif
@@ -1696,7 +1699,10 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
 #define DT_THIRDS_FROM_DEVICE()                                                                          \
     if (P.dtp) { const double dt_ = P.dtp[6]; cdtdx = dt_ / g.dx[0] / 3.0; cdtdy = dt_ / g.dx[1] / 3.0; cdtdz = dt_ / g.dx[2] / 3.0; }
 template <bool XRIEM, int DMASK = 7, int GEN = 2, bool LV = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : 2)))
+#ifndef TRACE_PAIR_WAVES        // A/B (round 6, profiles/r06f_*): 3 = the pair kernel held to 168 registers for a third wave per SIMD
+#define TRACE_PAIR_WAVES 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : TRACE_PAIR_WAVES)))
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
                                                     double dt, DevParams P, SkipBox skip, LevelTab lv)
 {
@@ -3303,6 +3309,7 @@ int g_fold_tile = -1;     // CASTRO_AMD_FOLD_TILE: 1 = k_trans1_tile<4, 2> (a 4 
                           // profiles/r05c_ab_fold_tile_kernel.txt); `contract` build only
 int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: != 0 = k_trans1_fold_lds (records parked in LDS;
                           // -0.35 ms per 256^3 step), 0 = two k_riemann1 launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
+int g_trace_one_zone = 0; // CASTRO_AMD_TRACE_ONE_ZONE=1: k_trace (one zone per thread) + k_riemann1<x> instead of k_trace_pair: an occupancy A/B, slower
 int g_side_stream = 0;    // 1: k_divu runs on the context's side stream beside the trace kernel (CASTRO_AMD_SIDE_STREAM); measured: no gain,
                           // two independent pipelines on two streams take as long as one after the other (tools/concurrency_probe.py)
 int g_tile_rows = 32;     // 0: plain row-major workgroup order; > 0: XCD-tiled order with this many rows per y-tile
@@ -3580,6 +3587,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // the join must precede the first reader of DIV (and every return path after this point)
     auto join_divu = [&]() { if (divu_forked) { hipStreamWaitEvent(stream, aux.ev_join, 0); divu_forked = false; } };
     bool x_done = false;      // first x Riemann solve already done inside the trace kernel
+    bool one_zone_trace = false;
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
@@ -3590,6 +3598,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
         else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none, nolv); }
+        else if (g_trace_one_zone && !second_half) {
+            // A/B (CASTRO_AMD_TRACE_ONE_ZONE=1, round 6): ONE zone per thread at the occupancy that leaves (the kernel of the runs with
+            // traced source terms, without the sources), the first x Riemann solve as a launch of its own
+            if (lean_q & 1) { KL("k_trace", (k_trace<false, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P); }
+            else { KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P); }
+            one_zone_trace = true;
+        }
         else if (second_half) {
             if (inner_ok) {
                 const int ns = shell_boxes(olo, ohi, inner_box.lo, inner_box.hi, slo, shi);
@@ -3606,7 +3621,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         } else {
             trace_with_xriemann(olo, ohi);
         }
-        x_done = P.ppm_type != 0 && !tfix;
+        x_done = P.ppm_type != 0 && !tfix && !one_zone_trace;
     }
     (void)staged;
 

@@ -46,7 +46,7 @@ dem = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capt
 print("%-64s %5s %5s %6s %6s %7s" % ("kernel", "vgpr", "agpr", "vspill", "lds", "scratch"))
 for r, d in zip(rows, dem):
     d = re.sub(r"\(.*", "", d).replace("void cad::", "").replace("cad::", "")
-    if not any(k in d for k in ("k_trace_pair", "k_trans1_fold_lds", "k_trans1_tile", "k_final_tile", "k_fab_ops", "k_final<", "k_finalx_consup", "k_ctoprim", "k_divu_pair", "k_hydro")): continue
+    if not any(k in d for k in ("k_trace_pair", "k_trace<", "k_riemann1<0", "k_trans1_fold_lds", "k_trans1_tile", "k_final_tile", "k_fab_ops", "k_final<", "k_finalx_consup", "k_ctoprim", "k_divu_pair", "k_hydro")): continue
     print("%-64s %5d %5d %6d %6d %7d" % (d[:64], r.get(".vgpr_count", -1), r.get(".agpr_count", 0), r.get(".vgpr_spill_count", 0), r.get(".group_segment_fixed_size", 0), r.get(".private_segment_fixed_size", 0)))
 PY
 rm -rf $T
