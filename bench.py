@@ -47,6 +47,8 @@ def path_bytes(reference_contract, numerics, fused_clean=True):
 KERNEL_BYTES_PER_UNIT = {
     "k_ctoprim": 8 * (STATE_PLANES_READ[False] + 8),
     "k_ctoprim_clean": 8 * (STATE_PLANES_READ[False] + 8),                       # + the pending clean_states; only changed components of U are written back
+    "k_ctoprim_shell": 8 * (STATE_PLANES_READ[False] + 8),                       # the ghost shell after CASTRO_AMD_STAGE_VALID (same zone work)
+    "k_ctoprim_bc": 8 * (8 + 8 + 8),                      # a boundary zone: the source zone's 8 components in, 8 out, its primitive record
     "k_divu": 8 * (3 + 1),
     "k_trace": 8 * (8 + 42 + 7),                          # + F1[x] (7-plane state form): the first x Riemann solve is fused in
     "k_riemann1": 8 * (14 + 1 + 8),
@@ -69,6 +71,8 @@ KERNEL_BYTES_PER_UNIT = {
 KERNEL_BYTES_PER_UNIT_LEAN = {
     "k_ctoprim": 8 * (STATE_PLANES_READ[True] + 6),       # neither the temperature nor the species of the state is read
     "k_ctoprim_clean": 8 * (STATE_PLANES_READ[True] + 6),
+    "k_ctoprim_shell": 8 * (STATE_PLANES_READ[True] + 6),
+    "k_ctoprim_bc": 8 * (8 + 8 + 6),
     "k_trace": 8 * (6 + 30 + 5),                          # Q without (rho e), X; 5-plane edge states; 5-plane F1[x]
     "k_trans1_fold": 8 * (30 + 5 + 1 + 36),               # F2 in the 6-plane state form
     "k_final_rmw": 8 * (10 + 12 + 1 + 1 + 6 + 8 + 17),
@@ -93,11 +97,15 @@ def kernel_bytes_per_unit(name, contract, lean=False):
     return tab.get(name, 0)
 
 
-def kernel_units(name, n):
+def kernel_units(name, n, bc_zones=0):
+    """zones / faces one launch of `name` processes on an n box; bc_zones: the zones of grow(box, 4) outside the domain that the
+    hydro call fills itself (k_ctoprim_bc: CASTRO_AMD_BC_FILL) -- k_ctoprim then covers the rest of the grown box only"""
     nx, ny, nz = n
     return {
-        "k_ctoprim": (nx + 8) * (ny + 8) * (nz + 8),
-        "k_ctoprim_clean": (nx + 8) * (ny + 8) * (nz + 8),
+        "k_ctoprim": (nx + 8) * (ny + 8) * (nz + 8) - bc_zones,
+        "k_ctoprim_clean": (nx + 8) * (ny + 8) * (nz + 8) - bc_zones,
+        "k_ctoprim_bc": bc_zones,
+        "k_ctoprim_shell": (nx + 8) * (ny + 8) * (nz + 8) - bc_zones - nx * ny * nz,
         "k_divu": (nx + 2) * (ny + 2) * (nz + 2),
         "k_trace": (nx + 2) * (ny + 2) * (nz + 2),
         "k_riemann1": ((nx + 2) * (ny + 1) * (nz + 2) + (nx + 2) * (ny + 2) * (nz + 1)) / 2.0,     # y and z launches
@@ -413,12 +421,15 @@ def main():
 
     # per-kernel HBM utilisation: compulsory bytes of a launch over its hipEvent-timed duration
     kutil = {}
+    # one rank, no periodic direction: every zone of the ghost shell is a physical-boundary zone, filled by the hydro call
+    nn = info["n"]
+    bc_zones = ((nn[0] + 8) * (nn[1] + 8) * (nn[2] + 8) - nn[0] * nn[1] * nn[2]) if ("k_ctoprim_bc" in prof and world == 1 and not args.periodic) else 0
     for name, (tot_ms, launches) in sorted(prof.items()):
         bpu = kernel_bytes_per_unit(name, contract, lean=(info["numerics"] == "contract"))
         avg_ms = tot_ms / launches
         e = {"avg_launch_ms": avg_ms, "launches_per_step": launches / ksteps, "ms_per_step": tot_ms / ksteps}
         if bpu:
-            nb = bpu * kernel_units(name, info["n"])
+            nb = bpu * kernel_units(name, info["n"], bc_zones)
             e.update({"compulsory_bytes_per_launch": nb, "GBs": nb / avg_ms / 1e6, "frac_of_hbm_peak": nb / avg_ms / 1e6 / HBM_PEAK_GBS})
         kutil[name] = e
     traffic_step, traffic_src = pmc_traffic_per_step() if (world == 1 and info["n"] == (256, 256, 256) and not contract) else (None, "n/a for this configuration")

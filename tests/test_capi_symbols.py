@@ -108,10 +108,14 @@ def test_bench_byte_tables_match_the_plane_counts_of_the_design_document():
     import bench
     names = ("k_ctoprim_clean", "k_divu", "k_trace", "k_trans1_fold", "k_final_y", "k_final_z", "k_finalx_consup")
     n = (256, 256, 256)
+    bc_zones = 264 ** 3 - 256 ** 3          # round 6: the boundary zones of the single-rank bench are filled by the hydro call (k_ctoprim_bc)
     for lean, planes in ((False, 8 + 8 + 4 + 57 + 92 + 56 + 56 + 73), (True, 6 + 6 + 4 + 41 + 72 + 47 + 47 + 63)):
         assert sum(bench.kernel_bytes_per_unit(k, False, lean) for k in names) == 8 * planes
         passes = sum(bench.kernel_bytes_per_unit(k, False, lean) * bench.kernel_units(k, n) for k in names) / 8.0 / 256 ** 3
         assert abs(passes - (291 if lean else 360)) < 1.0, passes
+        # the same with the boundary fill inside the call: k_ctoprim on the valid zones, 24 [22] planes per boundary zone
+        p2 = sum(bench.kernel_bytes_per_unit(k, False, lean) * bench.kernel_units(k, n, bc_zones) for k in names + ("k_ctoprim_bc",)) / 8.0 / 256 ** 3
+        assert abs(p2 - (292 if lean else 361.5)) < 1.0, p2
 
 
 def test_declared_path_bytes_are_the_planes_the_kernels_read():
