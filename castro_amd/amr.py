@@ -989,8 +989,17 @@ class CastroAmr:
             cm &= pn
             if not (ct & cm).any():
                 return []
-        return CL.boxes_from_coarse(ct, cm, o, a, grid_eff=self.grid_eff,
-                                    max_size=None if self.max_grid_size is None else max(self.max_grid_size // 2, a))
+        # The clustering is a pure function of the reduced arrays: a regrid that finds the tags of the last one (a front that has
+        # not crossed a blocking cell since) takes the boxes of the last one instead of 1-2 ms of Berger-Rigoutsos on the host
+        max_size = None if self.max_grid_size is None else max(self.max_grid_size // 2, a)
+        key = (ct.shape, ct.tobytes(), cm.tobytes(), tuple(o), a, self.grid_eff, max_size)
+        memo = self.__dict__.setdefault("_cluster_memo", {})
+        hit = memo.get(l)
+        if hit is not None and hit[0] == key:
+            return list(hit[1])
+        out = CL.boxes_from_coarse(ct, cm, o, a, grid_eff=self.grid_eff, max_size=max_size)
+        memo[l] = (key, list(out))
+        return out
 
     def tag_box(self, l=0):
         """The one-box form: (lo, hi) in level-l zones or None."""
