@@ -303,10 +303,15 @@ class Castro:
         # shell in one launch and the un-split update); "staged": the round-2 split (ctoprim + tracing of the inner zones beside
         # the exchange, split trace launches after it); "tiles": interior tile + six slabs
         self.overlap = overlap                                                   # True | "staged" | "tiles" | False
-        # the hydro call fills the physical-boundary zones of Sborder itself (CASTRO_AMD_BC_FILL: k_ctoprim_bc instead of
-        # k_bc_fill + the k_ctoprim pass over those zones); needs the image of a mirrored ghost layer inside the box
+        # the hydro call can fill the physical-boundary zones of Sborder itself (CASTRO_AMD_BC_FILL: the boundary-zone mode of
+        # k_ctoprim instead of k_bc_fill + the k_ctoprim pass over those zones); needs the image of a mirrored ghost layer inside
+        # the box.  The light overlap needs it (a boundary fill between its two stages would hand clean zones to a pass that
+        # cleans); the plain path keeps k_bc_fill + ONE k_ctoprim over the whole grown box, which is 0.05 ms faster per 256^3 step
+        # (a launch over (n+8)^3 zones of an (n+8)-wide FAB is one contiguous stream, the valid rows alone are not:
+        # profiles/r06h_*).  CASTRO_AMD_BC_IN_HYDRO=0: never; =2: in the plain path as well (A/B, tests).
         self.bc_in_hydro = (hasattr(self.hydro, "lib") and box is None and alloc and min(self.n) >= NUM_GROW
                             and os.environ.get("CASTRO_AMD_BC_IN_HYDRO", "1") != "0")
+        self.bc_in_hydro_plain = self.bc_in_hydro and os.environ.get("CASTRO_AMD_BC_IN_HYDRO", "1") == "2"
         self.fuse_clean = bool(fuse_clean)
         self.fuse_post_clean = True        # post_timestep's clean_state may ride in the fused pass (a level of CastroAmr: no)
         # the clean_state sweeps in front of the hydro update ride inside k_ctoprim (castro_amd_ctu_hydro_fab_ex) when the
@@ -666,7 +671,8 @@ class Castro:
         # hydro call cleans valid and ghost zones alike -- the same zone-local function of the same values.
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
         light = self._light_overlap()
-        bc_h = self.bc_in_hydro and not self.have_sources        # the hydro call fills the physical-boundary zones
+        # the hydro call fills the physical-boundary zones: in the light overlap, or on request (see __init__)
+        bc_h = (self.bc_in_hydro_plain or (self.bc_in_hydro and bool(use_overlap) and light)) and not self.have_sources
         sb_clean = 0
         if self._pending_cleans > 0:
             if self.fuse_sborder_clean and not self.have_sources and (not use_overlap or light):
@@ -944,7 +950,8 @@ class Castro:
         self._post_clean_done, self._whole_step, self._in_retry = True, True, False
         S = self.S_old_b
         use_overlap = self.overlap and self._comm_stream is not None and self.neighbors
-        light, bc_h = self._light_overlap(), self.bc_in_hydro
+        light = self._light_overlap()
+        bc_h = self.bc_in_hydro_plain or (self.bc_in_hydro and bool(use_overlap) and light)
         sb_clean = 2 if (self.fuse_sborder_clean and (not use_overlap or light)) else 0
         if not sb_clean:
             self.clean_state(S, 2)                  # clean_state(S_old) + clean_state(Sborder), see do_advance_ctu
