@@ -374,6 +374,7 @@ struct castro_amd_halo_group {
     long long stotal = 0, rtotal = 0;
     hipEvent_t ev_packed = nullptr;             // castro_amd_fill_boundary_group_ex: recorded behind the last pack launch
     bool packed_recorded = false;
+    std::vector<DFab> fabs;                     // descriptors of the FABs of the call in flight (sized once: no allocation per call)
 };
 
 static void group_chunks(const std::vector<castro_amd_halo_group::Msg>& msgs, int nfab, bool want_local, bool any,
@@ -443,6 +444,11 @@ int castro_amd_halo_group_create(castro_amd_halo_group** out, castro_amd_comm* c
         return g->sends[a].peer != g->sends[b].peer ? g->sends[a].peer < g->sends[b].peer : g->sends[a].tag < g->sends[b].tag; });
     std::sort(g->recv_order.begin(), g->recv_order.end(), [&](int a, int b) {
         return g->recvs[a].peer != g->recvs[b].peer ? g->recvs[a].peer < g->recvs[b].peer : g->recvs[a].tag < g->recvs[b].tag; });
+    g->fabs.resize((size_t)nfabs);
+    // two local sends with one tag: a local receive could not tell them apart
+    for (size_t i = 0; i < g->sends.size(); ++i)
+        for (size_t j = i + 1; j < g->sends.size(); ++j)
+            if (g->sends[i].local && g->sends[j].local && g->sends[i].tag == g->sends[j].tag) { delete g; return CASTRO_AMD_ERR_ARG; }
     // two messages of one pair of ranks with one tag would be matched arbitrarily: refuse
     for (size_t i = 1; i < g->send_order.size(); ++i) {
         const auto &a = g->sends[g->send_order[i - 1]], &b = g->sends[g->send_order[i]];
@@ -518,7 +524,7 @@ static int fill_boundary_group_impl(castro_amd_ctx* ctx, castro_amd_halo_group* 
     if (!ctx || !g || !states) return CASTRO_AMD_ERR_ARG;
     if (hipSetDevice(g->comm->device) != hipSuccess) return CASTRO_AMD_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
-    std::vector<DFab> f((size_t)g->nfab);
+    std::vector<DFab>& f = g->fabs;
     for (int i = 0; i < g->nfab; ++i) {
         const castro_amd_fab& st = states[i];
         if (!st.p || st.ncomp != g->ncomp) return CASTRO_AMD_ERR_ARG;

@@ -1445,6 +1445,11 @@ def test_many_boxes_per_rank_fill_boundary_group(hip, self_send, monkeypatch):
     low = dev[0].cpu().numpy()                   # box 0 touches y = 0: ghost rows j = -4 .. -1 equal row j = 0
     assert np.array_equal(low[:, :, 0:ng, :], np.repeat(low[:, :, ng:ng + 1, :], ng, axis=2))
     hip.halo_group_destroy(group)
+    # refused instead of mis-matched: two sends of one pair of ranks with one tag; a local receive without its send; a FAB index out of range
+    dup = [sends[0], (sends[0][0], sends[0][1], sends[0][2], sends[0][3])] + list(sends[1:])
+    for bad_s, bad_r in ((dup, recvs), (sends[1:], recvs), ([(9,) + tuple(sends[0][1:])] + list(sends[1:]), recvs)):
+        with pytest.raises(RuntimeError):
+            hip.halo_group(comm, 4, bad_s, bad_r, ncomp)
     hip.comm_destroy(comm)
 
 
