@@ -86,8 +86,12 @@ KERNEL_BYTES_PER_UNIT_LEAN = {
 }
 
 
-def kernel_bytes_per_unit(name, contract, lean=False):
+def kernel_bytes_per_unit(name, contract, lean=False, fused_divu=False):
+    """fused_divu: div(u) is computed inside the trace launch (round 6, `contract` build): one more plane written there, the three
+    velocity planes it reads are planes the trace kernel reads anyway, and k_divu's launch (3 + 1 planes) is gone"""
     tab = dict(KERNEL_BYTES_PER_UNIT, **KERNEL_BYTES_PER_UNIT_LEAN) if lean else KERNEL_BYTES_PER_UNIT
+    if name == "k_trace" and fused_divu:
+        return tab["k_trace"] + 8
     if name in ("k_final_x", "k_final_y", "k_final_z"):
         return tab["k_final_rmw" if contract else "k_final_assign"]
     if name == "k_finalx_consup":
@@ -425,7 +429,7 @@ def main():
     nn = info["n"]
     bc_zones = ((nn[0] + 8) * (nn[1] + 8) * (nn[2] + 8) - nn[0] * nn[1] * nn[2]) if ("k_ctoprim_bc" in prof and world == 1 and not args.periodic) else 0
     for name, (tot_ms, launches) in sorted(prof.items()):
-        bpu = kernel_bytes_per_unit(name, contract, lean=(info["numerics"] == "contract"))
+        bpu = kernel_bytes_per_unit(name, contract, lean=(info["numerics"] == "contract"), fused_divu="k_divu" not in prof)
         avg_ms = tot_ms / launches
         e = {"avg_launch_ms": avg_ms, "launches_per_step": launches / ksteps, "ms_per_step": tot_ms / ksteps}
         if bpu:

@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_final_tile; extern int g_gl_sources; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; extern int g_trace_one_zone; }
+namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_final_tile; extern int g_gl_sources; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; extern int g_trace_one_zone; extern int g_divu_in_trace; }
 
 using namespace cad;
 
@@ -226,6 +226,11 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     g_xpad = knob("CASTRO_AMD_XPAD", 0);                               // unused columns in front of every scratch row
     g_side_stream = knob("CASTRO_AMD_SIDE_STREAM", 0);
     g_trace_one_zone = knob("CASTRO_AMD_TRACE_ONE_ZONE", 0);
+#ifdef CAD_NUMERICS_CONTRACT
+    g_divu_in_trace = knob("CASTRO_AMD_DIVU_IN_TRACE", 1);
+#else
+    g_divu_in_trace = knob("CASTRO_AMD_DIVU_IN_TRACE", 0);
+#endif
     g_fold_r1 = knob("CASTRO_AMD_FOLD_R1", 2);
     g_fold_tile_rows = knob("CASTRO_AMD_FOLD_TILE_ROWS", -1);
     g_fold_tile = knob("CASTRO_AMD_FOLD_TILE", -1);

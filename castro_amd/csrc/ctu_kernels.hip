@@ -465,16 +465,11 @@ __global__ void __launch_bounds__(256) k_divu(Tile t, LinBox b, const double* __
 
 // the same for two x-adjacent nodes per thread (no shock flag): per velocity plane and row one 16-byte load of the
 // zones (i, i+1) and one 8-byte load of zone i-1 instead of four 8-byte loads
-template <bool LV = false>
-__global__ void __launch_bounds__(256) k_divu_pair(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
-                                                   double dxinv, double dyinv, double dzinv, LevelTab lv)
+// div(u) at the nodes (i, j, k) and (i+1, j, k) -- the low corners of the thread's two zones; shared by k_divu_pair and by
+// k_trace_pair, which computes it in front of its own work where the launch covers the same box (round 6: one launch less)
+__device__ __forceinline__ void divu_pair_body(const Tile& t, const double* __restrict__ Q, double* __restrict__ DIV, unsigned c, bool v1,
+                                               double dxinv, double dyinv, double dzinv)
 {
-    unsigned vb = blockIdx.x;
-    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_DIVU]; Q = B.S.Q; DIV = B.S.DIV; }
-    int i, j, k;
-    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
-    const bool v1 = i + 1 <= b.hi0;
-    const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const unsigned sx = s.x, sy = s.y, sz = s.z;
     const double* QU_ = Q + PU * t.NC;
@@ -505,6 +500,17 @@ __global__ void __launch_bounds__(256) k_divu_pair(Tile t, LinBox b, const doubl
     }
     if (v1) stg2(DIV, c, d[0], d[1]);
     else stg(DIV, c, d[0]);
+}
+
+template <bool LV = false>
+__global__ void __launch_bounds__(256) k_divu_pair(Tile t, LinBox b, const double* __restrict__ Q, double* __restrict__ DIV,
+                                                   double dxinv, double dyinv, double dzinv, LevelTab lv)
+{
+    unsigned vb = blockIdx.x;
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.b[LB_DIVU]; Q = B.S.Q; DIV = B.S.DIV; }
+    int i, j, k;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
+    divu_pair_body(t, Q, DIV, goff(t, i, j, k), i + 1 <= b.hi0, dxinv, dyinv, dzinv);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1704,7 +1710,7 @@ template <bool XRIEM, int DMASK = 7, int GEN = 2, bool LV = false>
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DMASK == 1 || DMASK == 2 || DMASK == 4) ? TRACE_SPLIT_WAVES : TRACE_PAIR_WAVES)))
 k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                                    double dt, DevParams P, SkipBox skip, LevelTab lv)
+                                                    double dt, DevParams P, SkipBox skip, LevelTab lv, int with_divu)
 {
     constexpr bool GL = gamma_law_edges(GEN) && DMASK == 7;
     if (P.dtp) dt = P.dtp[6];
@@ -1724,6 +1730,11 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
     const long NC = t.NC;
+
+    // Castro::divu (advection_util.cpp:458-475) for the low nodes of the two zones, in front of the tracing: the launch covers the
+    // box k_divu_pair would cover, its registers are free again before the stencils below are requested, and the velocities
+    // it reads are planes this kernel streams anyway (round 6: a launch of 0.18 ms at 256^3 folded in)
+    if (with_divu && valid) divu_pair_body(t, Q, S.DIV, c, v1, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]);
 
     // flattening coefficients of the two zones (Castro_ctu_hydro.cpp:228-266)
     double flat[2];
@@ -3309,6 +3320,14 @@ int g_fold_tile = -1;     // CASTRO_AMD_FOLD_TILE: 1 = k_trans1_tile<4, 2> (a 4 
                           // profiles/r05c_ab_fold_tile_kernel.txt); `contract` build only
 int g_fold_r1 = 2;        // the first y / z Riemann solves inside the transverse stage: != 0 = k_trans1_fold_lds (records parked in LDS;
                           // -0.35 ms per 256^3 step), 0 = two k_riemann1 launches + k_trans1 (CASTRO_AMD_FOLD_R1; profiles/r03c_*, r03d_*)
+// CASTRO_AMD_DIVU_IN_TRACE: div(u) inside k_trace_pair instead of a k_divu_pair launch of its own.  `contract`: on (-0.08 ms per 256^3 step,
+// -0.02 ms at 128^3: the launch of 0.18 ms becomes 0.09 ms more trace); `exact`: off (its trace kernel sits at 252 VGPRs: +0.1 ms).
+// profiles/r06j_*
+#ifdef CAD_NUMERICS_CONTRACT
+int g_divu_in_trace = 1;
+#else
+int g_divu_in_trace = 0;
+#endif
 int g_trace_one_zone = 0; // CASTRO_AMD_TRACE_ONE_ZONE=1: k_trace (one zone per thread) + k_riemann1<x> instead of k_trace_pair: an occupancy A/B, slower
 int g_side_stream = 0;    // 1: k_divu runs on the context's side stream beside the trace kernel (CASTRO_AMD_SIDE_STREAM); measured: no gain,
                           // two independent pipelines on two streams take as long as one after the other (tools/concurrency_probe.py)
@@ -3453,13 +3472,16 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // PPM tracing of the zones of [lo,hi] with the first x Riemann solve fused in, for the faces whose two zones the
     // launch covers; the faces at the workgroup starts follow in a one-thread-per-workgroup launch, those on the
     // x faces of the launch box (lo[0] and hi[0] + 1) are left to the caller.
+    // div(u) of the nodes of grow(bx, 1) inside the trace launches (every zone of that box goes through trace_with_xriemann on this
+    // path, staged or not) instead of a k_divu_pair launch of its own; the hybrid solver needs k_divu's shock flags before the trace
+    const bool divu_in_trace = g_divu_in_trace && !Src.p && P.ppm_type == 1 && !tfix && P.hybrid_riemann != 1 && !g_trace_one_zone;
     auto trace_with_xriemann = [&](const int lo[3], const int hi[3]) {
         // the trace launch and the block-start fix-up share one workgroup order: both see the trace's rows per y-tile
         struct RowsGuard { int keep; RowsGuard() : keep(tl_tile_rows) { if (g_trace_tile_rows >= 0) tl_tile_rows = g_trace_tile_rows; }
                            ~RowsGuard() { tl_tile_rows = keep; } } rows_guard;
         {
 #define K_(V) (k_trace_pair<true, 7, V>)
-            KL2_SOLV("k_trace", K_, lo, hi, S.Q, S, g, dt, P, none, nolv);
+            KL2_SOLV("k_trace", K_, lo, hi, S.Q, S, g, dt, P, none, nolv, divu_in_trace ? 1 : 0);
 #undef K_
         }
         long n_;
@@ -3571,6 +3593,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // Riemann solves already, so that form stays in line)
     bool divu_forked = false;
     if (P.hybrid_riemann == 1) { KL("k_divu", k_divu, olo, ohi, S.Q, S.DIV, S.SHK, 1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2]); }
+    else if (divu_in_trace) { /* k_trace_pair computes it */ }
     else if (aux.side && g_side_stream) {
         hipEventRecord(aux.ev_fork, stream);
         hipStreamWaitEvent(aux.side, aux.ev_fork, 0);
@@ -3597,7 +3620,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
     } else {
         if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
-        else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none, nolv); }
+        else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none, nolv, 0); }
         else if (g_trace_one_zone && !second_half) {
             // A/B (CASTRO_AMD_TRACE_ONE_ZONE=1, round 6): ONE zone per thread at the occupancy that leaves (the kernel of the runs with
             // traced source terms, without the sources), the first x Riemann solve as a launch of its own
@@ -3866,13 +3889,15 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
     else hipLaunchKernelGGL((k_ctoprim<false, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
                             hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0, 0, ShellBoxes{}, BcKinds{});
     prof_end(prof, stream);
-    prof_begin(prof, "k_divu", stream);
-    hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
-                       1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], lv(LB_DIVU));
-    prof_end(prof, stream);
+    if (!g_divu_in_trace) {
+        prof_begin(prof, "k_divu", stream);
+        hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
+                           1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], lv(LB_DIVU));
+        prof_end(prof, stream);
+    }
     prof_begin(prof, "k_trace", stream);
     hipLaunchKernelGGL((k_trace_pair<true, 7, 0, true>), dim3(total(LB_TRACE)), dim3(hb[0].b[LB_TRACE].wg), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g,
-                       dt, P, none, lv(LB_TRACE));
+                       dt, P, none, lv(LB_TRACE), g_divu_in_trace ? 1 : 0);
     prof_end(prof, stream);
     prof_begin(prof, "k_riemann1_blockstart", stream);
     hipLaunchKernelGGL((k_riemann1_blockstart<0, true>), dim3(total(LB_BSTART)), dim3(256), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g, P, lv(LB_BSTART));

@@ -113,6 +113,10 @@ def test_bench_byte_tables_match_the_plane_counts_of_the_design_document():
         assert sum(bench.kernel_bytes_per_unit(k, False, lean) for k in names) == 8 * planes
         passes = sum(bench.kernel_bytes_per_unit(k, False, lean) * bench.kernel_units(k, n) for k in names) / 8.0 / 256 ** 3
         assert abs(passes - (291 if lean else 360)) < 1.0, passes
+        # round 6, `contract` default: div(u) inside the trace launch -- k_divu's 4 planes go, the trace kernel writes one more
+        fused = [k for k in names if k != "k_divu"]
+        p3 = sum(bench.kernel_bytes_per_unit(k, False, lean, fused_divu=True) * bench.kernel_units(k, n) for k in fused) / 8.0 / 256 ** 3
+        assert abs(p3 - (288 if lean else 357)) < 1.0, p3
         # the same with the boundary fill inside the call: k_ctoprim on the valid zones, 24 [22] planes per boundary zone
         p2 = sum(bench.kernel_bytes_per_unit(k, False, lean) * bench.kernel_units(k, n, bc_zones) for k in names + ("k_ctoprim_bc",)) / 8.0 / 256 ** 3
         assert abs(p2 - (292 if lean else 361.5)) < 1.0, p2

@@ -1447,7 +1447,10 @@ def test_many_boxes_per_rank_fill_boundary_group(hip, self_send, monkeypatch):
     hip.halo_group_destroy(group)
     # refused instead of mis-matched: two sends of one pair of ranks with one tag; a local receive without its send; a FAB index out of range
     dup = [sends[0], (sends[0][0], sends[0][1], sends[0][2], sends[0][3])] + list(sends[1:])
-    for bad_s, bad_r in ((dup, recvs), (sends[1:], recvs), ([(9,) + tuple(sends[0][1:])] + list(sends[1:]), recvs)):
+    cases = [(dup, recvs), ([(9,) + tuple(sends[0][1:])] + list(sends[1:]), recvs)]
+    if not self_send:
+        cases.append((sends[1:], recvs))            # (through RCCL a missing partner cannot be seen from one end)
+    for bad_s, bad_r in cases:
         with pytest.raises(RuntimeError):
             hip.halo_group(comm, 4, bad_s, bad_r, ncomp)
     hip.comm_destroy(comm)
