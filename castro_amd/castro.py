@@ -211,9 +211,9 @@ class AdvanceFailure(RuntimeError):
 # smallest box side from which the halo overlap is on by default in a multi-rank run.  Round 6: the LIGHT split (ctoprim with the
 # pending cleans on the valid zones beside the exchange, the ghost shell as one launch, everything downstream un-split) is host-free
 # under castro.use_retry and lives inside the per-rank step graph, so it is compared graph against graph: with all 26 regions
-# through RCCL self-send on one GPU it costs +0.13 / -0.03 / -0.01 / +0.02 ms at 256^3 / 256x256x128 / 256x128x128 / 128^3 per rank
-# (profiles/r06b_overlap_light_split.txt: the loop-back copy and ctoprim compete for the same HBM; the kernel trace shows both
-# running side by side) and it can hide up to the 0.05-0.31 ms of that ctoprim behind real links: on for every box.  (Round 5 had
+# through RCCL self-send on one GPU it costs +0.09 / +0.03 / +0.03 / +0.01 ms at 256^3 / 256x256x128 / 256x128x128 / 128^3 per rank
+# (0.4-1.2 %; profiles/r06b_overlap_light_split.txt: ctoprim over the valid rows + the shell launch against one contiguous ctoprim, and
+# the loop-back copy competing with it for the same HBM; the kernel trace shows both running side by side) and it can hide up to the 0.05-0.31 ms of that ctoprim behind real links: on for every box.  (Round 5 had
 # 384 here: the round-2 staged form -- split trace launches, not host-free under use_retry -- cost 0.2-0.8 ms; overlap="staged".)
 OVERLAP_MIN_ZONES = 0
 
