@@ -64,6 +64,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_allreduce_min",
     "castro_amd_ctx_profile", "castro_amd_ctx_profile_count", "castro_amd_ctx_profile_get",
     "castro_amd_ctx_profile_reset",
+    "castro_amd_berger_rigoutsos",
     "castro_amd_cmpflx_points", "castro_amd_ppm_points", "castro_amd_flatten_points", "castro_amd_trans_points",
 )
 
@@ -272,6 +273,7 @@ def load(numerics=None):
     L.castro_amd_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int,
                                              C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.castro_amd_ctx_profile_reset.argtypes = [C.c_void_p]
+    L.castro_amd_berger_rigoutsos.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int]
     V = C.c_void_p
     L.castro_amd_cmpflx_points.argtypes = [C.c_longlong, C.c_int, V, V, V, V, V, V, C.POINTER(Params), V, V]
     L.castro_amd_ppm_points.argtypes = [C.c_longlong, V, V, V, V, C.c_double, V, V]

@@ -51,7 +51,7 @@ extern "C" {
  *      castro_amd_ctu_hydro_fab_ex / _mf (opts.d_out), castro_amd_clean_state_reduce_fab.
  *   4: castro_amd_numerics(), castro_amd_fill_boundary*(), castro_amd_abi_version().
  *   5: CASTRO_AMD_STAGE_VALID / _REST / CASTRO_AMD_BC_FILL, castro_amd_fill_boundary_ex, castro_amd_halo_plan_wait_packed,
- *      castro_amd_halo_group_* / castro_amd_fill_boundary_group (several boxes per rank);
+ *      castro_amd_halo_group_* / castro_amd_fill_boundary_group (several boxes per rank), castro_amd_berger_rigoutsos;
  *      castro_amd_hydro_opts.sborder_clean_ntimes is accepted by the staged calls.
  * A caller checks `castro_amd_abi_version() == CASTRO_AMD_ABI_VERSION` once after loading the library; a mismatch means
  * the library was built from another revision of this header (a 0.2 caller with 2-double vectors would be written 8 bytes
@@ -634,6 +634,18 @@ int castro_amd_fill_boundary_group_ex(castro_amd_ctx *ctx, castro_amd_halo_group
 int castro_amd_halo_group_wait_packed(castro_amd_halo_group *group, void *other_stream);
 /* ncclAllReduce(MIN) in place on n device doubles: the [dt estimate, min density, ...] reduction of a step */
 int castro_amd_allreduce_min(castro_amd_comm *comm, double *d_buf, int n, void *stream);
+
+/*
+ * Grid generation of a regrid on the HOST (no device work, no context): the point clustering of Berger & Rigoutsos (1991) that
+ * Amr::grid_places applies to the tags of Castro::errorEst (Source/driver/Castro.cpp:3131-3164) [3P: AMReX's ClusterList, restated
+ * from the paper, not pinned against an AMReX build].  tags / mask: nz*ny*nx bytes, [z][y][x], non-zero = tagged / allowed
+ * (mask NULL: everything allowed).  Every tagged, allowed cell ends up in exactly one box; a box lies inside the mask and is
+ * filled to at least grid_eff with tags or is no longer than min_cells a side.  boxes: 6 ints per box (z0, y0, x0, z1, y1, x1),
+ * inclusive.  Returns the number of boxes (only the first max_boxes are written: call again with a larger array if it is more)
+ * or a negative error.  Same boxes as castro_amd/cluster.py::berger_rigoutsos (tests/test_cluster_cpu.py).
+ */
+int castro_amd_berger_rigoutsos(const unsigned char *tags, const unsigned char *mask, int nz, int ny, int nx,
+                                double grid_eff, int min_cells, int *boxes, int max_boxes);
 
 /* Library/version introspection */
 const char *castro_amd_version(void);

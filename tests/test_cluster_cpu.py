@@ -81,3 +81,40 @@ def test_grid_eff_zero_gives_the_bounding_box_and_max_size_chops_it():
     c = CL.chop_max_size(b, 8)
     assert len(c) == 27 and _paint(c, (32, 32, 32)).max() == 1 and _paint(c, (32, 32, 32)).sum() == 20 ** 3
     assert all(h - l + 1 <= 8 for lo, hi in c for l, h in zip(lo, hi))
+
+
+def test_native_clustering_gives_the_boxes_of_the_numpy_form():
+    """castro_amd_berger_rigoutsos (csrc/cluster_host.hip: the host routine the AMR driver uses since round 6) against the numpy
+    statement of the algorithm in castro_amd/cluster.py: random tag clouds, shells, unions of boxes and sparse tags, with and without
+    an allowed region, several efficiencies and minimum sizes -- the same boxes in the same order, box for box."""
+    from castro_amd import cluster as CL
+    rng = np.random.default_rng(12)
+    for case in range(120):
+        shape = tuple(int(rng.integers(1, 36)) for _ in range(3))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            t = rng.random(shape) < rng.uniform(0.01, 0.6)
+        elif kind == 1:
+            z, y, x = np.meshgrid(*[np.arange(n) + 0.5 - n / 2 for n in shape], indexing="ij")
+            t = np.abs(np.sqrt(x * x + y * y + z * z) - rng.uniform(2, max(shape) / 2)) < rng.uniform(0.6, 2.5)
+        elif kind == 2:
+            t = np.zeros(shape, dtype=bool)
+            for _ in range(int(rng.integers(1, 5))):
+                lo = [int(rng.integers(0, n)) for n in shape]
+                hi = [int(rng.integers(l, n)) for l, n in zip(lo, shape)]
+                t[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] = True
+        else:
+            t = rng.random(shape) < 0.02
+        m = None if rng.random() < 0.4 else (rng.random(shape) < rng.uniform(0.7, 1.0))
+        eff, mc = float(rng.choice([0.5, 0.7, 0.9, 0.95])), int(rng.choice([1, 1, 2, 4]))
+        want = CL.berger_rigoutsos_numpy(t, m, eff, mc)
+        got = CL.berger_rigoutsos_native(t, m, eff, mc)
+        assert got == want, (case, shape, kind, eff, mc)
+        # and the properties either form has to have: every allowed tag covered exactly once, boxes inside the allowed region
+        cover = np.zeros(shape, dtype=int)
+        for (x0, y0, z0), (x1, y1, z1) in got:
+            cover[z0:z1 + 1, y0:y1 + 1, x0:x1 + 1] += 1
+            if m is not None:
+                assert m[z0:z1 + 1, y0:y1 + 1, x0:x1 + 1].all()
+        allowed = t if m is None else (t & m)
+        assert (cover[allowed] == 1).all() and cover.max(initial=0) <= 1
