@@ -294,7 +294,7 @@ class Castro:
         # tracing of the zones >= 3 from the box faces while the exchange is in flight, then the rest -- no
         # redundant work.  The older interior-tile + six-slab split ("tiles") re-does ctoprim/trace on 3x the
         # slab volume (+18 % at 256^3, +44 % at 128^3 per rank, tools/overlap_cost.sh).
-        # Default: OVERLAP_MIN_ZONES above (measured: the staged form costs more than the exchange it hides at 256^3 per rank).
+        # Default: OVERLAP_MIN_ZONES above (round 6: the light split, on for every multi-rank box).
         # proxy_ranks > 1 (bench.py --proxy-rank-of): this single-rank object stands for one rank of such a run -- the defaults
         # that depend on the communicator size are taken as that rank would take them
         if overlap is None:
