@@ -290,10 +290,10 @@ class Castro:
 
         self._plans = {}
         self.neighbors = self._build_neighbors() if box is None else []
-        # Overlap of the halo exchange with compute: "staged" (True) runs ctoprim on the valid zones and the PPM
-        # tracing of the zones >= 3 from the box faces while the exchange is in flight, then the rest -- no
-        # redundant work.  The older interior-tile + six-slab split ("tiles") re-does ctoprim/trace on 3x the
-        # slab volume (+18 % at 256^3, +44 % at 128^3 per rank, tools/overlap_cost.sh).
+        # Overlap of the halo exchange with compute (the forms are listed where self.overlap is set below): True = the light
+        # split of round 6; "staged" runs ctoprim on the valid zones and the PPM tracing of the zones >= 3 from the box faces
+        # while the exchange is in flight, then the rest -- no redundant work, split trace launches; the older interior-tile +
+        # six-slab split ("tiles") re-does ctoprim/trace on 3x the slab volume (+18 % at 256^3, +44 % at 128^3 per rank).
         # Default: OVERLAP_MIN_ZONES above (round 6: the light split, on for every multi-rank box).
         # proxy_ranks > 1 (bench.py --proxy-rank-of): this single-rank object stands for one rank of such a run -- the defaults
         # that depend on the communicator size are taken as that rank would take them
