@@ -281,6 +281,10 @@ def main():
                     help="untimed extra (single GPU): ms/step of ONE rank's box of the N-rank strong-scaling run of this workload "
                          "with a full 26-region halo exchange through RCCL self-send (default with extras: 2 4 8); a PROJECTION, "
                          "reported in config.rank_proxies, never in value")
+    ap.add_argument("--proxy-in-process", action="store_true", help="run the rank proxies in this process (default: in a child process, so "
+                    "that nothing they do can take the bench line down with it)")
+    ap.add_argument("--proxy-child", action="store_true", help=argparse.SUPPRESS)          # internal: this IS the child
+    ap.add_argument("--proxy-value", type=float, default=0.0, help=argparse.SUPPRESS)       # internal: the parent's cell-updates/s
     args = ap.parse_args()
 
     # `python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD torch.distributed.run (never an exec, and
@@ -343,6 +347,60 @@ def main():
         if comm is not None:
             comm.barrier()
             torch.cuda.synchronize()
+
+    def run_proxies(want, value):
+        """Projection of the strong-scaling curve from ONE GPU (clearly not a measurement of N GPUs): the box one rank of the N-rank run
+        owns (z, then y, then x halved), periodic in every direction so that all 26 neighbour regions exist, every region packed, sent to
+        and received from this same rank through ncclSend / ncclRecv of the kernel library's communicator (CASTRO_AMD_HALO_SELF_SEND),
+        unpacked, with the halo overlap exactly as a rank of that size would run it and the step graph of the RCCL form.  What it
+        leaves out: xGMI instead of a loopback copy, and the waiting for the slowest rank."""
+        proxies = {"note": "PROJECTED from one GPU: one rank's box of the N-rank strong-scaling run, 26-region exchange through RCCL self-send; "
+                           "projected_value = N x zones of the box / time, an upper bound of what N GPUs can reach"}
+        saved = {k: os.environ.get(k) for k in ("CASTRO_AMD_C_HALO", "CASTRO_AMD_HALO_SELF_SEND")}
+        os.environ["CASTRO_AMD_C_HALO"], os.environ["CASTRO_AMD_HALO_SELF_SEND"] = "1", "1"
+        try:
+            for N in want:
+                gN = castro_amd.default_grid(N)
+                nb = tuple(n_cell[d] // gN[d] for d in range(3))
+                try:
+                    c = castro_amd.Castro(nb, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), overlap=overlap, numerics=args.numerics, proxy_ranks=N)
+                    c.initData("sedov", r_init=0.01 * 256.0 / max(n_cell))
+                    ks = max(10, min(args.steps, 30))
+                    c.run_steps(6)
+                    c.prepare_step_graph()
+                    sync()
+                    t0 = time.perf_counter()
+                    c.run_steps(ks)
+                    sync()
+                    ms = (time.perf_counter() - t0) / ks * 1e3
+                    hs = c.halo_stats()
+                    proxies[str(N)] = {"box": list(nb), "ms_per_step": ms, "projected_value": N * nb[0] * nb[1] * nb[2] / ms * 1e3,
+                                       "projected_efficiency_vs_1gpu": ((N * nb[0] * nb[1] * nb[2] / ms * 1e3) / (N * value)) if value > 0 else None,
+                                       "overlap_halo": (c.overlap if c.overlap in ("tiles", "staged") else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
+                                       "step_graph": bool(getattr(c, "_graphs", None)), "regions": hs["regions"],
+                                       "bytes_exchanged_per_step": sum(nbr["sbuf"].numel() * 8 for nbr in c.neighbors),
+                                       "fillboundary_ms": hs["fillboundary_ms"], "issued_by": hs["issued_by"]}
+                    c.close()
+                    c.comm.close(c.hydro)          # the proxy's own one-rank RCCL communicator
+                    del c
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    proxies[str(N)] = {"box": list(nb), "error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.synchronize()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        return proxies
+
+    if args.proxy_child:
+        # the child of a default run: the proxies and nothing else, one JSON object on the real stdout
+        out = run_proxies(args.proxy_rank_of or [2, 4, 8], args.proxy_value)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps({"rank_proxies": out}) + "\n").encode())
+        return
 
     def run(contract_mode, steps, warmup, kernel_pass, stepwise=None, state="sedov", per_step=False, numerics=None, overlap_=None):
         """W untimed warm-up steps, K timed steps (no profiling events in the timed region), then -- untimed -- a second
@@ -503,53 +561,33 @@ def main():
                 extras[st + "_error"] = "%s: %s" % (type(e).__name__, e)
                 torch.cuda.synchronize()
 
-    # Projection of the strong-scaling curve from ONE GPU (clearly not a measurement of N GPUs): the box one rank of the N-rank run
-    # owns (z, then y, then x halved), periodic in every direction so that all 26 neighbour regions exist, every region packed,
-    # sent to and received from this same rank through ncclSend / ncclRecv of the kernel library's communicator
-    # (CASTRO_AMD_HALO_SELF_SEND), unpacked, with the staged overlap exactly as a rank of that size would run it and the step
-    # graph of the RCCL form.  What it leaves out: xGMI instead of a loopback copy, and the waiting for the slowest rank.
+    # Projection of the strong-scaling curve from ONE GPU (run_proxies above), by default in a CHILD process: the proxies drive RCCL
+    # self-send inside captured two-stream graphs, and whatever could go wrong there (round 6 met a segmentation fault inside
+    # hipStreamEndCapture with another stream arrangement) must not cost the measured line of this process
     proxies = None
     want = args.proxy_rank_of if args.proxy_rank_of is not None else ([2, 4, 8] if (world == 1 and not args.no_extras and not contract) else [])
-    if world == 1 and want:
-        proxies = {"note": "PROJECTED from one GPU: one rank's box of the N-rank strong-scaling run, 26-region exchange through RCCL self-send; "
-                           "projected_value = N x zones of the box / time, an upper bound of what N GPUs can reach"}
-        saved = {k: os.environ.get(k) for k in ("CASTRO_AMD_C_HALO", "CASTRO_AMD_HALO_SELF_SEND")}
-        os.environ["CASTRO_AMD_C_HALO"], os.environ["CASTRO_AMD_HALO_SELF_SEND"] = "1", "1"
+    if world == 1 and want and args.proxy_in_process:
+        proxies = run_proxies(want, value)
+    elif world == 1 and want:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--proxy-child", "--proxy-value", repr(value), "--proxy-rank-of"] + [str(N) for N in want] + [
+            "--ncell", str(args.ncell), "--steps", str(args.steps), "--numerics", args.numerics, "--no-cpu-baseline"]
+        for flag, on in (("--no-overlap", args.no_overlap), ("--force-overlap", args.force_overlap), ("--overlap-tiles", args.overlap_tiles),
+                         ("--overlap-staged", args.overlap_staged), ("--weak", args.weak)):
+            if on:
+                cmd.append(flag)
         try:
-            for N in want:
-                gN = castro_amd.default_grid(N)
-                nb = tuple(n_cell[d] // gN[d] for d in range(3))
-                try:
-                    c = castro_amd.Castro(nb, lo_bc=(0, 0, 0), hi_bc=(0, 0, 0), overlap=overlap, numerics=args.numerics, proxy_ranks=N)
-                    c.initData("sedov", r_init=0.01 * 256.0 / max(n_cell))
-                    ks = max(10, min(args.steps, 30))
-                    c.run_steps(6)
-                    c.prepare_step_graph()
-                    sync()
-                    t0 = time.perf_counter()
-                    c.run_steps(ks)
-                    sync()
-                    ms = (time.perf_counter() - t0) / ks * 1e3
-                    hs = c.halo_stats()
-                    proxies[str(N)] = {"box": list(nb), "ms_per_step": ms, "projected_value": N * nb[0] * nb[1] * nb[2] / ms * 1e3,
-                                       "projected_efficiency_vs_1gpu": (N * nb[0] * nb[1] * nb[2] / ms * 1e3) / (N * value),
-                                       "overlap_halo": (c.overlap if c.overlap in ("tiles", "staged") else bool(c.overlap and c._comm_stream is not None and c.neighbors)),
-                                       "step_graph": bool(getattr(c, "_graphs", None)), "regions": hs["regions"],
-                                       "bytes_exchanged_per_step": sum(nbr["sbuf"].numel() * 8 for nbr in c.neighbors),
-                                       "fillboundary_ms": hs["fillboundary_ms"], "issued_by": hs["issued_by"]}
-                    c.close()
-                    c.comm.close(c.hydro)          # the proxy's own one-rank RCCL communicator
-                    del c
-                    torch.cuda.empty_cache()
-                except Exception as e:
-                    proxies[str(N)] = {"box": list(nb), "error": "%s: %s" % (type(e).__name__, e)}
-                    torch.cuda.synchronize()
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()                 # the child needs the memory of the legs that are done
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and "rank_proxies" in ln]
+            if lines:
+                proxies = json.loads(lines[-1])["rank_proxies"]
+                proxies["run_in"] = "child process"
+            else:
+                proxies = {"error": "proxy child exited with code %d: %s" % (r.returncode, r.stderr[-400:])}
+        except Exception as e:
+            proxies = {"error": "%s: %s" % (type(e).__name__, e)}
 
     out = {
         "metric": "cell-updates/sec, Sedov 3D 256\u00b3 single-level at 1/2/4/8 MI355X; % HBM roofline",
