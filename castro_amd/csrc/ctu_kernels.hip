@@ -829,9 +829,9 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         double rhoe_g_ref = GL ? 0.0 : w.Im_re[0];
 
         // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
-        rho_ref = amax(rho_ref, P.small_dens);
+        rho_ref = amax_cu(rho_ref, P.small_dens);
         double rho_ref_inv = frcp(rho_ref);
-        p_ref = amax(p_ref, P.small_pres);
+        p_ref = amax_cu(p_ref, P.small_pres);
 
         double csq_ref = gam * p_ref * rho_ref_inv;
         double cc_ref = fsqrt(csq_ref);
@@ -881,9 +881,9 @@ __device__ __forceinline__ void trace_finish(const TraceW& w, double un, double 
         double rhoe_g_ref = GL ? 0.0 : w.Ip_re[2];
 
         // rho_ref >= small_dens, p_ref >= small_pres: every operand of the fast forms is a normal number far from the range ends
-        rho_ref = amax(rho_ref, P.small_dens);
+        rho_ref = amax_cu(rho_ref, P.small_dens);
         double rho_ref_inv = frcp(rho_ref);
-        p_ref = amax(p_ref, P.small_pres);
+        p_ref = amax_cu(p_ref, P.small_pres);
 
         double csq_ref = gam * p_ref * rho_ref_inv;
         double cc_ref = fsqrt(csq_ref);
@@ -1588,8 +1588,8 @@ __device__ __forceinline__ void final_flux_tail(const Tile& t, const DevScratch&
         double div1[2];
         div1[0] = 0.25 * (d00.a + d10.a + d01.a + d11.a);
         div1[1] = 0.25 * (d00.b + d10.b + d01.b + d11.b);
-        div1[0] = P.difmag * amin(0.0, div1[0]);
-        div1[1] = P.difmag * amin(0.0, div1[1]);
+        div1[0] = P.difmag * (kAsmMinMax ? amin_hw(0.0, div1[0]) : amin(0.0, div1[0]));
+        div1[1] = P.difmag * (kAsmMinMax ? amin_hw(0.0, div1[1]) : amin(0.0, div1[1]));
         double uR[2][NUM_STATE], uL[2][NUM_STATE];            // kept only by the flux limiters
 #pragma unroll
         for (int m = 0; m < NUM_STATE; ++m) {
@@ -1763,10 +1763,10 @@ k_trace_pair(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGe
         load_stencil_2<2>(Q + PW * NC, c, s.z, uzA, uzB);
         flat[0] = flatten_1d(pxA, uxA);
         flat[1] = flatten_1d(pxB, uxB);
-        flat[0] = amin(flat[0], flatten_1d(pyA, uyA));
-        flat[1] = amin(flat[1], flatten_1d(pyB, uyB));
-        flat[0] = amin(flat[0], flatten_1d(pzA, uzA));
-        flat[1] = amin(flat[1], flatten_1d(pzB, uzB));
+        flat[0] = amin_c(flat[0], flatten_1d(pyA, uyA));
+        flat[1] = amin_c(flat[1], flatten_1d(pyB, uyB));
+        flat[0] = amin_c(flat[0], flatten_1d(pzA, uzA));
+        flat[1] = amin_c(flat[1], flatten_1d(pzB, uzB));
     } else {
         flat[0] = flat[1] = 1.0;
     }

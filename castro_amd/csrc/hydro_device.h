@@ -40,11 +40,30 @@ __device__ __forceinline__ double fsqrt(double x)
     g = __builtin_fma(d, h, g);
     return __builtin_amdgcn_class(x, 0x260 /* +-0, +inf */) ? x : g;
 }
+// the same for 2^-767 <= x < inf WITHOUT the last select: +-0 and +inf come out as NaN.  For the wave speeds of the Riemann solver,
+// whose next operation is a hardware maximum against a positive floor (which drops a NaN operand: the floor is what 0 would have
+// given as well)
+__device__ __forceinline__ double fsqrt_floor(double x)
+{
+#ifdef NO_SQRT_NOCLASS
+    return fsqrt(x);
+#else
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+#endif
+}
 #else
 constexpr bool kContract = false;
 __device__ __forceinline__ double frcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ double fdiv(double a, double b) { return a / b; }
 __device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double fsqrt_floor(double x) { return sqrt(x); }
 #endif
 }
 
@@ -110,6 +129,29 @@ __device__ __forceinline__ double amax_hw(double a, double b) { return (a < b) ?
 __device__ __forceinline__ double amin_hw(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double amax_hw(double a, double b) { return __builtin_fmax(a, b); }
 #endif
+// `contract` only (round 6): the minimum / maximum of two VALUES as ONE v_min_f64 / v_max_f64, written as an asm statement so that
+// the compiler neither expands it to a compare and two 32-bit selects (the ternaries above: 3-4 VALU instructions; 17 % of the
+// trace kernel's and 8 % of the tile kernel's static VALU instructions were such expansions) nor puts a canonicalising
+// v_max_f64(x, x) in front of an operand that was loaded from memory (what llvm.maxnum costs in IEEE mode: a third of the
+// amin_hw / amax_hw instructions of the trace kernel were those).  Differences from the ternaries, both outside the contract of
+// this build (rtol 1e-10 on finite states; the flags already say -fno-signed-zeros): a NaN in the FIRST argument is dropped
+// instead of kept, and zeros of opposite sign may come out with the other sign.  Used only inside the per-interface functions
+// (flattening, PPM limiters, traced states, Riemann solver, transverse corrections), where a NaN state still reaches the result
+// through the other operands of the same expression; clean_state, the update and the time-step reductions keep the ternaries.
+// amin_cu / amax_cu: the second operand is uniform over the wave (a kernel parameter) and stays in scalar registers.
+#if defined(CAD_NUMERICS_CONTRACT) && !defined(NO_ASM_MINMAX)
+__device__ __forceinline__ double amin_c(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double amax_c(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double amin_cu(double a, double u) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(u)); return r; }
+__device__ __forceinline__ double amax_cu(double a, double u) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(u)); return r; }
+constexpr bool kAsmMinMax = true;
+#else
+__device__ __forceinline__ double amin_c(double a, double b) { return amin(a, b); }
+__device__ __forceinline__ double amax_c(double a, double b) { return amax(a, b); }
+__device__ __forceinline__ double amin_cu(double a, double u) { return amin(a, u); }
+__device__ __forceinline__ double amax_cu(double a, double u) { return amax(a, u); }
+constexpr bool kAsmMinMax = false;
+#endif
 // copysign(1.0, x) as the reference's x86-64 CPU build evaluates it when x is a NaN.  The sign of a NaN is outside
 // IEEE 754's value semantics, but the Riemann solvers branch on it: `sgnm = copysign(1.0, ustar)` decides
 // `spout = co - sgnm*uo`, and `spout < 0` returns the (finite) upwind state even when ustar is a NaN (met with
@@ -160,7 +202,7 @@ __device__ __forceinline__ double flatten_1d(const double p[7], const double u[5
     double tst = 0.0;
     if (u[1] - u[3] >= 0.0) tst = 1.0;
 
-    double tmp = amin(p[4], p[2]);
+    double tmp = amin_c(p[4], p[2]);
 
     double chi = 0.0;
     if (fabs(dp) > shktst * tmp) chi = tst;
@@ -182,17 +224,25 @@ __device__ __forceinline__ double flatten_1d(const double p[7], const double u[5
     tst = 0.0;
     if (um1 - up1 >= 0.0) tst = 1.0;
 
-    tmp = amin(pp1, pm1);
+    tmp = amin_c(pp1, pm1);
 
     double chi2 = 0.0;
     if (fabs(dp) > shktst * tmp) chi2 = tst;
 
-    return 1.0 - amax(chi2 * z2, chi * z);
+    return 1.0 - amax_c(chi2 * z2, chi * z);
 }
 
 // ---------------------------------------------------------------------------------------
 // PPM (Source/hydro/ppm.H)
 // ---------------------------------------------------------------------------------------
+// copysign(1.0, a) * m for m >= +0: the sign of `a` put on m (one v_bfi_b32 on the high word instead of a constant built in two
+// registers and a multiplication) -- the same bits for every finite m; `contract` only so that the other build stays literal
+#if defined(CAD_NUMERICS_CONTRACT) && !defined(NO_SLOPE_SIGN)
+#define CAD_SLOPE_SIGN(a, m) copysign((m), (a))
+#else
+#define CAD_SLOPE_SIGN(a, m) (copysign(1.0, (a)) * (m))      // a macro, not a function: the `exact` build keeps its expression tree
+#endif
+
 // ppm.H:54-139; s[0..4] = zones i-2..i+2
 __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn, double& sm, double& sp)
 {
@@ -204,7 +254,7 @@ __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn,
     double dsvl_l = 0.0;
     if (dsl * dsr > 0.0) {
         double dsc = 0.5 * (s[2] - s[0]);
-        dsvl_l = copysign(1.0, dsc) * amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr)));
+        dsvl_l = CAD_SLOPE_SIGN(dsc, amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr))));
     }
 
     dsl = 2.0 * (s[2] - s[1]);
@@ -213,13 +263,13 @@ __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn,
     double dsvl_r = 0.0;
     if (dsl * dsr > 0.0) {
         double dsc = 0.5 * (s[3] - s[1]);
-        dsvl_r = copysign(1.0, dsc) * amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr)));
+        dsvl_r = CAD_SLOPE_SIGN(dsc, amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr))));
     }
 
     sm = 0.5 * (s[2] + s[1]) - (1.0 / 6.0) * (dsvl_r - dsvl_l);
 
-    sm = amax(sm, amin(s[2], s[1]));
-    sm = amin(sm, amax(s[2], s[1]));
+    sm = amax_c(sm, amin_c(s[2], s[1]));
+    sm = amin_c(sm, amax_c(s[2], s[1]));
 
     // the slope at zone i (dsvl_r above) is recomputed by the reference with identical
     // operands: reuse it as the new "left" slope
@@ -231,13 +281,13 @@ __device__ __forceinline__ void ppm_reconstruct(const double s[5], double flatn,
     dsvl_r = 0.0;
     if (dsl * dsr > 0.0) {
         double dsc = 0.5 * (s[4] - s[2]);
-        dsvl_r = copysign(1.0, dsc) * amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr)));
+        dsvl_r = CAD_SLOPE_SIGN(dsc, amin_hw(fabs(dsc), amin_hw(fabs(dsl), fabs(dsr))));
     }
 
     sp = 0.5 * (s[3] + s[2]) - (1.0 / 6.0) * (dsvl_r - dsvl_l);
 
-    sp = amax(sp, amin(s[3], s[2]));
-    sp = amin(sp, amax(s[3], s[2]));
+    sp = amax_c(sp, amin_c(s[3], s[2]));
+    sp = amin_c(sp, amax_c(s[3], s[2]));
 
     sm = flatn * sm + (1.0 - flatn) * s[2];
     sp = flatn * sp + (1.0 - flatn) * s[2];
@@ -583,14 +633,14 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     // wsmall = small_dens * csmall is finite and >= +0, the square roots are >= +0 or NaN: amax_hw is exact
     // contract: a product below 2^-767 (both floors at work) may come out of fsqrt as a NaN, which amax_hw drops for wsmall;
     // wl + wr >= 2 small_dens csmall; ro, rstar >= small_dens; co >= csmall >= 1e-8
-    double wl = amax_hw(wsmall, fsqrt(fabs(ql.gamc * ql.p * ql.rho)));
-    double wr = amax_hw(wsmall, fsqrt(fabs(qr.gamc * qr.p * qr.rho)));
+    double wl = amax_hw(wsmall, fsqrt_floor(fabs(ql.gamc * ql.p * ql.rho)));
+    double wr = amax_hw(wsmall, fsqrt_floor(fabs(qr.gamc * qr.p * qr.rho)));
 
     double wwinv = frcp(wl + wr);
     double pstar = ((wr * ql.p + wl * qr.p) + wl * wr * (ql.un - qr.un)) * wwinv;
     double ustar = ((wl * ql.un + wr * qr.un) + (ql.p - qr.p)) * wwinv;
 
-    pstar = amax(pstar, P.small_pres);
+    pstar = amax_cu(pstar, P.small_pres);
 
     if (fabs(ustar) < smallu * 0.5 * (fabs(ql.un) + fabs(qr.un))) {
         ustar = 0.0;
@@ -612,7 +662,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
 
     double roinv = frcp(ro);
 
-    double co = fsqrt(fabs(gamco * po * roinv));
+    double co = fsqrt_floor(fabs(gamco * po * roinv));
     co = amax_hw(raux.csmall, co);                 // csmall = amax(small, ...) is a positive finite number
     double co2inv = frcp(co * co);
 
@@ -627,8 +677,9 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
     double estar = reo + (pstar - po) * entho;
 
     // pstar >= small_pres, small_dens <= rstar: far above 2^-767
-    double cstar = kContract ? fsqrt(fabs(gamco * pstar * frcp(rstar))) : sqrt(fabs(gamco * pstar / rstar));
-    cstar = amax(cstar, raux.csmall);
+    double cstar = kContract ? (kAsmMinMax ? fsqrt_floor(fabs(gamco * pstar * frcp(rstar))) : fsqrt(fabs(gamco * pstar * frcp(rstar))))
+                             : sqrt(fabs(gamco * pstar / rstar));
+    cstar = amax_c(cstar, raux.csmall);
 
     double spout = co - sgnm * uo;
     double spin = cstar - sgnm * ustar;
@@ -640,12 +691,20 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
         spout = ushock;
     }
 
-    double scr = spout - spin;                     // may be a denormal difference: its division stays IEEE
+    double scr = spout - spin;
     if (spout - spin == 0.0) {
         scr = small * raux.cavg;
     }
 
-    double frac = (1.0 + (spout + spin) / scr) * 0.5;
+#if defined(CAD_NUMERICS_CONTRACT) && !defined(NO_FAST_FRAC)
+    // co, cstar >= csmall >= 1e-8, so spout and spin are zero or above 2^-81 in magnitude and their non-zero difference is above
+    // 2^-133; small * cavg >= 1e-8 sqrt(small_pres / rho) is far above 2^-900 as well.  The floor below only keeps a difference that
+    // the reassociating compiler may have formed in another order out of the denormal range of frcp: it never changes a quotient
+    // that the clamp to [0, 1] lets through.
+    double frac = (1.0 + (spout + spin) * frcp(copysign(amax_hw(0x1p-900, fabs(scr)), scr))) * 0.5;
+#else
+    double frac = (1.0 + (spout + spin) / scr) * 0.5;      // exact: IEEE; (the `contract` build kept it IEEE until round 6)
+#endif
     frac = amax_hw(0.0, amin_hw(1.0, frac));       // constants first
 
     qint.rho = frac * rstar + (1.0 - frac) * ro;
@@ -667,7 +726,7 @@ __device__ __forceinline__ void riemannus(const RState& ql, const RState& qr, co
         regdnv = estar;
     }
 
-    qint.p = amax(qint.p, P.small_pres);
+    qint.p = amax_cu(qint.p, P.small_pres);
     qint.rhoe = regdnv;
 
     qint.un = qint.un * raux.bnd_fac;
@@ -1368,11 +1427,11 @@ __device__ __forceinline__ void interface_flux(const RState& ql_raw, const RStat
     } else {
         RState ql = ql_raw, qr = qr_raw;
         // riemann.H:70-71
-        ql.rho = amax(ql.rho, P.small_dens);
-        qr.rho = amax(qr.rho, P.small_dens);
+        ql.rho = amax_cu(ql.rho, P.small_dens);
+        qr.rho = amax_cu(qr.rho, P.small_dens);
 
         RAux raux;
-        raux.csmall = amax(small, small * amax(cr, cl));
+        raux.csmall = kAsmMinMax ? amax_hw(small, small * amax_c(cr, cl)) : amax(small, small * amax(cr, cl));
         raux.cavg = 0.5 * (cr + cl);
         raux.bnd_fac = bnd_fac;
 
@@ -1532,7 +1591,7 @@ __device__ __forceinline__ void trans_single(const double q[NEDGE], const double
             qo[PRE] = q[PRE];
         }
         double pnewn = q[PP] - cdtdx * (dup + pav * du * (gamc - 1.0));
-        qo[PP] = amax(pnewn, P.small_pres);
+        qo[PP] = amax_cu(pnewn, P.small_pres);
     } else {
         qo[PP] = q[PP];
         qo[PRE] = q[PRE];
@@ -1629,7 +1688,7 @@ __device__ __forceinline__ void trans_final(const double q[NEDGE],
         qo[PRE] = q[PRE];
     }
 
-    qo[PP] = amax(qo[PP], P.small_pres);
+    qo[PP] = amax_cu(qo[PP], P.small_pres);
     reset_edge_state_thermo(qo, P);
 }
 
