@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = (
     "castro_amd_fluxreg_fine_add_fab", "castro_amd_reflux_fab",
     "castro_amd_old_rotation_source_fab", "castro_amd_new_rotation_source_fab",
     "castro_amd_old_gravity_source_fab", "castro_amd_new_gravity_source_fab", "castro_amd_saxpy_fab", "castro_amd_clean_state_fab", "castro_amd_clean_state_reduce_fab",
-    "castro_amd_estdt_fab",
+    "castro_amd_estdt_fab", "castro_amd_sources_mf", "castro_amd_clean_state_reduce_mf", "castro_amd_estdt_mf",
     "castro_amd_bc_fill_fab", "castro_amd_copy_fab", "castro_amd_pack_fab", "castro_amd_unpack_fab",
     "castro_amd_pack_regions_fab", "castro_amd_unpack_regions_fab", "castro_amd_fillpatch_shell_fab", "castro_amd_apply_source_fab", "castro_amd_fab_ops",
     "castro_amd_sedov_init_fab", "castro_amd_sod_init_fab", "castro_amd_version", "castro_amd_abi_version", "castro_amd_numerics",
@@ -101,6 +101,16 @@ class HydroBox(C.Structure):
                 ("Sborder", Fab), ("src", Fab), ("S_new", Fab), ("flux", Fab * 3), ("mass_flux", Fab * 3), ("qe", Fab * 3)]
 
 
+class SourceBox(C.Structure):
+    """castro_amd_source_box: one box of a castro_amd_sources_mf call"""
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3), ("S_old", Fab), ("S_new", Fab), ("source", Fab), ("mass_flux", Fab * 3)]
+
+
+class StateBox(C.Structure):
+    """castro_amd_state_box: one box of castro_amd_clean_state_reduce_mf / castro_amd_estdt_mf"""
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3), ("state", Fab)]
+
+
 class Rotation(C.Structure):
     """castro_amd_rotation"""
     _fields_ = [("omega", C.c_double * 3), ("center", C.c_double * 3), ("include_centrifugal", C.c_int),
@@ -147,7 +157,7 @@ class FabOp(C.Structure):
                 ("side", C.c_int), ("a", C.c_double), ("b", C.c_double), ("dst", Fab), ("src", Fab), ("src2", Fab)]
 
 
-OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN, OP_AVGDOWN = 0, 1, 2, 3, 4, 5, 6, 7
+OP_COPY, OP_LINCOMB, OP_FLUXREG_CRSE_INIT, OP_FLUXREG_FINE_ADD, OP_REFLUX, OP_CLEAN, OP_INTERP_CLEAN, OP_AVGDOWN, OP_INTERP = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _libs = {}
 ABI_VERSION = 5          # CASTRO_AMD_ABI_VERSION of include/castro_hydro_amd.h this binding was written against
@@ -206,6 +216,11 @@ def load(numerics=None):
                                           C.POINTER(Geom), C.POINTER(Params), C.c_double, C.c_double, C.POINTER(HydroOpts),
                                           C.c_void_p]
     L.castro_amd_fab_ops_p.argtypes = [C.c_void_p, C.c_int, C.POINTER(FabOp), C.POINTER(Params), C.c_void_p]
+    L.castro_amd_sources_mf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(SourceBox), C.POINTER(C.c_double), C.c_int,
+                                        C.POINTER(Rotation), C.POINTER(Geom), C.POINTER(Params), C.c_double, C.c_int, C.c_void_p]
+    L.castro_amd_clean_state_reduce_mf.argtypes = [C.c_void_p, C.c_int, C.POINTER(StateBox), C.POINTER(Geom), C.POINTER(Params),
+                                                   C.c_int, C.c_void_p, C.c_void_p]
+    L.castro_amd_estdt_mf.argtypes = [C.c_void_p, C.c_int, C.POINTER(StateBox), C.POINTER(Geom), C.POINTER(Params), C.c_void_p, C.c_void_p]
     L.castro_amd_step_control.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_double, C.c_double,
                                           C.c_double, C.c_int, C.c_void_p]
     L.castro_amd_clean_state_fab.argtypes = [C.c_void_p, PF, I3, I3, C.POINTER(Params), C.c_int, C.c_void_p]

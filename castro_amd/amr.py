@@ -343,6 +343,30 @@ class _Level:
             for b in self.mine:
                 h.bc_fill(getattr(b, name), b.sbox, b.geom)
             return
+        if self.batched and self._level_calls():
+            # The same four passes with every box of the level in one launch each (as fill() does for the state): a level of
+            # 56 boxes made ~1000 launches here per advance.  Source_Type tensors keep their storage between regrids: one table
+            # per (pass, name), the time-interpolation weights rewritten per call.
+            mk, P = h.make_ops, self.params
+            for key, attr in ((("src_lincomb_ghost", "ssrc"), ("src_lincomb_valid", "ssrc_valid")) if self.l > 0 else ()):
+                ops = self._cached_ops((key,), (), lambda attr=attr: mk(
+                    [(L.OP_LINCOMB, 0, NSRC, lo, hi, 0.0, 0.0, (b.stmp, b.scbox), (p.old_source, p.sbox), (p.new_source_g, p.sbox))
+                     for b in self.boxes for p, (lo, hi) in getattr(b, attr)]))
+                arr, n = ops
+                for i in range(n):
+                    arr[i].a, arr[i].b = 1.0 - a, a
+                h.fab_ops(ops, params=P)
+            if self.l > 0:
+                h.fab_ops(self._cached_ops(("src_shell", name), (), lambda: mk(
+                    [(L.OP_INTERP, 0, NSRC, lo, hi, 0.0, 0.0, (getattr(b, name), b.sbox), (b.stmp, b.scbox), None)
+                     for b in self.boxes for lo, hi in b.sshell if all(hi[d] >= lo[d] for d in range(3))])), params=P)
+            h.fab_ops(self._cached_ops(("src_sib", name), (), lambda: mk(
+                [(L.OP_COPY, 0, NSRC, lo, hi, 0.0, 0.0, (getattr(b, name), b.sbox), (getattr(sb, name), _shift(sb.sbox, sh)), None)
+                 for b in self.boxes for sb, (lo, hi), sh in b.ssib])), params=P)
+            for b in self.boxes:
+                if b.at_domain_edge:
+                    h.bc_fill(getattr(b, name), b.sbox, b.geom)
+            return
         for b in self.boxes:
             for p, (lo, hi) in b.ssrc + b.ssrc_valid:           # ghost zones of the parents first, valid zones last
                 h.lincomb(b.stmp, b.scbox, 1.0 - a, p.old_source, p.sbox, a, p.new_source_g, p.sbox, NSRC, lo, hi)
@@ -389,7 +413,14 @@ class _Level:
         stage by stage over the boxes of the level; the per-box arithmetic is Castro._do_advance_with_sources'."""
         h = self.hydro
         fused = hasattr(h, "apply_source")
-        for b in self.mine:
+        lvl = self._source_level_calls()        # the per-box stages below as one library call per level (castro_amd_sources_mf)
+        if lvl is not None:
+            sp = tuple(t.data_ptr() for b in self.mine for t in (b.S_old_b, b.S_new_b))
+            h.sources_mf(0, self._cached_ops(("src_old",), sp, lambda: h.make_source_boxes(
+                [(b.lo, b.hi, (b.S_old_b, b.gbox), (b.S_new_b, b.gbox), (b.old_source, b.sbox), b.mass_fluxes, b.flux_boxes)
+                 for b in self.mine])), lvl.grav if lvl.do_grav else None, lvl.grav_source_type if lvl.do_grav else 4, lvl.rotation,
+                         lvl.geom, self.params, dt, ntimes=1)
+        for b in (self.mine if lvl is None else ()):
             S, lo, hi = b.S_old_b, b.lo, b.hi
             b.old_source.zero_()
             if b.do_grav:
@@ -414,14 +445,20 @@ class _Level:
                 if predictor:
                     b.hydro.set_source_corrector(None, None)      # the context must not keep a pointer into this box's tensor
             b._flux_clear = False
-        self._hydro_calls(hydro)
-        for b in self.mine:
-            h.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
+        if predictor or not self._hydro_level(time, dt, with_src=True):
+            self._hydro_calls(hydro)
+        self._clean_reduce_new()
         self.amr.comm.allreduce_min(self.red)
         _, rho_min, _ = self.red.tolist()
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
-        for b in self.mine:
+        if lvl is not None:
+            sp = tuple(t.data_ptr() for b in self.mine for t in (b.S_old_b, b.S_new_b))
+            h.sources_mf(1, self._cached_ops(("src_new",), sp, lambda: h.make_source_boxes(
+                [(b.lo, b.hi, (b.S_old_b, b.gbox), (b.S_new_b, b.gbox), (b.new_source, (b.lo, b.hi)), b.mass_fluxes, b.flux_boxes)
+                 for b in self.mine])), lvl.grav if lvl.do_grav else None, lvl.grav_source_type if lvl.do_grav else 4, lvl.rotation,
+                         lvl.geom, self.params, dt, ntimes=1)
+        for b in (self.mine if lvl is None else ()):
             S, lo, hi = b.S_old_b, b.lo, b.hi
             b.new_source.zero_()
             if b.do_grav:
@@ -439,6 +476,33 @@ class _Level:
         if self.params.change_max * new_dt < dt:
             return False, "timestep validity check failed", None
         return True, "", new_dt
+
+    def _source_level_calls(self):
+        """The box whose gravity / rotation settings stand for the level when the source stages go out as one library call per
+        level (device backend, every box on this rank, the same settings in every box -- they come from one set of inputs);
+        None: box by box."""
+        if not (self._level_calls() and len(self.mine) > 1 and hasattr(self.hydro, "sources_mf")):
+            return None
+        b0 = self.mine[0]
+        for b in self.mine:
+            if (b.do_grav != b0.do_grav or (b.do_grav and (tuple(b.grav) != tuple(b0.grav) or b.grav_source_type != b0.grav_source_type))
+                    or b.rotation is not b0.rotation):
+                return None
+        return b0
+
+    def _state_boxes(self, which):
+        sp = tuple(getattr(b, which).data_ptr() for b in self.mine)
+        return self._cached_ops(("state_boxes", which), sp, lambda: self.hydro.make_state_boxes(
+            [(b.lo, b.hi, (getattr(b, which), b.gbox)) for b in self.mine]))
+
+    def _clean_reduce_new(self):
+        """clean_state_reduce of S_new of every box into the level's reduction vector."""
+        h = self.hydro
+        if self._level_calls() and len(self.mine) > 1 and hasattr(h, "clean_state_reduce_mf"):
+            h.clean_state_reduce_mf(self._state_boxes("S_new_b"), self.mine[0].geom, self.params, self.red, ntimes=1)
+            return
+        for b in self.mine:
+            h.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
 
     # ---- Castro::advance over the boxes of the level (Castro_advance.cpp:19-121) ----------------------
     def _swap_state_time_levels(self):
@@ -505,8 +569,7 @@ class _Level:
                 b._flux_clear = False
             self._hydro_calls(hydro)
         if not self.fuse_clean:
-            for b in self.mine:
-                self.hydro.clean_state_reduce(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red, ntimes=1)
+            self._clean_reduce_new()
         self.amr.comm.allreduce_min(self.red)                 # the level's minima over the ranks that hold its boxes
         est_last, rho_min, est = self.red.tolist()    # [2]: the estimate after the first clean_state (the only one here
                                                       # unless post_timestep's rode along: then [0] is the one after it)
@@ -531,8 +594,11 @@ class _Level:
         if getattr(self, "_cached_est", None) is not None and self._post_clean_done and self.boxes:
             return min(self.max_dt, checked_estimate(self._cached_est) * self.params.cfl)
         self.red.fill_(1.e200)
-        for b in self.mine:
-            self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
+        if self._level_calls() and len(self.mine) > 1 and hasattr(self.hydro, "estdt_cfl_mf"):
+            self.hydro.estdt_cfl_mf(self._state_boxes("S_new_b"), self.mine[0].geom, self.params, self.red)
+        else:
+            for b in self.mine:
+                self.hydro.estdt_cfl(b.S_new_b, b.gbox, b.lo, b.hi, b.geom, b.params, self.red)
         self.amr.comm.allreduce_min(self.red)
         return min(self.max_dt, checked_estimate(self.red.tolist()[0], empty_ok=not self.boxes) * self.params.cfl)
 
@@ -557,16 +623,28 @@ class _Level:
              for b in self.mine]))
         self.hydro.fab_ops(ops, params=self.params)
 
-    def _hydro_level(self, time, dt):
+    def _hydro_level(self, time, dt, with_src=False):
         """The hydro update of every box of the level through ONE library call (the MFIter loop of
         construct_ctu_hydro_source in C++: boxes dealt round robin to the contexts / streams of the box-stream pool, forked
-        from and joined to the current stream inside the call).  False: not applicable, the caller loops over the boxes."""
+        from and joined to the current stream inside the call).  False: not applicable, the caller loops over the boxes.
+        with_src (_advance_with_sources_impl): every box hands its old-time source FAB to the call, which traces it and adds
+        the hydro update to the S_new the caller has prepared; the new-time sources follow, so nothing is fused behind it."""
         if not self._level_calls() or not self.mine:
             return False
         fa = [bool(b.flux_assign and b._flux_clear) for b in self.mine]
-        if any(x != fa[0] for x in fa) or any(b.have_sources or b.fuse_post_clean for b in self.mine):
+        if any(x != fa[0] for x in fa) or any(b.fuse_post_clean for b in self.mine) or any(b.have_sources != with_src for b in self.mine):
             return False
         sp = tuple(t.data_ptr() for b in self.mine for t in (b.S_old_b, b.S_new_b))
+        if with_src:
+            boxes = self._cached_ops(("hydro_mf_src",), sp, lambda: self.hydro.make_hydro_boxes(
+                [(b.bx, b.bx, (b.S_old_b, b.gbox), (b.S_new_b, b.gbox), b.fluxes, b.flux_boxes, b.mass_fluxes, (b.old_source, b.sbox))
+                 for b in self.mine]))
+            pool = self.amr._stream_pool(self.l) if len(self.mine) > 1 else None
+            self.hydro.construct_ctu_hydro_source_mf(pool, boxes, self.mine[0].geom, self.params, time, dt, update_from_sborder=False,
+                                                     flux_assign=fa[0], clean_ntimes=0, red=None)
+            for b in self.mine:
+                b._flux_clear = False
+            return True
         boxes = self._cached_ops(("hydro_mf",), sp, lambda: self.hydro.make_hydro_boxes(
             [(b.bx, b.bx, (b.S_old_b, b.gbox), (b.S_new_b, b.gbox), b.fluxes, b.flux_boxes, b.mass_fluxes) for b in self.mine]))
         pool = self.amr._stream_pool(self.l) if len(self.mine) > 1 else None

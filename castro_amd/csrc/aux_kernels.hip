@@ -848,7 +848,9 @@ __device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevP
     const long q = t / o.n[0];
     c[1] = o.lo[1] + (int)(q % o.n[1]);
     c[2] = o.lo[2] + (int)(q / o.n[1]);
-    if (o.kind == CASTRO_AMD_OP_INTERP_CLEAN) {
+    if (o.kind == CASTRO_AMD_OP_INTERP_CLEAN || o.kind == CASTRO_AMD_OP_INTERP) {
+        // OP_INTERP: the interpolation alone, on the first o.ncomp (<= 8) components (Source_Type data: 7)
+        const int nc = (o.kind == CASTRO_AMD_OP_INTERP) ? o.ncomp : NUM_STATE;
         // One thread per COARSE zone: the 27-point stencil, the three limited slopes and alpha of cc_interp_value are those of
         // all eight fine zones under it, so they are formed once (a thread per fine zone fetched 264 values for 8 results) and
         // evaluated at the children that lie inside the region -- the same expressions, the same bits.
@@ -856,6 +858,7 @@ __device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevP
         double u[8][NUM_STATE];
 #pragma unroll
         for (int n = 0; n < NUM_STATE; ++n) {
+            if (n >= nc) continue;
 #define CC(ii, jj, kk) C.p[fidx(C, c[0] + (ii), c[1] + (jj), c[2] + (kk), n)]
             const double u0 = CC(0, 0, 0);
             const double sx = mc_slope(CC(-1, 0, 0), u0, CC(1, 0, 0));
@@ -880,13 +883,14 @@ __device__ __forceinline__ void fab_op_thread(const FabOp& o, long t, const DevP
                 u[ch][n] = u0 + alpha * (sx * ox + sy * oy + sz * oz);
             }
         }
-        const int ntimes = (int)o.a;
+        const int ntimes = (o.kind == CASTRO_AMD_OP_INTERP) ? 0 : (int)o.a;
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
             const int fi = 2 * c[0] + (ch & 1), fj = 2 * c[1] + ((ch >> 1) & 1), fk = 2 * c[2] + ((ch >> 2) & 1);
             if (fi < o.flo[0] || fi > o.fhi[0] || fj < o.flo[1] || fj > o.fhi[1] || fk < o.flo[2] || fk > o.fhi[2]) continue;
             if (ntimes > 0) clean_zone(P, ntimes, u[ch][URHO], u[ch][UMX], u[ch][UMY], u[ch][UMZ], u[ch][UEDEN], u[ch][UEINT], u[ch][UTEMP], u[ch][UFS]);
-            for (int n = 0; n < NUM_STATE; ++n) o.D.p[fidx(o.D, fi, fj, fk, n)] = u[ch][n];
+#pragma unroll
+            for (int n = 0; n < NUM_STATE; ++n) if (n < nc) o.D.p[fidx(o.D, fi, fj, fk, n)] = u[ch][n];
         }
         return;
     }
@@ -953,7 +957,7 @@ int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const 
         if (n <= 0) return false;
         o.D = D[r]; o.X = X[r]; o.Y = Y[r];
         for (int d = 0; d < 3; ++d) { o.lo[d] = lo[3 * r + d]; o.n[d] = nn[d]; o.flo[d] = lo[3 * r + d]; o.fhi[d] = hi[3 * r + d]; }
-        if (kind[r] == CASTRO_AMD_OP_INTERP_CLEAN) {         // threads enumerate the coarse zones under the region
+        if (kind[r] == CASTRO_AMD_OP_INTERP_CLEAN || kind[r] == CASTRO_AMD_OP_INTERP) {         // threads enumerate the coarse zones under the region
             n = 1;
             for (int d = 0; d < 3; ++d) {
                 const int a_ = lo[3 * r + d], b_ = hi[3 * r + d];
@@ -990,9 +994,10 @@ int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const 
         long* dstart = (long*)(base + ((bo + 255) & ~(size_t)255));
         if (hipMemcpyAsync(base, ops.data(), bo, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
         if (hipMemcpyAsync(dstart, start.data(), bs, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
-        static const char* const kind_name[8] = { "k_fab_ops_copy", "k_fab_ops_lincomb", "k_fab_ops_crse_init", "k_fab_ops_fine_add",
-                                                  "k_fab_ops_reflux", "k_fab_ops_clean", "k_fab_ops_interp_clean", "k_fab_ops_avgdown" };
-        prof_begin(prof, kind_name[ops[0].kind & 7], stream);     // tables are built per purpose: one kind each
+        static const char* const kind_name[9] = { "k_fab_ops_copy", "k_fab_ops_lincomb", "k_fab_ops_crse_init", "k_fab_ops_fine_add",
+                                                  "k_fab_ops_reflux", "k_fab_ops_clean", "k_fab_ops_interp_clean", "k_fab_ops_avgdown",
+                                                  "k_fab_ops_interp" };
+        prof_begin(prof, kind_name[ops[0].kind >= 0 && ops[0].kind < 9 ? ops[0].kind : 0], stream);     // tables are built per purpose: one kind each
         hipLaunchKernelGGL(k_fab_ops_mem, dim3((unsigned)((start.back() + 255) / 256)), dim3(256), 0, stream,
                            (const FabOp*)base, (const long*)dstart, (int)ops.size(), P);
         prof_end(prof, stream);

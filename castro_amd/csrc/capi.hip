@@ -583,6 +583,59 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx* c, const castro_amd_fab* 
                                  (hipStream_t)stream, &c->prof);
 }
 
+// ---- the source stages and the level reductions for every box of a level in one call (include/castro_hydro_amd.h) ----
+int castro_amd_sources_mf(castro_amd_ctx* c, int stage, int nboxes, const castro_amd_source_box* boxes,
+                          const double* grav, int grav_source_type, const castro_amd_rotation* rot,
+                          const castro_amd_geom* geom, const castro_amd_params* params, double dt, int clean_ntimes, void* stream)
+{
+    if (!c || (stage != 0 && stage != 1) || nboxes < 0 || (nboxes > 0 && !boxes) || !geom || !params || clean_ntimes < 0) return CASTRO_AMD_ERR_ARG;
+    hipSetDevice(c->device);
+    for (int i = 0; i < nboxes; ++i) {
+        const castro_amd_source_box& b = boxes[i];
+        if (!b.source.p || b.source.ncomp < 7) return CASTRO_AMD_ERR_ARG;
+        size_t n = (size_t)b.source.ncomp;
+        for (int d = 0; d < 3; ++d) {
+            if (b.source.hi[d] < b.source.lo[d]) return CASTRO_AMD_ERR_ARG;
+            n *= (size_t)(b.source.hi[d] - b.source.lo[d] + 1);
+        }
+        if (hipMemsetAsync(b.source.p, 0, n * sizeof(double), (hipStream_t)stream) != hipSuccess) return CASTRO_AMD_ERR_HIP;
+        int rc = CASTRO_AMD_OK;
+        if (stage == 0) {
+            if (grav) rc = castro_amd_old_gravity_source_fab(c, &b.S_old, &b.source, b.lo, b.hi, grav, grav_source_type, dt, stream);
+            if (rc == CASTRO_AMD_OK && rot) rc = castro_amd_old_rotation_source_fab(c, &b.S_old, &b.source, b.lo, b.hi, rot, geom, dt, stream);
+            if (rc == CASTRO_AMD_OK) rc = castro_amd_apply_source_fab(c, &b.S_new, &b.S_old, dt, &b.source, 7, b.lo, b.hi, params, clean_ntimes, stream);
+        } else {
+            if (grav) rc = castro_amd_new_gravity_source_fab(c, &b.S_old, &b.S_new, &b.source, b.mass_flux, b.lo, b.hi, grav, grav_source_type, dt, geom, stream);
+            if (rc == CASTRO_AMD_OK && rot) rc = castro_amd_new_rotation_source_fab(c, &b.S_old, &b.S_new, &b.source, b.mass_flux, b.lo, b.hi, rot, geom, dt, stream);
+            if (rc == CASTRO_AMD_OK) rc = castro_amd_apply_source_fab(c, &b.S_new, &b.S_new, dt, &b.source, 7, b.lo, b.hi, params, clean_ntimes, stream);
+        }
+        if (rc != CASTRO_AMD_OK) return rc;
+    }
+    return CASTRO_AMD_OK;
+}
+
+int castro_amd_clean_state_reduce_mf(castro_amd_ctx* c, int nboxes, const castro_amd_state_box* boxes, const castro_amd_geom* geom,
+                                     const castro_amd_params* params, int ntimes, double* d_out, void* stream)
+{
+    if (!c || nboxes < 0 || (nboxes > 0 && !boxes)) return CASTRO_AMD_ERR_ARG;
+    for (int i = 0; i < nboxes; ++i) {
+        const int rc = castro_amd_clean_state_reduce_fab(c, &boxes[i].state, boxes[i].lo, boxes[i].hi, geom, params, ntimes, d_out, stream);
+        if (rc != CASTRO_AMD_OK) return rc;
+    }
+    return CASTRO_AMD_OK;
+}
+
+int castro_amd_estdt_mf(castro_amd_ctx* c, int nboxes, const castro_amd_state_box* boxes, const castro_amd_geom* geom,
+                        const castro_amd_params* params, double* d_out, void* stream)
+{
+    if (!c || nboxes < 0 || (nboxes > 0 && !boxes)) return CASTRO_AMD_ERR_ARG;
+    for (int i = 0; i < nboxes; ++i) {
+        const int rc = castro_amd_estdt_fab(c, &boxes[i].state, boxes[i].lo, boxes[i].hi, geom, params, d_out, stream);
+        if (rc != CASTRO_AMD_OK) return rc;
+    }
+    return CASTRO_AMD_OK;
+}
+
 int castro_amd_saxpy_fab(castro_amd_ctx* c, const castro_amd_fab* dst, double a, const castro_amd_fab* src, int ncomp,
                          const int lo[3], const int hi[3], void* stream)
 {
@@ -651,6 +704,12 @@ static int fab_ops_impl(castro_amd_ctx* c, int nops, const castro_amd_fab_op* op
         case CASTRO_AMD_OP_INTERP_CLEAN: {
             if (!params || o.ncomp != NUM_STATE || o.dst.ncomp != NUM_STATE || o.src.ncomp != NUM_STATE || o.a < 0.0) return CASTRO_AMD_ERR_ARG;
             // the coarse zones under the region, grown by one (the slopes of cell_cons_interp)
+            int clo[3], chi[3];
+            for (int d = 0; d < 3; ++d) { clo[d] = (o.lo[d] >= 0 ? o.lo[d] / 2 : -((-o.lo[d] + 1) / 2)) - 1; chi[d] = (o.hi[d] >= 0 ? o.hi[d] / 2 : -((-o.hi[d] + 1) / 2)) + 1; }
+            if (!fab_contains(&o.src, clo, chi)) return CASTRO_AMD_ERR_ARG;
+            break; }
+        case CASTRO_AMD_OP_INTERP: {
+            if (o.ncomp > NUM_STATE) return CASTRO_AMD_ERR_ARG;
             int clo[3], chi[3];
             for (int d = 0; d < 3; ++d) { clo[d] = (o.lo[d] >= 0 ? o.lo[d] / 2 : -((-o.lo[d] + 1) / 2)) - 1; chi[d] = (o.hi[d] >= 0 ? o.hi[d] / 2 : -((-o.hi[d] + 1) / 2)) + 1; }
             if (!fab_contains(&o.src, clo, chi)) return CASTRO_AMD_ERR_ARG;

@@ -265,16 +265,19 @@ class HipHydro:
 
     @staticmethod
     def make_hydro_boxes(specs):
-        """ctypes array of castro_amd_hydro_box from (bx, vbx, (Sborder, box), (S_new, box), fluxes, flux_boxes, mass_fluxes)."""
+        """ctypes array of castro_amd_hydro_box from (bx, vbx, (Sborder, box), (S_new, box), fluxes, flux_boxes, mass_fluxes
+        [, (src, box)]) -- src: the old-time source FAB of the box (Source_Type data with ghost zones), traced by the call."""
         arr = (L.HydroBox * max(len(specs), 1))()
-        for hb, (bx, vbx, sb, sn, fluxes, flux_boxes, mass_fluxes) in zip(arr, specs):
+        for hb, spec in zip(arr, specs):
+            bx, vbx, sb, sn, fluxes, flux_boxes, mass_fluxes = spec[:7]
+            src = spec[7] if len(spec) > 7 else None
             for d in range(3):
                 hb.bxlo[d], hb.bxhi[d], hb.vbxlo[d], hb.vbxhi[d] = bx[0][d], bx[1][d], vbx[0][d], vbx[1][d]
                 hb.flux[d] = L.fab_of(fluxes[d], *flux_boxes[d])
                 hb.mass_flux[d] = L.fab_of(mass_fluxes[d], *flux_boxes[d])
                 hb.qe[d] = L.fab_of(None, *flux_boxes[d])
             hb.Sborder, hb.S_new = L.fab_of(sb[0], *sb[1]), L.fab_of(sn[0], *sn[1])
-            hb.src = L.fab_desc(None, bx[0], bx[1], 0)
+            hb.src = L.fab_of(src[0], *src[1]) if src is not None else L.fab_desc(None, bx[0], bx[1], 0)
         return arr, len(specs)
 
     def construct_ctu_hydro_source_mf(self, pool, boxes, geom, params, time, dt, update_from_sborder=True, flux_assign=False,
@@ -297,6 +300,50 @@ class HipHydro:
             ctxs, sts, k = (C.c_void_p * 1)(self.h), (C.c_void_p * 1)(main), 1
         L.check(self.lib.castro_amd_ctu_hydro_mf(ctxs, sts, k, arr, n, C.byref(geom), C.byref(params), float(time), float(dt),
                                                  C.byref(o), main), "ctu_hydro_mf")
+
+    # ---- the per-box stages around the hydro update, for every box of a level in one call ----------------
+    @staticmethod
+    def make_source_boxes(specs):
+        """ctypes array of castro_amd_source_box from (lo, hi, (S_old, box), (S_new, box), (source, box), mass_fluxes, flux_boxes)."""
+        arr = (L.SourceBox * max(len(specs), 1))()
+        for sb, (lo, hi, so, sn, src, mass_fluxes, flux_boxes) in zip(arr, specs):
+            for d in range(3):
+                sb.lo[d], sb.hi[d] = lo[d], hi[d]
+                sb.mass_flux[d] = L.fab_of(mass_fluxes[d], *flux_boxes[d])
+            sb.S_old, sb.S_new, sb.source = L.fab_of(so[0], *so[1]), L.fab_of(sn[0], *sn[1]), L.fab_of(src[0], *src[1])
+        return arr, len(specs)
+
+    def sources_mf(self, stage, boxes, grav, grav_source_type, rot, geom, params, dt, ntimes=1, stream=None):
+        """castro_amd_sources_mf: stage 0 = old-time sources + S_new = S_old + dt * source + clean_state, stage 1 = new-time
+        sources + S_new += dt * source + clean_state, for every box of `boxes` (make_source_boxes)."""
+        arr, n = boxes
+        if n:
+            g = (C.c_double * 3)(*[float(x) for x in grav]) if grav is not None else None
+            L.check(self.lib.castro_amd_sources_mf(self.h, int(stage), n, arr, g, int(grav_source_type),
+                                                   C.byref(rot) if rot is not None else None, C.byref(geom), C.byref(params),
+                                                   float(dt), int(ntimes), _stream_ptr(stream)), "sources_mf")
+
+    @staticmethod
+    def make_state_boxes(specs):
+        """ctypes array of castro_amd_state_box from (lo, hi, (state, box))."""
+        arr = (L.StateBox * max(len(specs), 1))()
+        for sb, (lo, hi, st) in zip(arr, specs):
+            for d in range(3):
+                sb.lo[d], sb.hi[d] = lo[d], hi[d]
+            sb.state = L.fab_of(st[0], *st[1])
+        return arr, len(specs)
+
+    def clean_state_reduce_mf(self, boxes, geom, params, out, ntimes=1, stream=None):
+        arr, n = boxes
+        if n:
+            L.check(self.lib.castro_amd_clean_state_reduce_mf(self.h, n, arr, C.byref(geom), C.byref(params), int(ntimes),
+                                                              C.c_void_p(out.data_ptr()), _stream_ptr(stream)), "clean_state_reduce_mf")
+
+    def estdt_cfl_mf(self, boxes, geom, params, out, stream=None):
+        arr, n = boxes
+        if n:
+            L.check(self.lib.castro_amd_estdt_mf(self.h, n, arr, C.byref(geom), C.byref(params), C.c_void_p(out.data_ptr()),
+                                                 _stream_ptr(stream)), "estdt_mf")
 
     def lincomb(self, dst, dst_box, a, x, x_box, b, y, y_box, ncomp, lo, hi, stream=None):
         L.check(self.lib.castro_amd_lincomb_fab(self.h, C.byref(L.fab_of(dst, *dst_box)), float(a), C.byref(L.fab_of(x, *x_box)),

@@ -52,7 +52,8 @@ extern "C" {
  *   4: castro_amd_numerics(), castro_amd_fill_boundary*(), castro_amd_abi_version().
  *   5: CASTRO_AMD_STAGE_VALID / _REST / CASTRO_AMD_BC_FILL, castro_amd_fill_boundary_ex, castro_amd_halo_plan_wait_packed,
  *      castro_amd_halo_group_* / castro_amd_fill_boundary_group (several boxes per rank), castro_amd_berger_rigoutsos;
- *      castro_amd_hydro_opts.sborder_clean_ntimes is accepted by the staged calls.
+ *      castro_amd_hydro_opts.sborder_clean_ntimes is accepted by the staged calls; CASTRO_AMD_OP_INTERP, castro_amd_sources_mf,
+ *      castro_amd_clean_state_reduce_mf, castro_amd_estdt_mf.
  * A caller checks `castro_amd_abi_version() == CASTRO_AMD_ABI_VERSION` once after loading the library; a mismatch means
  * the library was built from another revision of this header (a 0.2 caller with 2-double vectors would be written 8 bytes
  * out of bounds by a 0.3 library). */
@@ -370,6 +371,37 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
                                        const int lo[3], const int hi[3], const castro_amd_rotation *rot,
                                        const castro_amd_geom *geom, double dt, void *stream);
 
+/* The source stages of do_advance_ctu for EVERY box of a level in one call (the MFIter loops of do_old_sources /
+ * do_new_sources, Source/sources/Castro_sources.cpp:230-349, around construct_ctu_hydro_source): a level of many small
+ * boxes is bound by the host's launch rate, and these stages are three to four launches per box.  Per box, in this order:
+ *   stage 0 (old time, Castro_advance_ctu.cpp:94, 127-131):  source = 0 (the whole FAB, ghost zones too);
+ *            += old gravity source (grav != NULL); += old rotation source (rot != NULL);
+ *            S_new = S_old + dt * source on [lo, hi], then clean_state x clean_ntimes      (castro_amd_apply_source_fab)
+ *   stage 1 (new time, :262-268):  source = 0; += new gravity source; += new rotation source (both read S_old, S_new and
+ *            mass_flux[d]);  S_new += dt * source on [lo, hi], then clean_state x clean_ntimes
+ * with the arithmetic -- and the kernels -- of the single-box entry points above: the same bits.  stage 0: `source` is the
+ * old-time Source_Type FAB with its ghost zones; stage 1: the new-time one (valid zones); mass_flux is read by stage 1 only. */
+typedef struct castro_amd_source_box {
+    int lo[3], hi[3];
+    castro_amd_fab S_old, S_new, source;
+    castro_amd_fab mass_flux[3];
+} castro_amd_source_box;
+int castro_amd_sources_mf(castro_amd_ctx *ctx, int stage, int nboxes, const castro_amd_source_box *boxes,
+                          const double *grav /* [3] or NULL */, int grav_source_type, const castro_amd_rotation *rot /* or NULL */,
+                          const castro_amd_geom *geom, const castro_amd_params *params, double dt, int clean_ntimes, void *stream);
+/* castro_amd_clean_state_reduce_fab / castro_amd_estdt_fab on the valid zones [lo, hi] of every box of a level, reduced
+ * into ONE d_out (3 device doubles initialised by the caller): Castro_advance_ctu.cpp:168-225 and Castro::estTimeStep
+ * (Castro.cpp:1507-1626) as one call per level. */
+typedef struct castro_amd_state_box {
+    int lo[3], hi[3];
+    castro_amd_fab state;
+} castro_amd_state_box;
+int castro_amd_clean_state_reduce_mf(castro_amd_ctx *ctx, int nboxes, const castro_amd_state_box *boxes,
+                                     const castro_amd_geom *geom, const castro_amd_params *params, int ntimes,
+                                     double *d_out, void *stream);
+int castro_amd_estdt_mf(castro_amd_ctx *ctx, int nboxes, const castro_amd_state_box *boxes,
+                        const castro_amd_geom *geom, const castro_amd_params *params, double *d_out, void *stream);
+
 /* Two-level AMR building blocks, refinement ratio 2 (first slice).  The reference calls AMReX for
  * all of these [3P, not in the reference tree]; the arithmetic is restated from the published descriptions and is
  * NOT pinned against an AMReX build:
@@ -410,6 +442,8 @@ int castro_amd_new_rotation_source_fab(castro_amd_ctx *ctx, const castro_amd_fab
                                          * (castro_amd_fillpatch_shell_fab does the six slabs of one box); castro_amd_fab_ops_p */
 #define CASTRO_AMD_OP_AVGDOWN 7         /* dst (coarse) = mean of the 8 fine zones of src under each zone of the region (castro_amd_avgdown_fab):
                                          * Castro::avgDown of a whole level in one call */
+#define CASTRO_AMD_OP_INTERP 8          /* dst (fine) = cell_cons_interp of src on the region, the first ncomp (<= 8) components, nothing else
+                                         * (castro_amd_cc_interp_fab): the ghost shells of the Source_Type FillPatch of a level in one call */
 typedef struct castro_amd_fab_op {
     int kind;
     int dir;                     /* FLUXREG_FINE_ADD, REFLUX */

@@ -2928,3 +2928,147 @@ def test_level_wide_launch_of_unequal_boxes_equals_the_per_box_calls(numerics, s
         if clean:
             assert torch.equal(red_mf, red_pb), (red_mf, red_pb)
     h.close()
+
+
+def test_fab_ops_interp_equals_cc_interp(hip):
+    """CASTRO_AMD_OP_INTERP (round 6: the ghost shells of the Source_Type FillPatch of a level in one launch): seven components,
+    forty boxes x six slabs through the device table and three operations through the by-value table, against
+    castro_amd_cc_interp_fab slab by slab, bit for bit; components beyond ncomp and zones outside the regions are not touched."""
+    import torch
+    import castro_amd
+    from castro_amd import _lib as L
+    rng = np.random.default_rng(61)
+    P = castro_amd.default_params()
+    nbox, g = 40, 3
+    vlo, vhi = (2, 4, 6), (9, 11, 13)
+    flo, fhi = tuple(x - g for x in vlo), tuple(x + g for x in vhi)
+    clo, chi = tuple(x // 2 - 1 if x >= 0 else -((-x + 1) // 2) - 1 for x in flo), tuple(x // 2 + 1 for x in fhi)
+    fbox, cbox = (flo, fhi), (clo, chi)
+    shell = [((flo[0], flo[1], flo[2]), (fhi[0], fhi[1], vlo[2] - 1)), ((flo[0], flo[1], vhi[2] + 1), (fhi[0], fhi[1], fhi[2])),
+             ((flo[0], flo[1], vlo[2]), (fhi[0], vlo[1] - 1, vhi[2])), ((flo[0], vhi[1] + 1, vlo[2]), (fhi[0], fhi[1], vhi[2])),
+             ((flo[0], vlo[1], vlo[2]), (vlo[0] - 1, vhi[1], vhi[2])), ((vhi[0] + 1, vlo[1], vlo[2]), (fhi[0], vhi[1], vhi[2]))]
+    cshape = (8,) + tuple(chi[d] - clo[d] + 1 for d in (2, 1, 0))
+    fshape = (8,) + tuple(fhi[d] - flo[d] + 1 for d in (2, 1, 0))
+    crse = [_to_dev(hip, rng.normal(size=cshape) * (1.0 + 10.0 * (rng.uniform(size=cshape) > 0.8))) for _ in range(nbox)]
+    one = [_to_dev(hip, np.full(fshape, 0.5)) for _ in range(nbox)]
+    many = [_to_dev(hip, np.full(fshape, 0.5)) for _ in range(nbox)]
+    for i in range(nbox):
+        for lo, hi in shell:
+            hip.cc_interp(crse[i], cbox, one[i], fbox, lo, hi, 7)
+    ops = hip.make_ops([(L.OP_INTERP, 0, 7, lo, hi, 0.0, 0.0, (many[i], fbox), (crse[i], cbox), None) for i in range(nbox) for lo, hi in shell])
+    hip.fab_ops(ops, params=P)
+    torch.cuda.synchronize()
+    for i in range(nbox):
+        assert torch.equal(one[i], many[i]), i
+        assert torch.equal(many[i][7], torch.full_like(many[i][7], 0.5))                       # the eighth component
+        v = many[i][:, g:-g, g:-g, g:-g]
+        assert torch.equal(v, torch.full_like(v, 0.5)) and not torch.equal(many[i][0], torch.full_like(many[i][0], 0.5))
+    few = [_to_dev(hip, np.full(fshape, 0.5)) for _ in range(3)]
+    hip.fab_ops(hip.make_ops([(L.OP_INTERP, 0, 7, shell[i][0], shell[i][1], 0.0, 0.0, (few[i], fbox), (crse[i], cbox), None) for i in range(3)]))
+    ref = [_to_dev(hip, np.full(fshape, 0.5)) for _ in range(3)]
+    for i in range(3):
+        hip.cc_interp(crse[i], cbox, ref[i], fbox, shell[i][0], shell[i][1], 7)
+    torch.cuda.synchronize()
+    assert all(torch.equal(few[i], ref[i]) for i in range(3))
+    small = ((clo[0] + 1, clo[1], clo[2]), chi)                                                 # the coarse data do not cover the slopes
+    with pytest.raises(RuntimeError, match="bad argument"):
+        hip.fab_ops(hip.make_ops([(L.OP_INTERP, 0, 7, flo, fhi, 0.0, 0.0, (few[0], fbox), (hip.alloc(8, *small), small), None)]))
+
+
+@pytest.mark.parametrize("numerics", ["exact", "contract"])
+def test_level_source_calls_equal_the_per_box_calls(numerics):
+    """castro_amd_sources_mf / castro_amd_clean_state_reduce_mf / castro_amd_estdt_mf (round 6: the per-box stages around the
+    hydro update as one library call per level) against the single-box entry points, box by box in the same order: gravity
+    alone, rotation alone, both; old- and new-time stage; unequal boxes.  Bit for bit, reductions included."""
+    import torch
+    import castro_amd
+    h = castro_amd.HipHydro(numerics=numerics)
+    rng = np.random.default_rng(67)
+    P = castro_amd.default_params(small_dens=0.2)
+    G = castro_amd.make_geom((32, 32, 32))
+    R = castro_amd.make_rotation(3.0, 3, rot_source_type=4)
+    dt = 3.e-3
+    shapes = [(8, 8, 8), (16, 8, 12), (8, 24, 8), (12, 12, 20), (8, 8, 16)]
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(h.device)
+    for grav, gst, rot in (((0.0, 0.0, -2.5), 4, None), (None, 4, R), ((0.3, -0.2, -1.0), 2, R)):
+        sets = []
+        for two in range(2):
+            rs = np.random.default_rng(5)
+            boxes = []
+            for n, shp in enumerate(shapes):
+                lo = (4 * n, 2 * n, n)
+                hi = tuple(lo[d] + shp[d] - 1 for d in range(3))
+                glo, ghi = tuple(x - 4 for x in lo), tuple(x + 4 for x in hi)
+                slo, shi = tuple(x - 3 for x in lo), tuple(x + 3 for x in hi)
+                So = physical_state(rs, glo, ghi, jump=True)
+                So[0] *= rs.uniform(0.1, 1.0, size=So[0].shape)          # some densities below small_dens: clean_state works
+                Sn = physical_state(rs, glo, ghi, jump=True)
+                mf, fb = [], []
+                for d in range(3):
+                    fhi = list(hi)
+                    fhi[d] += 1
+                    fb.append((lo, tuple(fhi)))
+                    mf.append(dev(rs.normal(size=tuple(fhi[a] - lo[a] + 1 for a in (2, 1, 0)))[None]))
+                boxes.append(dict(lo=lo, hi=hi, gbox=(glo, ghi), sbox=(slo, shi), So=dev(So), Sn=dev(Sn), Sn1=dev(Sn),
+                                  osrc=h.alloc(7, slo, shi, fill=9.0), nsrc=h.alloc(7, lo, hi, fill=9.0), mf=mf, fb=fb))
+            sets.append(boxes)
+        A, B = sets
+        for b in A:                                                   # box by box
+            b["osrc"].zero_()
+            if grav is not None:
+                h.old_gravity_source(b["So"], b["gbox"], b["osrc"], b["sbox"], b["lo"], b["hi"], grav, gst, dt)
+            if rot is not None:
+                h.old_rotation_source(b["So"], b["gbox"], b["osrc"], b["sbox"], b["lo"], b["hi"], rot, G, dt)
+            h.apply_source(b["Sn"], b["gbox"], b["So"], b["gbox"], dt, b["osrc"], b["sbox"], 7, b["lo"], b["hi"], P, ntimes=1)
+            b["nsrc"].zero_()
+            if grav is not None:
+                h.new_gravity_source(b["So"], b["gbox"], b["Sn1"], b["gbox"], b["nsrc"], (b["lo"], b["hi"]), b["mf"], b["fb"],
+                                     b["lo"], b["hi"], grav, gst, dt, G)
+            if rot is not None:
+                h.new_rotation_source(b["So"], b["gbox"], b["Sn1"], b["gbox"], b["nsrc"], (b["lo"], b["hi"]), b["mf"], b["fb"],
+                                      b["lo"], b["hi"], rot, G, dt)
+            h.apply_source(b["Sn1"], b["gbox"], b["Sn1"], b["gbox"], dt, b["nsrc"], (b["lo"], b["hi"]), 7, b["lo"], b["hi"], P, ntimes=1)
+        h.sources_mf(0, h.make_source_boxes([(b["lo"], b["hi"], (b["So"], b["gbox"]), (b["Sn"], b["gbox"]), (b["osrc"], b["sbox"]), b["mf"], b["fb"])
+                                             for b in B]), grav, gst, rot, G, P, dt, ntimes=1)
+        h.sources_mf(1, h.make_source_boxes([(b["lo"], b["hi"], (b["So"], b["gbox"]), (b["Sn1"], b["gbox"]), (b["nsrc"], (b["lo"], b["hi"])), b["mf"], b["fb"])
+                                             for b in B]), grav, gst, rot, G, P, dt, ntimes=1)
+        red_a = torch.full((3,), 1.e200, dtype=torch.float64, device=h.device)
+        red_b, est_a, est_b = red_a.clone(), red_a.clone(), red_a.clone()
+        for b in A:
+            h.clean_state_reduce(b["Sn"], b["gbox"], b["lo"], b["hi"], G, P, red_a, ntimes=1)
+            h.estdt_cfl(b["Sn1"], b["gbox"], b["lo"], b["hi"], G, P, est_a)
+        h.clean_state_reduce_mf(h.make_state_boxes([(b["lo"], b["hi"], (b["Sn"], b["gbox"])) for b in B]), G, P, red_b, ntimes=1)
+        h.estdt_cfl_mf(h.make_state_boxes([(b["lo"], b["hi"], (b["Sn1"], b["gbox"])) for b in B]), G, P, est_b)
+        torch.cuda.synchronize()
+        assert h.status() == 0
+        for n, (a, b) in enumerate(zip(A, B)):
+            for k in ("osrc", "nsrc", "Sn", "Sn1"):
+                assert torch.equal(a[k], b[k]), (k, n, grav, rot is not None)
+            assert a["osrc"].abs().max() > 0 and a["nsrc"].abs().max() > 0 and not torch.equal(a["Sn"], a["So"])
+        assert torch.equal(red_a, red_b) and torch.equal(est_a, est_b) and red_a[0].item() < 1.e100 and est_a[0].item() < 1.e100
+    h.close()
+
+
+def test_amr_source_stages_level_calls_equal_the_per_box_calls(monkeypatch):
+    """The same clustered three-level run with constant gravity and rotation twice: the source stages, the Source_Type FillPatch,
+    the hydro call with traced sources and the level reductions as one library call per level (round 6) and box by box
+    (CASTRO_AMD_LEVEL_CALLS=0).  Every box of every level bit for bit, and the same boxes."""
+    import torch
+    import castro_amd
+    res = []
+    for level_calls in ("1", "0"):
+        monkeypatch.setenv("CASTRO_AMD_LEVEL_CALLS", level_calls)
+        a = castro_amd.CastroAmr((32, 32, 32), params=castro_amd.default_params(init_shrink=0.1), max_level=2, cluster=True, grid_eff=0.9,
+                                 blocking_factor=4, max_grid_size=16, do_grav=True, const_grav=-2.0,
+                                 rotation=castro_amd.make_rotation(5.0, 3), lo_bc=(2, 4, 2), hi_bc=(2, 2, 3),
+                                 refine=[("density", "gradient", 0.02)])
+        a.initData("sedov", r_init=0.1, nsub=4)
+        for _ in range(6):
+            a.step()
+        torch.cuda.synchronize()
+        res.append([(b.bx, b.S_new().cpu().clone()) for l in range(len(a.levels)) for b in a.levels[l].boxes])
+        assert len(a.levels) == 3 and len(a.levels[2].boxes) > 2
+    assert len(res[0]) == len(res[1])
+    for (bx0, s0), (bx1, s1) in zip(*res):
+        assert bx0 == bx1 and torch.equal(s0, s1), bx0
