@@ -242,7 +242,7 @@ class _Level:
         pointer configuration (two in the steady state)."""
         ent = self._op_cache.get((key, ptrs))
         if ent is None:
-            if len(self._op_cache) > 64:
+            if len(self._op_cache) > 256:
                 self._op_cache.clear()
             ent = build()
             self._op_cache[(key, ptrs)] = ent

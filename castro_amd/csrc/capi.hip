@@ -768,10 +768,14 @@ int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, i
     {
         static const bool level_grid = [] { const char* e = std::getenv("CASTRO_AMD_LEVEL_GRID"); return !e || std::atoi(e) != 0; }();
         bool ok = level_grid && nboxes >= 2;
-        for (int i = 0; i < nboxes && ok; ++i) ok = !(boxes[i].src.p);
+        // traced source terms (round 6): every box with its source FAB or none; a context that carries a source corrector
+        // (castro.source_term_predictor = 1: one per box and context) stays box by box
+        const bool with_src = boxes[0].src.p != nullptr;
+        for (int i = 0; i < nboxes && ok; ++i) ok = (boxes[i].src.p != nullptr) == with_src;
+        if (with_src && (params->source_term_predictor == 1 || ctxs[0]->src_corr.p || opts->sborder_clean_ntimes > 0 || opts->clean_ntimes > 0)) ok = false;
         DevParams devP = to_devparams(params);
         devP.dtp = opts->d_dt;
-        if (ok && level_launch_supported(devP, opts->flags)) {
+        if (ok && level_launch_supported(devP, opts->flags, with_src)) {
             castro_amd_ctx* c0 = ctxs[0];
             hipSetDevice(c0->device);
             std::vector<PreparedBox> pb((size_t)nboxes);
@@ -826,7 +830,7 @@ int castro_amd_ctu_hydro_mf(castro_amd_ctx* const* ctxs, void* const* streams, i
                         LevelBoxDesc& L = lb[(size_t)(i - i0)];
                         L.t = B.t;
                         p = carve_scratch(p, B.t, false, L.S);
-                        L.U = B.dS; L.Unew = B.dN;
+                        L.U = B.dS; L.Unew = B.dN; L.Src = B.dSrc;
                         for (int d = 0; d < 3; ++d) { L.fl[d] = B.dF[d]; L.mass[d] = B.dM[d]; L.qe[d] = B.dQ[d]; L.acc_hi[d] = B.acc_hi[d]; }
                     }
                     const int rc = launch_ctu_hydro_level(i1 - i0, lb.data(), &c0->level_arena, dg, devP, dt, opts->flags, c0->d_status,

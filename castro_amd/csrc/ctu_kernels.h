@@ -85,9 +85,10 @@ struct LevelBoxDesc {
     DevScratch S;
     DFab U, Unew, fl[3], mass[3], qe[3];
     int acc_hi[3];
+    DFab Src;              // old-time source FAB to be traced (p == nullptr: none); all boxes of a launch alike
 };
-// default options only (PPM, CGF solver, no source terms, no staging, the default kernel forms): else box by box
-bool level_launch_supported(const DevParams& P, int flags);
+// default options only (PPM, CGF solver, no staging, the default kernel forms; traced source terms without a predictor): else box by box
+bool level_launch_supported(const DevParams& P, int flags, bool with_src = false);
 int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* table, const DevGeom& g, const DevParams& P, double dt,
                            int flags, int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, int sb_clean);
 

@@ -160,7 +160,8 @@ __device__ __forceinline__ bool box_thread(const LinBox& b, int& i, int& j, int&
 // zones is then 8 launches that fill the chip instead of ~450 that each fill a fraction of it.
 // ---------------------------------------------------------------------------------------
 struct XRows { int lo[3]; int hi0; int nslot, ny, nz; int ty; unsigned nb; unsigned wv; };   // k_finalx_consup; wv: waves per workgroup
-enum : int { LB_CTOPRIM = 0, LB_DIVU = 1, LB_TRACE = 2, LB_FOLD = 3, LB_FY = 4, LB_FZ = 5, LB_FX = 6, LB_BSTART = 7, NLB = 8 };
+enum : int { LB_CTOPRIM = 0, LB_DIVU = 1, LB_TRACE = 2, LB_FOLD = 3, LB_FY = 4, LB_FZ = 5, LB_FX = 6, LB_BSTART = 7,
+             LB_SRCPRIM = 8, LB_TRACE1 = 9, LB_R1X = 10, NLB = 11 };     // 8 .. 10: a level with traced source terms (round 6)
 struct LevelBox {
     Tile t;
     DevScratch S;
@@ -168,6 +169,8 @@ struct LevelBox {
     int acc_hi[3];
     LinBox b[6];           // LB_CTOPRIM .. LB_FZ
     XRows xr;              // LB_FX
+    DFab Src;              // the old-time source FAB of the box (p == nullptr: none)
+    LinBox bs[3];          // LB_SRCPRIM (grow(bx, 3), one zone per thread), LB_TRACE1 (grow(bx, 1), one zone per thread), LB_R1X (x faces, pairs)
 };
 struct LevelTab { const LevelBox* box; const unsigned* start; int nbox; };   // start: nbox + 1 entries of THIS launch; box == nullptr: one box, kernel arguments
 
@@ -354,11 +357,15 @@ __global__ void __launch_bounds__(256) k_ctoprim(Tile t, LinBox b, DFab U, doubl
 // ---------------------------------------------------------------------------------------
 // CORR (p != nullptr with source_term_predictor = 1): Castro::source_corrector, dt/2 of it time-centres the momentum sources
 // lean (gamma_law_edges): Q carries no (rho e) plane -- it is p / (gamma - 1) -- and nobody reads the (rho e) source plane
+template <bool LV = false>
 __global__ void __launch_bounds__(256) k_src_to_prim(Tile t, LinBox b, const double* __restrict__ Q, DFab SRC,
-                                                     double* __restrict__ SQ, DevParams P, DFab CORR, double dt, int lean)
+                                                     double* __restrict__ SQ, DevParams P, DFab CORR, double dt, int lean, LevelTab lv)
 {
+    unsigned vb = blockIdx.x;
+    // LV: every box of a level in one launch (round 6: levels with traced source terms) -- tile, launch box, planes and source FAB from the table
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.bs[0]; Q = B.S.Q; SRC = B.Src; SQ = B.S.SRCQ; }
     int i, j, k;
-    if (!box_thread(b, i, j, k)) return;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     if (P.dtp) dt = P.dtp[6];
     const unsigned c = goff(t, i, j, k);
     const unsigned cs = foff(SRC, i, j, k);
@@ -1259,12 +1266,14 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
     }
 }
 
-template <bool SRC, bool PLM, bool GL = false>
+template <bool SRC, bool PLM, bool GL = false, bool LV = false>
 __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S, DevGeom g,
-                                               double dt, DevParams P)
+                                               double dt, DevParams P, LevelTab lv)
 {
+    unsigned vb = blockIdx.x;
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.bs[1]; S = B.S; Q = B.S.Q; }      // see k_src_to_prim
     int i, j, k;
-    if (!box_thread(b, i, j, k)) return;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     if (P.dtp) dt = P.dtp[6];
     const unsigned c = goff(t, i, j, k);
     const Str s = gstr(t);
@@ -1524,12 +1533,14 @@ __device__ __forceinline__ void store_f1_2(double* __restrict__ F, long NC, unsi
 // TFIX: castro.ppm_temp_fix = 2 -- the EOS fix of riemann_state on the two input states (the reference changes them
 // in place; here the stored states stay as traced and every later reader applies the fix where the reference's
 // order of operations has it: see trans1_body / final_body)
-template <int D, bool TFIX = false, int GEN = 2>
+template <int D, bool TFIX = false, int GEN = 2, bool LV = false>
 __global__ void __launch_bounds__(256) k_riemann1(Tile t, LinBox b, const double* __restrict__ Q, DevScratch S,
-                                                  DevGeom g, DevParams P)
+                                                  DevGeom g, DevParams P, LevelTab lv)
 {
+    unsigned vb = blockIdx.x;
+    if (LV) { const LevelBox& B = level_box(lv, vb); t = B.t; b = B.bs[2]; S = B.S; Q = B.S.Q; }      // see k_src_to_prim
     int i, j, k;
-    if (!box_thread(b, i, j, k)) return;
+    if (!box_thread_at(b, vb, threadIdx.x, i, j, k)) return;
     const bool v1 = i + 1 <= b.hi0;               // two x-adjacent faces per thread
     const unsigned c = goff(t, i, j, k);
     const unsigned sd = dstr(gstr(t), D);
@@ -3614,18 +3625,18 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     if (Src.p) {
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
-        KL("k_src_to_prim", k_src_to_prim, q3lo, q3hi, S.Q, Src, S.SRCQ, P, SrcCorr, dt, lean_q & 1);
-        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P); }
-        else if (lean_q & 1) { KL("k_trace", (k_trace<true, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P); }
-        else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P); }
+        KL("k_src_to_prim", k_src_to_prim<false>, q3lo, q3hi, S.Q, Src, S.SRCQ, P, SrcCorr, dt, lean_q & 1, nolv);
+        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+        else if (lean_q & 1) { KL("k_trace", (k_trace<true, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+        else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P, nolv); }
     } else {
-        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P); }
+        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P, nolv); }
         else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none, nolv, 0); }
         else if (g_trace_one_zone && !second_half) {
             // A/B (CASTRO_AMD_TRACE_ONE_ZONE=1, round 6): ONE zone per thread at the occupancy that leaves (the kernel of the runs with
             // traced source terms, without the sources), the first x Riemann solve as a launch of its own
-            if (lean_q & 1) { KL("k_trace", (k_trace<false, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P); }
-            else { KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P); }
+            if (lean_q & 1) { KL("k_trace", (k_trace<false, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+            else { KL("k_trace", (k_trace<false, false>), olo, ohi, S.Q, S, g, dt, P, nolv); }
             one_zone_trace = true;
         }
         else if (second_half) {
@@ -3636,7 +3647,7 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
                 for (int side = 0; side < 2; ++side) {
                     const int xf = side ? inner_box.hi[0] + 1 : inner_box.lo[0];
                     const int plo[3] = { xf, inner_box.lo[1], inner_box.lo[2] }, phi[3] = { xf, inner_box.hi[1], inner_box.hi[2] };
-                    KL2_SOLV("k_riemann1", K_R1_0, plo, phi, S.Q, S, g, P);
+                    KL2_SOLV("k_riemann1", K_R1_0, plo, phi, S.Q, S, g, P, nolv);
                 }
             } else {
                 trace_with_xriemann(olo, ohi);
@@ -3651,14 +3662,14 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // the first y / z solves folded into the transverse stage (k_trans1_fold): default solver set, default final-stage form
     const bool fold_r1 = g_fold_r1 && solv == 0 && !tfix && P.reset_rhoe != 1 && g_fuse_consup;
     if (tfix) {
-        KL2("k_riemann1", (k_riemann1<0, true>), flo[0], fhi[0], S.Q, S, g, P);
-        KL2("k_riemann1", (k_riemann1<1, true>), flo[1], fhi[1], S.Q, S, g, P);
-        KL2("k_riemann1", (k_riemann1<2, true>), flo[2], fhi[2], S.Q, S, g, P);
+        KL2("k_riemann1", (k_riemann1<0, true>), flo[0], fhi[0], S.Q, S, g, P, nolv);
+        KL2("k_riemann1", (k_riemann1<1, true>), flo[1], fhi[1], S.Q, S, g, P, nolv);
+        KL2("k_riemann1", (k_riemann1<2, true>), flo[2], fhi[2], S.Q, S, g, P, nolv);
     } else {
-        if (!x_done) KL2_SOLV("k_riemann1", K_R1_0, flo[0], fhi[0], S.Q, S, g, P);
+        if (!x_done) KL2_SOLV("k_riemann1", K_R1_0, flo[0], fhi[0], S.Q, S, g, P, nolv);
         if (!fold_r1) {
-            KL2_SOLV("k_riemann1", K_R1_1, flo[1], fhi[1], S.Q, S, g, P);
-            KL2_SOLV("k_riemann1", K_R1_2, flo[2], fhi[2], S.Q, S, g, P);
+            KL2_SOLV("k_riemann1", K_R1_1, flo[1], fhi[1], S.Q, S, g, P, nolv);
+            KL2_SOLV("k_riemann1", K_R1_2, flo[2], fhi[2], S.Q, S, g, P, nolv);
         }
     }
 
@@ -3801,10 +3812,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
 // ---------------------------------------------------------------------------------------
 // The default path for every box of a level at once (see LevelTab): 8 launches whatever the number of boxes.
 // ---------------------------------------------------------------------------------------
-bool level_launch_supported(const DevParams& P, int flags)
+bool level_launch_supported(const DevParams& P, int flags, bool with_src)
 {
     const bool tfix = P.ppm_temp_fix == 2 && P.riemann_solver != 2;
     const bool lim = P.limit_small_dens == 1 || P.limit_large_vel == 1;
+    // traced source terms (round 6): the GEN == 0 kernels read (rho e) of an edge state from its p in the `contract` build, which
+    // the trace with sources promises only with CASTRO_AMD_GL_SOURCES (launch_ctu_hydro: gl_ok)
+    if (with_src && gamma_law_edges(0) && !g_gl_sources) return false;
     return P.ppm_type == 1 && P.riemann_solver == 0 && P.hybrid_riemann != 1 && !tfix && P.reset_rhoe != 1 && !lim &&
            g_fuse_consup == 1 && g_fold_r1 != 0 && (flags & (4 | 8 | 16 | 32 | 64)) == 0;
 }
@@ -3813,6 +3827,12 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
                            int flags, int* d_status, hipStream_t stream, Profiler* prof, int clean_ntimes, double* red, int sb_clean)
 {
     if (nbox < 1 || !boxes || !table) return -1;
+    // Traced source terms: every box of the launch has its old-time source FAB or none has.  The sequence is launch_ctu_hydro's
+    // for Src.p != nullptr -- k_divu_pair, k_src_to_prim, the one-zone trace with sources, the first x solves as a launch of
+    // their own -- through the table forms of those kernels; the transverse and final stages are the same either way.
+    const bool with_src = boxes[0].Src.p != nullptr;
+    for (int i = 1; i < nbox; ++i) if ((boxes[i].Src.p != nullptr) != with_src) return -1;
+    if (with_src && sb_clean > 0) return -1;
     std::vector<LevelBox> hb((size_t)nbox);
     std::vector<unsigned> start((size_t)NLB * (size_t)(nbox + 1), 0u);
     auto st = [&](int kind, int i) -> unsigned& { return start[(size_t)kind * (size_t)(nbox + 1) + (size_t)i]; };
@@ -3820,7 +3840,7 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
         const LevelBoxDesc& D = boxes[i];
         LevelBox& B = hb[(size_t)i];
         const Tile& t = D.t;
-        B.t = t; B.S = D.S; B.U = D.U; B.Unew = D.Unew;
+        B.t = t; B.S = D.S; B.U = D.U; B.Unew = D.Unew; B.Src = D.Src;
         for (int d = 0; d < 3; ++d) { B.fl[d] = D.fl[d]; B.mass[d] = D.mass[d]; B.qe[d] = D.qe[d]; B.acc_hi[d] = D.acc_hi[d]; }
         const int olo[3] = { t.lo[0] - 1, t.lo[1] - 1, t.lo[2] - 1 }, ohi[3] = { t.hi[0] + 1, t.hi[1] + 1, t.hi[2] + 1 };
         const int qlo[3] = { t.lo[0] - 4, t.lo[1] - 4, t.lo[2] - 4 }, qhi[3] = { t.hi[0] + 4, t.hi[1] + 4, t.hi[2] + 4 };
@@ -3835,6 +3855,14 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
         B.b[LB_FOLD].nb = (unsigned)(((n_ + 62) / 63 + FOLD_WG / 64 - 1) / (FOLD_WG / 64));      // 63 new slots per wave, see fold_thread
         if (B.b[LB_FOLD].ty > 0) B.b[LB_FOLD].nb = (B.b[LB_FOLD].nb + 7u) & ~7u;
         tl_tile_rows = -1;
+        for (int m = 0; m < 3; ++m) { B.bs[m] = LinBox{}; B.bs[m].nb = 0; }
+        if (with_src) {
+            const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 }, q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
+            const int f0lo[3] = { t.lo[0], t.lo[1] - 1, t.lo[2] - 1 }, f0hi[3] = { t.hi[0] + 1, t.hi[1] + 1, t.hi[2] + 1 };
+            B.bs[0] = linbox(q3lo, q3hi, n_);
+            B.bs[1] = linbox(olo, ohi, n_);
+            B.bs[2] = linbox2(f0lo, f0hi, n_);
+        }
         tl_wg = g_final_wg > 0 ? (unsigned)g_final_wg : 0u;
         for (int d = 1; d <= 2; ++d) {
             int nlo[3] = { t.lo[0], t.lo[1], t.lo[2] }, nhi[3] = { t.hi[0], t.hi[1], t.hi[2] };
@@ -3853,7 +3881,7 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
         xr.nb = ((unsigned)(((slots + 62) / 63 + xr.wv - 1) / xr.wv) + 7u) & ~7u;
         // workgroup ranges: multiples of 8 wherever the kernel maps ids to XCDs (every LinBox with ty > 0 is one already)
         const unsigned nbs[NLB] = { B.b[LB_CTOPRIM].nb, B.b[LB_DIVU].nb, B.b[LB_TRACE].nb, B.b[LB_FOLD].nb, B.b[LB_FY].nb, B.b[LB_FZ].nb,
-                                    xr.nb, (B.b[LB_TRACE].nb + 255u) / 256u };
+                                    xr.nb, (B.b[LB_TRACE].nb + 255u) / 256u, B.bs[0].nb, B.bs[1].nb, B.bs[2].nb };
         for (int kind = 0; kind < NLB; ++kind) {
             unsigned nb = nbs[kind];
             if (kind != LB_BSTART) nb = (nb + 7u) & ~7u;
@@ -3889,12 +3917,26 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
     else hipLaunchKernelGGL((k_ctoprim<false, true>), dim3(total(LB_CTOPRIM)), dim3(hb[0].b[LB_CTOPRIM].wg), 0, stream, t0, hb[0].b[LB_CTOPRIM],
                             hb[0].U, S0.Q, P, d_status, none, 0, lv(LB_CTOPRIM), gamma_law_edges(0) ? (clean_ntimes > 0 ? 3 : 1) : 0, 0, ShellBoxes{}, BcKinds{});
     prof_end(prof, stream);
-    if (!g_divu_in_trace) {
+    if (!g_divu_in_trace || with_src) {
         prof_begin(prof, "k_divu", stream);
         hipLaunchKernelGGL(k_divu_pair<true>, dim3(total(LB_DIVU)), dim3(hb[0].b[LB_DIVU].wg), 0, stream, t0, hb[0].b[LB_DIVU], S0.Q, S0.DIV,
                            1.0 / g.dx[0], 1.0 / g.dx[1], 1.0 / g.dx[2], lv(LB_DIVU));
         prof_end(prof, stream);
     }
+    if (with_src) {
+        const int lean = gamma_law_edges(0) ? 1 : 0;          // launch_ctu_hydro's lean_q & 1 on this path (solv == 0)
+        prof_begin(prof, "k_src_to_prim", stream);
+        hipLaunchKernelGGL(k_src_to_prim<true>, dim3(total(LB_SRCPRIM)), dim3(hb[0].bs[0].wg), 0, stream, t0, hb[0].bs[0], S0.Q, hb[0].Src, S0.SRCQ, P,
+                           DFab{ nullptr, { 0, 0, 0 }, 0, 0, 0 }, dt, lean, lv(LB_SRCPRIM));
+        prof_end(prof, stream);
+        prof_begin(prof, "k_trace", stream);
+        hipLaunchKernelGGL((k_trace<true, false, gamma_law_edges(0), true>), dim3(total(LB_TRACE1)), dim3(hb[0].bs[1].wg), 0, stream, t0, hb[0].bs[1], S0.Q, S0, g,
+                           dt, P, lv(LB_TRACE1));
+        prof_end(prof, stream);
+        prof_begin(prof, "k_riemann1", stream);
+        hipLaunchKernelGGL((k_riemann1<0, false, 0, true>), dim3(total(LB_R1X)), dim3(hb[0].bs[2].wg), 0, stream, t0, hb[0].bs[2], S0.Q, S0, g, P, lv(LB_R1X));
+        prof_end(prof, stream);
+    } else {
     prof_begin(prof, "k_trace", stream);
     hipLaunchKernelGGL((k_trace_pair<true, 7, 0, true>), dim3(total(LB_TRACE)), dim3(hb[0].b[LB_TRACE].wg), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g,
                        dt, P, none, lv(LB_TRACE), g_divu_in_trace ? 1 : 0);
@@ -3902,6 +3944,7 @@ int launch_ctu_hydro_level(int nbox, const LevelBoxDesc* boxes, FabOpsArena* tab
     prof_begin(prof, "k_riemann1_blockstart", stream);
     hipLaunchKernelGGL((k_riemann1_blockstart<0, true>), dim3(total(LB_BSTART)), dim3(256), 0, stream, t0, hb[0].b[LB_TRACE], S0.Q, S0, g, P, lv(LB_BSTART));
     prof_end(prof, stream);
+    }
     prof_begin(prof, "k_trans1_fold", stream);
     hipLaunchKernelGGL((k_trans1_fold_lds<0, true>), dim3(total(LB_FOLD)), dim3(FOLD_WG), 0, stream, t0, hb[0].b[LB_FOLD], S0.Q, S0, g, cdtdx, cdtdy, cdtdz, P,
                        lv(LB_FOLD));

@@ -3072,3 +3072,72 @@ def test_amr_source_stages_level_calls_equal_the_per_box_calls(monkeypatch):
     assert len(res[0]) == len(res[1])
     for (bx0, s0), (bx1, s1) in zip(*res):
         assert bx0 == bx1 and torch.equal(s0, s1), bx0
+
+
+@pytest.mark.parametrize("numerics", ["exact", "contract"])
+def test_level_wide_launch_with_traced_sources_equals_the_per_box_calls(numerics):
+    """castro_amd_ctu_hydro_mf with an old-time source FAB per box (round 6: the table forms of k_src_to_prim, of the one-zone
+    trace with sources and of the first x solves) over seven boxes of unequal and odd shapes against castro_amd_ctu_hydro_fab
+    box by box: S_new (the update added to what the caller prepared), fluxes and mass fluxes bit for bit, accumulate and
+    assign mode; with castro.source_term_predictor = 1 the call stays box by box and still gives the per-box bits."""
+    import torch
+    import castro_amd
+    h = castro_amd.HipHydro(0, numerics=numerics)
+    rng = np.random.default_rng(79)
+    dx = (0.02, 0.015, 0.03)
+    shapes = [(37, 9, 11), (8, 8, 8), (1, 5, 3), (130, 4, 3), (16, 70, 2), (5, 5, 40), (24, 24, 24)]
+    G = castro_amd.make_geom((400, 400, 400), prob_hi=tuple(400 * d for d in dx))
+    dt = 6.0e-4
+    for assign, pred in ((False, 0), (True, 0), (False, 1)):
+        P = castro_amd.default_params(source_term_predictor=pred)
+        specs, per_box, corr = [], [], []
+        for n, shape in enumerate(shapes):
+            lo = (3 + 17 * n, 40 - 5 * n, 7 + 11 * n)
+            hi = tuple(lo[d] + shape[d] - 1 for d in range(3))
+            sb_lo, sb_hi = tuple(x - 4 for x in lo), tuple(x + 4 for x in hi)
+            s_lo, s_hi = tuple(x - 3 for x in lo), tuple(x + 3 for x in hi)
+            U = _to_dev(h, physical_state(rng, sb_lo, sb_hi, jump=True))
+            src = rng.normal(size=(7,) + tuple(s_hi[d] - s_lo[d] + 1 for d in (2, 1, 0)))
+            src[:, ::3] = 0.0                                                     # stencils with and without a source under them
+            Src = _to_dev(h, src)
+            corr.append(_to_dev(h, rng.normal(size=src.shape)))
+            sl = (slice(None),) + tuple(slice(4, 4 + shape[2 - a]) for a in range(3))
+            two = []
+            for _ in range(2):
+                Sn = (U[sl] * 1.01).contiguous()
+                fl, mf, fb = [], [], []
+                for d in range(3):
+                    fhi = list(hi)
+                    fhi[d] += 1
+                    fb.append((lo, tuple(fhi)))
+                    fl.append(h.alloc(8, lo, fhi, fill=float("nan") if assign else 0.25))
+                    mf.append(h.alloc(1, lo, fhi))
+                two.append((Sn, fl, mf, fb))
+            specs.append(((lo, hi), (lo, hi), (U, (sb_lo, sb_hi)), (two[0][0], (lo, hi)), two[0][1], two[0][3], two[0][2], (Src, (s_lo, s_hi))))
+            per_box.append(((lo, hi), U, (sb_lo, sb_hi), two[1], two[0], Src, (s_lo, s_hi)))
+        if pred:
+            h.set_source_corrector(corr[0], per_box[0][6])                        # a context with a corrector: the level stays box by box
+            with pytest.raises(RuntimeError):                                     # ... and one corrector cannot serve boxes it does not cover
+                h.construct_ctu_hydro_source_mf(None, h.make_hydro_boxes(specs), G, P, 0.0, dt, update_from_sborder=False, flux_assign=assign)
+            h.set_source_corrector(None, None)
+            continue
+        h.construct_ctu_hydro_source_mf(None, h.make_hydro_boxes(specs), G, P, 0.0, dt, update_from_sborder=False, flux_assign=assign)
+        for bx, U, sbb, (Sn, fl, mf, fb), _, Src, sbox in per_box:
+            h.construct_ctu_hydro_source(bx, U, sbb, Sn, bx, G, P, 0.0, dt, fluxes=fl, flux_boxes=fb, mass_fluxes=mf, vbx=bx,
+                                         update_from_sborder=False, flux_assign=assign, src=Src, src_box=sbox)
+        torch.cuda.synchronize()
+        assert h.status() == 0
+        for n, (bx, U, sbb, pb, lv, Src, sbox) in enumerate(per_box):
+            assert torch.equal(pb[0], lv[0]), ("S_new", n, shapes[n], assign)
+            assert not torch.equal(pb[0], (U[(slice(None),) + tuple(slice(4, 4 + shapes[n][2 - a]) for a in range(3))] * 1.01))
+            for d in range(3):
+                assert torch.equal(pb[1][d], lv[1][d]), ("flux", d, n, shapes[n])
+                assert torch.equal(pb[2][d], lv[2][d]), ("mass flux", d, n, shapes[n])
+    # the level launch really took the table forms: its profile names the kernels once per level, not once per box
+    h.profile(True); h.profile_reset()
+    P = castro_amd.default_params()
+    h.construct_ctu_hydro_source_mf(None, h.make_hydro_boxes(specs), G, P, 0.0, dt, update_from_sborder=False, flux_assign=True)
+    torch.cuda.synchronize()
+    rep = h.profile_report()
+    assert rep["k_src_to_prim"][1] == 1 and rep["k_trace"][1] == 1 and rep["k_riemann1"][1] == 1, rep
+    h.close()
