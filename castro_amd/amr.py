@@ -481,7 +481,7 @@ class _Level:
         """The box whose gravity / rotation settings stand for the level when the source stages go out as one library call per
         level (device backend, every box on this rank, the same settings in every box -- they come from one set of inputs);
         None: box by box."""
-        if not (self._level_calls() and len(self.mine) > 1 and hasattr(self.hydro, "sources_mf")):
+        if not (self._level_calls() and self.mine and hasattr(self.hydro, "sources_mf")):
             return None
         b0 = self.mine[0]
         for b in self.mine:

@@ -765,18 +765,27 @@ class Castro:
         # MultiFab::Copy(S_new, Sborder) (:94); do_old_sources (:127-131): construct at t^n, apply with the full dt,
         # clean_state -- the copy, the update and the cleaning in one pass where the backend has it
         fused = hasattr(h, "apply_source")
-        if not fused:
+        # one pass (castro_amd_sources_mf, round 6): zero + gravity + rotation + apply + clean_state of a stage in one kernel
+        # -- the separate calls below read and write the source and the state three to four times
+        one_pass = hasattr(h, "sources_mf") and os.environ.get("CASTRO_AMD_SOURCES_ONE_PASS", "1") != "0"
+        if one_pass:
+            h.sources_mf(0, h.make_source_boxes([(lo, hi, (S, self.gbox), (self.S_new_b, self.gbox), (self.old_source, self.sbox),
+                                                  self.mass_fluxes, self.flux_boxes)]),
+                         self.grav if self.do_grav else None, self.grav_source_type if self.do_grav else 4, self.rotation, self.geom,
+                         self.params, dt, ntimes=1)
+        elif not fused:
             h.copy(self.S_new_b, self.gbox, S, self.gbox, lo, hi)
-        self.old_source.zero_()
-        if self.do_grav:
-            h.old_gravity_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.grav, self.grav_source_type, dt)
-        if self.rotation is not None:
-            h.old_rotation_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.rotation, self.geom, dt)
-        if fused:
-            h.apply_source(self.S_new_b, self.gbox, S, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi, self.params, ntimes=1)
-        else:
-            h.saxpy(self.S_new_b, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi)
-            h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+        if not one_pass:
+            self.old_source.zero_()
+            if self.do_grav:
+                h.old_gravity_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.grav, self.grav_source_type, dt)
+            if self.rotation is not None:
+                h.old_rotation_source(S, self.gbox, self.old_source, self.sbox, lo, hi, self.rotation, self.geom, dt)
+            if fused:
+                h.apply_source(self.S_new_b, self.gbox, S, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi, self.params, ntimes=1)
+            else:
+                h.saxpy(self.S_new_b, self.gbox, dt, self.old_source, self.sbox, 7, lo, hi)
+                h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
         # FillPatch of the source for the tracing
         self.expand_state(self.old_source, self.sbox, self.src_neighbors)
         # hydro with the old source traced in the predictor; S_new += (it already holds the old source)
@@ -793,19 +802,25 @@ class Castro:
         if rho_min < self.params.small_dens:
             return False, ("negative density" if rho_min < 0.0 else "small density") + " (density = %e)" % rho_min, None
         # do_new_sources (:262-268): corrector from the new state, apply, clean_state
-        self.new_source.zero_()
-        if self.do_grav:
-            h.new_gravity_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
-                                 self.flux_boxes, lo, hi, self.grav, self.grav_source_type, dt, self.geom)
-        if self.rotation is not None:
-            h.new_rotation_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
-                                  self.flux_boxes, lo, hi, self.rotation, self.geom, dt)
-        if fused:
-            h.apply_source(self.S_new_b, self.gbox, self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi,
-                           self.params, ntimes=1)
+        if one_pass:
+            h.sources_mf(1, h.make_source_boxes([(lo, hi, (S, self.gbox), (self.S_new_b, self.gbox), (self.new_source, (lo, hi)),
+                                                  self.mass_fluxes, self.flux_boxes)]),
+                         self.grav if self.do_grav else None, self.grav_source_type if self.do_grav else 4, self.rotation, self.geom,
+                         self.params, dt, ntimes=1)
         else:
-            h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
-            h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
+            self.new_source.zero_()
+            if self.do_grav:
+                h.new_gravity_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
+                                     self.flux_boxes, lo, hi, self.grav, self.grav_source_type, dt, self.geom)
+            if self.rotation is not None:
+                h.new_rotation_source(S, self.gbox, self.S_new_b, self.gbox, self.new_source, (lo, hi), self.mass_fluxes,
+                                      self.flux_boxes, lo, hi, self.rotation, self.geom, dt)
+            if fused:
+                h.apply_source(self.S_new_b, self.gbox, self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi,
+                               self.params, ntimes=1)
+            else:
+                h.saxpy(self.S_new_b, self.gbox, dt, self.new_source, (lo, hi), 7, lo, hi)
+                h.clean_state(self.S_new_b, self.gbox, lo, hi, self.params, ntimes=1)
         # timestep validity check (:386-392)
         new_dt = self.estTimeStep()
         if self.params.change_max * new_dt < dt:

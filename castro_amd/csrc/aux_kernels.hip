@@ -227,14 +227,12 @@ int launch_estdt(const DFab& U, const int lo[3], const int hi[3], const DevGeom&
 // ---------------------------------------------------------------------------------------
 constexpr int NSRC = 7;
 
-__global__ void __launch_bounds__(256) k_old_grav_source(DFab U, DFab SRC, Box3 b, double g0, double g1, double g2,
-                                                         int type, double dt)
+// the source of one zone (src[0 .. NSRC-1], every component set); the kernels below accumulate it into the Source_Type FAB
+__device__ __forceinline__ void old_grav_zone(const DFab& U, int i, int j, int k, const double grav[3], int type, double dt, double src[7])
 {
-    int i, j, k;
-    if (!box_thread3(b.lo, b.n, i, j, k)) return;
-    const double grav[3] = { g0, g1, g2 };
-    double snew[NUM_STATE], src[NSRC];
-    for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
+    constexpr int NSRC_ = 7;
+    double snew[NUM_STATE];
+    for (int n = 0; n < NSRC_; ++n) src[n] = 0.0;
     const long c = fidx(U, i, j, k, 0);
     double rho = U.p[c + U.sn * URHO];
     double rhoInv = 1.0 / rho;
@@ -260,20 +258,25 @@ __global__ void __launch_bounds__(256) k_old_grav_source(DFab U, DFab SRC, Box3 
         SrE = (u_mx * Sr[0] + u_my * Sr[1] + u_mz * Sr[2]) * rhoInv;
     }
     src[UEDEN] = SrE;
-
-    const long cs = fidx(SRC, i, j, k, 0);
-    for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
 }
 
-__global__ void __launch_bounds__(256) k_new_grav_source(DFab UO, DFab UN, DFab SRC, DFab M0, DFab M1, DFab M2, Box3 b,
-                                                         double g0, double g1, double g2, int type, double dt,
-                                                         double dx0, double dx1, double dx2)
+__global__ void __launch_bounds__(256) k_old_grav_source(DFab U, DFab SRC, Box3 b, double g0, double g1, double g2,
+                                                         int type, double dt)
 {
     int i, j, k;
     if (!box_thread3(b.lo, b.n, i, j, k)) return;
     const double grav[3] = { g0, g1, g2 };
-    const double vol = dx0 * dx1 * dx2;
     double src[NSRC];
+    old_grav_zone(U, i, j, k, grav, type, dt, src);
+    const long cs = fidx(SRC, i, j, k, 0);
+    for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
+}
+
+__device__ __forceinline__ void new_grav_zone(const DFab& UO, const DFab& UN, const DFab& M0, const DFab& M1, const DFab& M2, int i, int j, int k,
+                                              const double grav[3], int type, double dt, double dx0, double dx1, double dx2, double src[7])
+{
+    constexpr int NSRC = 7;
+    const double vol = dx0 * dx1 * dx2;
     for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
     double hdtInv = 0.5 / dt;
 
@@ -334,7 +337,17 @@ __global__ void __launch_bounds__(256) k_new_grav_source(DFab UO, DFab UN, DFab 
                              M2.p[fidx(M2, i, j, k + 1, 0)] * gzr * dx2) / vol;
     }
     src[UEDEN] = SrEcorr;
+}
 
+__global__ void __launch_bounds__(256) k_new_grav_source(DFab UO, DFab UN, DFab SRC, DFab M0, DFab M1, DFab M2, Box3 b,
+                                                         double g0, double g1, double g2, int type, double dt,
+                                                         double dx0, double dx1, double dx2)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    const double grav[3] = { g0, g1, g2 };
+    double src[NSRC];
+    new_grav_zone(UO, UN, M0, M1, M2, i, j, k, grav, type, dt, dx0, dx1, dx2, src);
     const long cs = fidx(SRC, i, j, k, 0);
     for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
 }
@@ -445,11 +458,9 @@ __device__ __forceinline__ double rot_phi_at(const RotDev& R, int i, int j, int 
     return phi;
 }
 
-__global__ void __launch_bounds__(256) k_old_rot_source(DFab U, DFab SRC, Box3 b, RotDev R, double dt)
+__device__ __forceinline__ void old_rot_zone(const DFab& U, int i, int j, int k, const RotDev& R, double dt, double src[NSRC])
 {
-    int i, j, k;
-    if (!box_thread3(b.lo, b.n, i, j, k)) return;
-    double Sr[3], src[NSRC], snew[NUM_STATE], loc[3], v[3];
+    double Sr[3], snew[NUM_STATE], loc[3], v[3];
     for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
     rot_position(R, i, j, k, loc);
     for (int d = 0; d < 3; ++d) loc[d] -= R.center[d];
@@ -476,16 +487,23 @@ __global__ void __launch_bounds__(256) k_old_rot_source(DFab U, DFab SRC, Box3 b
         SrE = umx * rhoInv * Sr[0] + umy * rhoInv * Sr[1] + umz * rhoInv * Sr[2];
     }
     src[UEDEN] += SrE;
+}
+
+__global__ void __launch_bounds__(256) k_old_rot_source(DFab U, DFab SRC, Box3 b, RotDev R, double dt)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    double src[NSRC];
+    old_rot_zone(U, i, j, k, R, dt, src);
     const long cs = fidx(SRC, i, j, k, 0);
     for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
 }
 
-__global__ void __launch_bounds__(256) k_new_rot_source(DFab UO, DFab UN, DFab SRC, DFab M0, DFab M1, DFab M2, Box3 b, RotDev R, double dt)
+__device__ __forceinline__ void new_rot_zone(const DFab& UO, const DFab& UN, const DFab& M0, const DFab& M1, const DFab& M2, int i, int j, int k,
+                                             const RotDev& R, double dt, double src[NSRC])
 {
-    int i, j, k;
-    if (!box_thread3(b.lo, b.n, i, j, k)) return;
     const double vol = R.dx[0] * R.dx[1] * R.dx[2];
-    double Sr_old[3], Sr_new[3], Srcorr[3], src[NSRC], snew[NUM_STATE], loc[3];
+    double Sr_old[3], Sr_new[3], Srcorr[3], snew[NUM_STATE], loc[3];
     for (int n = 0; n < NSRC; ++n) src[n] = 0.0;
     rot_position(R, i, j, k, loc);
     for (int d = 0; d < 3; ++d) loc[d] -= R.center[d];
@@ -555,9 +573,18 @@ __global__ void __launch_bounds__(256) k_new_rot_source(DFab UO, DFab UN, DFab S
                                            M2.p[fidx(M2, i, j, k + 1, 0)] * (phi - phizr) ) / vol;
     }
     src[UEDEN] = SrEcorr;
+}
+
+__global__ void __launch_bounds__(256) k_new_rot_source(DFab UO, DFab UN, DFab SRC, DFab M0, DFab M1, DFab M2, Box3 b, RotDev R, double dt)
+{
+    int i, j, k;
+    if (!box_thread3(b.lo, b.n, i, j, k)) return;
+    double src[NSRC];
+    new_rot_zone(UO, UN, M0, M1, M2, i, j, k, R, dt, src);
     const long cs = fidx(SRC, i, j, k, 0);
     for (int n = 0; n < NSRC; ++n) SRC.p[cs + SRC.sn * n] += src[n];
 }
+
 
 static Box3 make_box3(const int lo[3], const int hi[3], long& n)
 {
@@ -641,6 +668,105 @@ int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const
     prof_begin(prof, "k_new_rot_source", stream);
     hipLaunchKernelGGL(k_new_rot_source, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, UO, UN, SRC, M[0], M[1], M[2], b,
                        make_rotdev(r, g, dt), dt);
+    prof_end(prof, stream);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// castro_amd_sources_mf (round 6): a source stage of do_advance_ctu for every box of a level in ONE launch.  Per zone of the
+// Source_Type FAB of its box a thread does what memset + k_old/new_grav_source + k_old/new_rot_source + k_apply_source did in
+// three to four launches per box: outside the valid zones the source is zeroed; inside, the gravity and the rotation source
+// are formed by the zone functions of those kernels, added to a zero in their order, stored, and applied to the state
+// (base + dt * source, clean_state x ntimes) -- the same operations on the same values, hence the same bits.
+// ---------------------------------------------------------------------------------------
+struct GravDev { double g[3]; int type, on; };
+
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_sources_apply(const SrcBoxDev* __restrict__ tab, const long* __restrict__ start, int nbox,
+                                                       GravDev G, RotDev R, int rot_on, double dt, double dx0, double dx1, double dx2,
+                                                       DevParams P, int ntimes)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= start[nbox]) return;
+    int lo_ = 0, hi_ = nbox - 1;
+    while (lo_ < hi_) {
+        const int mid = (lo_ + hi_ + 1) >> 1;
+        if (start[mid] <= t) lo_ = mid; else hi_ = mid - 1;
+    }
+    const SrcBoxDev B = tab[lo_];
+    t -= start[lo_];
+    const int i = B.lo[0] + (int)(t % B.n[0]);
+    const long q = t / B.n[0];
+    const int j = B.lo[1] + (int)(q % B.n[1]), k = B.lo[2] + (int)(q / B.n[1]);
+    const long cs = fidx(B.Src, i, j, k, 0);
+    if (i < B.vlo[0] || i > B.vhi[0] || j < B.vlo[1] || j > B.vhi[1] || k < B.vlo[2] || k > B.vhi[2]) {
+        for (int n = 0; n < B.nsc; ++n) B.Src.p[cs + B.Src.sn * n] = 0.0;         // the memset of the ghost zones
+        return;
+    }
+    double acc[NSRC], src[NSRC];
+    for (int n = 0; n < NSRC; ++n) acc[n] = 0.0;
+    if (G.on) {
+        if (STAGE == 0) old_grav_zone(B.So, i, j, k, G.g, G.type, dt, src);
+        else new_grav_zone(B.So, B.Sn, B.M0, B.M1, B.M2, i, j, k, G.g, G.type, dt, dx0, dx1, dx2, src);
+        for (int n = 0; n < NSRC; ++n) acc[n] += src[n];
+    }
+    if (rot_on) {
+        if (STAGE == 0) old_rot_zone(B.So, i, j, k, R, dt, src);
+        else new_rot_zone(B.So, B.Sn, B.M0, B.M1, B.M2, i, j, k, R, dt, src);
+        for (int n = 0; n < NSRC; ++n) acc[n] += src[n];
+    }
+    for (int n = 0; n < B.nsc; ++n) B.Src.p[cs + B.Src.sn * n] = n < NSRC ? acc[n] : 0.0;
+    // k_apply_source: S_new = (S_old | S_new) + dt * source, clean_state x ntimes
+    const DFab& Bs = STAGE == 0 ? B.So : B.Sn;
+    const long cd = fidx(B.Sn, i, j, k, 0), cb = fidx(Bs, i, j, k, 0);
+    double u[NUM_STATE];
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) {
+        u[n] = Bs.p[cb + Bs.sn * n];
+        if (n < NSRC) u[n] += dt * acc[n];
+    }
+    if (ntimes > 0) clean_zone(P, ntimes, u[URHO], u[UMX], u[UMY], u[UMZ], u[UEDEN], u[UEINT], u[UTEMP], u[UFS]);
+#pragma unroll
+    for (int n = 0; n < NUM_STATE; ++n) B.Sn.p[cd + B.Sn.sn * n] = u[n];
+}
+
+static RotDev make_rotdev(const castro_amd_rotation* r, const castro_amd_geom* g, double dt);
+
+int launch_sources_apply(int stage, int nbox, const SrcBoxDev* boxes, const double* grav, int grav_type, const castro_amd_rotation* rot,
+                         const castro_amd_geom* geom, const DevParams& P, double dt, int ntimes, FabOpsArena* arena,
+                         hipStream_t stream, Profiler* prof)
+{
+    if (nbox < 1 || !boxes || !arena) return 0;
+    std::vector<long> start((size_t)nbox + 1, 0);
+    for (int r = 0; r < nbox; ++r) {
+        long n = 1;
+        for (int d = 0; d < 3; ++d) n *= boxes[r].n[d] > 0 ? boxes[r].n[d] : 0;
+        start[(size_t)r + 1] = start[(size_t)r] + n;
+    }
+    if (start.back() <= 0) return 0;
+    const size_t bo = (size_t)nbox * sizeof(SrcBoxDev), bs = start.size() * sizeof(long);
+    const size_t need = ((bo + 255) & ~(size_t)255) + bs;
+    if (need > arena->bytes) {
+        if (arena->p) { (void)hipStreamSynchronize(stream); (void)hipFree(arena->p); arena->p = nullptr; arena->bytes = 0; }
+        if (hipMalloc(&arena->p, 2 * need) != hipSuccess) return -3;
+        arena->bytes = 2 * need;
+    }
+    char* base = (char*)arena->p;
+    long* dstart = (long*)(base + ((bo + 255) & ~(size_t)255));
+    if (hipMemcpyAsync(base, boxes, bo, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
+    if (hipMemcpyAsync(dstart, start.data(), bs, hipMemcpyHostToDevice, stream) != hipSuccess) return -4;
+    GravDev G;
+    G.on = grav ? 1 : 0; G.type = grav_type;
+    for (int d = 0; d < 3; ++d) G.g[d] = grav ? grav[d] : 0.0;
+    RotDev R;
+    std::memset(&R, 0, sizeof(R));
+    if (rot) R = make_rotdev(rot, geom, dt);
+    const unsigned nb = (unsigned)((start.back() + 255) / 256);
+    prof_begin(prof, stage == 0 ? "k_sources_old" : "k_sources_new", stream);
+    if (stage == 0) hipLaunchKernelGGL(k_sources_apply<0>, dim3(nb), dim3(256), 0, stream, (const SrcBoxDev*)base, (const long*)dstart, nbox, G, R,
+                                       rot ? 1 : 0, dt, geom->dx[0], geom->dx[1], geom->dx[2], P, ntimes);
+    else hipLaunchKernelGGL(k_sources_apply<1>, dim3(nb), dim3(256), 0, stream, (const SrcBoxDev*)base, (const long*)dstart, nbox, G, R,
+                            rot ? 1 : 0, dt, geom->dx[0], geom->dx[1], geom->dx[2], P, ntimes);
     prof_end(prof, stream);
     return launch_status();
 }

@@ -589,29 +589,42 @@ int castro_amd_sources_mf(castro_amd_ctx* c, int stage, int nboxes, const castro
                           const castro_amd_geom* geom, const castro_amd_params* params, double dt, int clean_ntimes, void* stream)
 {
     if (!c || (stage != 0 && stage != 1) || nboxes < 0 || (nboxes > 0 && !boxes) || !geom || !params || clean_ntimes < 0) return CASTRO_AMD_ERR_ARG;
-    hipSetDevice(c->device);
+    // the checks of the single-box entry points (castro_amd_old/new_gravity_source_fab, _rotation_source_fab, _apply_source_fab)
+    if (grav && (grav_source_type < 1 || grav_source_type > 4)) return CASTRO_AMD_ERR_ARG;
+    if (rot && (rot->rot_source_type < 1 || rot->rot_source_type > 4)) return CASTRO_AMD_ERR_ARG;
+    if ((rot || (grav && stage == 1)) && geom->coord != 0) return CASTRO_AMD_ERR_ARG;
+    if (rot && stage == 1 && !(dt > 0.0)) return CASTRO_AMD_ERR_ARG;
+    if (nboxes == 0) return CASTRO_AMD_OK;
+    std::vector<SrcBoxDev> tab((size_t)nboxes);
     for (int i = 0; i < nboxes; ++i) {
         const castro_amd_source_box& b = boxes[i];
-        if (!b.source.p || b.source.ncomp < 7) return CASTRO_AMD_ERR_ARG;
-        size_t n = (size_t)b.source.ncomp;
+        if (!b.S_old.p || !b.S_new.p || !b.source.p || b.S_old.ncomp != NUM_STATE || b.S_new.ncomp != NUM_STATE || b.source.ncomp < 7)
+            return CASTRO_AMD_ERR_ARG;
+        if (!fab_contains(&b.S_old, b.lo, b.hi) || !fab_contains(&b.S_new, b.lo, b.hi) || !fab_contains(&b.source, b.lo, b.hi)) return CASTRO_AMD_ERR_ARG;
+        SrcBoxDev& T = tab[(size_t)i];
+        T.So = to_dfab(&b.S_old); T.Sn = to_dfab(&b.S_new); T.Src = to_dfab(&b.source);
+        T.M0 = T.M1 = T.M2 = to_dfab(nullptr);
+        if (stage == 1 && (grav || rot)) {
+            DFab M[3];
+            for (int d = 0; d < 3; ++d) {
+                int fhi[3] = { b.hi[0], b.hi[1], b.hi[2] };
+                fhi[d] += 1;
+                if (!b.mass_flux[d].p || b.mass_flux[d].ncomp != 1 || !fab_contains(&b.mass_flux[d], b.lo, fhi)) return CASTRO_AMD_ERR_ARG;
+                M[d] = to_dfab(&b.mass_flux[d]);
+            }
+            T.M0 = M[0]; T.M1 = M[1]; T.M2 = M[2];
+        }
         for (int d = 0; d < 3; ++d) {
             if (b.source.hi[d] < b.source.lo[d]) return CASTRO_AMD_ERR_ARG;
-            n *= (size_t)(b.source.hi[d] - b.source.lo[d] + 1);
+            T.lo[d] = b.source.lo[d]; T.n[d] = b.source.hi[d] - b.source.lo[d] + 1;
+            T.vlo[d] = b.lo[d]; T.vhi[d] = b.hi[d];
         }
-        if (hipMemsetAsync(b.source.p, 0, n * sizeof(double), (hipStream_t)stream) != hipSuccess) return CASTRO_AMD_ERR_HIP;
-        int rc = CASTRO_AMD_OK;
-        if (stage == 0) {
-            if (grav) rc = castro_amd_old_gravity_source_fab(c, &b.S_old, &b.source, b.lo, b.hi, grav, grav_source_type, dt, stream);
-            if (rc == CASTRO_AMD_OK && rot) rc = castro_amd_old_rotation_source_fab(c, &b.S_old, &b.source, b.lo, b.hi, rot, geom, dt, stream);
-            if (rc == CASTRO_AMD_OK) rc = castro_amd_apply_source_fab(c, &b.S_new, &b.S_old, dt, &b.source, 7, b.lo, b.hi, params, clean_ntimes, stream);
-        } else {
-            if (grav) rc = castro_amd_new_gravity_source_fab(c, &b.S_old, &b.S_new, &b.source, b.mass_flux, b.lo, b.hi, grav, grav_source_type, dt, geom, stream);
-            if (rc == CASTRO_AMD_OK && rot) rc = castro_amd_new_rotation_source_fab(c, &b.S_old, &b.S_new, &b.source, b.mass_flux, b.lo, b.hi, rot, geom, dt, stream);
-            if (rc == CASTRO_AMD_OK) rc = castro_amd_apply_source_fab(c, &b.S_new, &b.S_new, dt, &b.source, 7, b.lo, b.hi, params, clean_ntimes, stream);
-        }
-        if (rc != CASTRO_AMD_OK) return rc;
+        T.nsc = b.source.ncomp;
     }
-    return CASTRO_AMD_OK;
+    hipSetDevice(c->device);
+    const int rc = launch_sources_apply(stage, nboxes, tab.data(), grav, grav_source_type, rot, geom, to_devparams(params), dt, clean_ntimes,
+                                        &c->ops_arena, (hipStream_t)stream, &c->prof);
+    return rc == 0 ? CASTRO_AMD_OK : (rc < 0 ? CASTRO_AMD_ERR_HIP : rc);
 }
 
 int castro_amd_clean_state_reduce_mf(castro_amd_ctx* c, int nboxes, const castro_amd_state_box* boxes, const castro_amd_geom* geom,

@@ -109,6 +109,12 @@ int launch_old_rot_source(const DFab& U, const DFab& SRC, const int lo[3], const
                           const ::castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof);
 int launch_new_rot_source(const DFab& UO, const DFab& UN, const DFab& SRC, const DFab M[3], const int lo[3], const int hi[3],
                           const ::castro_amd_rotation* r, const ::castro_amd_geom* g, double dt, hipStream_t stream, Profiler* prof);
+// one box of castro_amd_sources_mf: states, Source_Type FAB (nsc components), mass fluxes; [lo, lo + n): the zones of the source FAB
+// (thread range), [vlo, vhi]: the valid zones
+struct SrcBoxDev { DFab So, Sn, Src, M0, M1, M2; int lo[3], n[3]; int vlo[3], vhi[3]; int nsc; };
+int launch_sources_apply(int stage, int nbox, const SrcBoxDev* boxes, const double* grav, int grav_type, const ::castro_amd_rotation* rot,
+                         const ::castro_amd_geom* geom, const DevParams& P, double dt, int ntimes, FabOpsArena* arena,
+                         hipStream_t stream, Profiler* prof);
 int launch_saxpy(const DFab& D, const DFab& S, const int lo[3], const int hi[3], double a, int ncomp,
                  hipStream_t stream, Profiler* prof);
 int launch_fab_ops(int nops, const DFab* D, const DFab* X, const DFab* Y, const int* lo, const int* hi, const int* kind,
