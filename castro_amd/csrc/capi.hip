@@ -9,7 +9,7 @@
 #include "../../include/castro_hydro_amd.h"
 #include <cstdlib>
 #include "ctu_kernels.h"
-namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_final_tile; extern int g_gl_sources; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; extern int g_trace_one_zone; extern int g_divu_in_trace; }
+namespace cad { extern int g_tile_rows; extern int g_xpad; extern int g_fuse_consup; extern int g_fused_tile_rows; extern int g_trace_tile_rows; extern int g_side_stream; extern int g_fold_r1; extern int g_fold_tile; extern int g_final_tile; extern int g_gl_sources; extern int g_gl_plm; extern int g_fold_tile_rows; extern int g_wg; extern int g_final_wg; extern int g_fused_wg; extern int g_trace_one_zone; extern int g_divu_in_trace; }
 
 using namespace cad;
 
@@ -236,6 +236,7 @@ int castro_amd_ctx_create(castro_amd_ctx** out, int device)
     g_fold_tile = knob("CASTRO_AMD_FOLD_TILE", -1);
     g_final_tile = knob("CASTRO_AMD_FINAL_TILE", 0);
     g_gl_sources = knob("CASTRO_AMD_GL_SOURCES", 1);
+    g_gl_plm = knob("CASTRO_AMD_GL_PLM", 1);
     g_wg = wg_knob("CASTRO_AMD_WG", 256);
     g_fused_wg = wg_knob("CASTRO_AMD_FUSED_WG", 128);
     g_final_wg = wg_knob("CASTRO_AMD_FINAL_WG", 0);

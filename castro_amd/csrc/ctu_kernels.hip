@@ -1066,7 +1066,11 @@ __device__ __forceinline__ void trace_pair_dir(const Tile& t, const double* __re
 // reflecting-boundary fix-up of Castro::ctu_plm_states (Castro_ctu.cpp:287-433): at a Symmetry
 // face the zone inside the domain writes both edge states and the ghost zone writes neither.
 // ---------------------------------------------------------------------------------------
-template <int D, bool SRC>
+// GL (the `contract` build's default-solver path, round 6): the gamma-law shortcut of trace_finish for the PLM trace.  With (rho e) =
+// p / (gamma - 1) in every zone the limited slope of (rho e) is that of p over (gamma - 1) (every limiter of uslope is invariant under a
+// positive scaling; castro.use_pslope = 1 changes the slope of p alone and is excluded by the launcher), enth = 1 / (gamma - 1), alpha0e
+// vanishes and the traced (rho e) is the traced p over (gamma - 1): neither loaded, traced nor stored -- and neither is the one species.
+template <int D, bool SRC, bool GL = false>
 __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __restrict__ Q, const double* __restrict__ SQ,
                                               unsigned c, unsigned sd, int idx, const DevGeom& g,
                                               double flat, double dt, const DevParams& P,
@@ -1096,7 +1100,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
     const double csq = cc * cc;
     const double rho = srho[2];
     const double p = sp[2];
-    const double enth_rhoe = ldg(Q + PRE * NC, c);
+    const double enth_rhoe = GL ? 0.0 : ldg(Q + PRE * NC, c);
 
     const double dq_rho = uslope(srho, flat, false, false, P);
     LOAD5(Q, QUN, s);
@@ -1109,14 +1113,17 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
     const double utt = s[2];
     const double dq_utt = uslope(s, flat, false, false, P);
     double dq_p = uslope(sp, flat, false, false, P);
-    LOAD5(Q, PRE, s);
-    const double rhoe = enth_rhoe;
-    const double dq_re = uslope(s, flat, false, false, P);
-    LOAD5(Q, PX, s);
-    const double X = s[2];
-    const double dX = uslope(s, flat, false, false, P);
+    double rhoe = 0.0, dq_re = 0.0, X = 1.0, dX = 0.0, enth = 0.0;
+    if (!GL) {
+        LOAD5(Q, PRE, s);
+        rhoe = enth_rhoe;
+        dq_re = uslope(s, flat, false, false, P);
+        LOAD5(Q, PX, s);
+        X = s[2];
+        dX = uslope(s, flat, false, false, P);
 
-    const double enth = (rhoe + p) / (rho * csq);
+        enth = (rhoe + p) / (rho * csq);
+    }
 
     if (P.use_pslope == 1) {
         double src[5];
@@ -1134,7 +1141,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
         sq_ut = ldg(SQ + (long)QUT * NC, c);
         sq_utt = ldg(SQ + (long)QUTT * NC, c);
         sq_p = ldg(SQ + PP * NC, c);
-        sq_re = ldg(SQ + PRE * NC, c);
+        if (!GL) sq_re = ldg(SQ + PRE * NC, c);
     }
 
     const double alpham = 0.5 * (dq_p / (rho * cc) - dq_un) * (rho / cc);
@@ -1191,8 +1198,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
         stg(QPd + QUT * NC, c, o_ut);
         stg(QPd + QUTT * NC, c, o_utt);
         stg(QPd + PP * NC, c, o_p);
-        stg(QPd + PRE * NC, c, o_re);
-        stg(QPd + PX * NC, c, o_X);
+        if (!GL) { stg(QPd + PRE * NC, c, o_re); stg(QPd + PX * NC, c, o_X); }
         if (lo_bc_test) {
             // Castro_ctu.cpp:293-318: the left state on the Symmetry face mirrors the right one
             stg(QMd + PRHO * NC, c, o_rho);
@@ -1200,8 +1206,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
             stg(QMd + QUT * NC, c, o_ut);
             stg(QMd + QUTT * NC, c, o_utt);
             stg(QMd + PP * NC, c, o_p);
-            stg(QMd + PRE * NC, c, o_re);
-            stg(QMd + PX * NC, c, o_X);
+            if (!GL) { stg(QMd + PRE * NC, c, o_re); stg(QMd + PX * NC, c, o_X); }
         }
     }
 
@@ -1251,8 +1256,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
         stg(QMd + QUT * NC, cp, o_ut);
         stg(QMd + QUTT * NC, cp, o_utt);
         stg(QMd + PP * NC, cp, o_p);
-        stg(QMd + PRE * NC, cp, o_re);
-        stg(QMd + PX * NC, cp, o_X);
+        if (!GL) { stg(QMd + PRE * NC, cp, o_re); stg(QMd + PX * NC, cp, o_X); }
         if (hi_bc_test) {
             // Castro_ctu.cpp:320-345
             stg(QPd + PRHO * NC, cp, o_rho);
@@ -1260,8 +1264,7 @@ __device__ __forceinline__ void trace_plm_dir(const Tile& t, const double* __res
             stg(QPd + QUT * NC, cp, o_ut);
             stg(QPd + QUTT * NC, cp, o_utt);
             stg(QPd + PP * NC, cp, o_p);
-            stg(QPd + PRE * NC, cp, o_re);
-            stg(QPd + PX * NC, cp, o_X);
+            if (!GL) { stg(QPd + PRE * NC, cp, o_re); stg(QPd + PX * NC, cp, o_X); }
         }
     }
 }
@@ -1314,9 +1317,9 @@ __global__ void __launch_bounds__(256) k_trace(Tile t, LinBox b, const double* _
     }
 
     if (PLM) {
-        trace_plm_dir<0, SRC>(t, Q, S.SRCQ, c, s.x, i, g, flat, dt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
-        trace_plm_dir<1, SRC>(t, Q, S.SRCQ, c, s.y, j, g, flat, dt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
-        trace_plm_dir<2, SRC>(t, Q, S.SRCQ, c, s.z, k, g, flat, dt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
+        trace_plm_dir<0, SRC, GL>(t, Q, S.SRCQ, c, s.x, i, g, flat, dt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
+        trace_plm_dir<1, SRC, GL>(t, Q, S.SRCQ, c, s.y, j, g, flat, dt, P, j >= t.lo[1], j <= t.hi[1], S.QM[1], S.QP[1]);
+        trace_plm_dir<2, SRC, GL>(t, Q, S.SRCQ, c, s.z, k, g, flat, dt, P, k >= t.lo[2], k <= t.hi[2], S.QM[2], S.QP[2]);
     } else {
         const double hdt = 0.5 * dt;
         trace_dir<0, SRC, GL>(t, Q, S.SRCQ, c, s.x, flat, dt / g.dx[0], hdt, P, i >= t.lo[0], i <= t.hi[0], S.QM[0], S.QP[0]);
@@ -3325,6 +3328,7 @@ k_final_tile(Tile t, TileRows b, const double* __restrict__ Q, DevScratch S, Dev
 // ---------------------------------------------------------------------------------------
 int g_fold_tile_rows = -1; // rows per y-tile of the k_trans1_fold launch (-1: g_tile_rows)
 int g_gl_sources = 1;     // CASTRO_AMD_GL_SOURCES=0: traced source terms run the 7-variable kernels as in round 4 (A/B)
+int g_gl_plm = 1;         // CASTRO_AMD_GL_PLM=0: the PLM trace (ppm_type = 0) runs the 7-variable kernels as before round 6 (A/B)
 int g_final_tile = 0;     // CASTRO_AMD_FINAL_TILE: 1 = the final stage as ONE zone-centred launch (k_final_tile<4, 2>); `contract` build only
 int g_fold_tile = -1;     // CASTRO_AMD_FOLD_TILE: 1 = k_trans1_tile<4, 2> (a 4 x 2 tile of rows per workgroup), 2 = <2, 4>, 0 = k_trans1_fold_lds;
                           // -1 (default): <4, 2> for boxes of at least 96 rows in y and z (128^3: equal, 64^3: the fold kernel is faster;
@@ -3462,7 +3466,16 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // gamma_law_edges (contract build): the GEN == 0 readers take (rho e) of an edge state from its p, which only the trace
     // kernel of the no-source PPM path promises (k_trace_pair<true, 7, 0>); traces with source terms or PLM run the GEN >= 1 set
     // (round 5: traced source terms keep the identity -- trace_dir<D, SRC, GL> -- so only PLM is left out)
-    const bool gl_ok = !gamma_law_edges(0) || (P.ppm_type == 1 && (!Src.p || g_gl_sources));
+    // (round 6: the PLM trace keeps it too -- trace_plm_dir<D, SRC, GL>.  castro.use_pslope = 1 (the default) gives p a slope of its own:
+    // without a source term and away from a Symmetry face it is uslope's expression on half the differences -- the same number in real
+    // arithmetic --, with one it carries the hydrostatic part and at such a face it drops the differences across it, and the slope of
+    // (rho e) would no longer be that of p over (gamma - 1): those runs keep the 7-variable kernels.  CASTRO_AMD_GL_PLM=0 is the A/B knob)
+    bool plm_gl = P.ppm_type == 0 && g_gl_plm;
+    if (plm_gl && P.use_pslope == 1) {
+        if (Src.p) plm_gl = false;
+        for (int d = 0; d < 3; ++d) if (g.sym_lo[d] || g.sym_hi[d]) plm_gl = false;
+    }
+    const bool gl_ok = !gamma_law_edges(0) || ((P.ppm_type == 1 || plm_gl) && (!Src.p || g_gl_sources));
     const int solv = (P.riemann_solver == 1) ? 2 : ((P.riemann_solver == 2 || P.hybrid_riemann == 1 || !plain_path || !gl_ok) ? 1 : 0);
     const int lean_q = (gamma_law_edges(0) && solv == 0) ? (clean_ntimes > 0 ? 3 : 1) : 0;      // see k_ctoprim
     const bool stage_a = (flags & 4) != 0, stage_b = (flags & 8) != 0, staged = stage_a || stage_b;
@@ -3626,11 +3639,13 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
         const int q3lo[3] = { t.lo[0] - 3, t.lo[1] - 3, t.lo[2] - 3 };
         const int q3hi[3] = { t.hi[0] + 3, t.hi[1] + 3, t.hi[2] + 3 };
         KL("k_src_to_prim", k_src_to_prim<false>, q3lo, q3hi, S.Q, Src, S.SRCQ, P, SrcCorr, dt, lean_q & 1, nolv);
-        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+        if (P.ppm_type == 0 && (lean_q & 1)) { KL("k_trace_plm", (k_trace<true, true, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+        else if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<true, true>), olo, ohi, S.Q, S, g, dt, P, nolv); }
         else if (lean_q & 1) { KL("k_trace", (k_trace<true, false, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P, nolv); }
         else { KL("k_trace", (k_trace<true, false>), olo, ohi, S.Q, S, g, dt, P, nolv); }
     } else {
-        if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+        if (P.ppm_type == 0 && (lean_q & 1)) { KL("k_trace_plm", (k_trace<false, true, gamma_law_edges(0)>), olo, ohi, S.Q, S, g, dt, P, nolv); }
+        else if (P.ppm_type == 0) { KL("k_trace_plm", (k_trace<false, true>), olo, ohi, S.Q, S, g, dt, P, nolv); }
         else if (tfix) { KL2("k_trace", k_trace_pair<false>, olo, ohi, S.Q, S, g, dt, P, none, nolv, 0); }
         else if (g_trace_one_zone && !second_half) {
             // A/B (CASTRO_AMD_TRACE_ONE_ZONE=1, round 6): ONE zone per thread at the occupancy that leaves (the kernel of the runs with
