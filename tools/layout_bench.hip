@@ -64,5 +64,10 @@ int main()
     std::printf("%-28s %12s %12s\n", "planes in + out", "plane-major", "row-major");
 #define CASE(NI, NO) std::printf("%2d + %2d %20s %9.0f GB/s %9.0f GB/s\n", NI, NO, "", run<NI, NO, 0>(in, out, nx, nrows), run<NI, NO, 1>(in, out, nx, nrows));
     CASE(1, 1) CASE(8, 8) CASE(16, 8) CASE(37, 18) CASE(48, 9) CASE(14, 42) CASE(48, 42)
+    // the compulsory plane mixes of the `contract` kernels of round 6: what a kernel that ONLY moves those planes takes
+    std::printf("%-36s %10s %10s\n", "kernel (planes in + out)", "GB/s", "ms");
+#define MIX(name, NI, NO) { const double r = run<NI, NO, 0>(in, out, nx, nrows); \
+        std::printf("%-36s %10.0f %10.3f\n", name " (" #NI " + " #NO ")", r, (double)(NI + NO) * nx * nrows * 8.0 / r / 1e6); }
+    MIX("k_ctoprim", 6, 6) MIX("k_trace_pair", 7, 36) MIX("k_trans1_tile", 36, 36) MIX("k_final<y,z>", 30, 17) MIX("k_finalx_consup", 46, 17)
     return 0;
 }
