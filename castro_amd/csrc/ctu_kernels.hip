@@ -3468,11 +3468,15 @@ int launch_ctu_hydro(const Tile& t, const DevScratch& S, const DFab& Sborder, co
     // (round 5: traced source terms keep the identity -- trace_dir<D, SRC, GL> -- so only PLM is left out)
     // (round 6: the PLM trace keeps it too -- trace_plm_dir<D, SRC, GL>.  castro.use_pslope = 1 (the default) gives p a slope of its own:
     // without a source term and away from a Symmetry face it is uslope's expression on half the differences -- the same number in real
-    // arithmetic --, with one it carries the hydrostatic part and at such a face it drops the differences across it, and the slope of
-    // (rho e) would no longer be that of p over (gamma - 1): those runs keep the 7-variable kernels.  CASTRO_AMD_GL_PLM=0 is the A/B knob)
+    // arithmetic (for the default fourth-order limiter, plm_limiter = 2) --, with one it carries the hydrostatic part and at such a face it
+    // drops the differences across it, and the slope of (rho e) would no longer be that of p over (gamma - 1): those runs keep the
+    // 7-variable kernels.  CASTRO_AMD_GL_PLM=0 is the A/B knob)
     bool plm_gl = P.ppm_type == 0 && g_gl_plm;
     if (plm_gl && P.use_pslope == 1) {
         if (Src.p) plm_gl = false;
+        // pslope is the fourth-order form whatever castro.plm_limiter says: with plm_limiter = 1 the other variables -- (rho e) among
+        // them -- take the second-order slope and the two no longer agree (found by the contract test of that option: 1e-2)
+        if (P.plm_iorder != 1 && P.plm_limiter != 2) plm_gl = false;
         for (int d = 0; d < 3; ++d) if (g.sym_lo[d] || g.sym_hi[d]) plm_gl = false;
     }
     const bool gl_ok = !gamma_law_edges(0) || ((P.ppm_type == 1 || plm_gl) && (!Src.p || g_gl_sources));

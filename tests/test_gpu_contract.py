@@ -303,15 +303,17 @@ def test_contract_one_256_cubed_box_of_the_512_cubed_decomposition_within_rtol(o
     hip.close()
 
 
-@pytest.mark.parametrize("case", ["plm", "hllc", "hybrid", "cg", "gravity"])
+@pytest.mark.parametrize("case", ["plm", "plm_iorder1", "plm_limiter1", "plm_nopslope", "hllc", "hybrid", "cg", "gravity"])
 def test_contract_non_default_options_within_rtol(oracle, case):
     """The `contract` build on the option sets that leave its default-solver path (whose edge states carry no (rho e) plane,
-    gamma_law_edges): PLM, HLLC, the hybrid solver, Colella-Glaz, and a constant-gravity source (traced source terms):
+    gamma_law_edges): HLLC, the hybrid solver, Colella-Glaz; and on those that keep it through identities of their own: a
+    constant-gravity source (traced source terms) and -- since round 6 -- PLM with its slope options (trace_plm_dir<D, SRC, GL>):
     Sedov 32^3, 30 steps, the conserved state and dt against the oracle at the same tolerance."""
     import torch
     import castro_amd
-    pkw = {"plm": dict(ppm_type=0), "hllc": dict(riemann_solver=2), "hybrid": dict(hybrid_riemann=1), "cg": dict(riemann_solver=1),
-           "gravity": {}}[case]
+    pkw = {"plm": dict(ppm_type=0), "plm_iorder1": dict(ppm_type=0, plm_iorder=1), "plm_limiter1": dict(ppm_type=0, plm_limiter=1),
+           "plm_nopslope": dict(ppm_type=0, use_pslope=0), "hllc": dict(riemann_solver=2), "hybrid": dict(hybrid_riemann=1),
+           "cg": dict(riemann_solver=1), "gravity": {}}[case]
     n = (32, 32, 32)
     grav = dict(do_grav=True, const_grav=-2.0) if case == "gravity" else {}
     c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), numerics="contract", **grav)
