@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_estdt(DFab U, Box3 b, double dx0, doubl
 __global__ void k_step_control(double* red, double* ctl, double cfl, double change_max, double small_dens, double max_dt,
                                double fixed_dt, double stop_time, int retry_form)
 {
-    // the host's expressions in the host's order in BOTH builds: with the `contract` build's -fassociative-math the single
+    // the host's expressions in the host's order in BOTH builds: with -fassociative-math (part of the `contract` build's flags until round 6) the single
     // subcycle (time + dt) - time below was folded to dt, one ulp away from what Castro.subcycle_advance_ctu (and the
     // reference, Castro_advance_ctu.cpp:463-471) computes every now and then -- a graph-replayed batch then left the bits of
     // the stepwise driver (round 6, profiles/r06a_*)

@@ -9,7 +9,7 @@
 
 // Numerics modes.  The default build is `exact`: -ffp-contract=off, IEEE division and sqrt, bit-identical
 // to the CPU restatement of the reference the tests check against.  The `contract` build (-DCAD_NUMERICS_CONTRACT with
-// -ffp-contract=fast -fassociative-math) additionally replaces the divisions and square roots of the hot device functions by
+// -ffp-contract=fast; without -fassociative-math since round 6: see the Makefile) additionally replaces the divisions and square roots of the hot device functions by
 // frcp / fdiv / fsqrt below -- v_rcp_f64 / v_rsq_f64 plus Newton steps, <= 1.5 ulp, no range scaling -- at the sites whose
 // operands are bounded away from the denormal and overflow ranges by the floors of the scheme (every call site says by which);
 // all other divisions and roots stay IEEE.  Agreement with `exact`: rtol 1e-10 on every plotfile field (tests/test_gpu_contract.py).
@@ -1216,6 +1216,12 @@ template <int D>
 __device__ __forceinline__ void hllc_flux(const RState& ql, const RState& qr, double Xl, double Xr,
                                           double cl_zone, double cr_zone, double bnd_fac, const DevParams& P, IFlux& F)
 {
+    // No FMA contraction in here, in either build.  The solver picks its star state by the sign of the contact speed S_c, and on a wall
+    // face (bnd_fac = 0: compute_flux keeps the pressure alone, the S_k (U* - U) terms stay) the two choices give mass, transverse
+    // momentum and energy fluxes of OPPOSITE sign.  For the mirror states of such a face S_c is exactly zero as long as the two products
+    // of its numerator are rounded alike -- which a contracted a * b - c * d does not do: the `contract` build then took either branch
+    // at random and came out 1e-2 ... 1 away from the reference on runs with walls (tools/fuzz_contract.py, round 6).
+#pragma clang fp contract(off)
     constexpr double small = 1.e-8;
     constexpr double smallu = 1.e-12;
 
@@ -1287,6 +1293,9 @@ __device__ __forceinline__ void hllc_flux(const RState& ql, const RState& qr, do
 
     double S_c = (pr - pl + rl * ul * (S_l - ul) - rr * ur * (S_r - ur)) /
         (rl * (S_l - ul) - rr * (S_r - ur));
+    // `contract`: the two states of a wall face are mirror images in the reference's arithmetic and its S_c is an exact zero there; traced
+    // with contracted FMAs they are mirror images up to a rounding, and the sign of that rounding would pick the star state (see above)
+    if (kContract && bnd_fac == 0.0) S_c = 0.0;
 
     // cons_state / HLLC_state (riemann.H:379-440) of the RAW state q with passive X
     auto cons = [&](const RState& q, double X, CState& U) {

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../castro_amd/csrc"
 D=/tmp/variant_$1; mkdir -p $D
-if [ "${NUMERICS:-exact}" = contract ]; then NF="-fno-fast-math -ffp-contract=fast -fassociative-math -fno-signed-zeros -fno-trapping-math -DCAD_NUMERICS_CONTRACT -DHW_MINMAX_ON"
+if [ "${NUMERICS:-exact}" = contract ]; then NF="-fno-fast-math -ffp-contract=fast -fno-signed-zeros -fno-trapping-math -DCAD_NUMERICS_CONTRACT -DHW_MINMAX_ON"
 else NF="-ffp-contract=off -fno-fast-math"; fi
 F="-O3 -std=c++17 -fPIC $NF --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $2"
 for f in ctu_kernels aux_kernels unit_kernels capi halo_rccl cluster_host; do /opt/rocm/bin/hipcc $F -c $f.hip -o $D/$f.o & done; wait
