@@ -24,11 +24,14 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 only = set(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else None      # replay these cases only (verbose)
 import os
 NUM = os.environ.get("FUZZ_NUMERICS", "contract")
-EXTRA = os.environ.get("FUZZ_EXTRA", "0") == "1"        # "exact": the other build through the same campaign (must match bit for bit)
+EXTRA = os.environ.get("FUZZ_EXTRA", "0") == "1"
+BIG = os.environ.get("FUZZ_BIG", "0") == "1"        # "exact": the other build through the same campaign (must match bit for bit)
 RTOL = 1.e-10
 bad, worst, lean, skipped, illcond, onesided = 0, 0.0, 0, 0, 0, 0
 for case in range(ncases):
     n = tuple(int(rng.integers(10, 21)) for _ in range(3))
+    if BIG:        # FUZZ_BIG=1: boxes of 96 .. 112 zones a side -- the tile form of the transverse kernel (>= 96 rows) with walls and options
+        n = tuple(int(rng.integers(96, 113)) for _ in range(3))
     bcs = [int(rng.choice([2, 2, 3, 4])) for _ in range(6)]
     pkw = dict(ppm_type=int(rng.integers(0, 2)), plm_iorder=int(rng.choice([1, 2, 2])), plm_limiter=int(rng.choice([1, 2, 2])),
                use_pslope=int(rng.integers(0, 2)), use_flattening=int(rng.choice([0, 1, 1])), first_order_hydro=int(rng.choice([0, 0, 0, 1])),
@@ -58,7 +61,7 @@ for case in range(ncases):
         continue
     c = castro_amd.Castro(n, params=castro_amd.default_params(**pkw), do_grav=grav, const_grav=cg, grav_source_type=gst,
                           rotation=castro_amd.make_rotation(per, ax, **rkw) if rot else None, numerics=NUM, **ckw)
-    lev = oracle.Level(n, oracle.make_geom(n, **ckw), oracle.default_params(**pkw), nthreads=4)
+    lev = oracle.Level(n, oracle.make_geom(n, **ckw), oracle.default_params(**pkw), nthreads=0 if BIG else 4)
     if grav:
         lev.set_gravity(cg, gst)
     if rot:
@@ -73,7 +76,7 @@ for case in range(ncases):
     # the same initial state on both sides, and a second oracle run one ulp away from it
     S0 = lev.state().copy()
     c.set_state(S0.copy())
-    lev2 = oracle.Level(n, oracle.make_geom(n, **ckw), oracle.default_params(**pkw), nthreads=4)
+    lev2 = oracle.Level(n, oracle.make_geom(n, **ckw), oracle.default_params(**pkw), nthreads=0 if BIG else 4)
     if grav:
         lev2.set_gravity(cg, gst)
     if rot:
@@ -123,6 +126,8 @@ for case in range(ncases):
         continue
     rep = c.hydro.profile_report()
     lean += int("k_trans1_fold" in rep and "k_trans1" not in rep)
+    if BIG:
+        print("case %d: n=%s %s  kernels %s" % (case, n, {k: pkw[k] for k in ("ppm_type", "riemann_solver", "hybrid_riemann", "use_pslope")}, sorted(k for k in rep if "trans1" in k or "trace" in k)))
     got, want = c.S_new().cpu().numpy(), lev.state()
     dev = {k: np.abs(got[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-300) for k in range(8)}
     mom = max(max(np.abs(want[k]).max() for k in (1, 2, 3)), 1e-300)
